@@ -1,0 +1,700 @@
+"""
+CPU ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this module.
+Nothing under slepc_amd/ imports it; the product path fails loudly without the HIP library.
+
+What it is: a CPU restatement of the SLEPc 3.22.2 EPS Krylov-Schur path
+  * heavy kernels (CSR SpMV, BV ops, Gram-Schmidt, BVMatLanczos/Arnoldi): oracle/ks_oracle.c via ctypes
+  * host dense step (DS HEP: DSArrowTridiag + LAPACK steqr, sort, extra row, truncate) and the
+    restart driver (EPSSolve_KrylovSchur_Default, EPSKrylovConvergence): numpy restatement here,
+    calling the SAME LAPACK routines the reference calls (dsteqr/dlartg/drot through
+    scipy.linalg.cython_lapack's C entry points).
+Citations are relative to /root/reference.
+
+Pinning: PETSc/SLEPc cannot be built here (no PETSc in the image), so the oracle
+is pinned by the reference's own golden outputs (tests/golden/*.out, copied from
+src/sys/classes/bv/tests/output and src/eps/*/output) and by the analytic Laplacian spectra
+(src/eps/tutorials/ex19.c:19-45) -- see tests/test_oracle_golden.py.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+CGS, MGS = 0, 1
+REFINE_IFNEEDED, REFINE_NEVER, REFINE_ALWAYS = 0, 1, 2
+NORM_1, NORM_2, NORM_FROBENIUS, NORM_INFINITY = 0, 1, 2, 3
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def _build_if_needed():
+    src = os.path.join(_HERE, "ks_oracle.c")
+    for so in ("liboracle.so", "liboracle_omp.so"):
+        p = os.path.join(_HERE, so)
+        if not os.path.exists(p) or os.path.getmtime(p) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, so], stdout=subprocess.DEVNULL)
+
+
+def _load(name):
+    _build_if_needed()
+    lib = C.CDLL(os.path.join(_HERE, name))
+    vp = C.c_void_p
+    sig = {
+        "orc_bv_create": (vp, [C.c_int, C.c_int, C.c_int]),
+        "orc_bv_destroy": (None, [vp]),
+        "orc_bv_array": (_dp, [vp]), "orc_bv_buffer": (_dp, [vp]), "orc_bv_column": (_dp, [vp, C.c_int]),
+        "orc_bv_ld": (C.c_int, [vp]),
+        "orc_bv_set_active": (None, [vp, C.c_int, C.c_int]),
+        "orc_bv_set_orthog": (None, [vp, C.c_int, C.c_int, C.c_double]),
+        "orc_bv_passes_last": (C.c_int, [vp]), "orc_bv_passes_total": (C.c_long, [vp]),
+        "orc_bv_mult": (C.c_int, [vp, C.c_double, C.c_double, vp, _dp, C.c_int]),
+        "orc_bv_multvec": (C.c_int, [vp, C.c_double, C.c_double, _dp, _dp]),
+        "orc_bv_multcolumn": (C.c_int, [vp, C.c_double, C.c_double, C.c_int, _dp]),
+        "orc_bv_multinplace": (C.c_int, [vp, _dp, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "orc_bv_dot": (C.c_int, [vp, vp, _dp, C.c_int]),
+        "orc_bv_dotvec": (C.c_int, [vp, _dp, _dp]),
+        "orc_bv_dotcolumn": (C.c_int, [vp, C.c_int, _dp]),
+        "orc_bv_scale": (C.c_int, [vp, C.c_int, C.c_double]),
+        "orc_bv_norm": (C.c_int, [vp, C.c_int, C.c_int, _dp]),
+        "orc_bv_copy": (C.c_int, [vp, vp]), "orc_bv_copycolumn": (C.c_int, [vp, C.c_int, C.c_int]),
+        "orc_bv_setrandomcolumn": (C.c_int, [vp, C.c_int, C.c_uint64, C.c_int]),
+        "orc_random_value": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint64]),
+        "orc_csr_mult": (None, [C.c_int, _ip, _ip, _dp, _dp, _dp]),
+        "orc_csr_wrap": (vp, [C.c_int, C.c_int, _ip, _ip, _dp]), "orc_csr_free": (None, [vp]),
+        "orc_bv_matmultcolumn": (C.c_int, [vp, vp, C.c_int]),
+        "orc_bv_matmult": (C.c_int, [vp, vp, vp]),
+        "orc_bv_orthogonalizevec": (C.c_int, [vp, _dp, _dp, _dp, _ip]),
+        "orc_bv_orthogonalizecolumn": (C.c_int, [vp, C.c_int, _dp, _dp, _ip]),
+        "orc_bv_orthogonalizesomecolumn": (C.c_int, [vp, C.c_int, _ip, _dp, _dp, _ip]),
+        "orc_bv_orthonormalizecolumn": (C.c_int, [vp, C.c_int, _dp, _ip]),
+        "orc_bv_matarnoldi": (C.c_int, [vp, vp, _dp, C.c_int, C.c_int, _ip, _dp, _ip]),
+        "orc_bv_matlanczos": (C.c_int, [vp, vp, _dp, C.c_int, C.c_int, _ip, _dp, _ip]),
+        "orc_num_threads": (C.c_int, []),
+        "orc_laplacian3d_nnz": (C.c_long, [C.c_int] * 5),
+        "orc_laplacian3d_fill": (None, [C.c_int] * 5 + [_ip, _ip, _dp]),
+        "orc_laplacian2d_nnz": (C.c_long, [C.c_int, C.c_int]),
+        "orc_laplacian2d_fill": (None, [C.c_int, C.c_int, _ip, _ip, _dp]),
+    }
+    for k, (res, args) in sig.items():
+        f = getattr(lib, k)
+        f.restype = res
+        f.argtypes = args
+    return lib
+
+
+_libs = {}
+
+
+def lib(omp=False):
+    name = "liboracle_omp.so" if omp else "liboracle.so"
+    if name not in _libs:
+        _libs[name] = _load(name)
+    return _libs[name]
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _pi(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _chk(ierr):
+    if ierr:
+        raise OracleError({1: "argument out of range / wrong", 2: "Invalid inner product (BV_SafeSqrt)"}.get(ierr, str(ierr)))
+
+
+# ------------------------------------------------------------------------------------------------
+# matrices
+
+
+class CSR:
+    """PETSc SeqAIJ-layout CSR (rowptr int32[n+1], col int32[nnz], val float64[nnz])."""
+
+    def __init__(self, n, rowptr, col, val, ncols=None, omp=False):
+        self.n = int(n)
+        self.ncols = int(ncols if ncols is not None else n)
+        self.rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        self.col = np.ascontiguousarray(col, dtype=np.int32)
+        self.val = np.ascontiguousarray(val, dtype=np.float64)
+        self.nnz = int(self.rowptr[-1])
+        self._lib = lib(omp)
+        self._h = self._lib.orc_csr_wrap(self.n, self.ncols, _pi(self.rowptr), _pi(self.col), _p(self.val))
+
+    def __del__(self):
+        try:
+            self._lib.orc_csr_free(self._h)
+        except Exception:
+            pass
+
+    def mult(self, x, y=None):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if y is None:
+            y = np.empty(self.n)
+        self._lib.orc_csr_mult(self.n, _pi(self.rowptr), _pi(self.col), _p(self.val), _p(x), _p(y))
+        return y
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csr_matrix((self.val, self.col, self.rowptr), shape=(self.n, self.ncols))
+
+
+def laplacian3d(nx, ny, nz, z0=0, nzl=None, omp=False):
+    """ex19.c:47-78 FillMatrix: 7-pt, diag 6, off -1, natural ordering (x fastest). Rows of planes z0..z0+nzl."""
+    L = lib(omp)
+    nzl = nz if nzl is None else nzl
+    n = nx * ny * nzl
+    nnz = L.orc_laplacian3d_nnz(nx, ny, nz, z0, nzl)
+    rowptr = np.empty(n + 1, np.int32)
+    col = np.empty(nnz, np.int32)
+    val = np.empty(nnz, np.float64)
+    L.orc_laplacian3d_fill(nx, ny, nz, z0, nzl, _pi(rowptr), _pi(col), _p(val))
+    return CSR(n, rowptr, col, val, ncols=nx * ny * nz, omp=omp)
+
+
+def laplacian2d(n, m=None, omp=False):
+    """ex2.c:44-51: 5-pt, diag 4, off -1, II=i*n+j."""
+    L = lib(omp)
+    m = n if m is None else m
+    N = n * m
+    nnz = L.orc_laplacian2d_nnz(n, m)
+    rowptr = np.empty(N + 1, np.int32)
+    col = np.empty(nnz, np.int32)
+    val = np.empty(nnz, np.float64)
+    L.orc_laplacian2d_fill(n, m, _pi(rowptr), _pi(col), _p(val))
+    return CSR(N, rowptr, col, val, omp=omp)
+
+
+def laplacian1d(n):
+    """ex1.c / test4.c: tridiag(-1,2,-1)."""
+    rowptr = [0]
+    col = []
+    val = []
+    for i in range(n):
+        if i > 0:
+            col.append(i - 1); val.append(-1.0)
+        col.append(i); val.append(2.0)
+        if i < n - 1:
+            col.append(i + 1); val.append(-1.0)
+        rowptr.append(len(col))
+    return CSR(n, rowptr, col, val)
+
+
+def laplacian_eigenvalues(dims):
+    """Analytic Dirichlet Laplacian spectrum 4*sum_d sin^2(i_d*pi/(2(N_d+1)))  (ex19.c:19-45)."""
+    ev = np.zeros(1)
+    for N in dims:
+        s = 4.0 * np.sin(np.arange(1, N + 1) * np.pi / (2.0 * (N + 1))) ** 2
+        ev = (ev[:, None] + s[None, :]).ravel()
+    return np.sort(ev)
+
+
+# ------------------------------------------------------------------------------------------------
+# BV
+
+
+class BV:
+    """Mirror of the BV interface slice used by the path (names follow slepcbv.h without the BV prefix)."""
+
+    def __init__(self, n, m, ld=0, omp=False):
+        self._lib = lib(omp)
+        self._h = self._lib.orc_bv_create(n, m, ld)
+        self.n, self.m = n, m
+        self.ld = self._lib.orc_bv_ld(self._h)
+        self.l, self.k = 0, m
+        arr = self._lib.orc_bv_array(self._h)
+        self.array = np.ctypeslib.as_array(arr, shape=(m * self.ld,)).reshape(m, self.ld).T  # (ld, m) view, col-major
+        buf = self._lib.orc_bv_buffer(self._h)
+        self.buffer = np.ctypeslib.as_array(buf, shape=(m * m,)).reshape(m, m).T              # (m, m) view, col-major
+
+    def __del__(self):
+        try:
+            self._lib.orc_bv_destroy(self._h)
+        except Exception:
+            pass
+
+    # -- layout
+    def column(self, j):
+        return self.array[: self.n, j]
+
+    def set_column(self, j, x):
+        self.array[: self.n, j] = x
+
+    def dense(self):
+        return np.array(self.array[: self.n, :])
+
+    def SetActiveColumns(self, l, k):
+        self.l, self.k = l, k
+        self._lib.orc_bv_set_active(self._h, l, k)
+
+    def SetOrthogonalization(self, type=CGS, refine=REFINE_IFNEEDED, eta=0.7071):
+        self._lib.orc_bv_set_orthog(self._h, type, refine, eta)
+
+    def SetRandomColumn(self, j, seed=0x12345678, row0=0):
+        _chk(self._lib.orc_bv_setrandomcolumn(self._h, j, seed, row0))
+
+    # -- ops
+    def Mult(self, alpha, beta, X, Q=None):
+        """Y(self) = beta*Y + alpha*X*Q."""
+        if Q is None:
+            _chk(self._lib.orc_bv_mult(self._h, alpha, beta, X._h, None, 0))
+        else:
+            Qf = np.asfortranarray(Q, dtype=np.float64)
+            _chk(self._lib.orc_bv_mult(self._h, alpha, beta, X._h, _p(Qf), Qf.shape[0]))
+
+    def MultVec(self, alpha, beta, y, q=None):
+        q = None if q is None else np.ascontiguousarray(q, dtype=np.float64)
+        _chk(self._lib.orc_bv_multvec(self._h, alpha, beta, _p(y), _p(q)))
+
+    def MultColumn(self, alpha, beta, j, q=None):
+        q = None if q is None else np.ascontiguousarray(q, dtype=np.float64)
+        _chk(self._lib.orc_bv_multcolumn(self._h, alpha, beta, j, _p(q)))
+
+    def MultInPlace(self, Q, s, e, trans=False):
+        Qf = np.asfortranarray(Q, dtype=np.float64)
+        _chk(self._lib.orc_bv_multinplace(self._h, _p(Qf), Qf.shape[0], s, e, int(trans)))
+
+    def Dot(self, Y, M):
+        """M = Y^H * X(self); M is a Fortran-ordered array with >= Y.k rows and >= X.k columns."""
+        assert M.flags.f_contiguous
+        _chk(self._lib.orc_bv_dot(self._h, Y._h, _p(M), M.shape[0]))
+
+    def DotVec(self, y, m=None):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        out = np.zeros(self.k - self.l) if m is None else m
+        _chk(self._lib.orc_bv_dotvec(self._h, _p(y), _p(out)))
+        return out
+
+    def DotColumn(self, j, q=True):
+        """q=None -> result goes to the buffer scratch (BVDotColumn(X,j,NULL))."""
+        if q is None:
+            _chk(self._lib.orc_bv_dotcolumn(self._h, j, None))
+            return None
+        out = np.zeros(j - self.l)
+        _chk(self._lib.orc_bv_dotcolumn(self._h, j, _p(out)))
+        return out
+
+    def Scale(self, alpha):
+        _chk(self._lib.orc_bv_scale(self._h, -1, alpha))
+
+    def ScaleColumn(self, j, alpha):
+        _chk(self._lib.orc_bv_scale(self._h, j, alpha))
+
+    def Norm(self, type=NORM_FROBENIUS):
+        v = C.c_double()
+        _chk(self._lib.orc_bv_norm(self._h, -1, type, C.byref(v)))
+        return v.value
+
+    def NormColumn(self, j, type=NORM_2):
+        v = C.c_double()
+        _chk(self._lib.orc_bv_norm(self._h, j, type, C.byref(v)))
+        return v.value
+
+    def Copy(self, W):
+        _chk(self._lib.orc_bv_copy(self._h, W._h))
+
+    def CopyColumn(self, j, i):
+        _chk(self._lib.orc_bv_copycolumn(self._h, j, i))
+
+    def MatMultColumn(self, A, j):
+        _chk(self._lib.orc_bv_matmultcolumn(self._h, A._h, j))
+
+    def MatMult(self, A, W):
+        _chk(self._lib.orc_bv_matmult(self._h, A._h, W._h))
+
+    def OrthogonalizeVec(self, v):
+        nrm = C.c_double(); lin = C.c_int()
+        H = np.zeros(self.k - self.l)
+        _chk(self._lib.orc_bv_orthogonalizevec(self._h, _p(v), _p(H), C.byref(nrm), C.byref(lin)))
+        return H, nrm.value, bool(lin.value)
+
+    def OrthogonalizeColumn(self, j):
+        nrm = C.c_double(); lin = C.c_int()
+        H = np.zeros(max(j - self.l, 0) + 1)
+        _chk(self._lib.orc_bv_orthogonalizecolumn(self._h, j, _p(H), C.byref(nrm), C.byref(lin)))
+        return H[: j - self.l], nrm.value, bool(lin.value)
+
+    def OrthogonalizeSomeColumn(self, j, which):
+        nrm = C.c_double(); lin = C.c_int()
+        w = np.ascontiguousarray(which, dtype=np.int32)
+        _chk(self._lib.orc_bv_orthogonalizesomecolumn(self._h, j, _pi(w), None, C.byref(nrm), C.byref(lin)))
+        return nrm.value, bool(lin.value)
+
+    def OrthonormalizeColumn(self, j):
+        nrm = C.c_double(); lin = C.c_int()
+        _chk(self._lib.orc_bv_orthonormalizecolumn(self._h, j, C.byref(nrm), C.byref(lin)))
+        return nrm.value, bool(lin.value)
+
+    def passes_last(self):
+        return self._lib.orc_bv_passes_last(self._h)
+
+    def passes_total(self):
+        return self._lib.orc_bv_passes_total(self._h)
+
+    def MatLanczos(self, A, T, k, m):
+        """T: Fortran array (ldt, >=2): column 0 = alpha, column 1 = beta (DS_MAT_T). Returns (m, beta, breakdown)."""
+        assert T.flags.f_contiguous
+        mm = C.c_int(m); beta = C.c_double(); brk = C.c_int()
+        _chk(self._lib.orc_bv_matlanczos(self._h, A._h, _p(T), T.shape[0], k, C.byref(mm), C.byref(beta), C.byref(brk)))
+        return mm.value, beta.value, bool(brk.value)
+
+    def MatArnoldi(self, A, H, k, m):
+        assert H.flags.f_contiguous
+        mm = C.c_int(m); beta = C.c_double(); brk = C.c_int()
+        _chk(self._lib.orc_bv_matarnoldi(self._h, A._h, _p(H), H.shape[0], k, C.byref(mm), C.byref(beta), C.byref(brk)))
+        return mm.value, beta.value, bool(brk.value)
+
+
+# ------------------------------------------------------------------------------------------------
+# LAPACK entry points (the very routines the reference calls), taken from scipy's bundled LAPACK
+
+
+def _capi(mod, name, restype, argtypes):
+    cap = mod.__pyx_capi__[name]
+    C.pythonapi.PyCapsule_GetName.restype = C.c_char_p
+    C.pythonapi.PyCapsule_GetName.argtypes = [C.py_object]
+    C.pythonapi.PyCapsule_GetPointer.restype = C.c_void_p
+    C.pythonapi.PyCapsule_GetPointer.argtypes = [C.py_object, C.c_char_p]
+    ptr = C.pythonapi.PyCapsule_GetPointer(cap, C.pythonapi.PyCapsule_GetName(cap))
+    return C.CFUNCTYPE(restype, *argtypes)(ptr)
+
+
+_lapack = {}
+
+
+def _L(name):
+    if not _lapack:
+        import scipy.linalg.cython_lapack as CL
+        import scipy.linalg.cython_blas as CB
+        cp = C.c_char_p
+        _lapack["dsteqr"] = _capi(CL, "dsteqr", None, [cp, _ip, _dp, _dp, _dp, _ip, _dp, _ip])
+        _lapack["dlartg"] = _capi(CL, "dlartg", None, [_dp, _dp, _dp, _dp, _dp])
+        _lapack["drot"] = _capi(CB, "drot", None, [_ip, _dp, _ip, _dp, _ip, _dp, _dp])
+        _lapack["dgehrd"] = _capi(CL, "dgehrd", None, [_ip, _ip, _ip, _dp, _ip, _dp, _dp, _ip, _ip])
+        _lapack["dorghr"] = _capi(CL, "dorghr", None, [_ip, _ip, _ip, _dp, _ip, _dp, _dp, _ip, _ip])
+        _lapack["dhseqr"] = _capi(CL, "dhseqr", None, [cp, cp, _ip, _ip, _ip, _dp, _ip, _dp, _dp, _dp, _ip, _dp, _ip, _ip])
+        _lapack["dtrexc"] = _capi(CL, "dtrexc", None, [cp, _ip, _dp, _ip, _dp, _ip, _ip, _ip, _dp, _ip])
+        _lapack["dtrevc"] = _capi(CL, "dtrevc", None, [cp, cp, _ip, _ip, _dp, _ip, _dp, _ip, _dp, _ip, _ip, _ip, _dp, _ip])
+    return _lapack[name]
+
+
+def _i(v):
+    return C.byref(C.c_int(v))
+
+
+def lartg(f, g):
+    cs = C.c_double(); sn = C.c_double(); r = C.c_double()
+    _L("dlartg")(C.byref(C.c_double(f)), C.byref(C.c_double(g)), C.byref(cs), C.byref(sn), C.byref(r))
+    return cs.value, sn.value, r.value
+
+
+# comparison functions, src/sys/slepcsc.c:152-300 (real scalars: |a| via SlepcAbsEigenvalue = hypot(re,im))
+def _cmp(a, b):
+    return 1 if a < b else (-1 if a > b else 0)
+
+
+WHICH = {
+    "largest_magnitude": lambda ar, ai, br, bi: _cmp(np.hypot(ar, ai), np.hypot(br, bi)),
+    "smallest_magnitude": lambda ar, ai, br, bi: -_cmp(np.hypot(ar, ai), np.hypot(br, bi)),
+    "largest_real": lambda ar, ai, br, bi: _cmp(ar, br),
+    "smallest_real": lambda ar, ai, br, bi: -_cmp(ar, br),
+}
+
+DS_STATE_RAW, DS_STATE_INTERMEDIATE, DS_STATE_CONDENSED, DS_STATE_TRUNCATED = 0, 1, 2, 3
+
+
+class DSHEP:
+    """DS type HEP, compact storage, extra row (krylovschur.c:160-168). T = [d | e] (dshep.c:26-48 picture)."""
+
+    def __init__(self, ld, compare):
+        self.ld = ld
+        self.T = np.zeros((ld, 3), order="F")   # DS_MAT_T: col 0 diag, col 1 offdiag
+        self.Q = np.zeros((ld, ld), order="F")
+        self.perm = np.zeros(ld, dtype=np.int64)
+        self.n = self.l = self.k = self.t = 0
+        self.state = DS_STATE_RAW
+        self.compare = compare
+
+    @property
+    def d(self):
+        return self.T[:, 0]
+
+    @property
+    def e(self):
+        return self.T[:, 1]
+
+    def SetDimensions(self, n, l, k):      # dsops.c:130-165
+        self.n = n; self.t = n; self.l = l; self.k = k
+
+    def SetState(self, st):                # dsops.c:63-80
+        self.state = st
+
+    def _arrow_tridiag(self, n, d, e, Q):  # DSArrowTridiag dshep.c:221-262 (d,e,Q are views offset by l)
+        if n <= 2:
+            return
+        drot = _L("drot")
+        one = _i(1)
+        ld = self.ld
+        for j in range(n - 2):
+            temp = e[j + 1]
+            c, s, r = lartg(temp, e[j]); e[j + 1] = r
+            s = -s
+            temp = d[j + 1]
+            e[j] = c * s * (temp - d[j])
+            d[j + 1] = s * s * d[j] + c * c * temp
+            d[j] = c * c * d[j] + s * s * temp
+            j2 = j + 2
+            self._rot(Q, j2, j, j + 1, c, s)
+            for i in range(j - 1, -1, -1):
+                off = -s * e[i]
+                e[i] = c * e[i]
+                temp = e[i + 1]
+                c, s, r = lartg(temp, off); e[i + 1] = r
+                s = -s
+                temp = (d[i] - d[i + 1]) * s - 2.0 * c * e[i]
+                p = s * temp
+                d[i + 1] += p
+                d[i] -= p
+                e[i] = -e[i] - c * temp
+                self._rot(Q, j2, i, i + 1, c, s)
+
+    @staticmethod
+    def _rot(Q, n, ix, iy, c, s):          # BLAS drot on the first n entries of columns ix, iy
+        x = Q[:n, ix].copy(); y = Q[:n, iy].copy()
+        Q[:n, ix] = c * x + s * y
+        Q[:n, iy] = c * y - s * x
+
+    def Solve(self, wr):                   # DSSolve dsops.c:723 -> DSSolve_HEP_QR dshep.c:383-426
+        if self.state >= DS_STATE_CONDENSED:
+            return
+        n, l, ld = self.n, self.l, self.ld
+        d, e = self.d, self.e
+        n1 = n - l
+        # DSIntermediate_HEP dshep.c:267-321 (compact branch)
+        self.Q[:, :] = 0.0
+        np.fill_diagonal(self.Q, 1.0)
+        if self.state < DS_STATE_INTERMEDIATE:
+            na = max(0, self.k - l + 1)
+            self._arrow_tridiag(na, d[l:], e[l:], self.Q[l:, l:])
+        wr[:l] = d[:l]
+        # LAPACKsteqr("V", n1, d+l, e+l, Q+off, ld, rwork)
+        Qsub = np.asfortranarray(self.Q[l:l + n1, l:l + n1])
+        dd = np.ascontiguousarray(d[l:n]); ee = np.ascontiguousarray(e[l:n])
+        work = np.zeros(max(1, 2 * n1))
+        info = C.c_int(0)
+        _L("dsteqr")(b"V", _i(n1), _p(dd), _p(ee), _p(Qsub), _i(Qsub.shape[0] if n1 else 1), _p(work), C.byref(info))
+        if info.value:
+            raise OracleError("steqr info=%d" % info.value)
+        d[l:n] = dd
+        self.Q[l:l + n1, l:l + n1] = Qsub
+        wr[l:n] = d[l:n]
+        e[: n - 1] = 0.0                    # compact: zero e[0..n-2], keep e[n-1] (extra row)
+        self.state = DS_STATE_CONDENSED
+
+    def Sort(self, wr):                    # DSSort dsops.c:329-345 -> DSSort_HEP dshep.c:323-347
+        n, l = self.n, self.l
+        d = self.d
+        perm = self.perm
+        perm[:n] = np.arange(n)
+        # DSSortEigenvaluesReal_Private dspriv.c:224-243 (insertion sort, n = ds->t)
+        nn = self.t
+        for i in range(l + 1, nn):
+            re = d[perm[i]]
+            j = i - 1
+            result = self.compare(re, 0.0, d[perm[j]], 0.0)
+            while result < 0 and j >= l:
+                perm[j], perm[j + 1] = perm[j + 1], perm[j]
+                j -= 1
+                if j >= l:
+                    result = self.compare(re, 0.0, d[perm[j]], 0.0)
+        self.last_perm = perm[:n].copy()
+        for i in range(l, n):
+            wr[i] = d[perm[i]]
+        # DSPermuteColumns_Private dspriv.c:248-270
+        Q = self.Q
+        for i in range(l, n):
+            p = perm[i]
+            if p != i:
+                j = i + 1
+                while perm[j] != i:
+                    j += 1
+                perm[j] = p; perm[i] = i
+                tmp = Q[:n, p].copy(); Q[:n, p] = Q[:n, i]; Q[:n, i] = tmp
+        d[l:n] = wr[l:n]
+
+    def UpdateExtraRow(self):              # DSUpdateExtraRow_HEP dshep.c:349-381 (compact)
+        n = self.n
+        beta = self.e[n - 1]
+        self.e[:n] = beta * self.Q[n - 1, :n]
+        self.k = n
+
+    def Vectors_resnorm(self, j):          # DSVectors_HEP dshep.c:137-175: rnorm = |Q(n-1,j)|
+        return abs(self.Q[self.n - 1, j])
+
+    def Truncate(self, n, trim):           # DSTruncate dsops.c + DSTruncate_HEP dshep.c:643-671 (compact)
+        if trim:
+            self.l = 0; self.k = 0; self.n = n; self.t = n
+            self.state = DS_STATE_RAW
+        else:
+            self.k = n; self.t = self.n; self.n = n
+            self.state = DS_STATE_TRUNCATED
+
+    def Qmat(self):                        # DSGetMat(DS_MAT_Q): rows = t if truncated else n; cols = n (dsops.c:276-296)
+        rows = self.t if self.state == DS_STATE_TRUNCATED else self.n
+        return self.Q[:rows, : self.n]
+
+
+class EPSResult:
+    pass
+
+
+def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which="largest_magnitude",
+                        keep=0.5, seed=0x12345678, omp=False, v0=None, orthog=(CGS, REFINE_IFNEEDED, 0.7071),
+                        max_steps=None, monitor=None):
+    """EPSSolve for a standard symmetric problem with the default Krylov-Schur solver.
+
+    EPSSetUp_KrylovSchur krylovschur.c:93-194 (EPS_KS_SYMM), EPSSetDimensions_Default epssetup.c:654-678,
+    EPSSolve_KrylovSchur_Default krylovschur.c:227-337, EPSKrylovConvergence epskrylov.c:207-295,
+    EPSConvergedRelative epsdefault.c:224, EPSStoppingBasic epsdefault.c:290, EPSGetStartVector epssolve.c:841-873,
+    final SlepcSortEigenvalues epssolve.c:178 / slepcsc.c:89-140.
+    """
+    n = A.n
+    if ncv is None:
+        if mpd is not None:
+            ncv = min(n, nev + mpd)
+        else:
+            ncv = min(n, max(2 * nev, nev + 15)) if nev < 500 else min(n, nev + 500)
+    if mpd is None:
+        mpd = ncv
+    assert ncv >= nev + 1 or (ncv == nev and ncv == n), "The value of ncv must be at least nev+1"
+    assert ncv <= nev + mpd
+    if max_it is None:
+        max_it = max(100, 2 * n // ncv)
+    compare = WHICH[which]
+
+    V = BV(n, ncv + 1, omp=omp)
+    V.SetOrthogonalization(*orthog)
+    ds = DSHEP(ncv + 1, compare)
+    eigr = np.zeros(ncv + 1); errest = np.zeros(ncv + 1)
+
+    # EPSGetStartVector(eps,0)
+    def start_vector(i):
+        if v0 is not None and i == 0:
+            V.set_column(0, v0)
+        else:
+            V.SetRandomColumn(i, seed)
+        _, norm, lindep = V.OrthogonalizeColumn(i)
+        if not (lindep or norm == 0.0):
+            V.ScaleColumn(i, 1.0 / norm)
+        return lindep or norm == 0.0
+
+    if start_vector(0):
+        raise OracleError("Initial vector is zero or belongs to the deflation space")
+    l = 0
+    nconv = 0
+    its = 0
+    reason = 0
+    steps = 0
+    cycles = []
+    while reason == 0:
+        its += 1
+        nv = min(nconv + mpd, ncv)
+        if max_steps is not None and steps + (nv - (nconv + l)) > max_steps:
+            nv = nconv + l + (max_steps - steps)
+        ds.SetDimensions(nv, nconv, nconv + l)
+        k0 = nconv + l
+        nv_req = nv
+        nv, beta, breakdown = V.MatLanczos(A, ds.T, nconv + l, nv)
+        steps += nv - k0
+        cycles.append((k0, nv, V.passes_total()))
+        ds.SetDimensions(nv, nconv, nconv + l)
+        ds.SetState(DS_STATE_RAW if l else DS_STATE_INTERMEDIATE)
+        V.SetActiveColumns(nconv, nv)
+
+        ds.Solve(eigr)
+        ds.Sort(eigr)
+        ds.UpdateExtraRow()
+
+        # EPSKrylovConvergence(eps,FALSE,nconv,nv-nconv,beta,0.0,1.0,&k)
+        marker = -1
+        kk = nconv
+        for kk in range(nconv, nv):
+            re = eigr[kk]                                   # shift ST with sigma=0: back-transform is identity
+            resnorm = ds.Vectors_resnorm(kk) * beta * 1.0
+            w = abs(re)
+            errest[kk] = resnorm / w if w != 0.0 else np.finfo(float).max
+            if marker == -1 and errest[kk] >= tol:
+                marker = kk
+            if marker != -1:
+                break
+        else:
+            kk = nv
+        k = marker if marker != -1 else nv
+        # EPSStoppingBasic
+        if k >= nev:
+            reason = 2      # EPS_CONVERGED_TOL
+        elif its >= max_it:
+            reason = -1     # EPS_DIVERGED_ITS
+        if max_steps is not None and steps >= max_steps and reason == 0:
+            reason = -99
+        # update l
+        if reason != 0 or breakdown or k == nv:
+            l = 0
+        else:
+            l = max(1, int((nv - k) * keep))
+        if reason == 0:
+            if breakdown or k == nv:
+                if k < nev:
+                    if start_vector(k):
+                        reason = -2  # EPS_DIVERGED_BREAKDOWN
+            else:
+                ds.Truncate(k + l, False)
+        V.MultInPlace(ds.Qmat(), nconv, k + l)
+        if reason == 0 and not breakdown:
+            V.CopyColumn(nv, k + l)
+        nconv = k
+        if monitor:
+            monitor(its, nconv, eigr[:nv].copy(), errest[:nv].copy(), nv)
+    ds.Truncate(nconv, True)
+
+    # EPSSolve epilogue: final sort of the converged values (SlepcSortEigenvalues slepcsc.c:89-140, all real)
+    perm = list(range(nconv))
+    for i in range(nconv - 1, -1, -1):
+        re = eigr[perm[i]]
+        j = i + 1
+        while j < nconv:
+            if compare(re, 0.0, eigr[perm[j]], 0.0) <= 0:
+                break
+            perm[j - 1], perm[j] = perm[j], perm[j - 1]
+            j += 1
+    res = EPSResult()
+    res.nconv = nconv; res.its = its; res.reason = reason; res.steps = steps
+    res.eigr = eigr[:nconv].copy(); res.perm = np.array(perm, dtype=np.int64)
+    res.errest = errest[:nconv].copy()
+    res.V = V; res.cycles = cycles; res.ncv = ncv
+    res.passes = V.passes_total()
+    return res
+
+
+def eps_compute_error(A, res, i, relative=True):
+    """EPSComputeError epssolve.c:742-815 with EPSComputeResidualNorm_Private :666-718 (real eigenvalue, B=I)."""
+    j = int(res.perm[i])
+    kr = res.eigr[j]
+    x = np.array(res.V.column(j))
+    u = A.mult(x)
+    if abs(kr) > np.finfo(float).eps:
+        u = u + (-kr) * x
+    err = np.linalg.norm(u)
+    if relative:
+        err /= abs(kr) * 1.0        # vecnorm = 1 for non-GHEP (epssolve.c:758,774)
+    return err
