@@ -1,0 +1,197 @@
+/*
+ * ksgpu.h -- C ABI of libksgpu: MI355X (gfx950) kernels for the SLEPc EPS Krylov-Schur hot path.
+ *
+ * Drop-in boundary.  Each entry point replaces one slot of the reference's plugin interfaces on raw
+ * pointers (no PETSc types, no torch types).  Citations are SLEPc 3.22.2 paths (file:line):
+ *
+ *   struct _BVOps (include/slepc/private/bvimpl.h:25-61)        ->  ks_bv_*  below
+ *   MatMult(Mat,Vec,Vec) reached through the ST shell
+ *       (src/sys/classes/st/interface/stsolve.c:16-25,244-259)    ->  ks_mat_mult
+ *   BVMatArnoldi / BVMatLanczos (bv/interface/bvkrylov.c:56,165)  ->  ks_bv_matarnoldi / ks_bv_matlanczos
+ *   EPSSetOperators/EPSSolve/EPSGetEigenpair/EPSComputeError
+ *       (src/eps/interface/epssetup.c:450, epssolve.c:119,406,742) ->  ks_eps_*
+ *
+ * Conventions (mirror the reference):
+ *   - every function returns an int error code, 0 = success; non-zero values reuse PETSc's
+ *     PetscErrorCode numbers (KS_ERR_*), so an adapter can `return (PetscErrorCode)rc;`
+ *   - scalars are real double (PetscScalar), indices 32-bit int (PetscInt default build)
+ *   - BV storage is ONE device array of m*ld doubles, column-major, like BVSVEC
+ *     (src/sys/classes/bv/impls/svec/svec.c:397-565); every op acts on the active window
+ *     [l,k) at array+(nc+l)*ld (svec.c:30,47,124); nc (constraints) is always 0 here
+ *   - Q / M / H arguments are caller-owned HOST column-major arrays, replicated on all ranks
+ *     (bvops.c:33-36); q / m coefficient arrays are host arrays, NULL means "use the BV's
+ *     device-resident buffer Vec" exactly as in BVMultVec/BVDotVec (svec.c:46,123)
+ *   - numerical conditions (lindep, breakdown) are flags, not errors (bvkrylov.c:92-97)
+ *   - single-threaded per context, collective across ranks: every rank calls in the same order
+ *   - all device work is enqueued on the context's HIP stream; functions that return a host
+ *     value synchronise that stream, the others do not.
+ */
+#ifndef KSGPU_H
+#define KSGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes (PETSc numbering) ---------------------------------------------------------- */
+#define KS_SUCCESS              0
+#define KS_ERR_MEM             55
+#define KS_ERR_SUP             56
+#define KS_ERR_ORDER           58
+#define KS_ERR_ARG_SIZ         60
+#define KS_ERR_ARG_WRONG       62
+#define KS_ERR_ARG_OUTOFRANGE  63
+#define KS_ERR_USER_INPUT      71   /* BV_SafeSqrt "Invalid inner product" bvimpl.h:137 */
+#define KS_ERR_ARG_WRONGSTATE  73
+#define KS_ERR_ARG_INCOMP      75
+#define KS_ERR_LIB             76   /* HIP / RCCL runtime failure (PetscCallHIP analogue) */
+#define KS_ERR_PLIB            77
+#define KS_ERR_CONV_FAILED     82
+#define KS_ERR_ARG_NULL        85
+#define KS_ERR_GPU             97   /* no usable gfx950 device */
+
+const char *ks_error_string(int rc);
+const char *ks_last_error_message(void);     /* detail of the last failure on this thread */
+
+typedef struct ks_ctx_s *ks_ctx;   /* device + stream + communicator + profiling state            */
+typedef struct ks_mat_s *ks_mat;   /* sparse operator (CSR / AIJ), row block owned by this rank   */
+typedef struct ks_bv_s  *ks_bv;    /* basis vectors                                               */
+typedef struct ks_eps_s *ks_eps;   /* Krylov-Schur eigensolver driver                             */
+
+/* enums mirror include/slepcbv.h, include/slepceps.h, PETSc NormType */
+enum { KS_BV_ORTHOG_CGS = 0, KS_BV_ORTHOG_MGS = 1 };
+enum { KS_BV_ORTHOG_REFINE_IFNEEDED = 0, KS_BV_ORTHOG_REFINE_NEVER = 1, KS_BV_ORTHOG_REFINE_ALWAYS = 2 };
+enum { KS_NORM_1 = 0, KS_NORM_2 = 1, KS_NORM_FROBENIUS = 2, KS_NORM_INFINITY = 3 };
+enum { KS_EPS_LARGEST_MAGNITUDE = 1, KS_EPS_SMALLEST_MAGNITUDE = 2, KS_EPS_LARGEST_REAL = 3, KS_EPS_SMALLEST_REAL = 4 };
+enum { KS_EPS_HEP = 1, KS_EPS_NHEP = 3 };
+enum { KS_EPS_ERROR_ABSOLUTE = 0, KS_EPS_ERROR_RELATIVE = 1 };
+enum { KS_EPS_CONVERGED_TOL = 1, KS_EPS_CONVERGED_USER = 2, KS_EPS_DIVERGED_ITS = -1, KS_EPS_DIVERGED_BREAKDOWN = -2,
+       KS_EPS_DIVERGED_SYMMETRY_LOST = -3, KS_EPS_CONVERGED_ITERATING = 0 };
+
+/* ---- context -------------------------------------------------------------------------------- */
+/* stream: a hipStream_t owned by the caller (e.g. torch's current stream) or NULL -> own stream. */
+int ks_ctx_create(int device, void *stream, ks_ctx *ctx);
+int ks_ctx_destroy(ks_ctx ctx);
+int ks_ctx_synchronize(ks_ctx ctx);
+int ks_ctx_device_info(ks_ctx ctx, char *arch, int arch_len, int *num_cu, size_t *mem_total);
+
+/* Row-wise distribution (PetscLayout, bvbasic.c:129-134).  Reductions inside BV ops
+   (bvblas.c:218,255; bvlapack.c:50) become an allreduce over all ranks.
+   Two providers: native RCCL (ks_comm_*) or a caller-supplied callback (e.g. GPU-aware MPI). */
+#define KS_UNIQUE_ID_BYTES 128
+int ks_comm_get_unique_id(unsigned char id[KS_UNIQUE_ID_BYTES]);                       /* rank 0, then broadcast by the launcher */
+int ks_comm_init_rccl(ks_ctx ctx, int rank, int size, const unsigned char id[KS_UNIQUE_ID_BYTES]);
+typedef int (*ks_allreduce_fn)(void *user, double *dev_buf, int count, void *stream);  /* in-place SUM on device memory */
+typedef int (*ks_halo_fn)(void *user, const double *dev_send, double *dev_recv, void *stream);
+int ks_comm_set_callbacks(ks_ctx ctx, int rank, int size, ks_allreduce_fn allreduce, void *user);
+int ks_comm_rank_size(ks_ctx ctx, int *rank, int *size);
+
+/* ---- Mat: the MatMult(AIJ) slot ------------------------------------------------------------- */
+/* CSR arrays as in PETSc SeqAIJ (i,j,a): rowptr[n_local+1], col[nnz] (GLOBAL column indices),
+   val[nnz].  Host arrays are copied to the device.  row_start = first global row owned by this
+   rank; n_global = global size.  With one rank: row_start=0, n_local=n_global.               */
+int ks_mat_create_csr(ks_ctx ctx, int n_local, int row_start, int n_global,
+                      const int *rowptr, const int *col, const double *val, ks_mat *A);
+/* Synthetic generators that build the SAME CSR arrays directly in device memory (bench inputs):
+   3-D 7-pt Laplacian of ex19.c:47-78 (rows of z-planes [z0,z0+nz_local) of an nx*ny*nz grid) and
+   2-D 5-pt Laplacian of ex2.c:44-51.                                                           */
+int ks_mat_create_laplacian3d(ks_ctx ctx, int nx, int ny, int nz, int z0, int nz_local, ks_mat *A);
+int ks_mat_create_laplacian2d(ks_ctx ctx, int n, int m, ks_mat *A);
+int ks_mat_destroy(ks_mat A);
+int ks_mat_get_sizes(ks_mat A, int *n_local, int *n_global, long long *nnz_local);
+/* MatMult: y = A x on device pointers (x, y: n_local doubles owned by this rank).
+   Multi-rank: performs the halo exchange of x (PETSc VecScatter inside MatMult_MPIAIJ).        */
+int ks_mat_mult(ks_mat A, const double *x_dev, double *y_dev);
+int ks_mat_mult_host(ks_mat A, const double *x_host, double *y_host);  /* convenience for tests (single rank) */
+
+/* ---- BV: the _BVOps slots ------------------------------------------------------------------- */
+int ks_bv_create(ks_ctx ctx, int n_local, int n_global, int m, int ld /*0: default*/, ks_bv *bv); /* ops->create, BV_SetDefaultLD bvimpl.h:471 */
+int ks_bv_destroy(ks_bv bv);                                                        /* ops->destroy */
+int ks_bv_duplicate(ks_bv bv, ks_bv *out);                                           /* ops->duplicate (storage only; no copy) */
+int ks_bv_get_sizes(ks_bv bv, int *n_local, int *n_global, int *m, int *ld);
+int ks_bv_set_active_columns(ks_bv bv, int l, int k);                               /* BVSetActiveColumns bvbasic.c:421 */
+int ks_bv_get_active_columns(ks_bv bv, int *l, int *k);
+int ks_bv_set_orthogonalization(ks_bv bv, int type, int refine, double eta);        /* BVSetOrthogonalization; eta<=0 keeps 0.7071 */
+int ks_bv_get_array(ks_bv bv, double **dev);                                        /* ops->getarray: device pointer of the m*ld block */
+int ks_bv_get_column(ks_bv bv, int j, double **dev);                                /* ops->getcolumn: device pointer view of column j */
+int ks_bv_get_buffer(ks_bv bv, double **dev);                                       /* BVGetBufferVec bvbasic.c:775: (nc+m)*m device doubles */
+int ks_bv_set_column_host(ks_bv bv, int j, const double *host);                     /* H2D of n_local doubles */
+int ks_bv_get_column_host(ks_bv bv, int j, double *host);                           /* D2H, synchronises */
+int ks_bv_get_buffer_host(ks_bv bv, double *host);                                  /* D2H of the (nc+m)*m coefficient buffer */
+int ks_bv_set_random_column(ks_bv bv, int j, uint64_t seed);                        /* BVSetRandomColumn with -bv_reproducible_random semantics */
+
+int ks_bv_mult(ks_bv Y, double alpha, double beta, ks_bv X, const double *Q, int ldq);          /* ops->mult; Q NULL -> Y=beta*Y+alpha*X */
+int ks_bv_multvec(ks_bv X, double alpha, double beta, double *y_dev, const double *q);          /* ops->multvec; q NULL -> buffer */
+int ks_bv_multcolumn(ks_bv X, double alpha, double beta, int j, const double *q);               /* BVMultColumn bvops.c:165 */
+int ks_bv_multinplace(ks_bv V, const double *Q, int ldq, int s, int e);                          /* ops->multinplace */
+int ks_bv_multinplace_trans(ks_bv V, const double *Q, int ldq, int s, int e);                    /* ops->multinplacetrans */
+int ks_bv_dot(ks_bv X, ks_bv Y, double *M, int ldm);                                             /* ops->dot: M = Y^H X (+allreduce) */
+int ks_bv_dotvec(ks_bv X, const double *y_dev, double *m);                                       /* ops->dotvec; m NULL -> buffer */
+int ks_bv_dotvec_local(ks_bv X, const double *y_dev, double *m);                                 /* ops->dotvec_local (no reduction) */
+int ks_bv_dotcolumn(ks_bv X, int j, double *q);                                                  /* BVDotColumn bvglobal.c:302 */
+int ks_bv_scale(ks_bv bv, double alpha);                                                         /* ops->scale(-1,alpha) */
+int ks_bv_scalecolumn(ks_bv bv, int j, double alpha);                                            /* ops->scale(j,alpha) */
+int ks_bv_norm(ks_bv bv, int type, double *val);                                                 /* ops->norm(-1,type) */
+int ks_bv_normcolumn(ks_bv bv, int j, int type, double *val);                                    /* ops->norm(j,type) */
+int ks_bv_norm_local(ks_bv bv, int j, int type, double *val);                                    /* ops->norm_local */
+int ks_bv_copy(ks_bv V, ks_bv W);                                                                /* ops->copy */
+int ks_bv_copycolumn(ks_bv V, int j, int i);                                                     /* ops->copycolumn */
+int ks_bv_matmult(ks_bv V, ks_mat A, ks_bv W);                                                   /* ops->matmult (column loop, svec.c:213) */
+int ks_bv_matmultcolumn(ks_bv V, ks_mat A, int j);                                               /* BVMatMultColumn bvops.c:862 */
+
+/* ops->gramschmidt (bvimpl.h:53): replaces BVOrthogonalizeCGS1/MGS1 wholesale (bvorthog.c:134).
+   Fused, device-resident classical Gram-Schmidt of column j against columns [0,j) with the
+   reference's refinement policy; coefficients accumulate in the buffer column j.               */
+int ks_bv_orthogonalizecolumn(ks_bv bv, int j, double *H, double *norm, int *lindep);            /* BVOrthogonalizeColumn bvorthog.c:315 */
+int ks_bv_orthonormalizecolumn(ks_bv bv, int j, int replace, double *norm, int *lindep);         /* BVOrthonormalizeColumn bvorthog.c:380 */
+int ks_bv_orthogonalizevec(ks_bv bv, double *v_dev, double *H, double *norm, int *lindep);       /* BVOrthogonalizeVec bvorthog.c:247 */
+int ks_bv_orthogonalizesomecolumn(ks_bv bv, int j, const int *which, double *H, double *norm, int *lindep); /* bvorthog.c:432 (MGS) */
+int ks_bv_gs_passes(ks_bv bv, long long *passes_total, int *passes_last);                        /* instrumentation */
+
+/* Krylov expansions (bvkrylov.c).  H: host ldh x >=m column-major; T: host, alpha = T[0..ldt),
+   beta = T[ldt..2ldt) (DS_MAT_T layout).  *m may be reduced on breakdown.  The whole run of
+   m-k steps is enqueued without host synchronisation; one D2H at the end (the reference's
+   VecGetArrayRead(buf), bvkrylov.c:103,215).                                                   */
+int ks_bv_matarnoldi(ks_bv V, ks_mat A, double *H, int ldh, int k, int *m, double *beta, int *breakdown);
+int ks_bv_matlanczos(ks_bv V, ks_mat A, double *T, int ldt, int k, int *m, double *beta, int *breakdown);
+
+/* ---- EPS: Krylov-Schur driver (host side; restates krylovschur.c:227-337) -------------------- */
+int ks_eps_create(ks_ctx ctx, ks_eps *eps);
+int ks_eps_destroy(ks_eps eps);
+int ks_eps_set_operators(ks_eps eps, ks_mat A, ks_mat B /* must be NULL: standard problems only */);
+int ks_eps_set_problem_type(ks_eps eps, int type);                         /* KS_EPS_HEP (Lanczos) | KS_EPS_NHEP (Arnoldi) */
+int ks_eps_set_dimensions(ks_eps eps, int nev, int ncv /*<=0: default*/, int mpd /*<=0: default*/);
+int ks_eps_set_tolerances(ks_eps eps, double tol /*<=0: 1e-8*/, int max_it /*<=0: default*/);
+int ks_eps_set_which_eigenpairs(ks_eps eps, int which);
+int ks_eps_set_krylovschur_restart(ks_eps eps, double keep);               /* EPSKrylovSchurSetRestart, default 0.5 */
+int ks_eps_set_random_seed(ks_eps eps, uint64_t seed);
+int ks_eps_set_initial_vector(ks_eps eps, const double *v_host);           /* EPSSetInitialSpace with one vector */
+int ks_eps_set_max_steps(ks_eps eps, long long max_steps);                 /* bench harness: stop after this many Arnoldi steps (0 = off) */
+int ks_eps_solve(ks_eps eps);
+int ks_eps_get_converged(ks_eps eps, int *nconv);
+int ks_eps_get_iteration_number(ks_eps eps, int *its);
+int ks_eps_get_converged_reason(ks_eps eps, int *reason);
+int ks_eps_get_dimensions(ks_eps eps, int *nev, int *ncv, int *mpd);
+int ks_eps_get_eigenvalue(ks_eps eps, int i, double *eigr, double *eigi);
+int ks_eps_get_eigenvector_host(ks_eps eps, int i, double *xr_host);       /* n_local doubles */
+int ks_eps_get_error_estimate(ks_eps eps, int i, double *errest);
+int ks_eps_compute_error(ks_eps eps, int i, int type, double *error);      /* EPSComputeError epssolve.c:742 */
+int ks_eps_get_bv(ks_eps eps, ks_bv *V);
+int ks_eps_get_stats(ks_eps eps, long long *arnoldi_steps, long long *gs_passes, int *restarts);
+
+/* ---- profiling: HIP-event timing per kernel class, on the context's stream -------------------- */
+enum { KS_K_SPMV = 0, KS_K_DOT, KS_K_GSFIN, KS_K_UPD_FUSED, KS_K_UPD, KS_K_SCALE, KS_K_MULTINPLACE, KS_K_COPY,
+       KS_K_MULT, KS_K_BVDOT, KS_K_NORM, KS_K_HALO, KS_K_ALLREDUCE, KS_K_OTHER, KS_K_COUNT };
+int ks_prof_enable(ks_ctx ctx, int on);
+int ks_prof_reset(ks_ctx ctx);
+/* launches, summed elapsed ms and summed algorithmic bytes (SURVEY.md 8d figures) of one class */
+int ks_prof_get(ks_ctx ctx, int kclass, long long *launches, double *ms, double *alg_bytes);
+const char *ks_prof_class_name(int kclass);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KSGPU_H */

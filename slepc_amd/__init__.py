@@ -1,0 +1,460 @@
+"""
+slepc_amd -- MI355X-native hot path of SLEPc's EPS Krylov-Schur solver (CSR SpMV + BV kernels + fused
+classical Gram-Schmidt + restart panel products), behind a C ABI (include/ksgpu.h, slepc_amd/libksgpu.so).
+
+This package is the thin host-side mirror of the reference's interfaces for that path:
+  Context  - device / HIP stream / communicator (PETSc's comm + default stream)
+  Mat      - MatCreateSeqAIJWithArrays-style CSR operator, `mult` = MatMult          (PETSc AIJ)
+  BV       - basis vectors, method names = the reference's BV functions without the prefix
+             (slepcbv.h: BVMult, BVMultVec, BVDot, BVDotVec, BVOrthogonalizeColumn, BVMatLanczos ...)
+  EPS      - EPSSetOperators / EPSSetDimensions / EPSSolve / EPSGetEigenpair / EPSComputeError
+
+Device memory belongs to the library; host<->device staging uses numpy arrays. torch is only
+plumbing (streams, torch.distributed bootstrap of the RCCL communicator) and is imported lazily.
+The library is gfx950-only and has NO CPU fallback: creating a Context without an MI355X raises.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import KsError
+
+CGS, MGS = 0, 1
+REFINE_IFNEEDED, REFINE_NEVER, REFINE_ALWAYS = 0, 1, 2
+NORM_1, NORM_2, NORM_FROBENIUS, NORM_INFINITY = 0, 1, 2, 3
+EPS_LARGEST_MAGNITUDE, EPS_SMALLEST_MAGNITUDE, EPS_LARGEST_REAL, EPS_SMALLEST_REAL = 1, 2, 3, 4
+EPS_HEP, EPS_NHEP = 1, 3
+EPS_ERROR_ABSOLUTE, EPS_ERROR_RELATIVE = 0, 1
+EPS_CONVERGED_TOL, EPS_CONVERGED_USER, EPS_DIVERGED_ITS, EPS_DIVERGED_BREAKDOWN = 1, 2, -1, -2
+WHICH = {"largest_magnitude": 1, "smallest_magnitude": 2, "largest_real": 3, "smallest_real": 4}
+
+KCLASSES = ["spmv_csr", "bv_dot_sweep", "gs_bookkeeping", "gs_update_fused_dot", "gs_update", "bv_scale", "bv_multinplace",
+            "bv_copy", "bv_mult", "bv_dot_panel", "bv_norm", "halo_exchange", "allreduce", "other"]
+
+_dp = _lib.dp
+_ip = _lib.ip
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _pi(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Context:
+    """Device + stream + communicator. stream: a raw hipStream_t (int) or None for a library-owned stream."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(self.L.ks_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.h = h
+        self.device = device
+        self._cb = None
+        self.rank, self.size = 0, 1
+
+    def close(self):
+        if self.h:
+            self.L.ks_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _lib.check(self.L.ks_ctx_synchronize(self.h))
+
+    def device_info(self):
+        arch = C.create_string_buffer(64); ncu = C.c_int(); mem = C.c_size_t()
+        _lib.check(self.L.ks_ctx_device_info(self.h, arch, 64, C.byref(ncu), C.byref(mem)))
+        return {"arch": arch.value.decode(), "num_cu": ncu.value, "mem_total": mem.value}
+
+    # -- communicator
+    def init_rccl(self, rank, size, unique_id):
+        """Native RCCL provider; unique_id: 128 bytes produced by get_unique_id() on rank 0 and broadcast."""
+        _lib.check(self.L.ks_comm_init_rccl(self.h, rank, size, bytes(unique_id)))
+        self.rank, self.size = rank, size
+
+    @staticmethod
+    def get_unique_id():
+        buf = C.create_string_buffer(_lib.KS_UNIQUE_ID_BYTES)
+        _lib.check(_lib.lib().ks_comm_get_unique_id(buf))
+        return buf.raw
+
+    def set_allreduce_callback(self, rank, size, fn):
+        """fn(dev_ptr:int, count:int, stream:int) -> 0 ; in-place SUM allreduce on device memory."""
+        def tramp(user, buf, count, stream):
+            try:
+                return int(fn(buf, count, stream) or 0)
+            except Exception:       # noqa: BLE001 - must not unwind through C
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = _lib.ALLREDUCE_FN(tramp)
+        _lib.check(self.L.ks_comm_set_callbacks(self.h, rank, size, self._cb, None))
+        self.rank, self.size = rank, size
+
+    # -- profiling
+    def prof_enable(self, on=True):
+        _lib.check(self.L.ks_prof_enable(self.h, int(on)))
+
+    def prof_reset(self):
+        _lib.check(self.L.ks_prof_reset(self.h))
+
+    def prof_get(self):
+        out = {}
+        for i, name in enumerate(KCLASSES):
+            n = C.c_longlong(); ms = C.c_double(); b = C.c_double()
+            _lib.check(self.L.ks_prof_get(self.h, i, C.byref(n), C.byref(ms), C.byref(b)))
+            if n.value:
+                out[name] = {"launches": n.value, "ms": ms.value, "alg_bytes": b.value}
+        return out
+
+
+class Mat:
+    """The MatMult(AIJ) slot. CSR arrays follow PETSc SeqAIJ (i, j, a); col holds GLOBAL column indices."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+        n = C.c_int(); N = C.c_int(); nnz = C.c_longlong()
+        _lib.check(ctx.L.ks_mat_get_sizes(self.h, C.byref(n), C.byref(N), C.byref(nnz)))
+        self.n, self.N, self.nnz = n.value, N.value, nnz.value
+
+    @classmethod
+    def from_csr(cls, ctx, rowptr, col, val, row_start=0, n_global=None):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = _f64(val)
+        n = len(rowptr) - 1
+        if n_global is None:
+            n_global = n
+        h = C.c_void_p()
+        _lib.check(ctx.L.ks_mat_create_csr(ctx.h, n, row_start, n_global, _pi(rowptr), _pi(col), _p(val), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def laplacian3d(cls, ctx, nx, ny, nz, z0=0, nz_local=None):
+        h = C.c_void_p()
+        _lib.check(ctx.L.ks_mat_create_laplacian3d(ctx.h, nx, ny, nz, z0, nz if nz_local is None else nz_local, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def laplacian2d(cls, ctx, n, m=None):
+        h = C.c_void_p()
+        _lib.check(ctx.L.ks_mat_create_laplacian2d(ctx.h, n, n if m is None else m, C.byref(h)))
+        return cls(ctx, h)
+
+    def destroy(self):
+        if self.h:
+            self.ctx.L.ks_mat_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def mult(self, x):
+        """y = A x with host vectors (test convenience, single rank)."""
+        x = _f64(x)
+        y = np.empty(self.n)
+        _lib.check(self.ctx.L.ks_mat_mult_host(self.h, _p(x), _p(y)))
+        return y
+
+    def mult_dev(self, x_ptr, y_ptr):
+        _lib.check(self.ctx.L.ks_mat_mult(self.h, C.c_void_p(x_ptr), C.c_void_p(y_ptr)))
+
+    def spmv_bytes(self):
+        """Algorithmic bytes of one MatMult: 12*nnz + 4*(n+1) + 16*n."""
+        return 12.0 * self.nnz + 4.0 * (self.n + 1) + 16.0 * self.n
+
+
+class BV:
+    """Basis vectors on the device; one m*ld column-major block (BVSVEC layout)."""
+
+    def __init__(self, ctx, n, m, ld=0, N=None, row_start=0, _handle=None):
+        self.ctx = ctx
+        L = ctx.L
+        if _handle is None:
+            h = C.c_void_p()
+            _lib.check(L.ks_bv_create(ctx.h, n, n if N is None else N, m, ld, C.byref(h)))
+            self.h = h
+            self._own = True
+        else:
+            self.h = _handle
+            self._own = False
+        nn = C.c_int(); NN = C.c_int(); mm = C.c_int(); ll = C.c_int()
+        _lib.check(L.ks_bv_get_sizes(self.h, C.byref(nn), C.byref(NN), C.byref(mm), C.byref(ll)))
+        self.n, self.N, self.m, self.ld = nn.value, NN.value, mm.value, ll.value
+
+    def destroy(self):
+        if self.h and self._own:
+            self.ctx.L.ks_bv_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    # -- layout / data movement
+    @property
+    def l(self):
+        l = C.c_int(); k = C.c_int()
+        _lib.check(self.ctx.L.ks_bv_get_active_columns(self.h, C.byref(l), C.byref(k)))
+        return l.value
+
+    @property
+    def k(self):
+        l = C.c_int(); k = C.c_int()
+        _lib.check(self.ctx.L.ks_bv_get_active_columns(self.h, C.byref(l), C.byref(k)))
+        return k.value
+
+    def SetActiveColumns(self, l, k):
+        _lib.check(self.ctx.L.ks_bv_set_active_columns(self.h, l, k))
+
+    def SetOrthogonalization(self, type=CGS, refine=REFINE_IFNEEDED, eta=0.7071):
+        _lib.check(self.ctx.L.ks_bv_set_orthogonalization(self.h, type, refine, eta))
+
+    def column_ptr(self, j):
+        p = C.c_void_p()
+        _lib.check(self.ctx.L.ks_bv_get_column(self.h, j, C.byref(p)))
+        return p.value
+
+    def set_column(self, j, x):
+        x = _f64(x)
+        assert x.shape == (self.n,)
+        _lib.check(self.ctx.L.ks_bv_set_column_host(self.h, j, _p(x)))
+
+    def column(self, j):
+        x = np.empty(self.n)
+        _lib.check(self.ctx.L.ks_bv_get_column_host(self.h, j, _p(x)))
+        return x
+
+    def dense(self):
+        return np.stack([self.column(j) for j in range(self.m)], axis=1)
+
+    def set_dense(self, X):
+        for j in range(X.shape[1]):
+            self.set_column(j, X[:, j])
+
+    def buffer(self):
+        """(m x m) coefficient buffer, column 0 = scratch, column j = H(:,j)  (BVGetBufferVec)."""
+        b = np.empty(self.m * self.m)
+        _lib.check(self.ctx.L.ks_bv_get_buffer_host(self.h, _p(b)))
+        return b.reshape(self.m, self.m).T.copy()
+
+    def SetRandomColumn(self, j, seed=0x12345678):
+        _lib.check(self.ctx.L.ks_bv_set_random_column(self.h, j, seed))
+
+    # -- ops
+    def Mult(self, alpha, beta, X, Q=None):
+        if Q is None:
+            _lib.check(self.ctx.L.ks_bv_mult(self.h, alpha, beta, X.h, None, 0))
+        else:
+            Qf = np.asfortranarray(Q, dtype=np.float64)
+            _lib.check(self.ctx.L.ks_bv_mult(self.h, alpha, beta, X.h, _p(Qf), Qf.shape[0]))
+
+    def MultVec(self, alpha, beta, y_ptr, q=None):
+        q = None if q is None else _f64(q)
+        _lib.check(self.ctx.L.ks_bv_multvec(self.h, alpha, beta, C.c_void_p(y_ptr), _p(q)))
+
+    def MultColumn(self, alpha, beta, j, q=None):
+        q = None if q is None else _f64(q)
+        _lib.check(self.ctx.L.ks_bv_multcolumn(self.h, alpha, beta, j, _p(q)))
+
+    def MultInPlace(self, Q, s, e, trans=False):
+        Qf = np.asfortranarray(Q, dtype=np.float64)
+        f = self.ctx.L.ks_bv_multinplace_trans if trans else self.ctx.L.ks_bv_multinplace
+        _lib.check(f(self.h, _p(Qf), Qf.shape[0], s, e))
+
+    def Dot(self, Y, M):
+        assert M.flags.f_contiguous and M.dtype == np.float64
+        _lib.check(self.ctx.L.ks_bv_dot(self.h, Y.h, _p(M), M.shape[0]))
+
+    def DotVec(self, y_ptr, to_buffer=False):
+        if to_buffer:
+            _lib.check(self.ctx.L.ks_bv_dotvec(self.h, C.c_void_p(y_ptr), None))
+            return None
+        out = np.zeros(max(self.k - self.l, 0))
+        _lib.check(self.ctx.L.ks_bv_dotvec(self.h, C.c_void_p(y_ptr), _p(out)))
+        return out
+
+    def DotColumn(self, j, q=True):
+        if q is None:
+            _lib.check(self.ctx.L.ks_bv_dotcolumn(self.h, j, None))
+            return None
+        out = np.zeros(max(j - self.l, 0))
+        _lib.check(self.ctx.L.ks_bv_dotcolumn(self.h, j, _p(out)))
+        return out
+
+    def Scale(self, alpha):
+        _lib.check(self.ctx.L.ks_bv_scale(self.h, alpha))
+
+    def ScaleColumn(self, j, alpha):
+        _lib.check(self.ctx.L.ks_bv_scalecolumn(self.h, j, alpha))
+
+    def Norm(self, type=NORM_FROBENIUS):
+        v = C.c_double()
+        _lib.check(self.ctx.L.ks_bv_norm(self.h, type, C.byref(v)))
+        return v.value
+
+    def NormColumn(self, j, type=NORM_2):
+        v = C.c_double()
+        _lib.check(self.ctx.L.ks_bv_normcolumn(self.h, j, type, C.byref(v)))
+        return v.value
+
+    def Copy(self, W):
+        _lib.check(self.ctx.L.ks_bv_copy(self.h, W.h))
+
+    def CopyColumn(self, j, i):
+        _lib.check(self.ctx.L.ks_bv_copycolumn(self.h, j, i))
+
+    def MatMult(self, A, W):
+        _lib.check(self.ctx.L.ks_bv_matmult(self.h, A.h, W.h))
+
+    def MatMultColumn(self, A, j):
+        _lib.check(self.ctx.L.ks_bv_matmultcolumn(self.h, A.h, j))
+
+    def OrthogonalizeColumn(self, j):
+        nrm = C.c_double(); lin = C.c_int()
+        H = np.zeros(max(j - self.l, 0) + 1)
+        _lib.check(self.ctx.L.ks_bv_orthogonalizecolumn(self.h, j, _p(H), C.byref(nrm), C.byref(lin)))
+        return H[: max(j - self.l, 0)], nrm.value, bool(lin.value)
+
+    def OrthonormalizeColumn(self, j, replace=False):
+        nrm = C.c_double(); lin = C.c_int()
+        _lib.check(self.ctx.L.ks_bv_orthonormalizecolumn(self.h, j, int(replace), C.byref(nrm), C.byref(lin)))
+        return nrm.value, bool(lin.value)
+
+    def OrthogonalizeVec(self, v_ptr):
+        nrm = C.c_double(); lin = C.c_int()
+        H = np.zeros(max(self.k - self.l, 1))
+        _lib.check(self.ctx.L.ks_bv_orthogonalizevec(self.h, C.c_void_p(v_ptr), _p(H), C.byref(nrm), C.byref(lin)))
+        return H, nrm.value, bool(lin.value)
+
+    def OrthogonalizeSomeColumn(self, j, which):
+        nrm = C.c_double(); lin = C.c_int()
+        w = np.ascontiguousarray(which, dtype=np.int32)
+        _lib.check(self.ctx.L.ks_bv_orthogonalizesomecolumn(self.h, j, _pi(w), None, C.byref(nrm), C.byref(lin)))
+        return nrm.value, bool(lin.value)
+
+    def gs_passes(self):
+        t = C.c_longlong(); l = C.c_int()
+        _lib.check(self.ctx.L.ks_bv_gs_passes(self.h, C.byref(t), C.byref(l)))
+        return t.value, l.value
+
+    def MatLanczos(self, A, T, k, m):
+        assert T.flags.f_contiguous and T.dtype == np.float64 and T.shape[1] >= 2
+        mm = C.c_int(m); beta = C.c_double(); brk = C.c_int()
+        _lib.check(self.ctx.L.ks_bv_matlanczos(self.h, A.h, _p(T), T.shape[0], k, C.byref(mm), C.byref(beta), C.byref(brk)))
+        return mm.value, beta.value, bool(brk.value)
+
+    def MatArnoldi(self, A, H, k, m):
+        assert H.flags.f_contiguous and H.dtype == np.float64
+        mm = C.c_int(m); beta = C.c_double(); brk = C.c_int()
+        _lib.check(self.ctx.L.ks_bv_matarnoldi(self.h, A.h, _p(H), H.shape[0], k, C.byref(mm), C.byref(beta), C.byref(brk)))
+        return mm.value, beta.value, bool(brk.value)
+
+
+class EPS:
+    """EPSCreate/EPSSetOperators/EPSSolve... for the default Krylov-Schur solver (symmetric problems)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        _lib.check(ctx.L.ks_eps_create(ctx.h, C.byref(h)))
+        self.h = h
+        self._A = None
+
+    def destroy(self):
+        if self.h:
+            self.ctx.L.ks_eps_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def SetOperators(self, A, B=None):
+        _lib.check(self.ctx.L.ks_eps_set_operators(self.h, A.h, None if B is None else B.h))
+        self._A = A
+
+    def SetProblemType(self, t):
+        _lib.check(self.ctx.L.ks_eps_set_problem_type(self.h, t))
+
+    def SetDimensions(self, nev, ncv=0, mpd=0):
+        _lib.check(self.ctx.L.ks_eps_set_dimensions(self.h, nev, ncv or 0, mpd or 0))
+
+    def SetTolerances(self, tol=0.0, max_it=0):
+        _lib.check(self.ctx.L.ks_eps_set_tolerances(self.h, tol or 0.0, max_it or 0))
+
+    def SetWhichEigenpairs(self, which):
+        _lib.check(self.ctx.L.ks_eps_set_which_eigenpairs(self.h, WHICH.get(which, which)))
+
+    def KrylovSchurSetRestart(self, keep):
+        _lib.check(self.ctx.L.ks_eps_set_krylovschur_restart(self.h, keep))
+
+    def SetRandomSeed(self, seed):
+        _lib.check(self.ctx.L.ks_eps_set_random_seed(self.h, seed))
+
+    def SetInitialVector(self, v):
+        _lib.check(self.ctx.L.ks_eps_set_initial_vector(self.h, _p(_f64(v)) if v is not None else None))
+
+    def SetMaxSteps(self, steps):
+        _lib.check(self.ctx.L.ks_eps_set_max_steps(self.h, steps))
+
+    def Solve(self):
+        _lib.check(self.ctx.L.ks_eps_solve(self.h))
+
+    def GetConverged(self):
+        v = C.c_int(); _lib.check(self.ctx.L.ks_eps_get_converged(self.h, C.byref(v))); return v.value
+
+    def GetIterationNumber(self):
+        v = C.c_int(); _lib.check(self.ctx.L.ks_eps_get_iteration_number(self.h, C.byref(v))); return v.value
+
+    def GetConvergedReason(self):
+        v = C.c_int(); _lib.check(self.ctx.L.ks_eps_get_converged_reason(self.h, C.byref(v))); return v.value
+
+    def GetDimensions(self):
+        a = C.c_int(); b = C.c_int(); c = C.c_int()
+        _lib.check(self.ctx.L.ks_eps_get_dimensions(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def GetEigenvalue(self, i):
+        r = C.c_double(); im = C.c_double()
+        _lib.check(self.ctx.L.ks_eps_get_eigenvalue(self.h, i, C.byref(r), C.byref(im)))
+        return r.value, im.value
+
+    def GetEigenvector(self, i):
+        x = np.empty(self._A.n)
+        _lib.check(self.ctx.L.ks_eps_get_eigenvector_host(self.h, i, _p(x)))
+        return x
+
+    def GetErrorEstimate(self, i):
+        v = C.c_double(); _lib.check(self.ctx.L.ks_eps_get_error_estimate(self.h, i, C.byref(v))); return v.value
+
+    def ComputeError(self, i, type=EPS_ERROR_RELATIVE):
+        v = C.c_double(); _lib.check(self.ctx.L.ks_eps_compute_error(self.h, i, type, C.byref(v))); return v.value
+
+    def GetBV(self):
+        h = C.c_void_p(); _lib.check(self.ctx.L.ks_eps_get_bv(self.h, C.byref(h)))
+        return BV(self.ctx, 0, 0, _handle=h)
+
+    def GetStats(self):
+        s = C.c_longlong(); p = C.c_longlong(); r = C.c_int()
+        _lib.check(self.ctx.L.ks_eps_get_stats(self.h, C.byref(s), C.byref(p), C.byref(r)))
+        return {"arnoldi_steps": s.value, "gs_passes": p.value, "restarts": r.value}

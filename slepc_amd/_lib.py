@@ -1,0 +1,153 @@
+"""ctypes binding of libksgpu.so (include/ksgpu.h). No fallback: if the HIP library is missing the import fails."""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libksgpu.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ksgpu.h")
+
+KS_UNIQUE_ID_BYTES = 128
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+vp = C.c_void_p
+llp = C.POINTER(C.c_longlong)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_int, vp)
+
+
+class KsError(RuntimeError):
+    def __init__(self, rc, msg):
+        super().__init__("libksgpu error %d: %s" % (rc, msg))
+        self.rc = rc
+
+
+_SIG = {
+    # context
+    "ks_ctx_create": [C.c_int, vp, C.POINTER(vp)],
+    "ks_ctx_destroy": [vp],
+    "ks_ctx_synchronize": [vp],
+    "ks_ctx_device_info": [vp, C.c_char_p, C.c_int, ip, C.POINTER(C.c_size_t)],
+    "ks_comm_get_unique_id": [C.c_char_p],
+    "ks_comm_init_rccl": [vp, C.c_int, C.c_int, C.c_char_p],
+    "ks_comm_set_callbacks": [vp, C.c_int, C.c_int, ALLREDUCE_FN, vp],
+    "ks_comm_rank_size": [vp, ip, ip],
+    # mat
+    "ks_mat_create_csr": [vp, C.c_int, C.c_int, C.c_int, ip, ip, dp, C.POINTER(vp)],
+    "ks_mat_create_laplacian3d": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
+    "ks_mat_create_laplacian2d": [vp, C.c_int, C.c_int, C.POINTER(vp)],
+    "ks_mat_destroy": [vp],
+    "ks_mat_get_sizes": [vp, ip, ip, llp],
+    "ks_mat_mult": [vp, vp, vp],
+    "ks_mat_mult_host": [vp, dp, dp],
+    # bv
+    "ks_bv_create": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
+    "ks_bv_destroy": [vp],
+    "ks_bv_duplicate": [vp, C.POINTER(vp)],
+    "ks_bv_get_sizes": [vp, ip, ip, ip, ip],
+    "ks_bv_set_active_columns": [vp, C.c_int, C.c_int],
+    "ks_bv_get_active_columns": [vp, ip, ip],
+    "ks_bv_set_orthogonalization": [vp, C.c_int, C.c_int, C.c_double],
+    "ks_bv_get_array": [vp, C.POINTER(vp)],
+    "ks_bv_get_column": [vp, C.c_int, C.POINTER(vp)],
+    "ks_bv_get_buffer": [vp, C.POINTER(vp)],
+    "ks_bv_set_column_host": [vp, C.c_int, dp],
+    "ks_bv_get_column_host": [vp, C.c_int, dp],
+    "ks_bv_get_buffer_host": [vp, dp],
+    "ks_bv_set_random_column": [vp, C.c_int, C.c_uint64],
+    "ks_bv_mult": [vp, C.c_double, C.c_double, vp, dp, C.c_int],
+    "ks_bv_multvec": [vp, C.c_double, C.c_double, vp, dp],
+    "ks_bv_multcolumn": [vp, C.c_double, C.c_double, C.c_int, dp],
+    "ks_bv_multinplace": [vp, dp, C.c_int, C.c_int, C.c_int],
+    "ks_bv_multinplace_trans": [vp, dp, C.c_int, C.c_int, C.c_int],
+    "ks_bv_dot": [vp, vp, dp, C.c_int],
+    "ks_bv_dotvec": [vp, vp, dp],
+    "ks_bv_dotvec_local": [vp, vp, dp],
+    "ks_bv_dotcolumn": [vp, C.c_int, dp],
+    "ks_bv_scale": [vp, C.c_double],
+    "ks_bv_scalecolumn": [vp, C.c_int, C.c_double],
+    "ks_bv_norm": [vp, C.c_int, dp],
+    "ks_bv_normcolumn": [vp, C.c_int, C.c_int, dp],
+    "ks_bv_norm_local": [vp, C.c_int, C.c_int, dp],
+    "ks_bv_copy": [vp, vp],
+    "ks_bv_copycolumn": [vp, C.c_int, C.c_int],
+    "ks_bv_matmult": [vp, vp, vp],
+    "ks_bv_matmultcolumn": [vp, vp, C.c_int],
+    "ks_bv_orthogonalizecolumn": [vp, C.c_int, dp, dp, ip],
+    "ks_bv_orthonormalizecolumn": [vp, C.c_int, C.c_int, dp, ip],
+    "ks_bv_orthogonalizevec": [vp, vp, dp, dp, ip],
+    "ks_bv_orthogonalizesomecolumn": [vp, C.c_int, ip, dp, dp, ip],
+    "ks_bv_gs_passes": [vp, llp, ip],
+    "ks_bv_matarnoldi": [vp, vp, dp, C.c_int, C.c_int, ip, dp, ip],
+    "ks_bv_matlanczos": [vp, vp, dp, C.c_int, C.c_int, ip, dp, ip],
+    # eps
+    "ks_eps_create": [vp, C.POINTER(vp)],
+    "ks_eps_destroy": [vp],
+    "ks_eps_set_operators": [vp, vp, vp],
+    "ks_eps_set_problem_type": [vp, C.c_int],
+    "ks_eps_set_dimensions": [vp, C.c_int, C.c_int, C.c_int],
+    "ks_eps_set_tolerances": [vp, C.c_double, C.c_int],
+    "ks_eps_set_which_eigenpairs": [vp, C.c_int],
+    "ks_eps_set_krylovschur_restart": [vp, C.c_double],
+    "ks_eps_set_random_seed": [vp, C.c_uint64],
+    "ks_eps_set_initial_vector": [vp, dp],
+    "ks_eps_set_max_steps": [vp, C.c_longlong],
+    "ks_eps_solve": [vp],
+    "ks_eps_get_converged": [vp, ip],
+    "ks_eps_get_iteration_number": [vp, ip],
+    "ks_eps_get_converged_reason": [vp, ip],
+    "ks_eps_get_dimensions": [vp, ip, ip, ip],
+    "ks_eps_get_eigenvalue": [vp, C.c_int, dp, dp],
+    "ks_eps_get_eigenvector_host": [vp, C.c_int, dp],
+    "ks_eps_get_error_estimate": [vp, C.c_int, dp],
+    "ks_eps_compute_error": [vp, C.c_int, C.c_int, dp],
+    "ks_eps_get_bv": [vp, C.POINTER(vp)],
+    "ks_eps_get_stats": [vp, llp, llp, ip],
+    # profiling
+    "ks_prof_enable": [vp, C.c_int],
+    "ks_prof_reset": [vp],
+    "ks_prof_get": [vp, C.c_int, llp, dp, dp],
+}
+_STR_FUNCS = ("ks_error_string", "ks_last_error_message", "ks_prof_class_name")
+
+
+def header_symbols():
+    """Every function name declared in include/ksgpu.h."""
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ks_[a-z0-9_]+)\s*\(", txt)) - {"ks_allreduce_fn", "ks_halo_fn"})
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libksgpu.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, args in _SIG.items():
+        f = getattr(lib, name)
+        f.argtypes = args
+        f.restype = C.c_int
+    lib.ks_error_string.argtypes = [C.c_int]
+    lib.ks_error_string.restype = C.c_char_p
+    lib.ks_last_error_message.argtypes = []
+    lib.ks_last_error_message.restype = C.c_char_p
+    lib.ks_prof_class_name.argtypes = [C.c_int]
+    lib.ks_prof_class_name.restype = C.c_char_p
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load()
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        L = lib()
+        detail = L.ks_last_error_message().decode()
+        raise KsError(rc, "%s: %s" % (L.ks_error_string(rc).decode(), detail))

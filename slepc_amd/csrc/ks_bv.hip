@@ -1,0 +1,606 @@
+// BV object and the generic _BVOps slots (everything except the fused Gram-Schmidt, see ks_gs.hip).
+// Storage mirrors BVSVEC (src/sys/classes/bv/impls/svec/svec.c): one device array of m*ld doubles,
+// column-major; ops act on the active window [l,k) at array+(nc+l)*ld.
+#include "ks_sweeps.cuh"
+#include <algorithm>
+
+using namespace ksk;
+
+namespace {
+
+__global__ void k_scale(double *__restrict__ x, size_t n, double alpha)
+{
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 2;
+  for (; i + 1 < n; i += stride) { double2 v = *reinterpret_cast<double2 *>(x + i); v.x *= alpha; v.y *= alpha; *reinterpret_cast<double2 *>(x + i) = v; }
+  if (i < n) x[i] *= alpha;
+}
+
+// splitmix64 stream shared verbatim with the CPU oracle (oracle/ks_oracle.c orc_random_value)
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
+{
+  x += 0x9E3779B97F4A7C15ULL; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL; x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL; return x ^ (x >> 31);
+}
+__global__ void k_random_column(double *__restrict__ x, int n, unsigned long long seed, unsigned long long col, unsigned long long row0)
+{
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long z = splitmix64(seed ^ splitmix64(col * 0x100000001B3ULL + (row0 + (unsigned long long)i) + 0x12345678ULL * (col + 1)));
+  x[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+__global__ void k_reduce_only(const double *__restrict__ partials, int nblocks, int ncols, double *__restrict__ out)
+{
+  __shared__ double c_lds[KS_MAX_COLS + 8];
+  reduce_partials_to_lds(partials, nblocks, ncols, c_lds);
+  if ((int)threadIdx.x < ncols) out[threadIdx.x] = c_lds[threadIdx.x];
+}
+
+// per-column partial reductions for norms: mode 0: sum of squares, 1: sum |x| ; partials[c*G + b]
+template <int MODE>
+__global__ __launch_bounds__(SW_BLOCK) void k_colsum(const double *__restrict__ A, long long lda, int n, int ncols, double *__restrict__ partials)
+{
+  __shared__ double red[SW_WAVES];
+  for (int c = 0; c < ncols; c++) {
+    double s = 0.0;
+    for (long long r = (long long)blockIdx.x * SW_BLOCK + threadIdx.x; r < n; r += (long long)gridDim.x * SW_BLOCK) {
+      const double v = A[(long long)c * lda + r];
+      s += MODE == 0 ? v * v : fabs(v);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = red[0]; for (int w = 1; w < SW_WAVES; w++) t += red[w]; partials[(size_t)c * gridDim.x + blockIdx.x] = t; }
+    __syncthreads();
+  }
+}
+// infinity norm: max over rows of sum_c |A(r,c)| ; one partial (max) per block
+__global__ __launch_bounds__(SW_BLOCK) void k_rowsum_max(const double *__restrict__ A, long long lda, int n, int ncols, double *__restrict__ partials)
+{
+  __shared__ double red[SW_WAVES];
+  double mx = 0.0;
+  for (long long r = (long long)blockIdx.x * SW_BLOCK + threadIdx.x; r < n; r += (long long)gridDim.x * SW_BLOCK) {
+    double s = 0.0;
+    for (int c = 0; c < ncols; c++) s += fabs(A[(long long)c * lda + r]);
+    mx = fmax(mx, s);
+  }
+  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_down(mx, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) { double t = red[0]; for (int w = 1; w < SW_WAVES; w++) t = fmax(t, red[w]); partials[blockIdx.x] = t; }
+}
+
+// C(:,0:nout) = beta*C + alpha * A(:,0:kin) * Q(0:kin,0:nout).  One row per thread, the row of A lives in
+// registers (so C may alias columns of A: in-place BVMultInPlace), Q is staged in LDS as [nout][KT]
+// (zero padded), read with wave-uniform (broadcast) addresses.   bvblas.c:24-49 and :74-106.
+template <int KT, bool TRANSQ>
+__global__ __launch_bounds__(SW_BLOCK) void k_panel_mult(const double *A, long long lda, int n, int kin, const double *__restrict__ Q, int ldq,
+                                                         int nout, double alpha, double beta, double *C, long long ldc)
+{
+  extern __shared__ __attribute__((aligned(16))) double q_lds[];   // nout*KT
+  for (int idx = threadIdx.x; idx < nout * KT; idx += SW_BLOCK) {
+    const int j = idx / KT, i = idx % KT;
+    q_lds[idx] = (i < kin) ? (TRANSQ ? Q[j + (size_t)i * ldq] : Q[i + (size_t)j * ldq]) : 0.0;
+  }
+  __syncthreads();
+  for (long long r = (long long)blockIdx.x * SW_BLOCK + threadIdx.x; r < n; r += (long long)gridDim.x * SW_BLOCK) {
+    double x[KT];
+#pragma unroll
+    for (int i = 0; i < KT; i++) { const int ii = i < kin ? i : kin - 1; x[i] = A[(long long)ii * lda + r]; }
+    for (int j = 0; j < nout; j++) {
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < KT; i++) s = fma(x[i], q_lds[j * KT + i], s);
+      double *c = C + (long long)j * ldc + r;
+      *c = (beta == 0.0) ? alpha * s : fma(alpha, s, beta * (*c));
+    }
+  }
+}
+
+// B = alpha*A + beta*B   (BVAXPY_BLAS_Private bvblas.c:163-192)
+__global__ void k_axpby(const double *__restrict__ A, long long lda, double *__restrict__ B, long long ldb, int n, int ncols, double alpha, double beta)
+{
+  for (int c = 0; c < ncols; c++)
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) {
+      double *b = B + (long long)c * ldb + r;
+      *b = (beta != 1.0) ? alpha * A[(long long)c * lda + r] + beta * (*b) : fma(alpha, A[(long long)c * lda + r], *b);
+    }
+}
+
+int sweep_grid(ks_ctx ctx, int n, int vec)
+{
+  long long tile = (long long)SW_BLOCK * vec;
+  long long ntiles = ((long long)n + tile - 1) / tile;
+  long long g = std::min<long long>(std::max<long long>(ntiles, 1), (long long)ctx->num_cu * 4);
+  return (int)std::min<long long>(g, KS_MAX_BLOCKS);
+}
+
+bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+} // namespace
+
+// ---- launchers shared with ks_gs.hip -----------------------------------------------------------
+
+int ksk_dot(ks_bv bv, const double *A, int lda, int ncols, const double *y, bool gate)
+{
+  ks_ctx ctx = bv->ctx;
+  KS_CHECK(ncols >= 1 && ncols <= KS_MAX_COLS, KS_ERR_PLIB, "dot sweep with %d columns", ncols);
+  const bool v2 = (lda % 2 == 0) && aligned16(A) && aligned16(y);
+  const int grid = sweep_grid(ctx, bv->n, v2 ? 2 : 1);
+  bv->last_grid = grid;
+  const KsGsState *g = gate ? bv->gs : nullptr;
+  KsProfScope ps(ctx, KS_K_DOT, 8.0 * bv->n * (ncols + (y >= A && y < A + (size_t)ncols * lda ? 0 : 1)));
+#define LAUNCH_DOT(KT)                                                                                                                        \
+  do {                                                                                                                                        \
+    if (v2) hipLaunchKernelGGL((k_dot_sweep<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, y, bv->partials, g); \
+    else hipLaunchKernelGGL((k_dot_sweep<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, y, bv->partials, g);   \
+  } while (0)
+  KS_KT_DISPATCH(ncols, LAUNCH_DOT);
+#undef LAUNCH_DOT
+  KS_HIP(hipGetLastError());
+  return KS_SUCCESS;
+}
+
+int ksk_reduce_partials(ks_bv bv, int ncols, double *out_dev)
+{
+  ks_ctx ctx = bv->ctx;
+  hipLaunchKernelGGL(k_reduce_only, dim3(1), dim3(1024), 0, ctx->stream, bv->partials, bv->last_grid, ncols, out_dev);
+  KS_HIP(hipGetLastError());
+  return KS_SUCCESS;
+}
+
+int ksk_multvec(ks_bv bv, const double *A, int lda, int ncols, double alpha, double beta, const double *q_dev, double *y)
+{
+  ks_ctx ctx = bv->ctx;
+  const bool v2 = (lda % 2 == 0) && aligned16(A) && aligned16(y);
+  const int grid = sweep_grid(ctx, bv->n, v2 ? 2 : 1);
+  KsProfScope ps(ctx, KS_K_UPD, 8.0 * bv->n * (ncols + 2));
+  if (v2) hipLaunchKernelGGL((k_multvec<2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, alpha, beta, q_dev, y);
+  else hipLaunchKernelGGL((k_multvec<1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, alpha, beta, q_dev, y);
+  KS_HIP(hipGetLastError());
+  return KS_SUCCESS;
+}
+
+int ksk_scale(ks_ctx ctx, double *x, size_t n, double alpha)
+{
+  if (n == 0 || alpha == 1.0) return KS_SUCCESS;
+  KsProfScope ps(ctx, KS_K_SCALE, 16.0 * n);
+  if (alpha == 0.0) { KS_HIP(hipMemsetAsync(x, 0, n * sizeof(double), ctx->stream)); return KS_SUCCESS; }   // bvblas.c:271
+  if (!aligned16(x)) { hipLaunchKernelGGL(k_scale, dim3(1), dim3(1), 0, ctx->stream, x, (size_t)1, alpha); x++; n--; if (!n) return KS_SUCCESS; }
+  size_t blocks = std::min<size_t>((n / 2 + 255) / 256 + 1, (size_t)ctx->num_cu * 8);
+  hipLaunchKernelGGL(k_scale, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, x, n, alpha);
+  KS_HIP(hipGetLastError());
+  return KS_SUCCESS;
+}
+
+int ksk_copy(ks_ctx ctx, const double *src, double *dst, size_t n)
+{
+  if (!n || src == dst) return KS_SUCCESS;
+  KsProfScope ps(ctx, KS_K_COPY, 16.0 * n);
+  KS_HIP(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  return KS_SUCCESS;
+}
+
+// stage host coefficients into the BV's device scratch (async from pinned memory when they fit)
+static int stage_coefs(ks_bv bv, const double *host, size_t len, double **dev)
+{
+  ks_ctx ctx = bv->ctx;
+  KS_CHECK(len <= bv->coef_len, KS_ERR_ARG_SIZ, "coefficient block of %zu doubles exceeds scratch (%zu)", len, bv->coef_len);
+  // the pinned area may still be in use by an earlier async copy: make the copy synchronous w.r.t. the host
+  KS_HIP(hipMemcpyAsync(bv->coef, host, len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  KS_HIP(hipStreamSynchronize(ctx->stream));
+  *dev = bv->coef;
+  return KS_SUCCESS;
+}
+
+// ---- lifecycle -----------------------------------------------------------------------------------
+extern "C" int ks_bv_create(ks_ctx ctx, int n_local, int n_global, int m, int ld, ks_bv *out)
+{
+  KS_CHECK(ctx && out, KS_ERR_ARG_NULL, "ctx/out is NULL");
+  KS_CHECK(n_local >= 0 && n_global >= n_local && m >= 1, KS_ERR_ARG_OUTOFRANGE, "bad sizes n=%d N=%d m=%d", n_local, n_global, m);
+  KS_HIP(hipSetDevice(ctx->device));
+  ks_bv bv = new ks_bv_s();
+  bv->ctx = ctx; bv->n = n_local; bv->N = n_global; bv->m = m; bv->l = 0; bv->k = m; bv->nc = 0;
+  if (ld) {   // BV_SetDefaultLD bvimpl.h:471-484: a user value must be >= n
+    if (ld < n_local) { delete bv; KS_FAIL(KS_ERR_USER_INPUT, "The leading dimension %d should be larger or equal to the local number of rows %d", ld, n_local); }
+    bv->ld = ld;
+  } else bv->ld = std::max(32, ((n_local + 31) / 32) * 32);   // default: 256-byte aligned columns (reference: 16-byte)
+  const size_t cells = (size_t)m * bv->ld;
+  bv->coef_len = std::max<size_t>((size_t)m * m, (size_t)KS_MAX_COLS * KS_MAX_COLS) + 64;
+  hipError_t e = hipMalloc(&bv->array, cells * sizeof(double));
+  if (e != hipSuccess) { delete bv; KS_FAIL(KS_ERR_MEM, "hipMalloc of %zu bytes for the BV failed", cells * sizeof(double)); }
+  KS_HIP(hipMemsetAsync(bv->array, 0, cells * sizeof(double), ctx->stream));
+  KS_HIP(hipMalloc(&bv->buffer, (size_t)m * m * sizeof(double)));
+  KS_HIP(hipMemsetAsync(bv->buffer, 0, (size_t)m * m * sizeof(double), ctx->stream));
+  KS_HIP(hipMalloc(&bv->partials, (size_t)KS_MAX_BLOCKS * KS_PSTRIDE * sizeof(double)));
+  KS_HIP(hipMalloc(&bv->coef, bv->coef_len * sizeof(double)));
+  KS_HIP(hipMalloc(&bv->hc, (size_t)2 * (m + 8) * sizeof(double)));
+  KS_HIP(hipMalloc(&bv->gs, sizeof(KsGsState)));
+  KS_HIP(hipMemsetAsync(bv->gs, 0, sizeof(KsGsState), ctx->stream));
+  KS_HIP(hipMalloc(&bv->recs, (size_t)(m + 1) * sizeof(KsStepRec)));
+  KS_HIP(hipMemsetAsync(bv->recs, 0, (size_t)(m + 1) * sizeof(KsStepRec), ctx->stream));
+  KS_HIP(hipStreamSynchronize(ctx->stream));
+  *out = bv;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_destroy(ks_bv bv)
+{
+  if (!bv) return KS_SUCCESS;
+  hipSetDevice(bv->ctx->device);
+  hipStreamSynchronize(bv->ctx->stream);
+  hipFree(bv->array); hipFree(bv->buffer); hipFree(bv->partials); hipFree(bv->coef); hipFree(bv->hc); hipFree(bv->gs); hipFree(bv->recs);
+  delete bv;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_duplicate(ks_bv bv, ks_bv *out)
+{
+  KS_CHECK(bv && out, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CALL(ks_bv_create(bv->ctx, bv->n, bv->N, bv->m, bv->ld, out));
+  (*out)->orthog_type = bv->orthog_type; (*out)->orthog_ref = bv->orthog_ref; (*out)->orthog_eta = bv->orthog_eta;
+  (*out)->l = bv->l; (*out)->k = bv->k; (*out)->row_start = bv->row_start;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_get_sizes(ks_bv bv, int *n, int *N, int *m, int *ld)
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  if (n) *n = bv->n; if (N) *N = bv->N; if (m) *m = bv->m; if (ld) *ld = bv->ld;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_set_active_columns(ks_bv bv, int l, int k)   // bvbasic.c:421-440
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  if (k < 0) k = bv->m;     // PETSC_DETERMINE
+  if (l < 0) l = 0;
+  KS_CHECK(k <= bv->m, KS_ERR_ARG_OUTOFRANGE, "Illegal value of k. Must be between 0 and m");
+  KS_CHECK(l <= k, KS_ERR_ARG_OUTOFRANGE, "Illegal value of l. Must be less than k");
+  bv->l = l; bv->k = k;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_get_active_columns(ks_bv bv, int *l, int *k)
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  if (l) *l = bv->l; if (k) *k = bv->k;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_set_orthogonalization(ks_bv bv, int type, int refine, double eta)   // bvorthog / bvbasic.c BVSetOrthogonalization
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  KS_CHECK(type == KS_BV_ORTHOG_CGS || type == KS_BV_ORTHOG_MGS, KS_ERR_ARG_WRONG, "Unknown orthogonalization type");
+  KS_CHECK(refine >= 0 && refine <= 2, KS_ERR_ARG_WRONG, "Unknown refinement type");
+  if (eta > 0.0) { KS_CHECK(eta <= 1.0, KS_ERR_ARG_OUTOFRANGE, "Invalid eta value"); bv->orthog_eta = eta; }
+  bv->orthog_type = type; bv->orthog_ref = refine;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_get_array(ks_bv bv, double **dev) { KS_CHECK(bv && dev, KS_ERR_ARG_NULL, "NULL argument"); *dev = bv->array; return KS_SUCCESS; }
+extern "C" int ks_bv_get_buffer(ks_bv bv, double **dev) { KS_CHECK(bv && dev, KS_ERR_ARG_NULL, "NULL argument"); *dev = bv->buffer; return KS_SUCCESS; }
+extern "C" int ks_bv_get_column(ks_bv bv, int j, double **dev)
+{
+  KS_CHECK(bv && dev, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(j >= 0 && j < bv->m, KS_ERR_ARG_OUTOFRANGE, "You requested column %d but only columns 0 to %d are available", j, bv->m - 1);
+  *dev = ks_bv_col(bv, j);
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_set_column_host(ks_bv bv, int j, const double *host)
+{
+  KS_CHECK(bv && host, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(j >= 0 && j < bv->m, KS_ERR_ARG_OUTOFRANGE, "column %d out of range", j);
+  KS_HIP(hipSetDevice(bv->ctx->device));
+  KS_HIP(hipMemcpyAsync(ks_bv_col(bv, j), host, sizeof(double) * bv->n, hipMemcpyHostToDevice, bv->ctx->stream));
+  KS_HIP(hipStreamSynchronize(bv->ctx->stream));
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_get_column_host(ks_bv bv, int j, double *host)
+{
+  KS_CHECK(bv && host, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(j >= 0 && j < bv->m, KS_ERR_ARG_OUTOFRANGE, "column %d out of range", j);
+  KS_HIP(hipSetDevice(bv->ctx->device));
+  KS_HIP(hipMemcpyAsync(host, ks_bv_col(bv, j), sizeof(double) * bv->n, hipMemcpyDeviceToHost, bv->ctx->stream));
+  KS_HIP(hipStreamSynchronize(bv->ctx->stream));
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_get_buffer_host(ks_bv bv, double *host)
+{
+  KS_CHECK(bv && host, KS_ERR_ARG_NULL, "NULL argument");
+  KS_HIP(hipSetDevice(bv->ctx->device));
+  KS_HIP(hipMemcpyAsync(host, bv->buffer, sizeof(double) * bv->m * bv->m, hipMemcpyDeviceToHost, bv->ctx->stream));
+  KS_HIP(hipStreamSynchronize(bv->ctx->stream));
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_set_random_column(ks_bv bv, int j, uint64_t seed)   // BVSetRandomColumn bvops.c:482, reproducible variant :368-376
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  KS_CHECK(j >= 0 && j < bv->m, KS_ERR_ARG_OUTOFRANGE, "Argument j has wrong value %d, the number of columns is %d", j, bv->m);
+  KS_HIP(hipSetDevice(bv->ctx->device));
+  if (bv->n) hipLaunchKernelGGL(k_random_column, dim3((bv->n + 255) / 256), dim3(256), 0, bv->ctx->stream, ks_bv_col(bv, j), bv->n, (unsigned long long)seed, (unsigned long long)j, (unsigned long long)bv->row_start);
+  KS_HIP(hipGetLastError());
+  return KS_SUCCESS;
+}
+
+// ---- ops->mult / multvec / multinplace -----------------------------------------------------------
+static int panel_mult(ks_ctx ctx, int kclass, const double *A, int lda, int n, int kin, const double *Qdev, int ldq, bool transq,
+                      int nout, double alpha, double beta, double *C, int ldc)
+{
+  if (n == 0 || nout == 0) return KS_SUCCESS;
+  KS_CHECK(kin >= 1 && kin <= KS_MAX_COLS, KS_ERR_SUP, "panel product with %d inner columns (max %d)", kin, KS_MAX_COLS);
+  const int grid = (int)std::min<long long>(((long long)n + SW_BLOCK - 1) / SW_BLOCK, (long long)ctx->num_cu * 8);
+  KsProfScope ps(ctx, kclass, 8.0 * n * (kin + nout * (beta == 0.0 ? 1 : 2)));
+#define LAUNCH_PM(KT)                                                                                                                      \
+  do {                                                                                                                                     \
+    const size_t sh = (size_t)nout * KT * sizeof(double);                                                                                  \
+    if (transq) hipLaunchKernelGGL((k_panel_mult<KT, true>), dim3(grid), dim3(SW_BLOCK), sh, ctx->stream, A, (long long)lda, n, kin, Qdev, ldq, nout, alpha, beta, C, (long long)ldc); \
+    else hipLaunchKernelGGL((k_panel_mult<KT, false>), dim3(grid), dim3(SW_BLOCK), sh, ctx->stream, A, (long long)lda, n, kin, Qdev, ldq, nout, alpha, beta, C, (long long)ldc);       \
+  } while (0)
+  KS_KT_DISPATCH(kin, LAUNCH_PM);
+#undef LAUNCH_PM
+  KS_HIP(hipGetLastError());
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_mult(ks_bv Y, double alpha, double beta, ks_bv X, const double *Q, int ldq)   // bvops.c:49, svec.c:17-36
+{
+  KS_CHECK(Y && X, KS_ERR_ARG_NULL, "BV is NULL");
+  KS_CHECK(X != Y, KS_ERR_ARG_WRONG, "X and Y arguments must be different");
+  KS_CHECK(X->n == Y->n, KS_ERR_ARG_INCOMP, "Mismatching local dimension X %d, Y %d", X->n, Y->n);
+  ks_ctx ctx = Y->ctx;
+  KS_HIP(hipSetDevice(ctx->device));
+  const int ny = Y->k - Y->l, kx = X->k - X->l;
+  double *py = Y->array + (size_t)(Y->nc + Y->l) * Y->ld; const double *px = X->array + (size_t)(X->nc + X->l) * X->ld;
+  if (ny <= 0) return KS_SUCCESS;
+  if (!Q) {
+    KS_CHECK(kx >= ny, KS_ERR_ARG_SIZ, "X has fewer active columns than Y");
+    if (!Y->n) return KS_SUCCESS;
+    KsProfScope ps(ctx, KS_K_MULT, 24.0 * Y->n * ny);
+    const int grid = (int)std::min<long long>(((long long)Y->n + 255) / 256, (long long)ctx->num_cu * 8);
+    hipLaunchKernelGGL(k_axpby, dim3(grid), dim3(256), 0, ctx->stream, px, (long long)X->ld, py, (long long)Y->ld, Y->n, ny, alpha, beta);
+    KS_HIP(hipGetLastError());
+    return KS_SUCCESS;
+  }
+  KS_CHECK(ldq >= X->k, KS_ERR_ARG_SIZ, "Mat argument has %d rows, should have at least %d", ldq, X->k);
+  if (kx <= 0) { if (beta != 1.0) for (int j = 0; j < ny; j++) KS_CALL(ksk_scale(ctx, py + (size_t)j * Y->ld, Y->n, beta)); return KS_SUCCESS; }
+  // stage the (X->k) x (Y->k) leading block of Q on the device (bvimpl.h:565-586 does the same per call)
+  const size_t qlen = (size_t)ldq * Y->k;
+  double *qdev = nullptr;
+  KS_CALL(stage_coefs(Y, Q, qlen, &qdev));
+  return panel_mult(ctx, KS_K_MULT, px, X->ld, Y->n, kx, qdev + (size_t)Y->l * ldq + X->l, ldq, false, ny, alpha, beta, py, Y->ld);
+}
+
+extern "C" int ks_bv_multvec(ks_bv X, double alpha, double beta, double *y_dev, const double *q)   // bvops.c:110, svec.c:38-52
+{
+  KS_CHECK(X && y_dev, KS_ERR_ARG_NULL, "NULL argument");
+  ks_ctx ctx = X->ctx;
+  KS_HIP(hipSetDevice(ctx->device));
+  const int kx = X->k - X->l;
+  const double *qdev = X->buffer;            // q==NULL: coefficients are in the buffer Vec (svec.c:46)
+  if (q && kx > 0) { double *tmp; KS_CALL(stage_coefs(X, q, (size_t)kx, &tmp)); qdev = tmp; }
+  if (kx <= 0) { if (beta != 1.0) return ksk_scale(ctx, y_dev, X->n, beta); return KS_SUCCESS; }
+  const double *A = X->array + (size_t)(X->nc + X->l) * X->ld;
+  for (int c0 = 0; c0 < kx; c0 += KS_MAX_COLS) {
+    const int nc = std::min(KS_MAX_COLS, kx - c0);
+    KS_CALL(ksk_multvec(X, A + (size_t)c0 * X->ld, X->ld, nc, alpha, c0 == 0 ? beta : 1.0, qdev + c0, y_dev));
+  }
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_multcolumn(ks_bv X, double alpha, double beta, int j, const double *q)   // bvops.c:165-198
+{
+  KS_CHECK(X, KS_ERR_ARG_NULL, "BV is NULL");
+  KS_CHECK(j >= 0, KS_ERR_ARG_OUTOFRANGE, "Index j must be non-negative");
+  KS_CHECK(j < X->m, KS_ERR_ARG_OUTOFRANGE, "Index j=%d but BV only has %d columns", j, X->m);
+  const int ksave = X->k;
+  X->k = j;
+  int rc = ks_bv_multvec(X, alpha, beta, ks_bv_col(X, j), q);
+  X->k = ksave;
+  return rc;
+}
+
+static int multinplace(ks_bv V, const double *Q, int ldq, int s, int e, bool trans)   // bvops.c:220-250, svec.c:54-87
+{
+  KS_CHECK(V && Q, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(s >= V->l && s <= V->m, KS_ERR_ARG_OUTOFRANGE, "Argument s has wrong value %d, should be between %d and %d", s, V->l, V->m);
+  KS_CHECK(e >= V->l && e <= V->m, KS_ERR_ARG_OUTOFRANGE, "Argument e has wrong value %d, should be between %d and %d", e, V->l, V->m);
+  KS_CHECK(ldq >= (trans ? e : V->k), KS_ERR_ARG_SIZ, "Mat argument has %d rows, should have at least %d", ldq, trans ? e : V->k);
+  if (s >= e || !V->n) return KS_SUCCESS;
+  ks_ctx ctx = V->ctx;
+  KS_HIP(hipSetDevice(ctx->device));
+  const int kin = V->k - V->l;
+  KS_CHECK(kin >= 1, KS_ERR_ARG_WRONGSTATE, "no active columns");
+  // Q block needed: rows l..k-1, cols s..e-1 (or transposed); stage the leading max(k,e) x max(k,e) block
+  const int ncolsq = trans ? V->k : e;
+  double *qdev = nullptr;
+  KS_CALL(stage_coefs(V, Q, (size_t)ldq * ncolsq, &qdev));
+  double *A = V->array + (size_t)(V->nc + V->l) * V->ld;
+  const double *B = qdev + (size_t)V->l * ldq + V->l;
+  const int ss = s - V->l, ee = e - V->l;
+  const double *pb = trans ? B + ss : B + (size_t)ss * ldq;
+  return panel_mult(ctx, KS_K_MULTINPLACE, A, V->ld, V->n, kin, pb, ldq, trans, ee - ss, 1.0, 0.0, A + (size_t)ss * V->ld, V->ld);
+}
+extern "C" int ks_bv_multinplace(ks_bv V, const double *Q, int ldq, int s, int e) { return multinplace(V, Q, ldq, s, e, false); }
+extern "C" int ks_bv_multinplace_trans(ks_bv V, const double *Q, int ldq, int s, int e) { return multinplace(V, Q, ldq, s, e, true); }
+
+// ---- ops->dot / dotvec -----------------------------------------------------------------------------
+static int dotvec_impl(ks_bv X, const double *y_dev, double *m, bool reduce)
+{
+  KS_CHECK(X && y_dev, KS_ERR_ARG_NULL, "NULL argument");
+  ks_ctx ctx = X->ctx;
+  KS_HIP(hipSetDevice(ctx->device));
+  const int kx = X->k - X->l;
+  if (kx <= 0) return KS_SUCCESS;
+  const double *A = X->array + (size_t)(X->nc + X->l) * X->ld;
+  double *out = m ? X->coef : X->buffer;      // m==NULL: result goes to the buffer scratch (svec.c:123)
+  KS_CHECK((size_t)kx <= X->coef_len, KS_ERR_ARG_SIZ, "too many columns");
+  for (int c0 = 0; c0 < kx; c0 += KS_MAX_COLS) {
+    const int nc = std::min(KS_MAX_COLS, kx - c0);
+    if (X->n > 0) { KS_CALL(ksk_dot(X, A + (size_t)c0 * X->ld, X->ld, nc, y_dev, false)); KS_CALL(ksk_reduce_partials(X, nc, out + c0)); }
+    else KS_HIP(hipMemsetAsync(out + c0, 0, sizeof(double) * nc, ctx->stream));
+  }
+  if (reduce) KS_CALL(ks_allreduce_sum(ctx, out, kx));
+  if (m) { KS_HIP(hipMemcpyAsync(m, out, sizeof(double) * kx, hipMemcpyDeviceToHost, ctx->stream)); KS_HIP(hipStreamSynchronize(ctx->stream)); }
+  return KS_SUCCESS;
+}
+extern "C" int ks_bv_dotvec(ks_bv X, const double *y_dev, double *m) { return dotvec_impl(X, y_dev, m, true); }          // bvglobal.c:151
+extern "C" int ks_bv_dotvec_local(ks_bv X, const double *y_dev, double *m) { return dotvec_impl(X, y_dev, m, false); }   // ops->dotvec_local
+
+extern "C" int ks_bv_dotcolumn(ks_bv X, int j, double *q)   // bvglobal.c:302-327
+{
+  KS_CHECK(X, KS_ERR_ARG_NULL, "BV is NULL");
+  KS_CHECK(j >= 0, KS_ERR_ARG_OUTOFRANGE, "Index j must be non-negative");
+  KS_CHECK(j < X->m, KS_ERR_ARG_OUTOFRANGE, "Index j=%d but BV only has %d columns", j, X->m);
+  const int ksave = X->k;
+  X->k = j;
+  int rc = ks_bv_dotvec(X, ks_bv_col(X, j), q);
+  X->k = ksave;
+  return rc;
+}
+
+extern "C" int ks_bv_dot(ks_bv X, ks_bv Y, double *M, int ldm)   // bvglobal.c:86-116, svec.c:89-107: M = Y^H X
+{
+  KS_CHECK(X && Y && M, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(ldm >= Y->k, KS_ERR_ARG_SIZ, "Mat argument has %d rows, should have at least %d", ldm, Y->k);
+  KS_CHECK(X->n == Y->n, KS_ERR_ARG_INCOMP, "Mismatching local dimension X %d, Y %d", X->n, Y->n);
+  if (X->l == X->k || Y->l == Y->k) return KS_SUCCESS;
+  ks_ctx ctx = X->ctx;
+  KS_HIP(hipSetDevice(ctx->device));
+  const int my = Y->k - Y->l, nx = X->k - X->l;
+  KS_CHECK(my <= KS_MAX_COLS, KS_ERR_SUP, "BVDot with more than %d active columns in Y", KS_MAX_COLS);
+  KS_CHECK((size_t)my * nx <= X->coef_len, KS_ERR_ARG_SIZ, "result block too large");
+  const double *py = Y->array + (size_t)(Y->nc + Y->l) * Y->ld;
+  {
+    KsProfScope ps(ctx, KS_K_BVDOT, 8.0 * X->n * (my + nx));
+    const bool save = ctx->prof_on; ctx->prof_on = false;       // account the whole panel product as one class
+    for (int jx = 0; jx < nx; jx++) {
+      const double *xcol = X->array + (size_t)(X->nc + X->l + jx) * X->ld;
+      if (X->n > 0) { KS_CALL(ksk_dot(X, py, Y->ld, my, xcol, false)); KS_CALL(ksk_reduce_partials(X, my, X->coef + (size_t)jx * my)); }
+      else KS_HIP(hipMemsetAsync(X->coef + (size_t)jx * my, 0, sizeof(double) * my, ctx->stream));
+    }
+    ctx->prof_on = save;
+  }
+  KS_CALL(ks_allreduce_sum(ctx, X->coef, my * nx));
+  std::vector<double> tmp((size_t)my * nx);
+  KS_HIP(hipMemcpyAsync(tmp.data(), X->coef, sizeof(double) * my * nx, hipMemcpyDeviceToHost, ctx->stream));
+  KS_HIP(hipStreamSynchronize(ctx->stream));
+  double *C = M + (size_t)X->l * ldm + Y->l;
+  for (int j = 0; j < nx; j++) memcpy(C + (size_t)j * ldm, tmp.data() + (size_t)j * my, sizeof(double) * my);
+  return KS_SUCCESS;
+}
+
+// ---- ops->scale / norm / copy ------------------------------------------------------------------------
+extern "C" int ks_bv_scale(ks_bv bv, double alpha)   // bvops.c:311, svec.c:150-162 (j<0: (k-l)*ld contiguous scalars)
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  if (alpha == 1.0 || !bv->n || bv->k <= bv->l) return KS_SUCCESS;
+  KS_HIP(hipSetDevice(bv->ctx->device));
+  return ksk_scale(bv->ctx, bv->array + (size_t)(bv->nc + bv->l) * bv->ld, (size_t)(bv->k - bv->l) * bv->ld, alpha);
+}
+
+extern "C" int ks_bv_scalecolumn(ks_bv bv, int j, double alpha)   // bvops.c:341
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  KS_CHECK(j >= 0 && j < bv->m, KS_ERR_ARG_OUTOFRANGE, "Argument j has wrong value %d, the number of columns is %d", j, bv->m);
+  if (alpha == 1.0 || !bv->n) return KS_SUCCESS;
+  KS_HIP(hipSetDevice(bv->ctx->device));
+  return ksk_scale(bv->ctx, ks_bv_col(bv, j), bv->n, alpha);
+}
+
+static int norm_impl(ks_bv bv, int j, int type, double *val, bool reduce)   // svec.c:164-190, bvlapack.c:37-83
+{
+  KS_CHECK(bv && val, KS_ERR_ARG_NULL, "NULL argument");
+  ks_ctx ctx = bv->ctx;
+  KS_HIP(hipSetDevice(ctx->device));
+  const double *A; int ncols;
+  if (j < 0) { A = bv->array + (size_t)(bv->nc + bv->l) * bv->ld; ncols = bv->k - bv->l; }
+  else { KS_CHECK(j < bv->m, KS_ERR_ARG_OUTOFRANGE, "Argument j has wrong value %d, the number of columns is %d", j, bv->m); A = ks_bv_col(bv, j); ncols = 1; }
+  if (ncols <= 0) { *val = 0.0; return KS_SUCCESS; }
+  KS_CHECK(ncols <= KS_PSTRIDE - 8, KS_ERR_SUP, "norm over more than %d columns", KS_PSTRIDE - 8);
+  const int grid = std::max(1, std::min((bv->n + SW_BLOCK - 1) / SW_BLOCK, std::min(ctx->num_cu * 4, KS_MAX_BLOCKS)));
+  KsProfScope ps(ctx, KS_K_NORM, 8.0 * bv->n * ncols);
+  std::vector<double> h;
+  if (type == KS_NORM_FROBENIUS || type == KS_NORM_2 || type == KS_NORM_1) {
+    if (type == KS_NORM_2) KS_CHECK(j >= 0, KS_ERR_SUP, "Requested norm not available");   // bvglobal.c:506
+    if (type == KS_NORM_1) hipLaunchKernelGGL(k_colsum<1>, dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)bv->ld, bv->n, ncols, bv->partials);
+    else hipLaunchKernelGGL(k_colsum<0>, dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)bv->ld, bv->n, ncols, bv->partials);
+    KS_HIP(hipGetLastError());
+    // column totals -> coef[0..ncols)
+    for (int c0 = 0; c0 < ncols; c0 += KS_MAX_COLS) {
+      const int nc = std::min(KS_MAX_COLS, ncols - c0);
+      hipLaunchKernelGGL(k_reduce_only, dim3(1), dim3(1024), 0, ctx->stream, bv->partials + (size_t)c0 * grid, grid, nc, bv->coef + c0);
+    }
+    if (reduce) KS_CALL(ks_allreduce_sum(ctx, bv->coef, ncols));     // sum of squares / abs sums add across ranks
+    h.resize(ncols);
+    KS_HIP(hipMemcpyAsync(h.data(), bv->coef, sizeof(double) * ncols, hipMemcpyDeviceToHost, ctx->stream));
+    KS_HIP(hipStreamSynchronize(ctx->stream));
+    if (type == KS_NORM_1) { double mx = 0.0; for (double v : h) mx = std::max(mx, v); *val = mx; }
+    else { double s = 0.0; for (double v : h) s += v; *val = sqrt(s); }
+  } else if (type == KS_NORM_INFINITY) {
+    KS_CHECK(!reduce || ctx->comm.size == 1, KS_ERR_SUP, "infinity norm across ranks needs a MAX reduction (not provided)");
+    hipLaunchKernelGGL(k_rowsum_max, dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)bv->ld, bv->n, ncols, bv->partials);
+    KS_HIP(hipGetLastError());
+    h.resize(grid);
+    KS_HIP(hipMemcpyAsync(h.data(), bv->partials, sizeof(double) * grid, hipMemcpyDeviceToHost, ctx->stream));
+    KS_HIP(hipStreamSynchronize(ctx->stream));
+    double mx = 0.0; for (double v : h) mx = std::max(mx, v); *val = mx;
+  } else KS_FAIL(KS_ERR_ARG_WRONG, "unknown norm type %d", type);
+  return KS_SUCCESS;
+}
+extern "C" int ks_bv_norm(ks_bv bv, int type, double *val)                   // bvglobal.c:498
+{
+  KS_CHECK(type != KS_NORM_2, KS_ERR_SUP, "Requested norm not available");
+  return norm_impl(bv, -1, type, val, true);
+}
+extern "C" int ks_bv_normcolumn(ks_bv bv, int j, int type, double *val)      // bvglobal.c:662
+{
+  KS_CHECK(j >= 0, KS_ERR_ARG_OUTOFRANGE, "Argument j has wrong value %d", j);
+  return norm_impl(bv, j, type, val, true);
+}
+extern "C" int ks_bv_norm_local(ks_bv bv, int j, int type, double *val) { return norm_impl(bv, j, type, val, false); }
+
+extern "C" int ks_bv_copy(ks_bv V, ks_bv W)   // svec.c:232-247
+{
+  KS_CHECK(V && W, KS_ERR_ARG_NULL, "BV is NULL");
+  KS_CHECK(V->n == W->n, KS_ERR_ARG_INCOMP, "Mismatching local dimension V %d, W %d", V->n, W->n);
+  KS_CHECK(V->k - V->l == W->k - W->l, KS_ERR_ARG_SIZ, "W has %d active columns, should match %d active columns in V", W->k - W->l, V->k - V->l);
+  if (V == W || !V->n) return KS_SUCCESS;
+  KS_HIP(hipSetDevice(V->ctx->device));
+  for (int j = 0; j < V->k - V->l; j++) KS_CALL(ksk_copy(V->ctx, ks_bv_col(V, V->l + j), ks_bv_col(W, W->l + j), V->n));
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_copycolumn(ks_bv V, int j, int i)   // svec.c:249-259
+{
+  KS_CHECK(V, KS_ERR_ARG_NULL, "BV is NULL");
+  KS_CHECK(j >= 0 && j < V->m && i >= 0 && i < V->m, KS_ERR_ARG_OUTOFRANGE, "column index out of range (%d -> %d, m=%d)", j, i, V->m);
+  if (j == i) return KS_SUCCESS;
+  KS_HIP(hipSetDevice(V->ctx->device));
+  return ksk_copy(V->ctx, ks_bv_col(V, j), ks_bv_col(V, i), V->n);
+}
+
+// ---- ops->matmult -----------------------------------------------------------------------------------
+extern "C" int ks_bv_matmultcolumn(ks_bv V, ks_mat A, int j)   // bvops.c:862-885
+{
+  KS_CHECK(V && A, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(j >= 0, KS_ERR_ARG_OUTOFRANGE, "Index j must be non-negative");
+  KS_CHECK(j + 1 < V->m, KS_ERR_ARG_OUTOFRANGE, "Result should go in index j+1=%d but BV only has %d columns", j + 1, V->m);
+  KS_CHECK(A->n == V->n, KS_ERR_ARG_INCOMP, "Mismatching local row dimension A %d, V %d", A->n, V->n);
+  KS_HIP(hipSetDevice(V->ctx->device));
+  return ks_mat_mult_internal(A, ks_bv_col(V, j), ks_bv_col(V, j + 1));
+}
+
+extern "C" int ks_bv_matmult(ks_bv V, ks_mat A, ks_bv W)   // bvops.c BVMatMult, svec.c:213-222 (column loop)
+{
+  KS_CHECK(V && A && W, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(A->n == W->n && A->n == V->n, KS_ERR_ARG_INCOMP, "Mismatching local row dimension");
+  KS_CHECK(V->k - V->l == W->k - W->l, KS_ERR_ARG_SIZ, "Y has %d active columns, should match %d active columns in V", W->k - W->l, V->k - V->l);
+  KS_HIP(hipSetDevice(V->ctx->device));
+  for (int j = 0; j < V->k - V->l; j++) KS_CALL(ks_mat_mult_internal(A, ks_bv_col(V, V->l + j), ks_bv_col(W, W->l + j)));
+  return KS_SUCCESS;
+}

@@ -1,0 +1,256 @@
+// Context, error reporting, HIP-event profiling and the allreduce providers (RCCL / callback).
+#include "ksgpu_internal.h"
+#include <cstdarg>
+#include <dlfcn.h>
+
+static thread_local char g_errmsg[512] = "";
+
+void ks_set_error(const char *fmt, ...)
+{
+  va_list ap; va_start(ap, fmt); vsnprintf(g_errmsg, sizeof(g_errmsg), fmt, ap); va_end(ap);
+}
+
+extern "C" const char *ks_last_error_message(void) { return g_errmsg; }
+
+extern "C" const char *ks_error_string(int rc)
+{
+  switch (rc) {
+    case KS_SUCCESS: return "success";
+    case KS_ERR_MEM: return "out of memory";
+    case KS_ERR_SUP: return "no support for the requested operation";
+    case KS_ERR_ORDER: return "operation done in wrong order";
+    case KS_ERR_ARG_SIZ: return "nonconforming object sizes";
+    case KS_ERR_ARG_WRONG: return "wrong argument";
+    case KS_ERR_ARG_OUTOFRANGE: return "argument out of range";
+    case KS_ERR_USER_INPUT: return "invalid user input (invalid inner product)";
+    case KS_ERR_ARG_WRONGSTATE: return "object in wrong state";
+    case KS_ERR_ARG_INCOMP: return "arguments are incompatible";
+    case KS_ERR_LIB: return "error in external library (HIP/RCCL)";
+    case KS_ERR_PLIB: return "internal library error";
+    case KS_ERR_CONV_FAILED: return "convergence failed";
+    case KS_ERR_ARG_NULL: return "null argument";
+    case KS_ERR_GPU: return "no usable gfx950 GPU";
+    default: return "unknown error";
+  }
+}
+
+extern "C" int ks_ctx_create(int device, void *stream, ks_ctx *out)
+{
+  KS_CHECK(out, KS_ERR_ARG_NULL, "ctx output pointer is NULL");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) KS_FAIL(KS_ERR_GPU, "no HIP device available (%s); libksgpu has no CPU fallback", hipGetErrorString(e));
+  KS_CHECK(device >= 0 && device < ndev, KS_ERR_ARG_OUTOFRANGE, "device %d out of range (have %d)", device, ndev);
+  KS_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  KS_HIP(hipGetDeviceProperties(&prop, device));
+  ks_ctx ctx = new ks_ctx_s();
+  ctx->device = device;
+  ctx->num_cu = prop.multiProcessorCount;
+  snprintf(ctx->arch, sizeof(ctx->arch), "%s", prop.gcnArchName);
+  ctx->mem_total = prop.totalGlobalMem;
+  if (strncmp(ctx->arch, "gfx950", 6) != 0) {
+    delete ctx;
+    KS_FAIL(KS_ERR_GPU, "device %d is %s; libksgpu carries gfx950 code objects only", device, prop.gcnArchName);
+  }
+  if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
+  else { KS_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+  ctx->h_pinned_len = 16384;
+  KS_HIP(hipHostMalloc((void **)&ctx->h_pinned, ctx->h_pinned_len * sizeof(double), hipHostMallocDefault));
+  *out = ctx;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_ctx_destroy(ks_ctx ctx)
+{
+  if (!ctx) return KS_SUCCESS;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  for (auto &p : ctx->pending) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
+  for (auto &e : ctx->event_pool) hipEventDestroy(e);
+  if (ctx->comm.nccl_comm && ctx->comm.rccl_lib) {
+    typedef int (*destroy_t)(void *);
+    destroy_t f = (destroy_t)dlsym(ctx->comm.rccl_lib, "ncclCommDestroy");
+    if (f) f(ctx->comm.nccl_comm);
+  }
+  if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_ctx_synchronize(ks_ctx ctx)
+{
+  KS_CHECK(ctx, KS_ERR_ARG_NULL, "ctx is NULL");
+  KS_HIP(hipStreamSynchronize(ctx->stream));
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_ctx_device_info(ks_ctx ctx, char *arch, int arch_len, int *num_cu, size_t *mem_total)
+{
+  KS_CHECK(ctx, KS_ERR_ARG_NULL, "ctx is NULL");
+  if (arch && arch_len > 0) snprintf(arch, arch_len, "%s", ctx->arch);
+  if (num_cu) *num_cu = ctx->num_cu;
+  if (mem_total) *mem_total = ctx->mem_total;
+  return KS_SUCCESS;
+}
+
+// ---- profiling ----------------------------------------------------------------------------------
+static const char *g_class_names[KS_K_COUNT] = {
+  "spmv_csr", "bv_dot_sweep", "gs_bookkeeping", "gs_update_fused_dot", "gs_update", "bv_scale", "bv_multinplace", "bv_copy",
+  "bv_mult", "bv_dot_panel", "bv_norm", "halo_exchange", "allreduce", "other" };
+
+extern "C" const char *ks_prof_class_name(int k) { return (k >= 0 && k < KS_K_COUNT) ? g_class_names[k] : "?"; }
+
+static int get_event(ks_ctx ctx, hipEvent_t *e)
+{
+  if (!ctx->event_pool.empty()) { *e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return KS_SUCCESS; }
+  KS_HIP(hipEventCreate(e));
+  return KS_SUCCESS;
+}
+
+int ks_prof_begin(ks_ctx ctx, int kclass, double bytes)
+{
+  KsProfPending p; p.kclass = kclass; p.bytes = bytes;
+  KS_CALL(get_event(ctx, &p.e0)); KS_CALL(get_event(ctx, &p.e1));
+  KS_HIP(hipEventRecord(p.e0, ctx->stream));
+  ctx->pending.push_back(p);
+  return KS_SUCCESS;
+}
+
+int ks_prof_end(ks_ctx ctx)
+{
+  if (ctx->pending.empty()) return KS_SUCCESS;
+  KS_HIP(hipEventRecord(ctx->pending.back().e1, ctx->stream));
+  if (ctx->pending.size() > 60000) KS_CALL(ks_prof_flush(ctx));
+  return KS_SUCCESS;
+}
+
+int ks_prof_flush(ks_ctx ctx)
+{
+  if (ctx->pending.empty()) return KS_SUCCESS;
+  KS_HIP(hipStreamSynchronize(ctx->stream));
+  for (auto &p : ctx->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+      ctx->prof[p.kclass].launches++; ctx->prof[p.kclass].ms += ms; ctx->prof[p.kclass].bytes += p.bytes;
+    }
+    ctx->event_pool.push_back(p.e0); ctx->event_pool.push_back(p.e1);
+  }
+  ctx->pending.clear();
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_prof_enable(ks_ctx ctx, int on)
+{
+  KS_CHECK(ctx, KS_ERR_ARG_NULL, "ctx is NULL");
+  if (!on) KS_CALL(ks_prof_flush(ctx));
+  ctx->prof_on = on != 0;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_prof_reset(ks_ctx ctx)
+{
+  KS_CHECK(ctx, KS_ERR_ARG_NULL, "ctx is NULL");
+  KS_CALL(ks_prof_flush(ctx));
+  for (int i = 0; i < KS_K_COUNT; i++) ctx->prof[i] = KsProfSlot();
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_prof_get(ks_ctx ctx, int kclass, long long *launches, double *ms, double *bytes)
+{
+  KS_CHECK(ctx, KS_ERR_ARG_NULL, "ctx is NULL");
+  KS_CHECK(kclass >= 0 && kclass < KS_K_COUNT, KS_ERR_ARG_OUTOFRANGE, "kernel class %d out of range", kclass);
+  KS_CALL(ks_prof_flush(ctx));
+  if (launches) *launches = ctx->prof[kclass].launches;
+  if (ms) *ms = ctx->prof[kclass].ms;
+  if (bytes) *bytes = ctx->prof[kclass].bytes;
+  return KS_SUCCESS;
+}
+
+// ---- communicator -------------------------------------------------------------------------------
+// RCCL is resolved at run time: a launcher that already loaded librccl (torch.distributed's "nccl"
+// backend IS RCCL) shares that copy; otherwise /opt/rocm/lib/librccl.so.1 is opened.
+struct NcclUniqueIdRaw { char internal[KS_UNIQUE_ID_BYTES]; };
+typedef int (*nccl_getuid_t)(NcclUniqueIdRaw *);
+typedef int (*nccl_initrank_t)(void **, int, NcclUniqueIdRaw, int);
+typedef int (*nccl_allreduce_t)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef const char *(*nccl_errstr_t)(int);
+
+static void *open_rccl()
+{
+  void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  return h;
+}
+
+extern "C" int ks_comm_get_unique_id(unsigned char id[KS_UNIQUE_ID_BYTES])
+{
+  KS_CHECK(id, KS_ERR_ARG_NULL, "id is NULL");
+  void *h = open_rccl();
+  KS_CHECK(h, KS_ERR_LIB, "cannot open librccl: %s", dlerror());
+  nccl_getuid_t f = (nccl_getuid_t)dlsym(h, "ncclGetUniqueId");
+  KS_CHECK(f, KS_ERR_LIB, "ncclGetUniqueId not found");
+  NcclUniqueIdRaw raw; memset(&raw, 0, sizeof(raw));
+  int rc = f(&raw);
+  KS_CHECK(rc == 0, KS_ERR_LIB, "ncclGetUniqueId failed (%d)", rc);
+  memcpy(id, raw.internal, KS_UNIQUE_ID_BYTES);
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_comm_init_rccl(ks_ctx ctx, int rank, int size, const unsigned char id[KS_UNIQUE_ID_BYTES])
+{
+  KS_CHECK(ctx && id, KS_ERR_ARG_NULL, "ctx or id is NULL");
+  KS_CHECK(size >= 1 && rank >= 0 && rank < size, KS_ERR_ARG_OUTOFRANGE, "bad rank/size %d/%d", rank, size);
+  KS_HIP(hipSetDevice(ctx->device));
+  void *h = open_rccl();
+  KS_CHECK(h, KS_ERR_LIB, "cannot open librccl: %s", dlerror());
+  nccl_initrank_t f = (nccl_initrank_t)dlsym(h, "ncclCommInitRank");
+  KS_CHECK(f, KS_ERR_LIB, "ncclCommInitRank not found");
+  NcclUniqueIdRaw raw; memcpy(raw.internal, id, KS_UNIQUE_ID_BYTES);
+  void *comm = nullptr;
+  int rc = f(&comm, size, raw, rank);
+  KS_CHECK(rc == 0, KS_ERR_LIB, "ncclCommInitRank failed (%d)", rc);
+  ctx->comm.rccl_lib = h; ctx->comm.nccl_comm = comm; ctx->comm.rank = rank; ctx->comm.size = size;
+  ctx->comm.cb_allreduce = nullptr;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_comm_set_callbacks(ks_ctx ctx, int rank, int size, ks_allreduce_fn allreduce, void *user)
+{
+  KS_CHECK(ctx, KS_ERR_ARG_NULL, "ctx is NULL");
+  KS_CHECK(size >= 1 && rank >= 0 && rank < size, KS_ERR_ARG_OUTOFRANGE, "bad rank/size %d/%d", rank, size);
+  KS_CHECK(size == 1 || allreduce, KS_ERR_ARG_NULL, "allreduce callback required when size>1");
+  ctx->comm.rank = rank; ctx->comm.size = size; ctx->comm.cb_allreduce = allreduce; ctx->comm.cb_user = user;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_comm_rank_size(ks_ctx ctx, int *rank, int *size)
+{
+  KS_CHECK(ctx, KS_ERR_ARG_NULL, "ctx is NULL");
+  if (rank) *rank = ctx->comm.rank;
+  if (size) *size = ctx->comm.size;
+  return KS_SUCCESS;
+}
+
+// In-place SUM allreduce of `count` doubles in device memory, stream-ordered (bvblas.c:255 MPIU_Allreduce).
+int ks_allreduce_sum(ks_ctx ctx, double *dev_buf, int count)
+{
+  if (ctx->comm.size <= 1 || count <= 0) return KS_SUCCESS;
+  KsProfScope ps(ctx, KS_K_ALLREDUCE, 8.0 * count);
+  if (ctx->comm.cb_allreduce) {
+    int rc = ctx->comm.cb_allreduce(ctx->comm.cb_user, dev_buf, count, (void *)ctx->stream);
+    KS_CHECK(rc == 0, KS_ERR_LIB, "allreduce callback failed (%d)", rc);
+    return KS_SUCCESS;
+  }
+  KS_CHECK(ctx->comm.nccl_comm, KS_ERR_ORDER, "size>1 but no communicator: call ks_comm_init_rccl or ks_comm_set_callbacks");
+  static nccl_allreduce_t f = nullptr;
+  if (!f) f = (nccl_allreduce_t)dlsym(ctx->comm.rccl_lib, "ncclAllReduce");
+  KS_CHECK(f, KS_ERR_LIB, "ncclAllReduce not found");
+  const int ncclFloat64 = 8, ncclSum = 0;
+  int rc = f(dev_buf, dev_buf, (size_t)count, ncclFloat64, ncclSum, ctx->comm.nccl_comm, ctx->stream);
+  KS_CHECK(rc == 0, KS_ERR_LIB, "ncclAllReduce failed (%d)", rc);
+  return KS_SUCCESS;
+}

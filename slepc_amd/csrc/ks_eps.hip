@@ -1,0 +1,482 @@
+// Host side of the path: the Krylov-Schur restart driver and the dense projected problem (DS HEP).
+//
+// Restates, in plain C++ on host scalars (no device code here):
+//   EPSSetUp_KrylovSchur            src/eps/impls/krylov/krylovschur/krylovschur.c:93-194
+//   EPSSetDimensions_Default        src/eps/interface/epssetup.c:654-678
+//   EPSSolve_KrylovSchur_Default    krylovschur.c:227-337
+//   EPSKrylovConvergence            src/eps/impls/krylov/epskrylov.c:207-295
+//   EPSConvergedRelative / EPSStoppingBasic   src/eps/interface/epsdefault.c:224,290
+//   EPSGetStartVector               src/eps/interface/epssolve.c:841-873
+//   EPSSolve epilogue + SlepcSortEigenvalues  epssolve.c:119-208, src/sys/slepcsc.c:89-140
+//   EPSComputeError / EPSComputeResidualNorm_Private  epssolve.c:666-718,742-815
+//   DS HEP (compact, extra row):    src/sys/classes/ds/impls/hep/dshep.c:137-175 (vectors), :221-262
+//       (DSArrowTridiag), :267-321 (intermediate), :323-347 (sort), :349-381 (extra row), :383-426
+//       (solve), :643-671 (truncate); sort kernels src/sys/classes/ds/interface/dspriv.c:224-270
+// The reference calls LAPACK steqr / lartg / BLAS rot for the m x m (m <= 64) problem; LAPACK is not
+// part of this image's C toolchain, so the tridiagonal eigenproblem is solved by the implicit QL/QR
+// iteration written out below (same algorithm family as steqr; eigenvalues returned ascending as steqr
+// does, so that the insertion sort of DSSort sees the same input order).
+#include "ksgpu_internal.h"
+#include <algorithm>
+#include <limits>
+
+namespace {
+
+// ---- small dense kernels ---------------------------------------------------------------------------
+// Givens rotation with LAPACK-3.10 dlartg conventions: c >= 0, r = sign(f)*hypot(f,g)
+void lartg(double f, double g, double *c, double *s, double *r)
+{
+  if (g == 0.0) { *c = 1.0; *s = 0.0; *r = f; }
+  else if (f == 0.0) { *c = 0.0; *s = (g < 0.0) ? -1.0 : 1.0; *r = fabs(g); }
+  else { const double d = hypot(f, g); *c = fabs(f) / d; *r = copysign(d, f); *s = g / *r; }
+}
+
+// BLAS drot on the first n entries of two columns
+void rot(int n, double *x, double *y, double c, double s)
+{
+  for (int i = 0; i < n; i++) { const double t = c * x[i] + s * y[i]; y[i] = c * y[i] - s * x[i]; x[i] = t; }
+}
+
+// Symmetric tridiagonal eigenproblem by implicit QL with Wilkinson shifts, accumulating the rotations
+// into the columns of Z (Z <- Z * eigvecs), eigenvalues sorted ascending on exit (steqr 'V' contract).
+// d[0..n), e[0..n-1) ; Z is ldz x n column-major with n rows used (nz rows updated).
+int tridiag_ql(int n, double *d, double *e, double *Z, int ldz, int nz)
+{
+  if (n <= 1) return 0;
+  std::vector<double> ee(n, 0.0);
+  for (int i = 0; i < n - 1; i++) ee[i] = e[i];
+  const double eps = std::numeric_limits<double>::epsilon();
+  for (int l = 0; l < n; l++) {
+    int iter = 0, mm;
+    do {
+      for (mm = l; mm < n - 1; mm++) {
+        const double dd = fabs(d[mm]) + fabs(d[mm + 1]);
+        if (fabs(ee[mm]) <= eps * dd) break;
+      }
+      if (mm != l) {
+        if (iter++ == 60 * 4) return l + 1;
+        double g = (d[l + 1] - d[l]) / (2.0 * ee[l]);
+        double r = hypot(g, 1.0);
+        g = d[mm] - d[l] + ee[l] / (g + copysign(r, g));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = mm - 1; i >= l; i--) {
+          double f = s * ee[i];
+          const double b = c * ee[i];
+          r = hypot(f, g);
+          ee[i + 1] = r;
+          if (r == 0.0) { d[i + 1] -= p; ee[mm] = 0.0; break; }
+          s = f / r; c = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * s + 2.0 * c * b;
+          p = s * r;
+          d[i + 1] = g + p;
+          g = c * r - b;
+          for (int k = 0; k < nz; k++) {
+            double *zk = Z + k;
+            f = zk[(size_t)(i + 1) * ldz];
+            zk[(size_t)(i + 1) * ldz] = s * zk[(size_t)i * ldz] + c * f;
+            zk[(size_t)i * ldz] = c * zk[(size_t)i * ldz] - s * f;
+          }
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p; ee[l] = g; ee[mm] = 0.0;
+      }
+    } while (mm != l);
+  }
+  // selection sort, ascending, swapping eigenvector columns (dsteqr epilogue)
+  for (int ii = 1; ii < n; ii++) {
+    const int i = ii - 1; int k = i; double p = d[i];
+    for (int j = ii; j < n; j++) if (d[j] < p) { k = j; p = d[j]; }
+    if (k != i) { d[k] = d[i]; d[i] = p; for (int r = 0; r < nz; r++) std::swap(Z[r + (size_t)i * ldz], Z[r + (size_t)k * ldz]); }
+  }
+  for (int i = 0; i < n - 1; i++) e[i] = 0.0;
+  return 0;
+}
+
+// SlepcCompare* (src/sys/slepcsc.c:152-213), real scalars
+int compare_eig(int which, double ar, double ai, double br, double bi)
+{
+  double a, b;
+  switch (which) {
+    case KS_EPS_LARGEST_MAGNITUDE:  a = hypot(ar, ai); b = hypot(br, bi); return a < b ? 1 : (a > b ? -1 : 0);
+    case KS_EPS_SMALLEST_MAGNITUDE: a = hypot(ar, ai); b = hypot(br, bi); return a > b ? 1 : (a < b ? -1 : 0);
+    case KS_EPS_LARGEST_REAL:       return ar < br ? 1 : (ar > br ? -1 : 0);
+    case KS_EPS_SMALLEST_REAL:      return ar > br ? 1 : (ar < br ? -1 : 0);
+  }
+  return 0;
+}
+
+enum { DS_RAW = 0, DS_INTERMEDIATE = 1, DS_CONDENSED = 2, DS_TRUNCATED = 3 };
+
+// DS type HEP, compact storage with extra row (krylovschur.c:160-168)
+struct DsHep {
+  int ld = 0, n = 0, l = 0, k = 0, t = 0, state = DS_RAW, which = KS_EPS_LARGEST_MAGNITUDE;
+  std::vector<double> T, Q; std::vector<int> perm;
+  void allocate(int ld_) { ld = ld_; T.assign((size_t)3 * ld, 0.0); Q.assign((size_t)ld * ld, 0.0); perm.assign(ld, 0); }
+  double *d() { return T.data(); }
+  double *e() { return T.data() + ld; }
+  void set_dimensions(int n_, int l_, int k_) { n = n_; t = n_; l = l_; k = k_; }           // dsops.c:130-165
+
+  void arrow_tridiag(int nn, double *dd, double *ee, double *QQ)                             // dshep.c:221-262
+  {
+    if (nn <= 2) return;
+    for (int j = 0; j < nn - 2; j++) {
+      double c, s, temp = ee[j + 1];
+      lartg(temp, ee[j], &c, &s, &ee[j + 1]);
+      s = -s;
+      temp = dd[j + 1];
+      ee[j] = c * s * (temp - dd[j]);
+      dd[j + 1] = s * s * dd[j] + c * c * temp;
+      dd[j] = c * c * dd[j] + s * s * temp;
+      const int j2 = j + 2;
+      rot(j2, QQ + (size_t)j * ld, QQ + (size_t)(j + 1) * ld, c, s);
+      for (int i = j - 1; i >= 0; i--) {
+        const double off = -s * ee[i];
+        ee[i] = c * ee[i];
+        temp = ee[i + 1];
+        lartg(temp, off, &c, &s, &ee[i + 1]);
+        s = -s;
+        temp = (dd[i] - dd[i + 1]) * s - 2.0 * c * ee[i];
+        const double p = s * temp;
+        dd[i + 1] += p;
+        dd[i] -= p;
+        ee[i] = -ee[i] - c * temp;
+        rot(j2, QQ + (size_t)i * ld, QQ + (size_t)(i + 1) * ld, c, s);
+      }
+    }
+  }
+
+  int solve(double *wr)                                                                     // dsops.c:723, dshep.c:383-426
+  {
+    if (state >= DS_CONDENSED) return 0;
+    const int n1 = n - l; const size_t off = (size_t)l + (size_t)l * ld;
+    std::fill(Q.begin(), Q.end(), 0.0);
+    for (int i = 0; i < ld; i++) Q[(size_t)i + (size_t)i * ld] = 1.0;                       // DSSetIdentity
+    if (state < DS_INTERMEDIATE) arrow_tridiag(std::max(0, k - l + 1), d() + l, e() + l, Q.data() + off);   // DSIntermediate_HEP
+    for (int i = 0; i < l; i++) wr[i] = d()[i];
+    int info = tridiag_ql(n1, d() + l, e() + l, Q.data() + off, ld, n1);
+    if (info) return info;
+    for (int i = l; i < n; i++) wr[i] = d()[i];
+    for (int i = 0; i < n - 1; i++) e()[i] = 0.0;                                           // compact: zero e(0:n-2), keep e(n-1)
+    state = DS_CONDENSED;
+    return 0;
+  }
+
+  void sort(double *wr)                                                                     // dsops.c:329-345, dshep.c:323-347
+  {
+    for (int i = 0; i < n; i++) perm[i] = i;
+    double *dd = d();
+    // DSSortEigenvaluesReal_Private dspriv.c:224-243: insertion sort of the first t values from l
+    for (int i = l + 1; i < t; i++) {
+      const double re = dd[perm[i]];
+      int j = i - 1;
+      int result = compare_eig(which, re, 0.0, dd[perm[j]], 0.0);
+      while (result < 0 && j >= l) {
+        std::swap(perm[j], perm[j + 1]); j--;
+        if (j >= l) result = compare_eig(which, re, 0.0, dd[perm[j]], 0.0);
+      }
+    }
+    for (int i = l; i < n; i++) wr[i] = dd[perm[i]];
+    // DSPermuteColumns_Private dspriv.c:248-270
+    for (int i = l; i < n; i++) {
+      const int p = perm[i];
+      if (p != i) {
+        int j = i + 1;
+        while (perm[j] != i) j++;
+        perm[j] = p; perm[i] = i;
+        for (int r = 0; r < n; r++) std::swap(Q[(size_t)r + (size_t)p * ld], Q[(size_t)r + (size_t)i * ld]);
+      }
+    }
+    for (int i = l; i < n; i++) dd[i] = wr[i];
+  }
+
+  void update_extra_row()                                                                   // dshep.c:349-381 (compact)
+  {
+    const double beta = e()[n - 1];
+    for (int i = 0; i < n; i++) e()[i] = beta * Q[(size_t)(n - 1) + (size_t)i * ld];
+    k = n;
+  }
+  double vectors_resnorm(int j) { return fabs(Q[(size_t)(n - 1) + (size_t)j * ld]); }       // dshep.c:152
+
+  void truncate(int nn, bool trim)                                                          // dsops.c DSTruncate + dshep.c:643-671
+  {
+    if (trim) { l = 0; k = 0; n = nn; t = nn; state = DS_RAW; }
+    else { k = nn; t = n; n = nn; state = DS_TRUNCATED; }
+  }
+};
+
+} // namespace
+
+struct ks_eps_s {
+  ks_ctx ctx = nullptr;
+  ks_mat A = nullptr;
+  ks_bv V = nullptr, W = nullptr;      // basis (ncv+1 columns), work vectors (2 columns)
+  int problem_type = KS_EPS_HEP;
+  int nev = 1, ncv = 0, mpd = 0, ncv_user = 0, mpd_user = 0;
+  double tol = 1e-8; int max_it = 0, max_it_user = 0;
+  int which = KS_EPS_LARGEST_MAGNITUDE;
+  double keep = 0.5;
+  uint64_t seed = 0x12345678ULL;
+  std::vector<double> v0; bool have_v0 = false;
+  long long max_steps = 0;
+  // results
+  std::vector<double> eigr, eigi, errest; std::vector<int> perm;
+  int nconv = 0, its = 0, reason = 0;
+  long long steps = 0, passes = 0; int restarts = 0;
+  bool solved = false;
+  DsHep ds;
+};
+
+extern "C" int ks_eps_create(ks_ctx ctx, ks_eps *out)
+{
+  KS_CHECK(ctx && out, KS_ERR_ARG_NULL, "ctx/out is NULL");
+  ks_eps eps = new ks_eps_s(); eps->ctx = ctx; *out = eps;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_eps_destroy(ks_eps eps)
+{
+  if (!eps) return KS_SUCCESS;
+  ks_bv_destroy(eps->V); ks_bv_destroy(eps->W);
+  delete eps;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_eps_set_operators(ks_eps eps, ks_mat A, ks_mat B)   // epssetup.c:450
+{
+  KS_CHECK(eps && A, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(!B, KS_ERR_SUP, "generalized problems (B != NULL) are outside this build's scope");
+  if (eps->V && eps->A && eps->A->n != A->n) { ks_bv_destroy(eps->V); ks_bv_destroy(eps->W); eps->V = eps->W = nullptr; }
+  eps->A = A; eps->solved = false;
+  return KS_SUCCESS;
+}
+extern "C" int ks_eps_set_problem_type(ks_eps eps, int type)
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  KS_CHECK(type == KS_EPS_HEP, KS_ERR_SUP, "only EPS_HEP (symmetric, Lanczos) is driven end to end in this build; use ks_bv_matarnoldi for the non-symmetric expansion");
+  eps->problem_type = type; return KS_SUCCESS;
+}
+extern "C" int ks_eps_set_dimensions(ks_eps eps, int nev, int ncv, int mpd)
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  KS_CHECK(nev >= 1, KS_ERR_ARG_OUTOFRANGE, "Illegal value of nev. Must be > 0");
+  eps->nev = nev; eps->ncv_user = ncv > 0 ? ncv : 0; eps->mpd_user = mpd > 0 ? mpd : 0; eps->solved = false;
+  return KS_SUCCESS;
+}
+extern "C" int ks_eps_set_tolerances(ks_eps eps, double tol, int max_it)
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  eps->tol = tol > 0.0 ? tol : 1e-8;                 // SLEPC_DEFAULT_TOL epssetup.c:378, slepcmath.h:25
+  eps->max_it_user = max_it > 0 ? max_it : 0;
+  return KS_SUCCESS;
+}
+extern "C" int ks_eps_set_which_eigenpairs(ks_eps eps, int which)
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  KS_CHECK(which >= KS_EPS_LARGEST_MAGNITUDE && which <= KS_EPS_SMALLEST_REAL, KS_ERR_ARG_OUTOFRANGE, "Invalid 'which' value");
+  eps->which = which; return KS_SUCCESS;
+}
+extern "C" int ks_eps_set_krylovschur_restart(ks_eps eps, double keep)   // krylovschur.c:339-350
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  KS_CHECK(keep >= 0.1 && keep <= 0.9, KS_ERR_ARG_OUTOFRANGE, "The keep argument %g must be in the range [.1,.9]", keep);
+  eps->keep = keep; return KS_SUCCESS;
+}
+extern "C" int ks_eps_set_random_seed(ks_eps eps, uint64_t seed) { KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL"); eps->seed = seed; return KS_SUCCESS; }
+extern "C" int ks_eps_set_initial_vector(ks_eps eps, const double *v)
+{
+  KS_CHECK(eps && eps->A, KS_ERR_ORDER, "set the operators first");
+  if (!v) { eps->have_v0 = false; return KS_SUCCESS; }
+  eps->v0.assign(v, v + eps->A->n); eps->have_v0 = true;
+  return KS_SUCCESS;
+}
+extern "C" int ks_eps_set_max_steps(ks_eps eps, long long s) { KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL"); eps->max_steps = s > 0 ? s : 0; return KS_SUCCESS; }
+
+// EPSGetStartVector epssolve.c:841-873
+static int start_vector(ks_eps eps, int i, bool *breakdown)
+{
+  if (i == 0 && eps->have_v0) KS_CALL(ks_bv_set_column_host(eps->V, 0, eps->v0.data()));
+  else KS_CALL(ks_bv_set_random_column(eps->V, i, eps->seed));
+  double norm = 0.0; int lindep = 0;
+  KS_CALL(ks_bv_orthogonalizecolumn(eps->V, i, nullptr, &norm, &lindep));
+  if (breakdown) *breakdown = lindep != 0;
+  else if (lindep || norm == 0.0) {
+    if (i == 0) KS_FAIL(KS_ERR_PLIB, "Initial vector is zero or belongs to the deflation space");
+    KS_FAIL(KS_ERR_CONV_FAILED, "Unable to generate more start vectors");
+  }
+  KS_CALL(ks_bv_scalecolumn(eps->V, i, 1.0 / norm));
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve_KrylovSchur_Default krylovschur.c:227
+{
+  KS_CHECK(eps && eps->A, KS_ERR_ORDER, "EPSSetOperators must be called first");
+  ks_mat A = eps->A;
+  const int n = A->n_global;
+  // ---- EPSSetUp ----
+  int nev = eps->nev, ncv = eps->ncv_user, mpd = eps->mpd_user;
+  if (ncv) { KS_CHECK(ncv >= nev + 1 || (ncv == nev && ncv == n), KS_ERR_USER_INPUT, "The value of ncv must be at least nev+1"); }
+  else if (mpd) ncv = std::min(n, nev + mpd);
+  else { if (nev < 500) ncv = std::min(n, std::max(2 * nev, nev + 15)); else { mpd = 500; ncv = std::min(n, nev + mpd); } }
+  if (!mpd) mpd = ncv;
+  KS_CHECK(ncv <= nev + mpd, KS_ERR_USER_INPUT, "The value of ncv must not be larger than nev+mpd");
+  KS_CHECK(ncv + 1 <= KS_MAX_COLS || getenv("KSGPU_NO_FUSED_GS"), KS_ERR_SUP, "ncv+1 = %d exceeds the %d columns supported by the fused kernels", ncv + 1, KS_MAX_COLS);
+  eps->ncv = ncv; eps->mpd = mpd;
+  eps->max_it = eps->max_it_user ? eps->max_it_user : std::max(100, 2 * n / ncv);
+  if (eps->V) { int vm = 0; ks_bv_get_sizes(eps->V, nullptr, nullptr, &vm, nullptr); if (vm != ncv + 1) { ks_bv_destroy(eps->V); eps->V = nullptr; } }
+  if (!eps->V) { KS_CALL(ks_bv_create(eps->ctx, A->n, A->n_global, ncv + 1, 0, &eps->V)); eps->V->row_start = A->row_start; }   // EPSAllocateSolution(eps,1)
+  if (!eps->W) { KS_CALL(ks_bv_create(eps->ctx, A->n, A->n_global, 2, 0, &eps->W)); }
+  eps->eigr.assign(ncv + 1, 0.0); eps->eigi.assign(ncv + 1, 0.0); eps->errest.assign(ncv + 1, 0.0);
+  eps->perm.resize(ncv + 1); for (int i = 0; i <= ncv; i++) eps->perm[i] = i;
+  DsHep &ds = eps->ds;
+  ds.allocate(ncv + 1); ds.which = eps->which; ds.state = DS_RAW;
+  eps->nconv = 0; eps->its = 0; eps->reason = KS_EPS_CONVERGED_ITERATING; eps->steps = 0; eps->restarts = 0; eps->solved = false;
+  long long passes0 = 0; ks_bv_gs_passes(eps->V, &passes0, nullptr);
+  ks_bv V = eps->V;
+  KS_CALL(ks_bv_set_active_columns(V, 0, ncv + 1));
+
+  // ---- EPSSolve_KrylovSchur_Default ----
+  KS_CALL(start_vector(eps, 0, nullptr));
+  int l = 0;
+  while (eps->reason == KS_EPS_CONVERGED_ITERATING) {
+    eps->its++;
+    int nv = std::min(eps->nconv + mpd, ncv);
+    if (eps->max_steps && eps->steps + (nv - (eps->nconv + l)) > eps->max_steps) nv = eps->nconv + l + (int)(eps->max_steps - eps->steps);
+    ds.set_dimensions(nv, eps->nconv, eps->nconv + l);
+    double beta = 0.0; int breakdown = 0;
+    const int k0 = eps->nconv + l;
+    KS_CALL(ks_bv_matlanczos(V, A, ds.T.data(), ds.ld, k0, &nv, &beta, &breakdown));
+    eps->steps += nv - k0;
+    ds.set_dimensions(nv, eps->nconv, eps->nconv + l);
+    ds.state = l ? DS_RAW : DS_INTERMEDIATE;
+    KS_CALL(ks_bv_set_active_columns(V, eps->nconv, nv));
+
+    // solve projected problem
+    int info = ds.solve(eps->eigr.data());
+    KS_CHECK(info == 0, KS_ERR_LIB, "tridiagonal QL iteration failed to converge (info=%d)", info);
+    ds.sort(eps->eigr.data());
+    ds.update_extra_row();
+
+    // EPSKrylovConvergence(eps,FALSE,nconv,nv-nconv,beta,0.0,1.0,&k)
+    int marker = -1, k;
+    for (k = eps->nconv; k < nv; k++) {
+      const double re = eps->eigr[k];              // shift ST with sigma=0: STBackTransform is the identity (shift.c:49)
+      const double resnorm = ds.vectors_resnorm(k) * beta * 1.0;
+      const double w = fabs(re);
+      eps->errest[k] = (w != 0.0) ? resnorm / w : std::numeric_limits<double>::max();     // EPSConvergedRelative
+      if (marker == -1 && eps->errest[k] >= eps->tol) marker = k;
+      if (marker != -1) break;
+    }
+    if (marker != -1) k = marker;
+    // EPSStoppingBasic
+    if (k >= nev) eps->reason = KS_EPS_CONVERGED_TOL;
+    else if (eps->its >= eps->max_it) eps->reason = KS_EPS_DIVERGED_ITS;
+    if (eps->reason == KS_EPS_CONVERGED_ITERATING && eps->max_steps && eps->steps >= eps->max_steps) eps->reason = KS_EPS_CONVERGED_USER;
+
+    // update l
+    if (eps->reason != KS_EPS_CONVERGED_ITERATING || breakdown || k == nv) l = 0;
+    else l = std::max(1, (int)((nv - k) * eps->keep));
+    if (eps->reason == KS_EPS_CONVERGED_ITERATING) {
+      if (breakdown || k == nv) {
+        if (k < nev) {
+          bool brk = false;
+          KS_CALL(start_vector(eps, k, &brk));
+          if (brk) eps->reason = KS_EPS_DIVERGED_BREAKDOWN;
+        }
+      } else ds.truncate(k + l, false);
+    }
+    // V(:,nconv:k+l) = V(:,nconv:nv) * Q(nconv:nv, nconv:k+l)      krylovschur.c:324-327
+    KS_CALL(ks_bv_multinplace(V, ds.Q.data(), ds.ld, eps->nconv, k + l));
+    if (eps->reason == KS_EPS_CONVERGED_ITERATING && !breakdown) KS_CALL(ks_bv_copycolumn(V, nv, k + l));
+    eps->nconv = k;
+    eps->restarts++;
+  }
+  ds.truncate(eps->nconv, true);
+
+  // ---- EPSSolve epilogue ----
+  KS_CALL(ks_bv_set_active_columns(V, 0, eps->nconv));
+  // SlepcSortEigenvalues slepcsc.c:89-140 (all eigenvalues real here)
+  const int nc = eps->nconv;
+  for (int i = 0; i <= ncv; i++) eps->perm[i] = i;
+  for (int i = nc - 1; i >= 0; i--) {
+    const double re = eps->eigr[eps->perm[i]];
+    int j = i + 1;
+    while (j < nc) {
+      if (compare_eig(eps->which, re, 0.0, eps->eigr[eps->perm[j]], 0.0) <= 0) break;
+      std::swap(eps->perm[j - 1], eps->perm[j]); j++;
+    }
+  }
+  long long passes1 = 0; ks_bv_gs_passes(V, &passes1, nullptr);
+  eps->passes = passes1 - passes0;
+  eps->solved = true;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_eps_get_converged(ks_eps eps, int *nconv) { KS_CHECK(eps && nconv, KS_ERR_ARG_NULL, "NULL argument"); KS_CHECK(eps->solved, KS_ERR_ARG_WRONGSTATE, "Must call EPSSolve() first"); *nconv = eps->nconv; return KS_SUCCESS; }
+extern "C" int ks_eps_get_iteration_number(ks_eps eps, int *its) { KS_CHECK(eps && its, KS_ERR_ARG_NULL, "NULL argument"); *its = eps->its; return KS_SUCCESS; }
+extern "C" int ks_eps_get_converged_reason(ks_eps eps, int *reason) { KS_CHECK(eps && reason, KS_ERR_ARG_NULL, "NULL argument"); KS_CHECK(eps->solved, KS_ERR_ARG_WRONGSTATE, "Must call EPSSolve() first"); *reason = eps->reason; return KS_SUCCESS; }
+extern "C" int ks_eps_get_dimensions(ks_eps eps, int *nev, int *ncv, int *mpd)
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  if (nev) *nev = eps->nev; if (ncv) *ncv = eps->ncv; if (mpd) *mpd = eps->mpd;
+  return KS_SUCCESS;
+}
+extern "C" int ks_eps_get_eigenvalue(ks_eps eps, int i, double *eigr, double *eigi)   // EPSGetEigenvalue epssolve.c:478: through perm
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  KS_CHECK(eps->solved, KS_ERR_ARG_WRONGSTATE, "Must call EPSSolve() first");
+  KS_CHECK(i >= 0, KS_ERR_ARG_OUTOFRANGE, "The index cannot be negative");
+  KS_CHECK(i < eps->nconv, KS_ERR_ARG_OUTOFRANGE, "The index can be nconv-1 at most, see EPSGetConverged()");
+  const int k = eps->perm[i];
+  if (eigr) *eigr = eps->eigr[k];
+  if (eigi) *eigi = 0.0;
+  return KS_SUCCESS;
+}
+extern "C" int ks_eps_get_eigenvector_host(ks_eps eps, int i, double *xr)
+{
+  KS_CHECK(eps && xr, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(eps->solved, KS_ERR_ARG_WRONGSTATE, "Must call EPSSolve() first");
+  KS_CHECK(i >= 0 && i < eps->nconv, KS_ERR_ARG_OUTOFRANGE, "The index can be nconv-1 at most, see EPSGetConverged()");
+  return ks_bv_get_column_host(eps->V, eps->perm[i], xr);      // EPSComputeVectors_Hermitian: V already holds the Ritz vectors
+}
+extern "C" int ks_eps_get_error_estimate(ks_eps eps, int i, double *errest)
+{
+  KS_CHECK(eps && errest, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(eps->solved, KS_ERR_ARG_WRONGSTATE, "Must call EPSSolve() first");
+  KS_CHECK(i >= 0 && i < eps->nconv, KS_ERR_ARG_OUTOFRANGE, "The index can be nconv-1 at most, see EPSGetConverged()");
+  *errest = eps->errest[eps->perm[i]];
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_eps_compute_error(ks_eps eps, int i, int type, double *error)   // epssolve.c:742-815 with :666-718
+{
+  KS_CHECK(eps && error, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(eps->solved, KS_ERR_ARG_WRONGSTATE, "Must call EPSSolve() first");
+  KS_CHECK(i >= 0 && i < eps->nconv, KS_ERR_ARG_OUTOFRANGE, "The index can be nconv-1 at most, see EPSGetConverged()");
+  const int j = eps->perm[i];
+  const double kr = eps->eigr[j];
+  ks_bv W = eps->W, V = eps->V;
+  // W0 = x ; W1 = u = A*x ; u -= kr*x ; ||u||
+  KS_CALL(ksk_copy(eps->ctx, ks_bv_col(V, j), ks_bv_col(W, 0), V->n));
+  KS_CALL(ks_mat_mult_internal(eps->A, ks_bv_col(W, 0), ks_bv_col(W, 1)));
+  if (fabs(kr) > std::numeric_limits<double>::epsilon()) {
+    KS_CALL(ks_bv_set_active_columns(W, 0, 1));
+    const double q = -kr;                                   // VecAXPY(u,-kr,w)
+    KS_CALL(ks_bv_multvec(W, 1.0, 1.0, ks_bv_col(W, 1), &q));
+  }
+  double nrm = 0.0;
+  KS_CALL(ks_bv_normcolumn(W, 1, KS_NORM_2, &nrm));
+  if (type == KS_EPS_ERROR_RELATIVE) nrm /= fabs(kr) * 1.0;  // vecnorm = 1 (not GHEP)
+  else KS_CHECK(type == KS_EPS_ERROR_ABSOLUTE, KS_ERR_ARG_OUTOFRANGE, "Invalid error type");
+  *error = nrm;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_eps_get_bv(ks_eps eps, ks_bv *V) { KS_CHECK(eps && V, KS_ERR_ARG_NULL, "NULL argument"); *V = eps->V; return KS_SUCCESS; }
+extern "C" int ks_eps_get_stats(ks_eps eps, long long *steps, long long *passes, int *restarts)
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  if (steps) *steps = eps->steps; if (passes) *passes = eps->passes; if (restarts) *restarts = eps->restarts;
+  return KS_SUCCESS;
+}

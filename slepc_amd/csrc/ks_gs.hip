@@ -1,0 +1,657 @@
+// Gram-Schmidt orthogonalization and the Krylov expansions (BVMatLanczos / BVMatArnoldi) for gfx950.
+//
+// Reference semantics: src/sys/classes/bv/interface/bvorthog.c (BVOrthogonalizeCGS1 :91-132,
+// BVOrthogonalizeGS :145-217, BVOrthogonalizeColumn :315, BVOrthonormalizeColumn :380-427),
+// coefficient helpers include/slepc/private/bvimpl.h:121-141,289-415, loops bvkrylov.c:56-113,165-226.
+//
+// MI355X design ("ops->gramschmidt" slot, bvimpl.h:53).  One classical Gram-Schmidt pass in the
+// reference is gemv-C (h = V^T v, k+1 dots incl. v.v) -> allreduce -> ~8 tiny host-synchronous helper
+// calls -> gemv-N (v -= V h); CGS with refinement repeats it.  Here:
+//   * the pass bookkeeping (BV_SquareRoot, BV_SquareSum, Pythagoras norm estimate, the refinement test
+//     |nrm| < eta*|onrm|, lindep, BV_AddCoefficients, BV_SetValue) runs in a 1-block kernel on device
+//     state (KsGsState) - no host round trip inside a Krylov run;
+//   * the update sweep of pass p ALSO produces the dot products of pass p+1 (they are row-local:
+//     h'_i = sum_r V(r,i) v'(r) with v'(r) just computed from the same V(r,:) held in registers), so a
+//     CGS2 step reads V three times instead of four;
+//   * the final update applies the 1/nrm scaling of BVOrthonormalizeColumn while storing (nrm is known
+//     from the coefficients before the update runs);
+//   * later passes are launched unconditionally and gate themselves on the device state, so the
+//     reference's data-dependent control flow (1-3 passes, explicit-norm fallback, breakdown) is
+//     reproduced exactly; a breakdown turns the rest of the enqueued run into no-ops.
+// Multi-rank: the reduce and bookkeeping halves are split around an allreduce of k+1 doubles
+// (bvblas.c:255 MPIU_Allreduce) on the same stream.
+#include "ks_sweeps.cuh"
+#include <algorithm>
+
+using namespace ksk;
+
+namespace {
+
+struct GsArgs {
+  int k;           // column being orthogonalized (number of previous columns)
+  int slot;        // 1..4 position in the launch sequence of this column
+  int refine;      // KS_BV_ORTHOG_REFINE_*
+  int normalize;   // BVOrthonormalizeColumn: scale by 1/nrm
+  int krylov;      // inside BVMatLanczos/Arnoldi: lindep halts the rest of the run
+  int ldb;         // leading dimension of the coefficient buffer (nc+m)
+  double eta, deftol;
+};
+
+// Bookkeeping for one slot.  Thread 0 only.  c[0..k] are the (globally reduced) dots of the current
+// vector against columns 0..k-1 and itself.
+__device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict__ buffer, KsGsState *st, KsStepRec *recs)
+{
+  const int k = a.k;
+  int upd = 0, fuse = 0, scal = 0;
+  double *H = buffer + (size_t)k * a.ldb;        // H(:,k): buffer column k (bvbasic.c:784-786)
+  bool process = true, finalize = false, after_update = false;
+  double nrm = st->nrm, onrm = st->onrm;
+
+  if (a.slot == 1) { st->pass = 0; st->expl = 0; st->pending_scale = 0; st->lindep = 0; st->do_update = 0; }
+  else {
+    if (st->expl) {
+      // explicit norm of the updated vector (BV_NormVecOrColumn, bvorthog.c:126 / :191): c[k] = v'.v'
+      nrm = sqrt(c[k] < 0.0 ? 0.0 : c[k]);
+      st->expl = 0;
+      bool more;
+      if (a.refine == KS_BV_ORTHOG_REFINE_IFNEEDED) more = (st->pass < 3 && nrm != 0.0 && fabs(nrm) < a.eta * fabs(onrm));
+      else more = false;
+      if (!more) { process = false; finalize = true; after_update = true; }
+      st->more_ = more ? 1 : 0;
+    } else if (!st->more_) process = false;
+  }
+
+  if (process) {
+    st->pass++; st->passes_total++;
+    // BV_SquareRoot -> BV_SafeSqrt (bvimpl.h:121-141)
+    const double vv = c[k];
+    if (!(vv > -a.deftol)) { st->err = KS_ERR_USER_INPUT; st->active = 0; st->do_update = 0; st->more_ = 0; return; }
+    const double beta = vv < 0.0 ? 0.0 : sqrt(vv);
+    // BV_SquareSum (bvimpl.h:347-360) and BV_AddCoefficients (bvimpl.h:308-322)
+    double sum = 0.0;
+    for (int i = 0; i < k; i++) sum += c[i] * c[i];
+    if (st->pass == 1) for (int i = 0; i < k; i++) H[i] = c[i];         // BV_CleanCoefficients + add
+    else for (int i = 0; i < k; i++) H[i] += c[i];
+    upd = 1;
+    if (a.refine == KS_BV_ORTHOG_REFINE_NEVER) {
+      // one pass, then explicit norm (bvorthog.c:189-195)
+      st->expl = 1; fuse = 1; st->more_ = 0; onrm = beta;
+    } else if (a.refine == KS_BV_ORTHOG_REFINE_ALWAYS && st->pass == 1) {
+      st->more_ = 1; fuse = 1; onrm = beta;                              // bvorthog.c:197-198
+    } else {
+      onrm = beta;
+      const double n2 = beta * beta - sum;                               // bvorthog.c:124-127
+      if (n2 <= 0.0) { st->expl = 1; fuse = 1; st->more_ = 0; }
+      else {
+        nrm = sqrt(n2);
+        bool more;
+        if (a.refine == KS_BV_ORTHOG_REFINE_IFNEEDED) more = (st->pass < 3 && nrm != 0.0 && fabs(nrm) < a.eta * fabs(onrm));   // bvorthog.c:179
+        else more = false;
+        st->more_ = more ? 1 : 0;
+        if (more) fuse = 1; else finalize = true;
+      }
+    }
+  }
+
+  if (finalize) {
+    int lindep;
+    if (a.refine == KS_BV_ORTHOG_REFINE_NEVER) lindep = (nrm == 0.0);                                       // bvorthog.c:193
+    else lindep = !(nrm != 0.0 && fabs(nrm) >= a.eta * fabs(onrm));                                          // bvorthog.c:186,201
+    H[k] = lindep ? 0.0 : nrm;                                                                               // BV_SetValue bvorthog.c:209-214
+    const double alpha = (nrm != 1.0 && nrm != 0.0) ? 1.0 / nrm : 1.0;                                       // bvorthog.c:417-419
+    st->alpha = alpha; st->lindep = lindep;
+    if (a.normalize && alpha != 1.0) { if (after_update) st->pending_scale = 1; else scal = 1; }
+    KsStepRec r; r.nrm = nrm; r.onrm = onrm; r.passes = st->pass; r.lindep = lindep; r.expl = after_update ? 1 : 0; r.col = k;
+    recs[k] = r;
+    if (a.krylov && lindep) st->active = 0;          // bvkrylov.c:92-95: stop the expansion
+    st->more_ = 0;
+  }
+  st->nrm = nrm; st->onrm = onrm;
+  st->do_update = upd; st->fuse_dot = fuse; st->scale_now = scal;
+}
+
+// REDUCE: sum block partials -> c (LDS, and global scratch = buffer column 0).  BOOK: run the bookkeeping.
+template <bool REDUCE, bool BOOK>
+__global__ __launch_bounds__(1024) void k_gs_finish(const double *__restrict__ partials, int nblocks, GsArgs a, double *buffer, KsGsState *st, KsStepRec *recs)
+{
+  __shared__ double c_lds[KS_MAX_COLS + 8];
+  const int ncols = a.k + 1;
+  // Slot gating is decided by ONE thread and broadcast through LDS: thread 0 rewrites the state later in
+  // this kernel, so letting every wave read it would let a late wave take a different branch around the
+  // barriers below.
+  __shared__ int go;
+  if (threadIdx.x == 0) {
+    go = 1;
+    if (BOOK && (!st->active || (a.slot > 1 && !st->expl && !st->more_))) { go = 0; st->do_update = 0; }   // halted run / column already final
+  }
+  __syncthreads();
+  if (!go) return;
+  if (REDUCE) {
+    reduce_partials_to_lds(partials, nblocks, ncols, c_lds);
+    if ((int)threadIdx.x < ncols) buffer[threadIdx.x] = c_lds[threadIdx.x];     // scratch c = buffer column 0
+  } else {
+    if ((int)threadIdx.x < ncols) c_lds[threadIdx.x] = buffer[threadIdx.x];
+    __syncthreads();
+  }
+  if (BOOK && threadIdx.x == 0) gs_bookkeep(a, c_lds, buffer, st, recs);
+}
+
+// v <- v - V(:,0:k) c   [* alpha if final]   and, when st->fuse_dot, partials <- [V(:,0:k) v]^T v  (k+1 values)
+template <int KT, int VEC>
+__global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long long ld, int n, int k, double *v, const double *__restrict__ cg,
+                                                        double *__restrict__ partials, const KsGsState *__restrict__ st)
+{
+  if (!st->do_update) return;
+  const bool fuse = st->fuse_dot != 0;
+  const bool scal = st->scale_now != 0;
+  const double alpha = st->alpha;
+  const long long tile = (long long)SW_BLOCK * VEC;
+  const long long ntiles = ((long long)n + tile - 1) / tile;
+
+  if (!fuse) {
+    // light path: pure gemv-N stream, 8 independent column loads in flight per step
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+      const long long r = t * tile + (long long)threadIdx.x * VEC;
+      if (VEC == 2 && r + 1 < n) {
+        double2 s = *reinterpret_cast<const double2 *>(v + r);
+        int i = 0;
+        for (; i + 8 <= k; i += 8) {
+          double2 xv[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) xv[u] = *reinterpret_cast<const double2 *>(V + (long long)(i + u) * ld + r);
+#pragma unroll
+          for (int u = 0; u < 8; u++) { const double c = -cg[i + u]; s.x = fma(c, xv[u].x, s.x); s.y = fma(c, xv[u].y, s.y); }
+        }
+        for (; i < k; i++) { const double2 xv = *reinterpret_cast<const double2 *>(V + (long long)i * ld + r); const double c = -cg[i]; s.x = fma(c, xv.x, s.x); s.y = fma(c, xv.y, s.y); }
+        if (scal) { s.x *= alpha; s.y *= alpha; }
+        *reinterpret_cast<double2 *>(v + r) = s;
+      } else {
+        for (int q = 0; q < VEC; q++) {
+          const long long rr = r + q;
+          if (rr < n) {
+            double s = v[rr];
+            for (int i = 0; i < k; i++) s = fma(-cg[i], V[(long long)i * ld + rr], s);
+            if (scal) s *= alpha;
+            v[rr] = s;
+          }
+        }
+      }
+    }
+    return;
+  }
+
+  // fused path: the row panel V(r,0:k) stays in registers between the update and the next pass's dots
+  double acc[KT + 1];
+#pragma unroll
+  for (int i = 0; i <= KT; i++) acc[i] = 0.0;
+  double cc[KT];
+#pragma unroll
+  for (int i = 0; i < KT; i++) cc[i] = (i < k) ? -cg[i] : 0.0;
+  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long long r = t * tile + (long long)threadIdx.x * VEC;
+    if (VEC == 2 && r + 1 < n) {
+      double2 s = *reinterpret_cast<const double2 *>(v + r);
+      double2 xv[KT];
+#pragma unroll
+      for (int i = 0; i < KT; i++) { const int ii = i < k ? i : (k > 0 ? k - 1 : 0); xv[i] = *reinterpret_cast<const double2 *>(V + (long long)ii * ld + r); }
+#pragma unroll
+      for (int i = 0; i < KT; i++) { s.x = fma(cc[i], xv[i].x, s.x); s.y = fma(cc[i], xv[i].y, s.y); }
+      *reinterpret_cast<double2 *>(v + r) = s;
+#pragma unroll
+      for (int i = 0; i < KT; i++) { acc[i] = fma(xv[i].x, s.x, acc[i]); acc[i] = fma(xv[i].y, s.y, acc[i]); }
+      acc[KT] = fma(s.x, s.x, acc[KT]); acc[KT] = fma(s.y, s.y, acc[KT]);
+    } else {
+      for (int q = 0; q < VEC; q++) {
+        const long long rr = r + q;
+        if (rr < n) {
+          double s = v[rr];
+          double xs[KT];
+#pragma unroll
+          for (int i = 0; i < KT; i++) { const int ii = i < k ? i : (k > 0 ? k - 1 : 0); xs[i] = V[(long long)ii * ld + rr]; }
+#pragma unroll
+          for (int i = 0; i < KT; i++) s = fma(cc[i], xs[i], s);
+          v[rr] = s;
+#pragma unroll
+          for (int i = 0; i < KT; i++) acc[i] = fma(xs[i], s, acc[i]);
+          acc[KT] = fma(s, s, acc[KT]);
+        }
+      }
+    }
+  }
+  // block combine: partial index i<k <- acc[i]; index k <- acc[KT] (the self dot)
+  __shared__ double red[SW_WAVES][KT + 1];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i <= KT; i++) { const double s = wave_sum(acc[i]); if (lane == 0) red[w][i] = s; }
+  __syncthreads();
+  if ((int)threadIdx.x <= k) {
+    const int src = ((int)threadIdx.x == k) ? KT : (int)threadIdx.x;
+    double s = red[0][src];
+#pragma unroll
+    for (int ww = 1; ww < SW_WAVES; ww++) s += red[ww][src];
+    partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s;
+  }
+}
+
+__global__ void k_scale_if(double *__restrict__ x, int n, const KsGsState *__restrict__ st)
+{
+  if (!st->pending_scale) return;
+  const double alpha = st->alpha;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= alpha;
+}
+
+__global__ void k_gs_begin_run(KsGsState *st) { st->active = 1; st->err = 0; st->do_update = 0; st->more_ = 0; st->expl = 0; st->pending_scale = 0; }
+
+bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+int sweep_grid(ks_ctx ctx, int n, int vec)
+{
+  long long tile = (long long)SW_BLOCK * vec;
+  long long ntiles = ((long long)n + tile - 1) / tile;
+  long long g = std::min<long long>(std::max<long long>(ntiles, 1), (long long)ctx->num_cu * 4);
+  return (int)std::min<long long>(g, KS_MAX_BLOCKS);
+}
+
+int launch_finish(ks_bv bv, const GsArgs &a)
+{
+  ks_ctx ctx = bv->ctx;
+  const bool multi = ctx->comm.size > 1;
+  KsProfScope ps(ctx, KS_K_GSFIN, 8.0 * bv->last_grid * (a.k + 1));
+  if (!multi) hipLaunchKernelGGL((k_gs_finish<true, true>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, bv->last_grid, a, bv->buffer, bv->gs, bv->recs);
+  else {
+    hipLaunchKernelGGL((k_gs_finish<true, false>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, bv->last_grid, a, bv->buffer, bv->gs, bv->recs);
+    KS_CALL(ks_allreduce_sum(ctx, bv->buffer, a.k + 1));
+    hipLaunchKernelGGL((k_gs_finish<false, true>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, bv->last_grid, a, bv->buffer, bv->gs, bv->recs);
+  }
+  KS_HIP(hipGetLastError());
+  return KS_SUCCESS;
+}
+
+int launch_update(ks_bv bv, int k, double *v)
+{
+  ks_ctx ctx = bv->ctx;
+  const double *V = ks_bv_col(bv, 0);
+  const bool v2 = (bv->ld % 2 == 0) && aligned16(V) && aligned16(v);
+  const int grid = sweep_grid(ctx, bv->n, v2 ? 2 : 1);
+  bv->last_grid = grid;
+  KsProfScope ps(ctx, KS_K_UPD_FUSED, 8.0 * bv->n * (k + 2));
+  const int kk = std::max(k, 1);
+#define LAUNCH_UPD(KT)                                                                                                                                 \
+  do {                                                                                                                                                 \
+    if (v2) hipLaunchKernelGGL((k_gs_update<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->buffer, bv->partials, bv->gs); \
+    else hipLaunchKernelGGL((k_gs_update<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->buffer, bv->partials, bv->gs);   \
+  } while (0)
+  KS_KT_DISPATCH(kk, LAUNCH_UPD);
+#undef LAUNCH_UPD
+  KS_HIP(hipGetLastError());
+  return KS_SUCCESS;
+}
+
+// Enqueue the complete fused CGS of column j (against columns 0..j-1) on the stream. No host sync.
+int enqueue_fused_gs(ks_bv bv, int j, int normalize, int krylov)
+{
+  ks_ctx ctx = bv->ctx;
+  KS_CHECK(j + 1 <= KS_MAX_COLS, KS_ERR_SUP, "fused Gram-Schmidt supports at most %d columns", KS_MAX_COLS);
+  GsArgs a; a.k = j; a.refine = bv->orthog_ref; a.normalize = normalize; a.krylov = krylov; a.ldb = bv->nc + bv->m; a.eta = bv->orthog_eta; a.deftol = bv->deftol;
+  double *v = ks_bv_col(bv, j);
+  // h = V(:,0:j+1)^T v  (BVDotColumnInc bvorthog.c:32-47: k+1 dots including (v,v))
+  KS_CALL(ksk_dot(bv, ks_bv_col(bv, 0), bv->ld, j + 1, v, krylov != 0));
+  const int nslots = (bv->orthog_ref == KS_BV_ORTHOG_REFINE_IFNEEDED) ? 3 : (bv->orthog_ref == KS_BV_ORTHOG_REFINE_ALWAYS ? 2 : 1);
+  for (int p = 1; p <= nslots; p++) {
+    a.slot = p;
+    KS_CALL(launch_finish(bv, a));
+    KS_CALL(launch_update(bv, j, v));
+  }
+  a.slot = nslots + 1;                  // resolves an explicit-norm request of the last update
+  KS_CALL(launch_finish(bv, a));
+  if (normalize) {
+    KsProfScope ps(ctx, KS_K_SCALE, 0.0);
+    const int grid = std::max(1, std::min((bv->n + 255) / 256, ctx->num_cu * 4));
+    hipLaunchKernelGGL(k_scale_if, dim3(grid), dim3(256), 0, ctx->stream, v, bv->n, bv->gs);
+    KS_HIP(hipGetLastError());
+  }
+  return KS_SUCCESS;
+}
+
+int begin_run(ks_bv bv)
+{
+  hipLaunchKernelGGL(k_gs_begin_run, dim3(1), dim3(1), 0, bv->ctx->stream, bv->gs);
+  KS_HIP(hipGetLastError());
+  return KS_SUCCESS;
+}
+
+struct HostGs { KsGsState st; };
+
+int fetch_state(ks_bv bv, KsGsState *st, KsStepRec *recs, int j0, int j1)
+{
+  ks_ctx ctx = bv->ctx;
+  KS_HIP(hipMemcpyAsync(st, bv->gs, sizeof(KsGsState), hipMemcpyDeviceToHost, ctx->stream));
+  if (recs && j1 >= j0) KS_HIP(hipMemcpyAsync(recs, bv->recs + j0, sizeof(KsStepRec) * (j1 - j0 + 1), hipMemcpyDeviceToHost, ctx->stream));
+  KS_HIP(hipStreamSynchronize(ctx->stream));
+  if (st->err) KS_FAIL(st->err, "Invalid inner product (BV_SafeSqrt): negative v^H v");
+  return KS_SUCCESS;
+}
+
+// ---- host-driven generic Gram-Schmidt (MGS, vector argument, `which` selection) -----------------
+// Literal restatement of bvorthog.c on top of the primitive ops; every step synchronises, as the
+// reference's GPU backend does.  h/c are host arrays of nc+m entries when v is given, else the buffer.
+struct GenericGs {
+  ks_bv bv; std::vector<double> h, c; bool use_vec;
+};
+
+int generic_norm(ks_bv bv, int j, double *v, double *nrm)     // BV_NormVecOrColumn bvorthog.c:20-26
+{
+  if (!v) return ks_bv_normcolumn(bv, j, KS_NORM_2, nrm);
+  // VecNorm of an arbitrary device vector: dot with itself
+  KS_CALL(ksk_dot(bv, v, bv->ld, 1, v, false));
+  KS_CALL(ksk_reduce_partials(bv, 1, bv->coef));
+  KS_CALL(ks_allreduce_sum(bv->ctx, bv->coef, 1));
+  double s = 0.0;
+  KS_HIP(hipMemcpyAsync(&s, bv->coef, sizeof(double), hipMemcpyDeviceToHost, bv->ctx->stream));
+  KS_HIP(hipStreamSynchronize(bv->ctx->stream));
+  *nrm = sqrt(s);
+  return KS_SUCCESS;
+}
+
+int generic_mgs1(ks_bv bv, int j, double *v, const int *which, double *hh, double *cc, double *onrm, double *nrm)   // bvorthog.c:52-85
+{
+  double *w = v ? v : ks_bv_col(bv, j);
+  if (onrm) KS_CALL(generic_norm(bv, j, v, onrm));
+  for (int i = -bv->nc; i < j; i++) {
+    if (which && i >= 0 && !which[i]) continue;
+    double dot = 0.0;
+    // VecDot(w, vi) with the global reduction
+    KS_CALL(ksk_dot(bv, ks_bv_col(bv, i), bv->ld, 1, w, false));
+    KS_CALL(ksk_reduce_partials(bv, 1, bv->coef));
+    KS_CALL(ks_allreduce_sum(bv->ctx, bv->coef, 1));
+    KS_HIP(hipMemcpyAsync(&dot, bv->coef, sizeof(double), hipMemcpyDeviceToHost, bv->ctx->stream));
+    KS_HIP(hipStreamSynchronize(bv->ctx->stream));
+    cc[bv->nc + i] = dot;                                                   // BV_SetValue(bv,i,0,c,dot)
+    // VecAXPY(w,-dot,vi)
+    double mdot = dot;
+    KS_HIP(hipMemcpyAsync(bv->coef + 8, &mdot, sizeof(double), hipMemcpyHostToDevice, bv->ctx->stream));
+    KS_HIP(hipStreamSynchronize(bv->ctx->stream));
+    KS_CALL(ksk_multvec(bv, ks_bv_col(bv, i), bv->ld, 1, -1.0, 1.0, bv->coef + 8, w));
+  }
+  if (nrm) KS_CALL(generic_norm(bv, j, v, nrm));
+  for (int i = 0; i < bv->nc + j; i++) hh[i] += cc[i];                       // BV_AddCoefficients
+  return KS_SUCCESS;
+}
+
+int generic_cgs1(ks_bv bv, int j, double *v, double *hh, double *cc, double *onorm, double *norm)   // bvorthog.c:91-132
+{
+  double beta = 0.0;
+  const int ksave = bv->k;
+  bv->k = j;
+  int rc = KS_SUCCESS;
+  do {
+    if (onorm || norm) {
+      if (!v) {
+        bv->k = j + 1;                                                       // BVDotColumnInc
+        if ((rc = ks_bv_dotvec(bv, ks_bv_col(bv, j), cc))) break;
+        bv->k = j;
+        const double vv = cc[bv->nc + j];
+        if (!(vv > -bv->deftol)) { ks_set_error("Invalid inner product: %g", vv); rc = KS_ERR_USER_INPUT; break; }
+        beta = vv < 0.0 ? 0.0 : sqrt(vv);
+      } else {
+        if ((rc = ks_bv_dotvec(bv, v, cc))) break;
+        if ((rc = generic_norm(bv, j, v, &beta))) break;
+      }
+    } else {
+      if ((rc = ks_bv_dotvec(bv, v ? v : ks_bv_col(bv, j), cc))) break;
+    }
+    if ((rc = ks_bv_multvec(bv, -1.0, 1.0, v ? v : ks_bv_col(bv, j), cc))) break;
+    if (onorm) *onorm = beta;
+    if (norm) {
+      double sum = 0.0;
+      for (int i = 0; i < bv->nc + j; i++) sum += cc[i] * cc[i];
+      *norm = beta * beta - sum;
+      if (*norm <= 0.0) { if ((rc = generic_norm(bv, j, v, norm))) break; }
+      else *norm = sqrt(*norm);
+    }
+    for (int i = 0; i < bv->nc + j; i++) hh[i] += cc[i];
+  } while (0);
+  bv->k = ksave;
+  return rc;
+}
+
+// BVOrthogonalizeGS bvorthog.c:145-217 (host-driven). hh: destination coefficients (nc+k+1 entries).
+int generic_gs(ks_bv bv, int j, double *v, const int *which, double *hh, double *norm, int *lindep, int *passes)
+{
+  const int k = v ? bv->k : j;
+  const bool mgs = bv->orthog_type == KS_BV_ORTHOG_MGS;
+  std::vector<double> cc(bv->nc + bv->m + 1, 0.0);
+  double onrm = 0.0, nrm = 0.0;
+  const bool dolindep = lindep != nullptr;
+  int np = 0;
+  for (int i = 0; i < bv->nc + k; i++) hh[i] = 0.0;                          // BV_CleanCoefficients
+  auto gs1 = [&](double *on, double *nr) -> int { np++; return mgs ? generic_mgs1(bv, k, v, which, hh, cc.data(), on, nr) : generic_cgs1(bv, k, v, hh, cc.data(), on, nr); };
+  switch (bv->orthog_ref) {
+    case KS_BV_ORTHOG_REFINE_IFNEEDED: {
+      KS_CALL(gs1(&onrm, &nrm));
+      int l = 1;
+      while (l < 3 && nrm != 0.0 && fabs(nrm) < bv->orthog_eta * fabs(onrm)) {
+        l++;
+        if (mgs) onrm = nrm;
+        KS_CALL(gs1(mgs ? nullptr : &onrm, &nrm));
+      }
+      if (dolindep) *lindep = !(nrm != 0.0 && fabs(nrm) >= bv->orthog_eta * fabs(onrm));
+    } break;
+    case KS_BV_ORTHOG_REFINE_NEVER:
+      KS_CALL(gs1(nullptr, nullptr));
+      if (norm || dolindep) KS_CALL(generic_norm(bv, k, v, &nrm));
+      if (dolindep) *lindep = (nrm == 0.0);
+      break;
+    case KS_BV_ORTHOG_REFINE_ALWAYS:
+      KS_CALL(gs1(nullptr, nullptr));
+      KS_CALL(gs1(dolindep ? &onrm : nullptr, (norm || dolindep) ? &nrm : nullptr));
+      if (dolindep) *lindep = !(nrm != 0.0 && fabs(nrm) >= bv->orthog_eta * fabs(onrm));
+      break;
+    default: KS_FAIL(KS_ERR_ARG_WRONG, "unknown refinement");
+  }
+  if (norm) { *norm = nrm; if (!v) hh[bv->nc + k] = (dolindep && *lindep) ? 0.0 : nrm; }
+  if (passes) *passes = np;
+  return KS_SUCCESS;
+}
+
+// write host coefficients hh (nc+j+1 entries incl. the norm slot) into buffer column j
+int store_buffer_column(ks_bv bv, int j, const double *hh, int len)
+{
+  KS_HIP(hipMemcpyAsync(bv->buffer + (size_t)j * (bv->nc + bv->m), hh, sizeof(double) * len, hipMemcpyHostToDevice, bv->ctx->stream));
+  KS_HIP(hipStreamSynchronize(bv->ctx->stream));
+  return KS_SUCCESS;
+}
+
+bool use_fused(ks_bv bv) { return bv->orthog_type == KS_BV_ORTHOG_CGS && bv->m <= KS_MAX_COLS && !getenv("KSGPU_NO_FUSED_GS"); }
+
+// Orthogonalize column j; fused or generic. Returns norm/lindep on the host (synchronises).
+int orthogonalize_column(ks_bv bv, int j, int normalize, double *H, double *norm, int *lindep)
+{
+  ks_ctx ctx = bv->ctx;
+  KS_HIP(hipSetDevice(ctx->device));
+  if (use_fused(bv)) {
+    KS_CALL(begin_run(bv));
+    KS_CALL(enqueue_fused_gs(bv, j, normalize, 0));
+    KsGsState st; KsStepRec rec;
+    KS_CALL(fetch_state(bv, &st, &rec, j, j));
+    bv->passes_last_host = rec.passes; bv->passes_total_host += rec.passes;
+    if (norm) *norm = rec.nrm;
+    if (lindep) *lindep = rec.lindep;
+    if (H && j > bv->l) {   // BV_StoreCoefficients bvimpl.h:403-415: entries l..j-1
+      KS_HIP(hipMemcpyAsync(H, bv->buffer + (size_t)j * (bv->nc + bv->m) + bv->nc + bv->l, sizeof(double) * (j - bv->l), hipMemcpyDeviceToHost, ctx->stream));
+      KS_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return KS_SUCCESS;
+  }
+  std::vector<double> hh(bv->nc + bv->m + 1, 0.0);
+  double nrm = 0.0; int lin = 0, np = 0;
+  const int lsave = bv->l, ksave = bv->k;
+  bv->l = -bv->nc;
+  int rc = generic_gs(bv, j, nullptr, nullptr, hh.data(), &nrm, &lin, &np);
+  bv->l = lsave; bv->k = ksave;
+  if (rc) return rc;
+  bv->passes_last_host = np; bv->passes_total_host += np;
+  KS_CALL(store_buffer_column(bv, j, hh.data(), bv->nc + j + 1));
+  if (normalize && nrm != 1.0 && nrm != 0.0) KS_CALL(ksk_scale(ctx, ks_bv_col(bv, j), bv->n, 1.0 / nrm));
+  if (norm) *norm = nrm;
+  if (lindep) *lindep = lin;
+  if (H) for (int i = bv->l; i < j; i++) H[i - bv->l] = hh[bv->nc + i];
+  return KS_SUCCESS;
+}
+
+} // namespace
+
+// ---- public GS entry points ----------------------------------------------------------------------
+extern "C" int ks_bv_orthogonalizecolumn(ks_bv bv, int j, double *H, double *norm, int *lindep)   // bvorthog.c:315-339
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  KS_CHECK(j >= 0, KS_ERR_ARG_OUTOFRANGE, "Index j must be non-negative");
+  KS_CHECK(j < bv->m, KS_ERR_ARG_OUTOFRANGE, "Index j=%d but BV only has %d columns", j, bv->m);
+  return orthogonalize_column(bv, j, 0, H, norm, lindep);
+}
+
+extern "C" int ks_bv_orthonormalizecolumn(ks_bv bv, int j, int replace, double *norm, int *lindep)   // bvorthog.c:380-427
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  KS_CHECK(j >= 0, KS_ERR_ARG_OUTOFRANGE, "Index j must be non-negative");
+  KS_CHECK(j < bv->m, KS_ERR_ARG_OUTOFRANGE, "Index j=%d but BV only has %d columns", j, bv->m);
+  double nrm = 0.0; int lin = 0;
+  if (!replace) { KS_CALL(orthogonalize_column(bv, j, 1, nullptr, &nrm, &lin)); }
+  else {
+    // the replacement decision needs nrm/lindep before scaling: orthogonalize, decide, then scale
+    KS_CALL(orthogonalize_column(bv, j, 0, nullptr, &nrm, &lin));
+    for (int attempt = 0; attempt < 2 && (nrm == 0.0 || lin); attempt++) {
+      KS_CALL(ks_bv_set_random_column(bv, j, 0x12345678ULL + 7919ULL * (attempt + 1)));
+      KS_CALL(orthogonalize_column(bv, j, 0, nullptr, &nrm, &lin));
+    }
+    if (nrm != 1.0 && nrm != 0.0) KS_CALL(ksk_scale(bv->ctx, ks_bv_col(bv, j), bv->n, 1.0 / nrm));
+  }
+  if (norm) *norm = nrm;
+  if (lindep) *lindep = lin;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_orthogonalizevec(ks_bv bv, double *v_dev, double *H, double *norm, int *lindep)   // bvorthog.c:247-269
+{
+  KS_CHECK(bv && v_dev, KS_ERR_ARG_NULL, "NULL argument");
+  KS_HIP(hipSetDevice(bv->ctx->device));
+  std::vector<double> hh(bv->nc + bv->m + 1, 0.0);
+  const int lsave = bv->l, ksave = bv->k;
+  bv->l = -bv->nc;
+  int np = 0;
+  int rc = generic_gs(bv, 0, v_dev, nullptr, hh.data(), norm, lindep, &np);
+  bv->l = lsave; bv->k = ksave;
+  if (rc) return rc;
+  bv->passes_last_host = np; bv->passes_total_host += np;
+  if (H) for (int i = bv->l; i < bv->k; i++) H[i - bv->l] = hh[bv->nc + i];
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_orthogonalizesomecolumn(ks_bv bv, int j, const int *which, double *H, double *norm, int *lindep)   // bvorthog.c:432-470
+{
+  KS_CHECK(bv && which, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(j >= 0, KS_ERR_ARG_OUTOFRANGE, "Index j must be non-negative");
+  KS_CHECK(j < bv->m, KS_ERR_ARG_OUTOFRANGE, "Index j=%d but BV only has %d columns", j, bv->m);
+  KS_CHECK(bv->orthog_type == KS_BV_ORTHOG_MGS, KS_ERR_SUP, "Operation only available for MGS orthogonalization");
+  KS_HIP(hipSetDevice(bv->ctx->device));
+  std::vector<double> hh(bv->nc + bv->m + 1, 0.0);
+  const int lsave = bv->l, ksave = bv->k;
+  bv->l = -bv->nc;
+  int np = 0; double nrm = 0.0;
+  int rc = generic_gs(bv, j, nullptr, which, hh.data(), &nrm, lindep, &np);
+  bv->l = lsave; bv->k = ksave;
+  if (rc) return rc;
+  KS_CALL(store_buffer_column(bv, j, hh.data(), bv->nc + j + 1));
+  if (norm) *norm = nrm;
+  if (H) for (int i = bv->l; i < j; i++) H[i - bv->l] = hh[bv->nc + i];
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_gs_passes(ks_bv bv, long long *total, int *last)
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  if (total) *total = bv->passes_total_host;
+  if (last) *last = bv->passes_last_host;
+  return KS_SUCCESS;
+}
+
+// ---- Krylov expansions ---------------------------------------------------------------------------
+// Common loop of BVMatArnoldi (bvkrylov.c:88-96) and BVMatLanczos (:198-206).
+static int krylov_run(ks_bv V, ks_mat A, int k, int *m, double *beta, int *breakdown, std::vector<double> &buf)
+{
+  KS_CHECK(V && A && m, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(k >= 0 && k <= V->m, KS_ERR_ARG_OUTOFRANGE, "Argument k has wrong value %d, should be between 0 and %d", k, V->m);
+  KS_CHECK(*m > 0 && *m <= V->m, KS_ERR_ARG_OUTOFRANGE, "Argument m has wrong value %d, should be between 1 and %d", *m, V->m);
+  KS_CHECK(*m > k, KS_ERR_ARG_OUTOFRANGE, "Argument m should be at least equal to k+1");
+  KS_CHECK(*m < V->m, KS_ERR_ARG_OUTOFRANGE, "BV needs m+1 columns to hold an m-step factorization (m=%d, columns=%d)", *m, V->m);
+  KS_CHECK(A->n == V->n, KS_ERR_ARG_INCOMP, "Mismatching local row dimension A %d, V %d", A->n, V->n);
+  ks_ctx ctx = V->ctx;
+  KS_HIP(hipSetDevice(ctx->device));
+  const int m0 = *m;
+  int lin = 0;
+  double nrm_last = 0.0;
+  if (use_fused(V) && m0 < V->N) {
+    // the whole run is enqueued; a device-side breakdown turns the remaining steps into no-ops
+    KS_CALL(begin_run(V));
+    for (int j = k; j < m0; j++) {
+      KS_CALL(ks_mat_mult_internal(A, ks_bv_col(V, j), ks_bv_col(V, j + 1)));    // BVMatMultColumn (not gated: harmless after a halt)
+      KS_CALL(enqueue_fused_gs(V, j + 1, 1, 1));
+    }
+    KsGsState st; std::vector<KsStepRec> recs(m0 - k);
+    KS_CALL(fetch_state(V, &st, recs.data(), k + 1, m0));
+    int mm = m0;
+    for (int j = k; j < m0; j++) {
+      const KsStepRec &r = recs[j - k];
+      V->passes_last_host = r.passes; V->passes_total_host += r.passes;
+      nrm_last = r.nrm;
+      if (r.lindep) { lin = 1; mm = j + 1; break; }
+    }
+    *m = mm;
+  } else {
+    for (int j = k; j < m0; j++) {
+      KS_CALL(ks_mat_mult_internal(A, ks_bv_col(V, j), ks_bv_col(V, j + 1)));
+      if (j == V->N - 1) {
+        // BV_OrthogonalizeColumn_Safe bvimpl.h:452-465: no refinement, norm=0, lindep=TRUE
+        const int ref = V->orthog_ref; V->orthog_ref = KS_BV_ORTHOG_REFINE_NEVER;
+        int rc = orthogonalize_column(V, j + 1, 0, nullptr, nullptr, nullptr);
+        V->orthog_ref = ref;
+        if (rc) return rc;
+        nrm_last = 0.0; lin = 1;
+      } else KS_CALL(orthogonalize_column(V, j + 1, 1, nullptr, &nrm_last, &lin));
+      if (lin) { *m = j + 1; break; }
+    }
+  }
+  if (beta) *beta = nrm_last;
+  if (breakdown) *breakdown = lin;
+  buf.resize((size_t)V->m * (V->nc + V->m));
+  KS_HIP(hipMemcpyAsync(buf.data(), V->buffer, sizeof(double) * buf.size(), hipMemcpyDeviceToHost, ctx->stream));   // VecGetArrayRead(buf) bvkrylov.c:103,215
+  KS_HIP(hipStreamSynchronize(ctx->stream));
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_matarnoldi(ks_bv V, ks_mat A, double *H, int ldh, int k, int *m, double *beta, int *breakdown)   // bvkrylov.c:56-113
+{
+  std::vector<double> a;
+  if (H && m) KS_CHECK(ldh >= *m, KS_ERR_ARG_SIZ, "Matrix H has %d rows, should have at least %d", ldh, *m);
+  KS_CALL(krylov_run(V, A, k, m, beta, breakdown, a));
+  if (H) {
+    const int nb = V->nc + V->m, mm = *m;
+    for (int j = k; j < mm - 1; j++) memcpy(H + (size_t)j * ldh, a.data() + V->nc + (size_t)(j + 1) * nb, sizeof(double) * (j + 2));
+    memcpy(H + (size_t)(mm - 1) * ldh, a.data() + V->nc + (size_t)mm * nb, sizeof(double) * mm);
+    if (ldh > mm) H[mm + (size_t)(mm - 1) * ldh] = a[V->nc + mm + (size_t)mm * nb];
+  }
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_matlanczos(ks_bv V, ks_mat A, double *T, int ldt, int k, int *m, double *beta, int *breakdown)   // bvkrylov.c:165-226
+{
+  std::vector<double> a;
+  if (T && m) KS_CHECK(ldt >= *m, KS_ERR_ARG_SIZ, "Matrix T has %d rows, should have at least %d", ldt, *m);
+  KS_CALL(krylov_run(V, A, k, m, beta, breakdown, a));
+  if (T) {
+    const int nb = V->nc + V->m;
+    double *alpha = T, *betat = T + ldt;
+    for (int j = k; j < *m; j++) { alpha[j] = a[V->nc + j + (size_t)(j + 1) * nb]; betat[j] = a[V->nc + j + 1 + (size_t)(j + 1) * nb]; }
+  }
+  return KS_SUCCESS;
+}

@@ -1,0 +1,482 @@
+// MatMult(AIJ): CSR sparse matrix-vector product for gfx950.
+//
+// Replaces PETSc MatMult_SeqAIJ / MatMult_MPIAIJ as reached from BVMatMultColumn
+// (src/sys/classes/bv/interface/bvops.c:862-885) through MatMult_STOperator / STApply_Generic
+// (src/sys/classes/st/interface/stsolve.c:16-25,244-259).
+//
+// Layout in HBM (PETSc MPIAIJ style): the rank's row block is split into a "diagonal" block whose
+// columns are owned by this rank (stored with LOCAL column indices) and an "off-diagonal" block
+// whose columns live on other ranks (stored with compressed GHOST indices). rowptr int32[n+1],
+// col int32[nnz], val f64[nnz]. x, y are columns of the BV (contiguous, stride 1).
+//
+// Kernel: "CSR-vector with sub-wave row groups". G = 2^g lanes cooperate on one row (G chosen from
+// the mean row length: 8 for the 7-point Laplacian, 32 for ~32 nnz/row), so a 64-wide wavefront
+// streams 64/G consecutive rows whose val/col entries are contiguous in memory: the val (8 B/lane)
+// and col (4 B/lane) loads of a wave are one coalesced segment. Partial products are combined with
+// DPP/shuffle butterflies inside the group. Each thread keeps UNROLL independent rows in flight
+// so that rowptr -> (col,val) -> x[col] dependent chains of different rows overlap.
+// Algorithmic bytes per call: 12*nnz + 4*(n+1) + 16*n.
+#include "ksgpu_internal.h"
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <numeric>
+#include <dlfcn.h>
+
+namespace {
+
+constexpr int SPMV_BLOCK = 256;
+
+template <int G>
+__device__ __forceinline__ double group_reduce(double v)
+{
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// y[row] (+)= sum_p val[p] * x[col[p]]  over rows handled through an optional compressed row list
+template <int G, int UNROLL, bool ACCUM, bool ROWLIST>
+__global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_csr(int nrows, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                          const double *__restrict__ val, const double *__restrict__ x,
+                                                          double *__restrict__ y, const int *__restrict__ rowlist)
+{
+  constexpr int GPW = 64 / G;                       // row groups per wavefront
+  constexpr int RW = GPW * UNROLL;                  // rows per wavefront per sweep
+  const int lane = threadIdx.x & 63;
+  const int gi = lane / G, lane_g = lane % G;
+  const long long wave = ((long long)blockIdx.x * SPMV_BLOCK + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * SPMV_BLOCK) >> 6;
+  // for a fixed u the GPW groups of a wave own GPW CONSECUTIVE rows, so one wave-instruction
+  // reads one contiguous run of val/col entries
+  for (long long wb = wave * RW; wb < nrows; wb += nwaves * RW) {
+    int p0[UNROLL], p1[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      long long r = wb + u * GPW + gi;
+      if (r < nrows) { p0[u] = rowptr[r]; p1[u] = rowptr[r + 1]; } else { p0[u] = 0; p1[u] = 0; }
+    }
+    double s[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      double acc = 0.0;
+      for (int p = p0[u] + lane_g; p < p1[u]; p += G) acc = fma(val[p], x[col[p]], acc);
+      s[u] = acc;
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      double t = group_reduce<G>(s[u]);
+      long long r = wb + u * GPW + gi;
+      if (lane_g == 0 && r < nrows) {
+        long long out = ROWLIST ? rowlist[r] : r;
+        if (ACCUM) y[out] += t; else y[out] = t;
+      }
+    }
+  }
+}
+
+template <int G, bool ACCUM, bool ROWLIST>
+void launch_spmv_g(hipStream_t st, int num_cu, int nrows, const int *rowptr, const int *col, const double *val, const double *x, double *y, const int *rowlist)
+{
+  constexpr int UNROLL = 4;
+  constexpr int RW = (64 / G) * UNROLL;                        // rows per wavefront per sweep
+  long long waves = ((long long)nrows + RW - 1) / RW;
+  long long blocks = (waves * 64 + SPMV_BLOCK - 1) / SPMV_BLOCK;
+  long long maxb = (long long)num_cu * 32;
+  if (blocks > maxb) blocks = maxb;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((k_spmv_csr<G, UNROLL, ACCUM, ROWLIST>), dim3((unsigned)blocks), dim3(SPMV_BLOCK), 0, st, nrows, rowptr, col, val, x, y, rowlist);
+}
+
+template <bool ACCUM, bool ROWLIST>
+void launch_spmv(hipStream_t st, int num_cu, int lanes, int nrows, const int *rowptr, const int *col, const double *val, const double *x, double *y, const int *rowlist)
+{
+  switch (lanes) {
+    case 2:  launch_spmv_g<2, ACCUM, ROWLIST>(st, num_cu, nrows, rowptr, col, val, x, y, rowlist); break;
+    case 4:  launch_spmv_g<4, ACCUM, ROWLIST>(st, num_cu, nrows, rowptr, col, val, x, y, rowlist); break;
+    case 8:  launch_spmv_g<8, ACCUM, ROWLIST>(st, num_cu, nrows, rowptr, col, val, x, y, rowlist); break;
+    case 16: launch_spmv_g<16, ACCUM, ROWLIST>(st, num_cu, nrows, rowptr, col, val, x, y, rowlist); break;
+    case 32: launch_spmv_g<32, ACCUM, ROWLIST>(st, num_cu, nrows, rowptr, col, val, x, y, rowlist); break;
+    default: launch_spmv_g<64, ACCUM, ROWLIST>(st, num_cu, nrows, rowptr, col, val, x, y, rowlist); break;
+  }
+}
+
+int pick_lanes(long long nnz, int n)
+{
+  double mean = n > 0 ? (double)nnz / n : 1.0;
+  int g = 2;
+  while (g < 64 && g < mean) g <<= 1;      // smallest power of two >= mean row length
+  return g;
+}
+
+__global__ void k_pack(int n, const int *__restrict__ idx, const double *__restrict__ x, double *__restrict__ out)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = x[idx[i]];
+}
+
+// ---- synthetic generators, built directly in device memory -------------------------------------
+// 3-D 7-point Laplacian, ex19.c:47-78: diag 6, off -1, natural ordering (x fastest), Dirichlet.
+// Local rows = planes [z0,z0+nzl). Entries whose column is owned by another slab go to the
+// off-diagonal block with ghost index: lower plane -> [0,plane), upper plane -> [nlow, nlow+plane).
+__global__ void k_lap3d_count(int nx, int ny, int nz, int z0, int nzl, int *cnt_d, int *cnt_o)
+{
+  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)nx * ny * nzl;
+  if (r >= n) return;
+  int i = (int)(r % nx); long long t = r / nx; int j = (int)(t % ny); int kl = (int)(t / ny); int k = z0 + kl;
+  int cd = 1, co = 0;
+  if (k > 0) { if (kl > 0) cd++; else co++; }
+  if (j > 0) cd++;
+  if (i > 0) cd++;
+  if (i < nx - 1) cd++;
+  if (j < ny - 1) cd++;
+  if (k < nz - 1) { if (kl < nzl - 1) cd++; else co++; }
+  cnt_d[r] = cd; cnt_o[r] = co;
+}
+
+__global__ void k_lap3d_fill(int nx, int ny, int nz, int z0, int nzl, const int *rp_d, int *col_d, double *val_d,
+                             const int *rp_o, int *col_o, double *val_o)
+{
+  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long plane = (long long)nx * ny, n = plane * nzl;
+  if (r >= n) return;
+  int i = (int)(r % nx); long long t = r / nx; int j = (int)(t % ny); int kl = (int)(t / ny); int k = z0 + kl;
+  int p = rp_d[r], q = rp_o[r];
+  const int nlow = (z0 > 0) ? (int)plane : 0;
+  if (k > 0) { if (kl > 0) { col_d[p] = (int)(r - plane); val_d[p++] = -1.0; } else { col_o[q] = (int)(r); val_o[q++] = -1.0; } }
+  if (j > 0) { col_d[p] = (int)(r - nx); val_d[p++] = -1.0; }
+  if (i > 0) { col_d[p] = (int)(r - 1); val_d[p++] = -1.0; }
+  col_d[p] = (int)r; val_d[p++] = 6.0;
+  if (i < nx - 1) { col_d[p] = (int)(r + 1); val_d[p++] = -1.0; }
+  if (j < ny - 1) { col_d[p] = (int)(r + nx); val_d[p++] = -1.0; }
+  if (k < nz - 1) { if (kl < nzl - 1) { col_d[p] = (int)(r + plane); val_d[p++] = -1.0; } else { col_o[q] = nlow + (int)(r - (n - plane)); val_o[q++] = -1.0; } }
+}
+
+// 2-D 5-point Laplacian, ex2.c:44-51 (single slab): diag 4, off -1, II=i*n+j
+__global__ void k_lap2d_count(int n, int m, int *cnt)
+{
+  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= (long long)n * m) return;
+  int i = (int)(r / n), j = (int)(r % n);
+  cnt[r] = 1 + (i > 0) + (i < m - 1) + (j > 0) + (j < n - 1);
+}
+__global__ void k_lap2d_fill(int n, int m, const int *rp, int *col, double *val)
+{
+  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= (long long)n * m) return;
+  int i = (int)(r / n), j = (int)(r % n);
+  int p = rp[r];
+  if (i > 0) { col[p] = (int)(r - n); val[p++] = -1.0; }
+  if (j > 0) { col[p] = (int)(r - 1); val[p++] = -1.0; }
+  col[p] = (int)r; val[p++] = 4.0;
+  if (j < n - 1) { col[p] = (int)(r + 1); val[p++] = -1.0; }
+  if (i < m - 1) { col[p] = (int)(r + n); val[p++] = -1.0; }
+}
+
+__global__ void k_rows_with_entries(int n, const int *rp, int *flag)
+{
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) flag[r] = (rp[r + 1] > rp[r]) ? 1 : 0;
+}
+__global__ void k_compact_rows(int n, const int *rp, const int *pos, int *rows, int *rp_c)
+{
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n && rp[r + 1] > rp[r]) { rows[pos[r]] = r; rp_c[pos[r]] = rp[r]; }
+}
+
+int exclusive_scan_int(hipStream_t st, const int *in, int *out, long long nitems)
+{
+  size_t tmp_bytes = 0;
+  KS_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, in, out, (int)nitems, st));
+  void *tmp = nullptr;
+  KS_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+  hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, in, out, (int)nitems, st);
+  hipStreamSynchronize(st);
+  hipFree(tmp);
+  KS_HIP(e);
+  return KS_SUCCESS;
+}
+
+// RCCL point-to-point symbols for the halo exchange
+typedef int (*nccl_send_t)(const void *, size_t, int, int, void *, hipStream_t);
+typedef int (*nccl_recv_t)(void *, size_t, int, int, void *, hipStream_t);
+typedef int (*nccl_group_t)();
+typedef int (*nccl_allgather_t)(const void *, void *, size_t, int, void *, hipStream_t);
+
+struct RcclP2P { nccl_send_t send; nccl_recv_t recv; nccl_group_t gstart, gend; nccl_allgather_t allgather; };
+int get_p2p(ks_ctx ctx, RcclP2P *p)
+{
+  KS_CHECK(ctx->comm.rccl_lib && ctx->comm.nccl_comm, KS_ERR_ORDER, "multi-rank Mat needs the RCCL provider (ks_comm_init_rccl)");
+  p->send = (nccl_send_t)dlsym(ctx->comm.rccl_lib, "ncclSend");
+  p->recv = (nccl_recv_t)dlsym(ctx->comm.rccl_lib, "ncclRecv");
+  p->gstart = (nccl_group_t)dlsym(ctx->comm.rccl_lib, "ncclGroupStart");
+  p->gend = (nccl_group_t)dlsym(ctx->comm.rccl_lib, "ncclGroupEnd");
+  p->allgather = (nccl_allgather_t)dlsym(ctx->comm.rccl_lib, "ncclAllGather");
+  KS_CHECK(p->send && p->recv && p->gstart && p->gend && p->allgather, KS_ERR_LIB, "RCCL p2p symbols not found");
+  return KS_SUCCESS;
+}
+
+// Build the halo plan from the sorted list of needed global columns (garray, host).
+// Owners are found from the allgathered row_start array; every rank tells its owners which rows it needs.
+int build_halo_plan(ks_mat A, const std::vector<int> &garray)
+{
+  ks_ctx ctx = A->ctx;
+  const int size = ctx->comm.size, rank = ctx->comm.rank;
+  A->nghost = (int)garray.size();
+  if (size == 1) { KS_CHECK(garray.empty(), KS_ERR_ARG_OUTOFRANGE, "column index outside [0,n) on a single rank"); return KS_SUCCESS; }
+  RcclP2P p2p; KS_CALL(get_p2p(ctx, &p2p));
+  const int ncclInt32 = 2;
+  // 1. ownership ranges
+  int *d_tmp = nullptr; KS_HIP(hipMalloc(&d_tmp, sizeof(int) * (size + 1) * 2));
+  KS_HIP(hipMemcpyAsync(d_tmp + size, &A->row_start, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  KS_CHECK(p2p.allgather(d_tmp + size, d_tmp, 1, ncclInt32, ctx->comm.nccl_comm, ctx->stream) == 0, KS_ERR_LIB, "ncclAllGather failed");
+  std::vector<int> starts(size + 1);
+  KS_HIP(hipMemcpyAsync(starts.data(), d_tmp, sizeof(int) * size, hipMemcpyDeviceToHost, ctx->stream));
+  KS_HIP(hipStreamSynchronize(ctx->stream));
+  starts[size] = A->n_global;
+  // 2. recv counts per owner
+  std::vector<int> recv_cnt(size, 0), send_cnt(size, 0);
+  { int p = 0; for (int g : garray) { while (p + 1 < size && g >= starts[p + 1]) p++; KS_CHECK(p != rank, KS_ERR_PLIB, "ghost column owned by self"); recv_cnt[p]++; } }
+  // 3. exchange counts (all-to-all of one int)
+  int *d_cnt = nullptr; KS_HIP(hipMalloc(&d_cnt, sizeof(int) * size * 2));
+  KS_HIP(hipMemcpyAsync(d_cnt, recv_cnt.data(), sizeof(int) * size, hipMemcpyHostToDevice, ctx->stream));
+  p2p.gstart();
+  for (int p = 0; p < size; p++) if (p != rank) { p2p.send(d_cnt + p, 1, ncclInt32, p, ctx->comm.nccl_comm, ctx->stream); p2p.recv(d_cnt + size + p, 1, ncclInt32, p, ctx->comm.nccl_comm, ctx->stream); }
+  KS_CHECK(p2p.gend() == 0, KS_ERR_LIB, "ncclGroupEnd failed (counts)");
+  KS_HIP(hipMemcpyAsync(send_cnt.data(), d_cnt + size, sizeof(int) * size, hipMemcpyDeviceToHost, ctx->stream));
+  KS_HIP(hipStreamSynchronize(ctx->stream));
+  send_cnt[rank] = 0;
+  // 4. exchange index lists: I send my garray segments (global ids) to owners; owners receive the ids they must send me
+  int nsend = 0; for (int p = 0; p < size; p++) nsend += send_cnt[p];
+  int *d_g = nullptr, *d_sidx = nullptr;
+  KS_HIP(hipMalloc(&d_g, sizeof(int) * std::max<size_t>(garray.size(), 1)));
+  KS_HIP(hipMalloc(&d_sidx, sizeof(int) * std::max(nsend, 1)));
+  KS_HIP(hipMemcpyAsync(d_g, garray.data(), sizeof(int) * garray.size(), hipMemcpyHostToDevice, ctx->stream));
+  A->peers.clear(); A->send_cnt.clear(); A->recv_cnt.clear(); A->send_off.clear(); A->recv_off.clear();
+  int roff = 0, soff = 0;
+  p2p.gstart();
+  for (int p = 0; p < size; p++) {
+    if (p == rank || (recv_cnt[p] == 0 && send_cnt[p] == 0)) continue;
+    A->peers.push_back(p); A->recv_cnt.push_back(recv_cnt[p]); A->send_cnt.push_back(send_cnt[p]); A->recv_off.push_back(roff); A->send_off.push_back(soff);
+    if (recv_cnt[p]) p2p.send(d_g + roff, recv_cnt[p], ncclInt32, p, ctx->comm.nccl_comm, ctx->stream);
+    if (send_cnt[p]) p2p.recv(d_sidx + soff, send_cnt[p], ncclInt32, p, ctx->comm.nccl_comm, ctx->stream);
+    roff += recv_cnt[p]; soff += send_cnt[p];
+  }
+  KS_CHECK(p2p.gend() == 0, KS_ERR_LIB, "ncclGroupEnd failed (index lists)");
+  std::vector<int> sidx(std::max(nsend, 1));
+  KS_HIP(hipMemcpyAsync(sidx.data(), d_sidx, sizeof(int) * nsend, hipMemcpyDeviceToHost, ctx->stream));
+  KS_HIP(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < nsend; i++) { sidx[i] -= A->row_start; KS_CHECK(sidx[i] >= 0 && sidx[i] < A->n, KS_ERR_PLIB, "peer requested a row this rank does not own"); }
+  KS_HIP(hipMemcpy(d_sidx, sidx.data(), sizeof(int) * nsend, hipMemcpyHostToDevice));
+  A->send_idx = d_sidx; A->nsend = nsend;
+  KS_HIP(hipMalloc(&A->send_buf, sizeof(double) * std::max(nsend, 1)));
+  KS_HIP(hipMalloc(&A->ghost, sizeof(double) * std::max(A->nghost, 1)));
+  hipFree(d_tmp); hipFree(d_cnt); hipFree(d_g);
+  return KS_SUCCESS;
+}
+
+int compact_offdiag_rows(ks_mat A)
+{
+  // rows with off-diagonal entries -> compressed row list + compressed rowptr (PETSc "compressed row" AIJ)
+  ks_ctx ctx = A->ctx;
+  if (A->nnz_o == 0) { A->n_orows = 0; return KS_SUCCESS; }
+  int *flag = nullptr, *pos = nullptr;
+  KS_HIP(hipMalloc(&flag, sizeof(int) * (A->n + 1))); KS_HIP(hipMalloc(&pos, sizeof(int) * (A->n + 1)));
+  KS_HIP(hipMemsetAsync(flag, 0, sizeof(int) * (A->n + 1), ctx->stream));
+  hipLaunchKernelGGL(k_rows_with_entries, dim3((A->n + 255) / 256), dim3(256), 0, ctx->stream, A->n, A->o_rowptr, flag);
+  KS_CALL(exclusive_scan_int(ctx->stream, flag, pos, A->n + 1));
+  int norows = 0; KS_HIP(hipMemcpy(&norows, pos + A->n, sizeof(int), hipMemcpyDeviceToHost));
+  int *rows = nullptr, *rp_c = nullptr;
+  KS_HIP(hipMalloc(&rows, sizeof(int) * std::max(norows, 1))); KS_HIP(hipMalloc(&rp_c, sizeof(int) * (norows + 1)));
+  hipLaunchKernelGGL(k_compact_rows, dim3((A->n + 255) / 256), dim3(256), 0, ctx->stream, A->n, A->o_rowptr, pos, rows, rp_c);
+  int last = (int)A->nnz_o; KS_HIP(hipMemcpyAsync(rp_c + norows, &last, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  KS_HIP(hipStreamSynchronize(ctx->stream));
+  hipFree(flag); hipFree(pos); hipFree(A->o_rowptr);
+  A->o_rowptr = rp_c; A->o_rows = rows; A->n_orows = norows;
+  return KS_SUCCESS;
+}
+
+} // namespace
+
+extern "C" int ks_mat_create_csr(ks_ctx ctx, int n_local, int row_start, int n_global, const int *rowptr, const int *col, const double *val, ks_mat *out)
+{
+  KS_CHECK(ctx && out, KS_ERR_ARG_NULL, "ctx/out is NULL");
+  KS_CHECK(n_local >= 0 && row_start >= 0 && row_start + n_local <= n_global, KS_ERR_ARG_OUTOFRANGE, "bad row range [%d,%d) of %d", row_start, row_start + n_local, n_global);
+  KS_CHECK(rowptr && (rowptr[n_local] == 0 || (col && val)), KS_ERR_ARG_NULL, "CSR arrays are NULL");
+  KS_CHECK(rowptr[0] == 0, KS_ERR_ARG_WRONG, "rowptr[0] must be 0");
+  KS_HIP(hipSetDevice(ctx->device));
+  const long long nnz = rowptr[n_local];
+  ks_mat A = new ks_mat_s(); A->ctx = ctx; A->n = n_local; A->row_start = row_start; A->n_global = n_global; A->nnz = nnz;
+  // split diag / off-diag on the host (setup path)
+  std::vector<int> rp_d(n_local + 1, 0), rp_o(n_local + 1, 0), cd, co; std::vector<double> vd, vo;
+  cd.reserve(nnz); vd.reserve(nnz);
+  for (int r = 0; r < n_local; r++) {
+    KS_CHECK(rowptr[r + 1] >= rowptr[r], KS_ERR_ARG_WRONG, "rowptr not monotone at row %d", r);
+    for (int p = rowptr[r]; p < rowptr[r + 1]; p++) {
+      int c = col[p];
+      if (c < 0 || c >= n_global) { delete A; KS_FAIL(KS_ERR_ARG_OUTOFRANGE, "column %d out of range at row %d", c, r); }
+      if (c >= row_start && c < row_start + n_local) { cd.push_back(c - row_start); vd.push_back(val[p]); }
+      else { co.push_back(c); vo.push_back(val[p]); }
+    }
+    rp_d[r + 1] = (int)cd.size(); rp_o[r + 1] = (int)co.size();
+  }
+  std::vector<int> garray(co);
+  std::sort(garray.begin(), garray.end()); garray.erase(std::unique(garray.begin(), garray.end()), garray.end());
+  for (auto &c : co) c = (int)(std::lower_bound(garray.begin(), garray.end(), c) - garray.begin());
+  A->nnz_d = (long long)cd.size(); A->nnz_o = (long long)co.size();
+  KS_HIP(hipMalloc(&A->d_rowptr, sizeof(int) * (n_local + 1)));
+  KS_HIP(hipMalloc(&A->d_col, sizeof(int) * std::max<size_t>(cd.size(), 1)));
+  KS_HIP(hipMalloc(&A->d_val, sizeof(double) * std::max<size_t>(vd.size(), 1)));
+  KS_HIP(hipMemcpy(A->d_rowptr, rp_d.data(), sizeof(int) * (n_local + 1), hipMemcpyHostToDevice));
+  KS_HIP(hipMemcpy(A->d_col, cd.data(), sizeof(int) * cd.size(), hipMemcpyHostToDevice));
+  KS_HIP(hipMemcpy(A->d_val, vd.data(), sizeof(double) * vd.size(), hipMemcpyHostToDevice));
+  A->lanes_per_row = pick_lanes(A->nnz_d, n_local);
+  if (A->nnz_o) {
+    KS_HIP(hipMalloc(&A->o_rowptr, sizeof(int) * (n_local + 1)));
+    KS_HIP(hipMalloc(&A->o_col, sizeof(int) * co.size()));
+    KS_HIP(hipMalloc(&A->o_val, sizeof(double) * vo.size()));
+    KS_HIP(hipMemcpy(A->o_rowptr, rp_o.data(), sizeof(int) * (n_local + 1), hipMemcpyHostToDevice));
+    KS_HIP(hipMemcpy(A->o_col, co.data(), sizeof(int) * co.size(), hipMemcpyHostToDevice));
+    KS_HIP(hipMemcpy(A->o_val, vo.data(), sizeof(double) * vo.size(), hipMemcpyHostToDevice));
+  }
+  int rc = build_halo_plan(A, garray);
+  if (!rc) rc = compact_offdiag_rows(A);
+  if (rc) { ks_mat_destroy(A); return rc; }
+  *out = A;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_mat_create_laplacian3d(ks_ctx ctx, int nx, int ny, int nz, int z0, int nzl, ks_mat *out)
+{
+  KS_CHECK(ctx && out, KS_ERR_ARG_NULL, "ctx/out is NULL");
+  KS_CHECK(nx > 0 && ny > 0 && nz > 0 && z0 >= 0 && nzl > 0 && z0 + nzl <= nz, KS_ERR_ARG_OUTOFRANGE, "bad grid %dx%dx%d planes [%d,%d)", nx, ny, nz, z0, z0 + nzl);
+  const long long plane = (long long)nx * ny, n = plane * nzl, N = plane * nz;
+  KS_CHECK(N * 7 < 2147483647LL && n < 2147483647LL, KS_ERR_ARG_OUTOFRANGE, "problem exceeds 32-bit PetscInt indices");
+  KS_HIP(hipSetDevice(ctx->device));
+  ks_mat A = new ks_mat_s(); A->ctx = ctx; A->n = (int)n; A->row_start = (int)(plane * z0); A->n_global = (int)N;
+  int *cnt_d = nullptr, *cnt_o = nullptr;
+  KS_HIP(hipMalloc(&cnt_d, sizeof(int) * (n + 1))); KS_HIP(hipMalloc(&cnt_o, sizeof(int) * (n + 1)));
+  KS_HIP(hipMemsetAsync(cnt_d + n, 0, sizeof(int), ctx->stream)); KS_HIP(hipMemsetAsync(cnt_o + n, 0, sizeof(int), ctx->stream));
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_lap3d_count, dim3(nb), dim3(256), 0, ctx->stream, nx, ny, nz, z0, nzl, cnt_d, cnt_o);
+  KS_HIP(hipMalloc(&A->d_rowptr, sizeof(int) * (n + 1))); KS_HIP(hipMalloc(&A->o_rowptr, sizeof(int) * (n + 1)));
+  KS_CALL(exclusive_scan_int(ctx->stream, cnt_d, A->d_rowptr, n + 1));
+  KS_CALL(exclusive_scan_int(ctx->stream, cnt_o, A->o_rowptr, n + 1));
+  int nnzd = 0, nnzo = 0;
+  KS_HIP(hipMemcpy(&nnzd, A->d_rowptr + n, sizeof(int), hipMemcpyDeviceToHost));
+  KS_HIP(hipMemcpy(&nnzo, A->o_rowptr + n, sizeof(int), hipMemcpyDeviceToHost));
+  hipFree(cnt_d); hipFree(cnt_o);
+  A->nnz_d = nnzd; A->nnz_o = nnzo; A->nnz = (long long)nnzd + nnzo;
+  KS_HIP(hipMalloc(&A->d_col, sizeof(int) * std::max(nnzd, 1))); KS_HIP(hipMalloc(&A->d_val, sizeof(double) * std::max(nnzd, 1)));
+  KS_HIP(hipMalloc(&A->o_col, sizeof(int) * std::max(nnzo, 1))); KS_HIP(hipMalloc(&A->o_val, sizeof(double) * std::max(nnzo, 1)));
+  hipLaunchKernelGGL(k_lap3d_fill, dim3(nb), dim3(256), 0, ctx->stream, nx, ny, nz, z0, nzl, A->d_rowptr, A->d_col, A->d_val, A->o_rowptr, A->o_col, A->o_val);
+  KS_HIP(hipStreamSynchronize(ctx->stream));
+  A->lanes_per_row = pick_lanes(A->nnz_d, A->n);
+  // ghost columns: the plane below (owned by the previous slab) then the plane above
+  std::vector<int> garray;
+  if (z0 > 0) for (long long c = 0; c < plane; c++) garray.push_back((int)(plane * (z0 - 1) + c));
+  if (z0 + nzl < nz) for (long long c = 0; c < plane; c++) garray.push_back((int)(plane * (z0 + nzl) + c));
+  int rc = KS_SUCCESS;
+  if (ctx->comm.size == 1 && !garray.empty()) { ks_mat_destroy(A); KS_FAIL(KS_ERR_ARG_INCOMP, "a partial slab needs a multi-rank communicator"); }
+  rc = build_halo_plan(A, garray);
+  if (!rc) rc = compact_offdiag_rows(A);
+  if (rc) { ks_mat_destroy(A); return rc; }
+  *out = A;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_mat_create_laplacian2d(ks_ctx ctx, int n, int m, ks_mat *out)
+{
+  KS_CHECK(ctx && out, KS_ERR_ARG_NULL, "ctx/out is NULL");
+  KS_CHECK(n > 0 && m > 0 && (long long)n * m * 5 < 2147483647LL, KS_ERR_ARG_OUTOFRANGE, "bad grid %dx%d", n, m);
+  KS_CHECK(ctx->comm.size == 1, KS_ERR_SUP, "2-D generator is single-rank");
+  KS_HIP(hipSetDevice(ctx->device));
+  const long long N = (long long)n * m;
+  ks_mat A = new ks_mat_s(); A->ctx = ctx; A->n = (int)N; A->row_start = 0; A->n_global = (int)N;
+  int *cnt = nullptr; KS_HIP(hipMalloc(&cnt, sizeof(int) * (N + 1)));
+  KS_HIP(hipMemsetAsync(cnt + N, 0, sizeof(int), ctx->stream));
+  const unsigned nb = (unsigned)((N + 255) / 256);
+  hipLaunchKernelGGL(k_lap2d_count, dim3(nb), dim3(256), 0, ctx->stream, n, m, cnt);
+  KS_HIP(hipMalloc(&A->d_rowptr, sizeof(int) * (N + 1)));
+  KS_CALL(exclusive_scan_int(ctx->stream, cnt, A->d_rowptr, N + 1));
+  int nnz = 0; KS_HIP(hipMemcpy(&nnz, A->d_rowptr + N, sizeof(int), hipMemcpyDeviceToHost));
+  hipFree(cnt);
+  A->nnz = A->nnz_d = nnz;
+  KS_HIP(hipMalloc(&A->d_col, sizeof(int) * nnz)); KS_HIP(hipMalloc(&A->d_val, sizeof(double) * nnz));
+  hipLaunchKernelGGL(k_lap2d_fill, dim3(nb), dim3(256), 0, ctx->stream, n, m, A->d_rowptr, A->d_col, A->d_val);
+  KS_HIP(hipStreamSynchronize(ctx->stream));
+  A->lanes_per_row = pick_lanes(A->nnz_d, A->n);
+  *out = A;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_mat_destroy(ks_mat A)
+{
+  if (!A) return KS_SUCCESS;
+  hipSetDevice(A->ctx->device);
+  hipStreamSynchronize(A->ctx->stream);
+  hipFree(A->d_rowptr); hipFree(A->d_col); hipFree(A->d_val);
+  hipFree(A->o_rowptr); hipFree(A->o_col); hipFree(A->o_val); hipFree(A->o_rows);
+  hipFree(A->ghost); hipFree(A->send_idx); hipFree(A->send_buf);
+  delete A;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_mat_get_sizes(ks_mat A, int *n_local, int *n_global, long long *nnz_local)
+{
+  KS_CHECK(A, KS_ERR_ARG_NULL, "Mat is NULL");
+  if (n_local) *n_local = A->n;
+  if (n_global) *n_global = A->n_global;
+  if (nnz_local) *nnz_local = A->nnz;
+  return KS_SUCCESS;
+}
+
+// y = A x.  Multi-rank: pack boundary entries, exchange with the neighbours (RCCL send/recv over xGMI),
+// diagonal block product, then the off-diagonal rows add their ghost contributions.
+int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
+{
+  ks_ctx ctx = A->ctx;
+  const bool multi = ctx->comm.size > 1 && (A->nsend > 0 || A->nghost > 0);
+  if (multi) {
+    KsProfScope ps(ctx, KS_K_HALO, 8.0 * (A->nsend + A->nghost));
+    RcclP2P p2p; KS_CALL(get_p2p(ctx, &p2p));
+    const int ncclFloat64 = 8;
+    if (A->nsend) hipLaunchKernelGGL(k_pack, dim3((A->nsend + 255) / 256), dim3(256), 0, ctx->stream, A->nsend, A->send_idx, x, A->send_buf);
+    p2p.gstart();
+    for (size_t i = 0; i < A->peers.size(); i++) {
+      if (A->send_cnt[i]) p2p.send(A->send_buf + A->send_off[i], A->send_cnt[i], ncclFloat64, A->peers[i], ctx->comm.nccl_comm, ctx->stream);
+      if (A->recv_cnt[i]) p2p.recv(A->ghost + A->recv_off[i], A->recv_cnt[i], ncclFloat64, A->peers[i], ctx->comm.nccl_comm, ctx->stream);
+    }
+    KS_CHECK(p2p.gend() == 0, KS_ERR_LIB, "ncclGroupEnd failed (halo)");
+  }
+  {
+    KsProfScope ps(ctx, KS_K_SPMV, 12.0 * A->nnz + 4.0 * (A->n + 1) + 16.0 * A->n);
+    launch_spmv<false, false>(ctx->stream, ctx->num_cu, A->lanes_per_row, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, nullptr);
+    if (A->n_orows > 0)
+      launch_spmv<true, true>(ctx->stream, ctx->num_cu, 2, A->n_orows, A->o_rowptr, A->o_col, A->o_val, A->ghost, y, A->o_rows);
+  }
+  KS_HIP(hipGetLastError());
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_mat_mult(ks_mat A, const double *x_dev, double *y_dev)
+{
+  KS_CHECK(A && x_dev && y_dev, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(x_dev != y_dev, KS_ERR_ARG_WRONG, "x and y must be different vectors");   // MatMult requirement
+  KS_HIP(hipSetDevice(A->ctx->device));
+  return ks_mat_mult_internal(A, x_dev, y_dev);
+}
+
+extern "C" int ks_mat_mult_host(ks_mat A, const double *x_host, double *y_host)
+{
+  KS_CHECK(A && x_host && y_host, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(A->ctx->comm.size == 1, KS_ERR_SUP, "host convenience wrapper is single-rank");
+  KS_HIP(hipSetDevice(A->ctx->device));
+  double *x = nullptr, *y = nullptr;
+  KS_HIP(hipMalloc(&x, sizeof(double) * std::max(A->n_global, 1))); KS_HIP(hipMalloc(&y, sizeof(double) * std::max(A->n, 1)));
+  KS_HIP(hipMemcpy(x, x_host, sizeof(double) * A->n_global, hipMemcpyHostToDevice));
+  int rc = ks_mat_mult_internal(A, x, y);
+  if (!rc) { hipStreamSynchronize(A->ctx->stream); hipMemcpy(y_host, y, sizeof(double) * A->n, hipMemcpyDeviceToHost); }
+  hipFree(x); hipFree(y);
+  return rc;
+}

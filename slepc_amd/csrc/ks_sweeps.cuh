@@ -1,0 +1,150 @@
+// Row-sweep device kernels shared by the BV ops and the fused Gram-Schmidt (gfx950, wave64).
+//
+// All BV kernels on the Krylov path are HBM-bound tall-skinny sweeps over an n x k column-major
+// panel (n ~ 1e7 rows, k <= 64 columns, ld >= n). The mapping is the same everywhere:
+//   lane  <-> row  (VEC=2: two consecutive rows per lane, one 16-byte load per column per lane, so
+//                   one wave-instruction reads 1 KiB contiguous of ONE column),
+//   tile  = 256 threads x VEC rows, tiles dealt to blocks grid-stride,
+//   all k columns of the tile are loaded by independent loads issued back to back (k x 1 KiB in
+//   flight per wave -> deep memory-level parallelism at low occupancy),
+//   per-thread partial sums live in registers for the whole sweep, are combined once per block with
+//   wave64 shuffles + LDS, and leave the block as one row of the `partials` array; a 1-block kernel
+//   sums the partials in a fixed order (run-to-run deterministic, independent of scheduling).
+// Column counts are compile-time (KT) so accumulators stay in VGPRs; a launch uses the smallest
+// KT >= ncols and clamps the column index for the tail (duplicate loads hit L1, results discarded).
+#pragma once
+#include "ksgpu_internal.h"
+
+namespace ksk {
+
+constexpr int SW_BLOCK = 256;
+constexpr int SW_WAVES = SW_BLOCK / 64;
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Block-combine KT per-thread accumulators and write them to partials[i*gridDim.x + blockIdx.x], i<ncols.
+template <int KT>
+__device__ __forceinline__ void block_write_partials(double (&acc)[KT], int ncols, double *__restrict__ partials)
+{
+  __shared__ double red[SW_WAVES][KT];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < KT; i++) {
+    double s = wave_sum(acc[i]);
+    if (lane == 0) red[w][i] = s;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < ncols) {
+    double s = red[0][threadIdx.x];
+#pragma unroll
+    for (int ww = 1; ww < SW_WAVES; ww++) s += red[ww][threadIdx.x];
+    partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s;
+  }
+}
+
+// partials <- A(:,0:ncols)^T y        (gemv-C of BVDotVec_BLAS_Private, bvblas.c:240-261)
+template <int KT, int VEC>
+__global__ __launch_bounds__(SW_BLOCK) void k_dot_sweep(const double *__restrict__ A, long long lda, int n, int ncols,
+                                                        const double *__restrict__ y, double *__restrict__ partials,
+                                                        const KsGsState *__restrict__ gate)
+{
+  if (gate && !gate->active) return;
+  double acc[KT];
+#pragma unroll
+  for (int i = 0; i < KT; i++) acc[i] = 0.0;
+  const long long tile = (long long)SW_BLOCK * VEC;
+  const long long ntiles = ((long long)n + tile - 1) / tile;
+  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long long r = t * tile + (long long)threadIdx.x * VEC;
+    if (VEC == 2) {
+      if (r + 1 < n) {
+        const double2 yv = *reinterpret_cast<const double2 *>(y + r);
+#pragma unroll
+        for (int i = 0; i < KT; i++) {
+          const int ii = i < ncols ? i : ncols - 1;
+          const double2 xv = *reinterpret_cast<const double2 *>(A + (long long)ii * lda + r);
+          acc[i] = fma(xv.x, yv.x, acc[i]);
+          acc[i] = fma(xv.y, yv.y, acc[i]);
+        }
+      } else if (r < n) {
+        const double yv = y[r];
+#pragma unroll
+        for (int i = 0; i < KT; i++) { const int ii = i < ncols ? i : ncols - 1; acc[i] = fma(A[(long long)ii * lda + r], yv, acc[i]); }
+      }
+    } else {
+      if (r < n) {
+        const double yv = y[r];
+#pragma unroll
+        for (int i = 0; i < KT; i++) { const int ii = i < ncols ? i : ncols - 1; acc[i] = fma(A[(long long)ii * lda + r], yv, acc[i]); }
+      }
+    }
+  }
+  block_write_partials<KT>(acc, ncols, partials);
+}
+
+// y = beta*y + alpha*A(:,0:ncols) q   (gemv-N of BVMultVec_BLAS_Private, bvblas.c:56-67); q on device
+template <int VEC>
+__global__ __launch_bounds__(SW_BLOCK) void k_multvec(const double *__restrict__ A, long long lda, int n, int ncols, double alpha, double beta,
+                                                      const double *__restrict__ q, double *__restrict__ y)
+{
+  const long long tile = (long long)SW_BLOCK * VEC;
+  const long long ntiles = ((long long)n + tile - 1) / tile;
+  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long long r = t * tile + (long long)threadIdx.x * VEC;
+    if (VEC == 2 && r + 1 < n) {
+      double2 s;
+      if (beta == 0.0) { s.x = 0.0; s.y = 0.0; }
+      else { s = *reinterpret_cast<const double2 *>(y + r); if (beta != 1.0) { s.x *= beta; s.y *= beta; } }
+      int i = 0;
+      for (; i + 8 <= ncols; i += 8) {
+        double2 xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) xv[u] = *reinterpret_cast<const double2 *>(A + (long long)(i + u) * lda + r);
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const double c = alpha * q[i + u]; s.x = fma(c, xv[u].x, s.x); s.y = fma(c, xv[u].y, s.y); }
+      }
+      for (; i < ncols; i++) { const double2 xv = *reinterpret_cast<const double2 *>(A + (long long)i * lda + r); const double c = alpha * q[i]; s.x = fma(c, xv.x, s.x); s.y = fma(c, xv.y, s.y); }
+      *reinterpret_cast<double2 *>(y + r) = s;
+    } else {
+      for (int v = 0; v < VEC; v++) {
+        const long long rr = r + v;
+        if (rr < n) {
+          double s = (beta == 0.0) ? 0.0 : beta * y[rr];
+          for (int i = 0; i < ncols; i++) s = fma(alpha * q[i], A[(long long)i * lda + rr], s);
+          y[rr] = s;
+        }
+      }
+    }
+  }
+}
+
+// 1-block reduction of block partials: out[i] = sum_b partials[i*nblocks + b], i < ncols (fixed order)
+__device__ __forceinline__ void reduce_partials_to_lds(const double *__restrict__ partials, int nblocks, int ncols, double *c_lds)
+{
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int i = w; i < ncols; i += nw) {
+    double s = 0.0;
+    for (int b = lane; b < nblocks; b += 64) s += partials[(size_t)i * nblocks + b];
+    s = wave_sum(s);
+    if (lane == 0) c_lds[i] = s;
+  }
+  __syncthreads();
+}
+
+} // namespace ksk
+
+// dispatch helper: smallest compiled KT >= ncols
+#define KS_KT_DISPATCH(ncols, MACRO)                                              \
+  do {                                                                            \
+    if ((ncols) <= 4) { MACRO(4); } else if ((ncols) <= 8) { MACRO(8); }          \
+    else if ((ncols) <= 12) { MACRO(12); } else if ((ncols) <= 16) { MACRO(16); } \
+    else if ((ncols) <= 20) { MACRO(20); } else if ((ncols) <= 24) { MACRO(24); } \
+    else if ((ncols) <= 28) { MACRO(28); } else if ((ncols) <= 32) { MACRO(32); } \
+    else if ((ncols) <= 40) { MACRO(40); } else if ((ncols) <= 48) { MACRO(48); } \
+    else if ((ncols) <= 56) { MACRO(56); } else { MACRO(64); }                    \
+  } while (0)

@@ -1,0 +1,135 @@
+// Internal declarations of libksgpu (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <string>
+#include "../../include/ksgpu.h"
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void ks_set_error(const char *fmt, ...);
+#define KS_FAIL(rc, ...) do { ks_set_error(__VA_ARGS__); return (rc); } while (0)
+#define KS_CHECK(cond, rc, ...) do { if (!(cond)) KS_FAIL(rc, __VA_ARGS__); } while (0)
+#define KS_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    ks_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return KS_ERR_LIB; } } while (0)
+#define KS_CALL(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+// ---- profiling ----------------------------------------------------------------------------------
+struct KsProfSlot { long long launches = 0; double ms = 0.0; double bytes = 0.0; };
+struct KsProfPending { hipEvent_t e0, e1; int kclass; double bytes; };
+
+// ---- communicator -------------------------------------------------------------------------------
+struct KsComm {
+  int rank = 0, size = 1;
+  // native RCCL (resolved with dlopen so that a process that already holds librccl reuses it)
+  void *rccl_lib = nullptr;
+  void *nccl_comm = nullptr;
+  // callback provider
+  ks_allreduce_fn cb_allreduce = nullptr;
+  void *cb_user = nullptr;
+};
+
+struct ks_ctx_s {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int num_cu = 256;
+  char arch[64] = {0};
+  size_t mem_total = 0;
+  KsComm comm;
+  // profiling
+  bool prof_on = false;
+  KsProfSlot prof[KS_K_COUNT];
+  std::vector<KsProfPending> pending;
+  std::vector<hipEvent_t> event_pool;
+  // small pinned host staging area for coefficient transfers
+  double *h_pinned = nullptr; size_t h_pinned_len = 0;
+};
+
+int ks_prof_begin(ks_ctx ctx, int kclass, double bytes);   // records start event when profiling
+int ks_prof_end(ks_ctx ctx);
+int ks_prof_flush(ks_ctx ctx);
+struct KsProfScope {
+  ks_ctx ctx; bool on;
+  KsProfScope(ks_ctx c, int kclass, double bytes) : ctx(c), on(c->prof_on) { if (on) ks_prof_begin(c, kclass, bytes); }
+  ~KsProfScope() { if (on) ks_prof_end(ctx); }
+};
+
+int ks_allreduce_sum(ks_ctx ctx, double *dev_buf, int count);   // no-op when size==1
+
+// ---- Mat ----------------------------------------------------------------------------------------
+struct ks_mat_s {
+  ks_ctx ctx = nullptr;
+  int n = 0;             // local rows
+  int row_start = 0;     // first global row
+  int n_global = 0;
+  long long nnz = 0;     // local nonzeros (diag + offdiag blocks)
+  // diagonal block (columns owned by this rank, LOCAL column indices)
+  int *d_rowptr = nullptr; int *d_col = nullptr; double *d_val = nullptr; long long nnz_d = 0;
+  int lanes_per_row = 8;
+  // off-diagonal block (columns owned by other ranks), compressed to ghost indices [0,nghost)
+  int *o_rowptr = nullptr; int *o_col = nullptr; double *o_val = nullptr; long long nnz_o = 0;
+  int nghost = 0;
+  int *o_rows = nullptr; int n_orows = 0;     // rows that have off-diagonal entries (compressed row list)
+  double *ghost = nullptr;                    // received halo values (nghost)
+  // halo plan (size>1): peers, counts, send index lists
+  std::vector<int> peers, send_cnt, recv_cnt, send_off, recv_off;
+  int *send_idx = nullptr; int nsend = 0;     // local row indices to pack
+  double *send_buf = nullptr;
+};
+
+// ---- BV -----------------------------------------------------------------------------------------
+// Device-resident Gram-Schmidt state (one per BV).  Written by the 1-block bookkeeping kernel,
+// read by the sweep kernels; lets a whole Krylov run be enqueued with no host round trip.
+struct KsGsState {
+  int active;         // 0 after breakdown/error: every later kernel of the run is a no-op
+  int do_update;      // coefficients c are ready: the next update kernel must apply them
+  int fuse_dot;       // that update must also produce the partial dots of the next pass (or v'.v')
+  int scale_now;      // that update is the final one: multiply by alpha while writing
+  int expl;           // estimated norm^2 <= 0: explicit norm needed after the update (bvorthog.c:126)
+  int pending_scale;  // final scaling still to be applied by the stand-alone scale kernel
+  int pass;           // passes done for the current column
+  int err;            // sticky error (KS_ERR_USER_INPUT: invalid inner product)
+  int lindep;         // result for the current column
+  int more_;          // another pass follows the pending update (bvorthog.c:179 loop condition)
+  double onrm, nrm, alpha;
+  long long passes_total;
+};
+struct KsStepRec { double nrm, onrm; int passes, lindep, expl, col; };
+
+struct ks_bv_s {
+  ks_ctx ctx = nullptr;
+  int n = 0, N = 0, m = 0, l = 0, k = 0, nc = 0, ld = 0;
+  int orthog_type = KS_BV_ORTHOG_CGS, orthog_ref = KS_BV_ORTHOG_REFINE_IFNEEDED;
+  double orthog_eta = 0.7071;
+  double deftol = 10 * 2.220446049250313e-16;
+  double *array = nullptr;      // m*ld
+  double *buffer = nullptr;     // (nc+m)*m ; column 0 = scratch c
+  double *partials = nullptr;   // [KS_MAX_BLOCKS][KS_PSTRIDE] block partial sums
+  double *coef = nullptr;       // device scratch for host-provided q / Q (max(m*m, ...))
+  double *hc = nullptr;         // device h,c arrays for orthogonalizevec (2*(nc+m))
+  size_t coef_len = 0;
+  KsGsState *gs = nullptr;
+  KsStepRec *recs = nullptr;    // m records (one per column)
+  long long passes_total_host = 0; int passes_last_host = 0;
+  int row_start = 0;            // first global row (reproducible random)
+  int last_grid = 1;            // grid size of the sweep that last wrote `partials`
+};
+
+constexpr int KS_MAX_COLS   = 64;     // max columns handled by the register-tiled sweeps (k+1 <= 64)
+constexpr int KS_PSTRIDE    = 72;     // doubles per block in the partials array
+constexpr int KS_MAX_BLOCKS = 2048;
+
+static inline double *ks_bv_col(ks_bv bv, int j) { return bv->array + (size_t)(bv->nc + j) * bv->ld; }
+
+// kernel launchers (ks_bv_kernels.hip / ks_gs.hip)
+int ksk_dot(ks_bv bv, const double *A, int lda, int ncols, const double *y, bool gate);      // partials <- A(:,0:ncols)^T y
+int ksk_reduce_partials(ks_bv bv, int ncols, double *out_dev);                                // out[i] = sum_b partials[b][i]
+int ksk_multvec(ks_bv bv, const double *A, int lda, int ncols, double alpha, double beta, const double *q_dev, double *y);
+int ksk_scale(ks_ctx ctx, double *x, size_t n, double alpha);
+int ksk_copy(ks_ctx ctx, const double *src, double *dst, size_t n);
+
+int ks_mat_mult_internal(ks_mat A, const double *x, double *y);
