@@ -183,12 +183,18 @@ int ks_eps_get_bv(ks_eps eps, ks_bv *V);
 int ks_eps_get_stats(ks_eps eps, long long *arnoldi_steps, long long *gs_passes, int *restarts);
 
 /* ---- profiling: HIP-event timing per kernel class, on the context's stream -------------------- */
+/* A class is one __global__ kernel template; `variant` is its compile-time column tile KT (0 when
+   the kernel has none), so (class, variant) names ONE kernel symbol as rocprofv3 reports it.
+   Launches of the speculative Gram-Schmidt slots that gated themselves off on the device are
+   re-filed under KS_K_NOOP once the host has read back the pass counts.                          */
 enum { KS_K_SPMV = 0, KS_K_DOT, KS_K_GSFIN, KS_K_UPD_FUSED, KS_K_UPD, KS_K_SCALE, KS_K_MULTINPLACE, KS_K_COPY,
-       KS_K_MULT, KS_K_BVDOT, KS_K_NORM, KS_K_HALO, KS_K_ALLREDUCE, KS_K_OTHER, KS_K_COUNT };
+       KS_K_MULT, KS_K_BVDOT, KS_K_NORM, KS_K_HALO, KS_K_ALLREDUCE, KS_K_NOOP, KS_K_OTHER, KS_K_COUNT };
+#define KS_PROF_VARIANTS 17      /* variant index = KT/4, KT in {0,4,...,64} */
 int ks_prof_enable(ks_ctx ctx, int on);
 int ks_prof_reset(ks_ctx ctx);
-/* launches, summed elapsed ms and summed algorithmic bytes (SURVEY.md 8d figures) of one class */
-int ks_prof_get(ks_ctx ctx, int kclass, long long *launches, double *ms, double *alg_bytes);
+/* launches, summed elapsed ms, summed algorithmic bytes (SURVEY.md 8d formulas) and summed compulsory
+   HBM bytes (what the kernel as designed must move) of one class; variant<0 sums over all variants */
+int ks_prof_get(ks_ctx ctx, int kclass, int variant, long long *launches, double *ms, double *alg_bytes, double *hbm_bytes);
 const char *ks_prof_class_name(int kclass);
 
 #ifdef __cplusplus

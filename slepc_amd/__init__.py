@@ -29,7 +29,11 @@ EPS_CONVERGED_TOL, EPS_CONVERGED_USER, EPS_DIVERGED_ITS, EPS_DIVERGED_BREAKDOWN 
 WHICH = {"largest_magnitude": 1, "smallest_magnitude": 2, "largest_real": 3, "smallest_real": 4}
 
 KCLASSES = ["spmv_csr", "bv_dot_sweep", "gs_bookkeeping", "gs_update_fused_dot", "gs_update", "bv_scale", "bv_multinplace",
-            "bv_copy", "bv_mult", "bv_dot_panel", "bv_norm", "halo_exchange", "allreduce", "other"]
+            "bv_copy", "bv_mult", "bv_dot_panel", "bv_norm", "halo_exchange", "allreduce", "gated_noop", "other"]
+# kernel symbol behind each (class, variant) as rocprofv3 --kernel-trace names it (VEC=2 forms)
+KSYMBOL = {"spmv_csr": "k_spmv_csr<{G}, 4, false, false>", "bv_dot_sweep": "k_dot_sweep<{KT}, 2>",
+           "gs_update_fused_dot": "k_gs_update<{KT}, 2>", "gs_update": "k_gs_update<{KT}, 2>",
+           "gs_bookkeeping": "k_gs_finish<true, true>", "bv_multinplace": "k_panel_mult<{KT}, false>"}
 
 _dp = _lib.dp
 _ip = _lib.ip
@@ -110,13 +114,16 @@ class Context:
     def prof_reset(self):
         _lib.check(self.L.ks_prof_reset(self.h))
 
-    def prof_get(self):
+    def prof_get(self, by_variant=False):
+        """{class: {launches, ms, alg_bytes, hbm_bytes}}; by_variant=True keys are (class, KT)."""
         out = {}
         for i, name in enumerate(KCLASSES):
-            n = C.c_longlong(); ms = C.c_double(); b = C.c_double()
-            _lib.check(self.L.ks_prof_get(self.h, i, C.byref(n), C.byref(ms), C.byref(b)))
-            if n.value:
-                out[name] = {"launches": n.value, "ms": ms.value, "alg_bytes": b.value}
+            variants = [4 * v for v in range(17)] if by_variant else [-1]
+            for var in variants:
+                n = C.c_longlong(); ms = C.c_double(); b = C.c_double(); hb = C.c_double()
+                _lib.check(self.L.ks_prof_get(self.h, i, var, C.byref(n), C.byref(ms), C.byref(b), C.byref(hb)))
+                if n.value:
+                    out[(name, var) if by_variant else name] = {"launches": n.value, "ms": ms.value, "alg_bytes": b.value, "hbm_bytes": hb.value}
         return out
 
 
@@ -154,9 +161,9 @@ class Mat:
         return cls(ctx, h)
 
     def destroy(self):
-        if self.h:
+        if self.h and self.ctx.h:      # a closed context already released the device; never touch it again
             self.ctx.L.ks_mat_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -198,7 +205,7 @@ class BV:
         self.n, self.N, self.m, self.ld = nn.value, NN.value, mm.value, ll.value
 
     def destroy(self):
-        if self.h and self._own:
+        if self.h and self._own and self.ctx.h:
             self.ctx.L.ks_bv_destroy(self.h)
         self.h = None
 
@@ -379,9 +386,9 @@ class EPS:
         self._A = None
 
     def destroy(self):
-        if self.h:
+        if self.h and self.ctx.h:
             self.ctx.L.ks_eps_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:

@@ -106,7 +106,7 @@ _SIG = {
     # profiling
     "ks_prof_enable": [vp, C.c_int],
     "ks_prof_reset": [vp],
-    "ks_prof_get": [vp, C.c_int, llp, dp, dp],
+    "ks_prof_get": [vp, C.c_int, C.c_int, llp, dp, dp, dp],
 }
 _STR_FUNCS = ("ks_error_string", "ks_last_error_message", "ks_prof_class_name")
 

@@ -129,7 +129,7 @@ int ksk_dot(ks_bv bv, const double *A, int lda, int ncols, const double *y, bool
   const int grid = sweep_grid(ctx, bv->n, v2 ? 2 : 1);
   bv->last_grid = grid;
   const KsGsState *g = gate ? bv->gs : nullptr;
-  KsProfScope ps(ctx, KS_K_DOT, 8.0 * bv->n * (ncols + (y >= A && y < A + (size_t)ncols * lda ? 0 : 1)));
+  KsProfScope ps(ctx, KS_K_DOT, 8.0 * bv->n * (ncols + (y >= A && y < A + (size_t)ncols * lda ? 0 : 1)), ks_kt_for(ncols));
 #define LAUNCH_DOT(KT)                                                                                                                        \
   do {                                                                                                                                        \
     if (v2) hipLaunchKernelGGL((k_dot_sweep<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, y, bv->partials, g); \

@@ -98,7 +98,7 @@ extern "C" int ks_ctx_device_info(ks_ctx ctx, char *arch, int arch_len, int *num
 // ---- profiling ----------------------------------------------------------------------------------
 static const char *g_class_names[KS_K_COUNT] = {
   "spmv_csr", "bv_dot_sweep", "gs_bookkeeping", "gs_update_fused_dot", "gs_update", "bv_scale", "bv_multinplace", "bv_copy",
-  "bv_mult", "bv_dot_panel", "bv_norm", "halo_exchange", "allreduce", "other" };
+  "bv_mult", "bv_dot_panel", "bv_norm", "halo_exchange", "allreduce", "gated_noop", "other" };
 
 extern "C" const char *ks_prof_class_name(int k) { return (k >= 0 && k < KS_K_COUNT) ? g_class_names[k] : "?"; }
 
@@ -109,9 +109,10 @@ static int get_event(ks_ctx ctx, hipEvent_t *e)
   return KS_SUCCESS;
 }
 
-int ks_prof_begin(ks_ctx ctx, int kclass, double bytes)
+int ks_prof_begin(ks_ctx ctx, int kclass, int variant, double bytes, double hbm)
 {
-  KsProfPending p; p.kclass = kclass; p.bytes = bytes;
+  KsProfPending p; p.kclass = kclass; p.variant = (variant >= 0 && variant / 4 < KS_PROF_VARIANTS) ? variant / 4 : 0; p.bytes = bytes; p.hbm = hbm;
+  p.tag_col = -1; p.tag_slot = 0; p.tag_k = 0; p.tag_n = 0;
   KS_CALL(get_event(ctx, &p.e0)); KS_CALL(get_event(ctx, &p.e1));
   KS_HIP(hipEventRecord(p.e0, ctx->stream));
   ctx->pending.push_back(p);
@@ -133,7 +134,8 @@ int ks_prof_flush(ks_ctx ctx)
   for (auto &p : ctx->pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
-      ctx->prof[p.kclass].launches++; ctx->prof[p.kclass].ms += ms; ctx->prof[p.kclass].bytes += p.bytes;
+      KsProfSlot &sl = ctx->prof[p.kclass][p.variant];
+      sl.launches++; sl.ms += ms; sl.bytes += p.bytes; sl.hbm += p.hbm;
     }
     ctx->event_pool.push_back(p.e0); ctx->event_pool.push_back(p.e1);
   }
@@ -153,19 +155,53 @@ extern "C" int ks_prof_reset(ks_ctx ctx)
 {
   KS_CHECK(ctx, KS_ERR_ARG_NULL, "ctx is NULL");
   KS_CALL(ks_prof_flush(ctx));
-  for (int i = 0; i < KS_K_COUNT; i++) ctx->prof[i] = KsProfSlot();
+  for (int i = 0; i < KS_K_COUNT; i++) for (int v = 0; v < KS_PROF_VARIANTS; v++) ctx->prof[i][v] = KsProfSlot();
   return KS_SUCCESS;
 }
 
-extern "C" int ks_prof_get(ks_ctx ctx, int kclass, long long *launches, double *ms, double *bytes)
+extern "C" int ks_prof_get(ks_ctx ctx, int kclass, int variant, long long *launches, double *ms, double *bytes, double *hbm)
 {
   KS_CHECK(ctx, KS_ERR_ARG_NULL, "ctx is NULL");
   KS_CHECK(kclass >= 0 && kclass < KS_K_COUNT, KS_ERR_ARG_OUTOFRANGE, "kernel class %d out of range", kclass);
+  KS_CHECK(variant < 0 || variant / 4 < KS_PROF_VARIANTS, KS_ERR_ARG_OUTOFRANGE, "variant %d out of range", variant);
   KS_CALL(ks_prof_flush(ctx));
-  if (launches) *launches = ctx->prof[kclass].launches;
-  if (ms) *ms = ctx->prof[kclass].ms;
-  if (bytes) *bytes = ctx->prof[kclass].bytes;
+  KsProfSlot t;
+  for (int v = 0; v < KS_PROF_VARIANTS; v++) {
+    if (variant >= 0 && v != variant / 4) continue;
+    const KsProfSlot &sl = ctx->prof[kclass][v];
+    t.launches += sl.launches; t.ms += sl.ms; t.bytes += sl.bytes; t.hbm += sl.hbm;
+  }
+  if (launches) *launches = t.launches;
+  if (ms) *ms = t.ms;
+  if (bytes) *bytes = t.bytes;
+  if (hbm) *hbm = t.hbm;
   return KS_SUCCESS;
+}
+
+// Speculative Gram-Schmidt slots: the host learns from the step records which launches really ran.
+//   update slot p of column c ran iff p <= passes(c); it was the fused (update + next-pass dots) form iff
+//   p < passes(c) or the column needed the explicit-norm fallback; bookkeeping slot p ran iff p <= passes(c)
+//   (+1 with the fallback). Everything else exited at its gate and is re-filed under KS_K_NOOP.
+// Bytes: compulsory HBM traffic of an update = 8n(k+2) (read k columns + read/write v); the SURVEY 8d
+// algorithmic figure of the fused form adds the gemv-C of the next pass it replaces: 8n(k+2) + 8n(k+1).
+void ks_prof_resolve_gs(ks_ctx ctx, const KsStepRec *recs, int col0, int col1)
+{
+  for (auto &p : ctx->pending) {
+    if (p.tag_col < col0 || p.tag_col > col1) continue;
+    const KsStepRec &r = recs[p.tag_col - col0];
+    const int passes = r.passes, expl = r.expl;
+    const double n = (double)p.tag_n, k = (double)p.tag_k;
+    if (p.kclass == KS_K_UPD_FUSED || p.kclass == KS_K_UPD) {
+      if (p.tag_slot > passes) { p.kclass = KS_K_NOOP; p.bytes = 0.0; p.hbm = 0.0; }
+      else if (p.tag_slot < passes || expl) { p.kclass = KS_K_UPD_FUSED; p.hbm = 8.0 * n * (k + 2); p.bytes = p.hbm + 8.0 * n * (k + 1); }
+      else { p.kclass = KS_K_UPD; p.hbm = 8.0 * n * (k + 2); p.bytes = p.hbm; }
+    } else if (p.kclass == KS_K_GSFIN) {
+      if (p.tag_slot > passes + (expl ? 1 : 0)) { p.kclass = KS_K_NOOP; p.bytes = 0.0; p.hbm = 0.0; }
+    } else if (p.kclass == KS_K_SCALE) {
+      if (!expl) { p.kclass = KS_K_NOOP; p.bytes = 0.0; p.hbm = 0.0; } else { p.bytes = p.hbm = 16.0 * n; }
+    }
+    p.tag_col = -1;
+  }
 }
 
 // ---- communicator -------------------------------------------------------------------------------

@@ -257,6 +257,7 @@ int launch_finish(ks_bv bv, const GsArgs &a)
   ks_ctx ctx = bv->ctx;
   const bool multi = ctx->comm.size > 1;
   KsProfScope ps(ctx, KS_K_GSFIN, 8.0 * bv->last_grid * (a.k + 1));
+  ps.tag(a.k, a.slot, a.k, bv->n);
   if (!multi) hipLaunchKernelGGL((k_gs_finish<true, true>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, bv->last_grid, a, bv->buffer, bv->gs, bv->recs);
   else {
     hipLaunchKernelGGL((k_gs_finish<true, false>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, bv->last_grid, a, bv->buffer, bv->gs, bv->recs);
@@ -267,15 +268,16 @@ int launch_finish(ks_bv bv, const GsArgs &a)
   return KS_SUCCESS;
 }
 
-int launch_update(ks_bv bv, int k, double *v)
+int launch_update(ks_bv bv, int k, double *v, int slot)
 {
   ks_ctx ctx = bv->ctx;
   const double *V = ks_bv_col(bv, 0);
   const bool v2 = (bv->ld % 2 == 0) && aligned16(V) && aligned16(v);
   const int grid = sweep_grid(ctx, bv->n, v2 ? 2 : 1);
   bv->last_grid = grid;
-  KsProfScope ps(ctx, KS_K_UPD_FUSED, 8.0 * bv->n * (k + 2));
   const int kk = std::max(k, 1);
+  KsProfScope ps(ctx, KS_K_UPD_FUSED, 8.0 * bv->n * (k + 2), ks_kt_for(kk));
+  ps.tag(k, slot, k, bv->n);
 #define LAUNCH_UPD(KT)                                                                                                                                 \
   do {                                                                                                                                                 \
     if (v2) hipLaunchKernelGGL((k_gs_update<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->buffer, bv->partials, bv->gs); \
@@ -300,12 +302,13 @@ int enqueue_fused_gs(ks_bv bv, int j, int normalize, int krylov)
   for (int p = 1; p <= nslots; p++) {
     a.slot = p;
     KS_CALL(launch_finish(bv, a));
-    KS_CALL(launch_update(bv, j, v));
+    KS_CALL(launch_update(bv, j, v, p));
   }
   a.slot = nslots + 1;                  // resolves an explicit-norm request of the last update
   KS_CALL(launch_finish(bv, a));
   if (normalize) {
     KsProfScope ps(ctx, KS_K_SCALE, 0.0);
+    ps.tag(j, 0, j, bv->n);
     const int grid = std::max(1, std::min((bv->n + 255) / 256, ctx->num_cu * 4));
     hipLaunchKernelGGL(k_scale_if, dim3(grid), dim3(256), 0, ctx->stream, v, bv->n, bv->gs);
     KS_HIP(hipGetLastError());
@@ -474,6 +477,7 @@ int orthogonalize_column(ks_bv bv, int j, int normalize, double *H, double *norm
     KS_CALL(enqueue_fused_gs(bv, j, normalize, 0));
     KsGsState st; KsStepRec rec;
     KS_CALL(fetch_state(bv, &st, &rec, j, j));
+    ks_prof_resolve_gs(ctx, &rec, j, j);
     bv->passes_last_host = rec.passes; bv->passes_total_host += rec.passes;
     if (norm) *norm = rec.nrm;
     if (lindep) *lindep = rec.lindep;
@@ -599,6 +603,12 @@ static int krylov_run(ks_bv V, ks_mat A, int k, int *m, double *beta, int *break
     }
     KsGsState st; std::vector<KsStepRec> recs(m0 - k);
     KS_CALL(fetch_state(V, &st, recs.data(), k + 1, m0));
+    if (ctx->prof_on) {
+      // records of columns after a device-side halt were never written: treat them as 0 passes (all gated off)
+      std::vector<KsStepRec> rr(recs); bool halted = false;
+      for (int j = k; j < m0; j++) { if (halted) { rr[j - k].passes = 0; rr[j - k].expl = 0; } if (rr[j - k].lindep) halted = true; }
+      ks_prof_resolve_gs(ctx, rr.data(), k + 1, m0);
+    }
     int mm = m0;
     for (int j = k; j < m0; j++) {
       const KsStepRec &r = recs[j - k];

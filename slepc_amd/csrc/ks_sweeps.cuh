@@ -123,13 +123,22 @@ __global__ __launch_bounds__(SW_BLOCK) void k_multvec(const double *__restrict__
   }
 }
 
-// 1-block reduction of block partials: out[i] = sum_b partials[i*nblocks + b], i < ncols (fixed order)
+// 1-block reduction of block partials: out[i] = sum_b partials[i*nblocks + b], i < ncols (fixed order).
+// Each wave owns columns w, w+nw, ...; a lane first gathers its <= KS_MAX_BLOCKS/64 strided partials with
+// independent loads (all in flight together: the dependent-load chain was the whole cost of this kernel),
+// then sums them in index order, then the wave combines with a fixed shuffle tree.
 __device__ __forceinline__ void reduce_partials_to_lds(const double *__restrict__ partials, int nblocks, int ncols, double *c_lds)
 {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  constexpr int PER_LANE = KS_MAX_BLOCKS / 64;
   for (int i = w; i < ncols; i += nw) {
+    const double *p = partials + (size_t)i * nblocks;
+    double v[PER_LANE];
+#pragma unroll
+    for (int u = 0; u < PER_LANE; u++) { const int b = lane + 64 * u; v[u] = (b < nblocks) ? p[b] : 0.0; }
     double s = 0.0;
-    for (int b = lane; b < nblocks; b += 64) s += partials[(size_t)i * nblocks + b];
+#pragma unroll
+    for (int u = 0; u < PER_LANE; u++) s += v[u];
     s = wave_sum(s);
     if (lane == 0) c_lds[i] = s;
   }
@@ -137,6 +146,8 @@ __device__ __forceinline__ void reduce_partials_to_lds(const double *__restrict_
 }
 
 } // namespace ksk
+
+static inline int ks_kt_for(int ncols) { const int t[12] = {4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64}; for (int i = 0; i < 12; i++) if (ncols <= t[i]) return t[i]; return 64; }
 
 // dispatch helper: smallest compiled KT >= ncols
 #define KS_KT_DISPATCH(ncols, MACRO)                                              \

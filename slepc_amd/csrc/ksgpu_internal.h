@@ -18,8 +18,8 @@ void ks_set_error(const char *fmt, ...);
 #define KS_CALL(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
 // ---- profiling ----------------------------------------------------------------------------------
-struct KsProfSlot { long long launches = 0; double ms = 0.0; double bytes = 0.0; };
-struct KsProfPending { hipEvent_t e0, e1; int kclass; double bytes; };
+struct KsProfSlot { long long launches = 0; double ms = 0.0; double bytes = 0.0; double hbm = 0.0; };
+struct KsProfPending { hipEvent_t e0, e1; int kclass; int variant; double bytes; double hbm; int tag_col; int tag_slot; int tag_k; long long tag_n; };
 
 // ---- communicator -------------------------------------------------------------------------------
 struct KsComm {
@@ -42,21 +42,25 @@ struct ks_ctx_s {
   KsComm comm;
   // profiling
   bool prof_on = false;
-  KsProfSlot prof[KS_K_COUNT];
+  KsProfSlot prof[KS_K_COUNT][KS_PROF_VARIANTS];
   std::vector<KsProfPending> pending;
   std::vector<hipEvent_t> event_pool;
   // small pinned host staging area for coefficient transfers
   double *h_pinned = nullptr; size_t h_pinned_len = 0;
 };
 
-int ks_prof_begin(ks_ctx ctx, int kclass, double bytes);   // records start event when profiling
+int ks_prof_begin(ks_ctx ctx, int kclass, int variant, double alg_bytes, double hbm_bytes);   // records start event when profiling
 int ks_prof_end(ks_ctx ctx);
 int ks_prof_flush(ks_ctx ctx);
 struct KsProfScope {
   ks_ctx ctx; bool on;
-  KsProfScope(ks_ctx c, int kclass, double bytes) : ctx(c), on(c->prof_on) { if (on) ks_prof_begin(c, kclass, bytes); }
+  KsProfScope(ks_ctx c, int kclass, double bytes, int variant = 0, double hbm = -1.0) : ctx(c), on(c->prof_on) { if (on) ks_prof_begin(c, kclass, variant, bytes, hbm < 0 ? bytes : hbm); }
   ~KsProfScope() { if (on) ks_prof_end(ctx); }
+  // tag the record of a speculative Gram-Schmidt slot so it can be re-filed once pass counts are known
+  void tag(int col, int slot, int k, long long n) { if (on && !ctx->pending.empty()) { auto &p = ctx->pending.back(); p.tag_col = col; p.tag_slot = slot; p.tag_k = k; p.tag_n = n; } }
 };
+struct KsStepRec;
+void ks_prof_resolve_gs(ks_ctx ctx, const KsStepRec *recs, int col0, int col1);   // re-file tagged records of columns [col0,col1]
 
 int ks_allreduce_sum(ks_ctx ctx, double *dev_buf, int count);   // no-op when size==1
 
@@ -121,7 +125,7 @@ struct ks_bv_s {
 
 constexpr int KS_MAX_COLS   = 64;     // max columns handled by the register-tiled sweeps (k+1 <= 64)
 constexpr int KS_PSTRIDE    = 72;     // doubles per block in the partials array
-constexpr int KS_MAX_BLOCKS = 2048;
+constexpr int KS_MAX_BLOCKS = 1024;
 
 static inline double *ks_bv_col(ks_bv bv, int j) { return bv->array + (size_t)(bv->nc + j) * bv->ld; }
 

@@ -1,0 +1,173 @@
+"""The reference's BV test programs (src/sys/classes/bv/tests/test*.c) restated ONCE as backend-neutral
+scenarios, so that the CPU oracle (tests/test_oracle_golden.py) and the HIP path (tests/test_gpu_*.py)
+run literally the same sequence of BV calls and are compared with the same golden .out values."""
+import numpy as np
+
+import golden_inputs as gi
+
+
+class OracleBackend:
+    name = "oracle"
+
+    def __init__(self):
+        from oracle import oracle as O
+        self.O = O
+
+    def bv(self, n, m, ld=0):
+        return self.O.BV(n, m, ld)
+
+    def fill(self, bv, X):
+        for j in range(X.shape[1]):
+            bv.set_column(j, X[:, j])
+
+    def vecref(self, bv, j):          # what MultVec/DotVec take as the Vec argument
+        return bv.array[: bv.n, j]
+
+    def new_vec(self, bv, x):
+        return np.array(x, dtype=np.float64)
+
+    def vec_to_host(self, v, n):
+        return np.array(v[:n])
+
+    def csr(self, rowptr, col, val):
+        return self.O.CSR(len(rowptr) - 1, rowptr, col, val)
+
+
+class GpuBackend:
+    name = "gpu"
+
+    def __init__(self, ctx):
+        import slepc_amd as ks
+        self.ks, self.ctx = ks, ctx
+        self._scratch = []
+
+    def bv(self, n, m, ld=0):
+        return self.ks.BV(self.ctx, n, m, ld)
+
+    def fill(self, bv, X):
+        bv.set_dense(X)
+
+    def vecref(self, bv, j):
+        return bv.column_ptr(j)
+
+    def new_vec(self, bv, x):
+        w = self.ks.BV(self.ctx, bv.n, 1)      # a stand-alone device Vec
+        w.set_column(0, x)
+        self._scratch.append(w)
+        return w.column_ptr(0)
+
+    def vec_to_host(self, v, n):
+        for w in self._scratch:
+            if w.column_ptr(0) == v:
+                return w.column(0)
+        raise KeyError
+
+    def csr(self, rowptr, col, val):
+        return self.ks.Mat.from_csr(self.ctx, rowptr, col, val)
+
+
+def bv_test1(be, testlda=False):
+    """test1.c: BVMult, BVMultVec, BVDot, BVDotVec, BVMultInPlace, BVScale, BVNormColumn, BVNorm."""
+    n, k, l = 10, 5, 3
+    X = be.bv(n, k); Y = be.bv(n, l)
+    be.fill(X, gi.test1_X()); be.fill(Y, gi.test1_Y())
+    Q = gi.test1_Q()
+    if testlda:                       # MatDenseSetLDA(Q,k+2)
+        Qp = np.zeros((k + 2, l), order="F"); Qp[:k, :] = Q; Q = Qp
+    out = {}
+    Y.Mult(2.0, 1.0, X, Q); out["Mult"] = Y.dense()
+    z = np.array([2.0 * (-0.5) ** i for i in range(k)])
+    X.MultVec(-1.0, 1.0, be.vecref(Y, 0), z); out["MultVec"] = Y.dense()
+    M = np.zeros((l + (2 if testlda else 0), k), order="F")
+    X.Dot(Y, M); out["Dot"] = M[:l, :].copy()
+    out["DotVec"] = np.array(X.DotVec(be.vecref(Y, 0)))
+    X.MultInPlace(Q, 1, l); X.Scale(2.0); out["MultInPlace"] = X.dense()
+    out["NormColumn0"] = X.NormColumn(0)
+    out["NormF"] = X.Norm()
+    out["FirstRow"] = X.dense()[0, :]
+    return out
+
+
+def bv_test2(be, orthog_type=0, refine=0, n=20, k=8):
+    """test2.c: BVOrthogonalizeColumn loop, orthogonality level, BVOrthogonalizeVec of ones."""
+    X = be.bv(n, k)
+    X.SetOrthogonalization(orthog_type, refine, 0.7071)
+    be.fill(X, gi.test2_X(n, k))
+    norms = []
+    for j in range(k):
+        _, norm, _ = X.OrthogonalizeColumn(j)
+        norms.append(norm)
+        X.ScaleColumn(j, 1.0 / norm)
+    M = np.zeros((k, k), order="F")
+    X.Dot(X, M)
+    level = np.abs(M - np.eye(k)).sum(axis=0).max()       # MatShift(-1); MatNorm(NORM_1)
+    e = be.new_vec(X, np.ones(n))
+    _, norm_e, _ = X.OrthogonalizeVec(e)
+    return {"level": level, "norm_ones": norm_e, "norms": np.array(norms), "Xo": X.dense()}
+
+
+def bv_test4(be, n=18, kx=12, lx=3, ky=8, ly=2, trans=False):
+    """test4.c: the same ops on active/leading column windows."""
+    X = be.bv(n, kx + 4)            # BVResize(X,kx+4,TRUE) applied up front (columns kx+2.. stay zero)
+    Y = be.bv(n, ky + 1)
+    X.SetActiveColumns(lx, kx); Y.SetActiveColumns(ly, ky)
+    Xh = np.zeros((n, kx + 4))
+    Xh[:, : kx + 2] = gi.test1_X(n, kx + 2)
+    be.fill(X, Xh)
+    be.fill(Y, gi.test1_Y(n, ky + 1))
+    Q = np.array([[2.0 if i < j else -0.5 for j in range(ky)] for i in range(kx)], order="F")
+    out = {}
+    Y.Mult(2.0, 0.5, X, Q); out["Mult"] = Y.dense()
+    z = np.array([2.0 * (-0.5) ** i for i in range(kx - lx)])
+    X.MultVec(-1.0, 1.0, be.vecref(Y, 0), z); out["MultVec"] = Y.dense()
+    M = np.zeros((ky, kx), order="F")
+    X.Dot(Y, M); out["Dot"] = M.copy()
+    out["DotVec"] = np.array(X.DotVec(be.vecref(Y, 0)))
+    if trans:
+        X.MultInPlace(np.asfortranarray(Q.T), lx + 1, ky, trans=True)
+    else:
+        X.MultInPlace(Q, lx + 1, ky)
+    X.Scale(2.0)
+    out["X"] = X.dense()
+    out["NormColumn"] = X.NormColumn(lx)
+    out["NormF"] = X.Norm()
+    return out
+
+
+def bv_test13(be):
+    """test13.c: the NULL-array (buffer Vec) path used by Arnoldi: BVDotColumn(X,2,NULL); BVMultColumn(X,-1,1,2,NULL)."""
+    n, k = 10, 5
+    X = be.bv(n, k)
+    be.fill(X, gi.test1_X(n, k))
+    X.DotColumn(2, None)
+    X.MultColumn(-1.0, 1.0, 2, None)
+    return {"NormF": X.Norm(), "X": X.dense()}
+
+
+def bv_test8(be, n=20, k=8, refine=0):
+    """test8.c: MGS, BVOrthogonalizeSomeColumn against the odd columns."""
+    X = be.bv(n, k)
+    X.SetOrthogonalization(1, refine, 0.7071)
+    be.fill(X, gi.test2_X(n, k))
+    for j in range(k - 1):
+        _, norm, _ = X.OrthogonalizeColumn(j)
+        X.ScaleColumn(j, 1.0 / norm)
+    which = [1 if i % 2 else 0 for i in range(k)]
+    X.OrthogonalizeSomeColumn(k - 1, which)
+    z = np.array(X.DotColumn(k - 1))
+    z[np.abs(z) < 5.0 * np.finfo(float).eps] = 0.0
+    return {"z": z}
+
+
+def bv_test7(be, n=30, k=6):
+    """test7.c: BVMatMult versus the column loop of MatMult."""
+    from oracle import oracle as O
+    A1 = O.laplacian1d(n)
+    A = be.csr(A1.rowptr, A1.col, A1.val)
+    V = be.bv(n, k); W = be.bv(n, k)
+    rng = np.random.default_rng(7)
+    Vh = rng.standard_normal((n, k))
+    be.fill(V, Vh)
+    V.MatMult(A, W)
+    ref = A1.to_scipy() @ Vh
+    return {"err": np.abs(W.dense() - ref).max()}

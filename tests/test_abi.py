@@ -1,0 +1,66 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/ksgpu.h declares, binds with the ctypes signatures, and refuses to run without a GPU."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+import slepc_amd as ks
+from slepc_amd import _lib
+
+
+def test_library_is_in_tree_and_loads():
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    L = _lib.lib()
+    assert L.ks_error_string(0) == b"success"
+    assert b"inner product" in L.ks_error_string(71)
+
+
+def test_every_header_symbol_is_exported():
+    L = _lib.lib()
+    names = _lib.header_symbols()
+    assert len(names) >= 80
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_ctypes_signatures_cover_header():
+    declared = set(_lib.header_symbols())
+    bound = set(_lib._SIG) | set(_lib._STR_FUNCS)
+    assert declared == bound, (declared - bound, bound - declared)
+
+
+def test_no_torch_types_in_abi():
+    import re
+    raw = open(_lib.HEADER_PATH).read()
+    assert 'extern "C"' in raw
+    code = re.sub(r"/\*.*?\*/", "", raw, flags=re.S)            # declarations only
+    assert "torch" not in code.lower() and "at::" not in code and "c10" not in code and "Tensor" not in code
+    assert "#include <hip" not in code                             # plain pointers and sizes only
+
+
+def test_gfx950_code_object_present():
+    """The fat binary carries exactly one device code object and its target is gfx950."""
+    import re
+    blob = open(_lib.LIB_PATH, "rb").read()
+    targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-f]+)", blob))
+    assert targets == {b"gfx950"}, targets
+
+
+def test_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(ks.KsError) as ei:
+        ks.Context(0)
+    assert ei.value.rc == 97          # KS_ERR_GPU, no CPU fallback
+
+
+def test_product_does_not_import_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "slepc_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cuh", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f

@@ -1,0 +1,165 @@
+"""Parity of the HIP BV kernels (through the C ABI) with the CPU oracle and the reference's golden outputs.
+Tolerances: the test1/test4/test13 inputs are small integers/dyadic rationals, so results are EXACT (bit
+for bit); everything else is double arithmetic with a different summation order -> relative 1e-13."""
+import numpy as np
+import pytest
+
+import golden_inputs as gi
+import scenarios as sc
+from test_oracle_golden import check_test1
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-13
+
+
+@pytest.fixture(scope="module")
+def gpu(ctx):
+    return sc.GpuBackend(ctx)
+
+
+@pytest.fixture(scope="module")
+def cpu():
+    return sc.OracleBackend()
+
+
+def test_bv_test1_golden(gpu):
+    check_test1(sc.bv_test1(gpu), gi.read("bv/test1_1_bv_type-mat.out"))
+
+
+def test_bv_test1_bitexact_vs_oracle(gpu, cpu):
+    for lda in (False, True):
+        a, b = sc.bv_test1(gpu, testlda=lda), sc.bv_test1(cpu, testlda=lda)
+        for k in b:
+            if k in ("NormColumn0", "NormF"):
+                assert abs(a[k] - b[k]) <= 4 * np.finfo(float).eps * b[k], k
+            else:
+                assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+
+
+@pytest.mark.parametrize("otype", [0, 1])
+@pytest.mark.parametrize("refine", [0, 1, 2])
+def test_bv_test2(gpu, cpu, otype, refine):
+    txt = gi.read("bv/test2_1.out")
+    a, b = sc.bv_test2(gpu, otype, refine), sc.bv_test2(cpu, otype, refine)
+    if refine != 1:
+        assert a["level"] < 100 * np.finfo(float).eps                 # "Level of orthogonality < 100*eps"
+    assert abs(a["norm_ones"] - gi.value_after(txt, "after orthogonalizing against X:")) < 5e-6
+    assert np.allclose(a["norms"], b["norms"], rtol=1e-12)
+    assert np.allclose(a["Xo"], b["Xo"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("trans", [False, True])
+def test_bv_test4_active_columns(gpu, cpu, trans):
+    txt = gi.read("bv/test4_1.out")
+    a, b = sc.bv_test4(gpu, trans=trans), sc.bv_test4(cpu, trans=trans)
+    assert abs(a["NormColumn"] - gi.value_after(txt, "2-Norm of X[3] =")) < 5e-5
+    assert abs(a["NormF"] - gi.value_after(txt, "Frobenius Norm of X =")) < 5e-4
+    for k in ("Mult", "MultVec", "Dot", "DotVec", "X"):
+        assert np.array_equal(a[k], b[k]), k                         # dyadic inputs: exact
+
+
+def test_bv_test13_buffer_path(gpu, cpu):
+    txt = gi.read("bv/test13_1.out")
+    a, b = sc.bv_test13(gpu), sc.bv_test13(cpu)
+    assert abs(a["NormF"] - gi.value_after(txt, "Frobenius Norm or X =")) < 5e-4
+    assert np.array_equal(a["X"], b["X"])
+
+
+def test_bv_test8_mgs_some_columns(gpu):
+    txt = gi.read("bv/test8_1.out")
+    ref = np.array([r[0] for r in gi.numeric_blocks(txt)[-1]])
+    z = sc.bv_test8(gpu)["z"]
+    assert np.allclose(z, ref, atol=5e-7)
+    assert np.all(z[1::2] == 0.0)
+
+
+def test_bv_test7_matmult(gpu):
+    assert sc.bv_test7(gpu)["err"] < 1e-14
+
+
+# ---- random panels, ragged sizes, odd leading dimensions -----------------------------------------------
+@pytest.mark.parametrize("n,m,ld", [(1, 3, 0), (2, 2, 0), (63, 5, 0), (257, 9, 0), (1000, 31, 0), (4099, 33, 4101), (5000, 61, 0), (777, 7, 779)])
+def test_ops_random(ctx, gpu, cpu, n, m, ld):
+    rng = np.random.default_rng(n * 131 + m)
+    Xh = rng.standard_normal((n, m)); Yh = rng.standard_normal((n, m))
+    res = []
+    for be in (gpu, cpu):
+        X = be.bv(n, m, ld); Y = be.bv(n, m, ld)
+        be.fill(X, Xh); be.fill(Y, Yh)
+        l, k = (1, m - 1) if m > 3 else (0, m)
+        X.SetActiveColumns(l, k); Y.SetActiveColumns(l, k)
+        out = {}
+        q = rng.standard_normal(k - l) if be is gpu else res[0]["q"]
+        out["q"] = q
+        out["dotvec"] = np.array(X.DotVec(be.vecref(Y, 0)))
+        X.MultVec(0.75, -0.5, be.vecref(Y, m - 1), q); out["multvec"] = Y.dense()[:, m - 1].copy()
+        X.MultVec(2.0, 0.0, be.vecref(Y, m - 1), q); out["multvec_beta0"] = Y.dense()[:, m - 1].copy()
+        M = np.zeros((m, m), order="F"); X.Dot(Y, M); out["dot"] = M.copy()
+        Q = rng.standard_normal((m, m)) if be is gpu else res[0]["Q"]
+        out["Q"] = Q
+        Y.Mult(1.5, 0.25, X, np.asfortranarray(Q)); out["mult"] = Y.dense()
+        Y.Mult(-1.0, 2.0, X, None); out["axpy"] = Y.dense()
+        X.MultInPlace(np.asfortranarray(Q), l, k); out["mip"] = X.dense()
+        X.ScaleColumn(0, 3.0); X.Scale(-0.5); out["scale"] = X.dense()
+        out["norms"] = np.array([X.Norm(2), X.Norm(0), X.Norm(3), X.NormColumn(0, 1), X.NormColumn(m - 1, 0), X.NormColumn(m - 1, 3)])
+        X.CopyColumn(0, m - 1); Y.SetActiveColumns(l, k); X.Copy(Y); out["copy"] = np.hstack([X.dense(), Y.dense()])
+        res.append(out)
+    a, b = res
+    scale = max(1.0, np.abs(b["dot"]).max())
+    for key in b:
+        if key in ("q", "Q"):
+            continue
+        tol = RTOL * max(1.0, np.abs(b[key]).max()) * (n ** 0.5)
+        assert np.allclose(a[key], b[key], rtol=0, atol=tol), (key, np.abs(np.asarray(a[key]) - np.asarray(b[key])).max())
+
+
+def test_alpha_zero_scale_and_nan_safety(ctx, gpu):
+    """BVScale with alpha=0 zero-fills (bvblas.c:271) even over NaN; BVMultVec with beta=0 does not read y."""
+    n, m = 300, 4
+    X = gpu.bv(n, m)
+    Xh = np.full((n, m), np.nan); Xh[:, 1:] = 1.0
+    gpu.fill(X, Xh)
+    X.ScaleColumn(0, 0.0)
+    assert np.all(X.column(0) == 0.0)
+    X.set_column(0, np.full(n, np.nan))
+    X.SetActiveColumns(1, 4)
+    X.MultVec(1.0, 0.0, X.column_ptr(0), np.array([1.0, 1.0, 1.0]))
+    assert np.all(X.column(0) == 3.0)
+
+
+def test_argument_errors_mirror_reference(ctx, gpu):
+    import slepc_amd as ks
+    X = gpu.bv(10, 4)
+    with pytest.raises(ks.KsError) as e:
+        X.OrthogonalizeColumn(4)                      # "Index j=4 but BV only has 4 columns"
+    assert e.value.rc == 63
+    with pytest.raises(ks.KsError) as e:
+        X.OrthogonalizeColumn(-1)
+    assert e.value.rc == 63
+    with pytest.raises(ks.KsError) as e:
+        X.Mult(1.0, 1.0, X, np.eye(4, order="F"))     # "X and Y arguments must be different"
+    assert e.value.rc == 62
+    with pytest.raises(ks.KsError) as e:
+        X.MultInPlace(np.eye(3, order="F"), 0, 4)     # Mat has 3 rows, should have at least 4
+    assert e.value.rc == 60
+    with pytest.raises(ks.KsError) as e:
+        ks.BV(ctx, 10, 3, ld=8)                       # leading dimension smaller than n
+    assert e.value.rc == 71
+    with pytest.raises(ks.KsError) as e:
+        X.Norm(ks.NORM_2)                             # "Requested norm not available" for a whole BV
+    assert e.value.rc == 56
+    with pytest.raises(ks.KsError) as e:
+        X.SetActiveColumns(3, 2)
+    assert e.value.rc == 63
+
+
+def test_empty_active_window_is_noop(ctx, gpu):
+    X = gpu.bv(50, 4); Y = gpu.bv(50, 4)
+    gpu.fill(X, np.ones((50, 4))); gpu.fill(Y, np.ones((50, 4)))
+    X.SetActiveColumns(2, 2)
+    M = np.full((4, 4), 7.0, order="F")
+    X.Dot(Y, M)                                        # bvglobal.c:100: returns without touching M
+    assert np.all(M == 7.0)
+    X.Scale(5.0)
+    assert np.all(X.dense() == 1.0)

@@ -1,0 +1,362 @@
+"""SpMV, fused Gram-Schmidt, Lanczos/Arnoldi and the Krylov-Schur driver on the GPU versus the CPU oracle,
+the reference's golden eigenvalues and the analytic Laplacian spectra.
+
+Tolerances (north star): Ritz values within 1e-10 relative of the CPU reference path; relative residuals
+||Ax-kx||/|k| <= tol=1e-8 (EPSComputeError); permutation / pass-count / iteration-count work must be
+IDENTICAL to the oracle (integer control flow)."""
+import numpy as np
+import pytest
+
+import golden_inputs as gi
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _mat(ctx, Ao):
+    import slepc_amd as ks
+    return ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
+
+
+# ---- SpMV ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 1, 1), (2, 1, 1), (5, 4, 3), (16, 16, 16), (33, 17, 9), (64, 64, 20)])
+def test_spmv_laplacian3d(ctx, shape):
+    import slepc_amd as ks
+    Ao = O.laplacian3d(*shape)
+    x = np.random.default_rng(1).standard_normal(Ao.n)
+    y0 = Ao.mult(x)
+    for A in (_mat(ctx, Ao), ks.Mat.laplacian3d(ctx, *shape)):
+        assert A.nnz == Ao.nnz and A.n == Ao.n
+        y = A.mult(x)
+        assert np.abs(y - y0).max() <= 8 * np.finfo(float).eps * np.abs(x).max() * 12
+
+
+def test_spmv_laplacian2d_generator_matches_ex2(ctx):
+    import slepc_amd as ks
+    Ao = O.laplacian2d(37, 23)
+    x = np.random.default_rng(2).standard_normal(Ao.n)
+    assert np.abs(ks.Mat.laplacian2d(ctx, 37, 23).mult(x) - Ao.mult(x)).max() < 1e-13
+
+
+@pytest.mark.parametrize("n,mean", [(1000, 1), (3000, 3), (5000, 12), (4000, 32), (2000, 70), (300, 200)])
+def test_spmv_random_csr_ragged(ctx, n, mean):
+    """Ragged rows incl. EMPTY rows and rows longer than a wavefront; every lanes-per-row variant."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(n + mean)
+    lens = np.clip(rng.poisson(mean, n), 0, n)
+    lens[rng.integers(0, n, n // 20)] = 0
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate([np.sort(rng.choice(n, l, replace=False)) for l in lens] + [np.empty(0, int)]).astype(np.int32)
+    val = rng.uniform(-1, 1, rowptr[-1])
+    Ao = O.CSR(n, rowptr, col, val)
+    x = rng.standard_normal(n)
+    y0 = Ao.mult(x)
+    y = _mat(ctx, Ao).mult(x)
+    assert np.allclose(y, y0, rtol=0, atol=1e-13 * max(1, mean))
+    assert np.all(y[lens == 0] == 0.0)
+
+
+def test_spmv_rejects_bad_input(ctx):
+    import slepc_amd as ks
+    with pytest.raises(ks.KsError) as e:
+        ks.Mat.from_csr(ctx, [0, 1], [5], [1.0])          # column out of range
+    assert e.value.rc == 63
+
+
+# ---- fused Gram-Schmidt -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("refine", [0, 1, 2])
+@pytest.mark.parametrize("n,m", [(7, 3), (600, 12), (5000, 31), (3001, 33)])
+def test_fused_gs_matches_oracle(ctx, refine, n, m):
+    import slepc_amd as ks
+    rng = np.random.default_rng(n + m + refine)
+    Xh = rng.standard_normal((n, m))
+    Xh[:, m // 2] = Xh[:, 0] + 1e-9 * rng.standard_normal(n)       # forces refinement passes
+    Vg = ks.BV(ctx, n, m); Vo = O.BV(n, m)
+    Vg.SetOrthogonalization(ks.CGS, refine); Vo.SetOrthogonalization(O.CGS, refine)
+    Vg.set_dense(Xh)
+    for j in range(m):
+        Vo.set_column(j, Xh[:, j])
+    for j in range(m):
+        ng, lg = Vg.OrthonormalizeColumn(j)
+        no, lo = Vo.OrthonormalizeColumn(j)
+        assert lg == lo
+        assert Vg.gs_passes()[1] == Vo.passes_last(), (j, Vg.gs_passes(), Vo.passes_last())
+        # the norm comes from beta^2 - sum(h^2): its ABSOLUTE accuracy is eps*||x_j||, whatever is left of x_j
+        # column m//2 is what is left of a 1e-9 perturbation, i.e. known to ~1e-7 relative: later columns inherit that
+        rtol = 1e-12 if j <= m // 2 else 1e-5
+        assert abs(ng - no) <= 1e-13 * np.linalg.norm(Xh[:, j]) + rtol * abs(no), (j, ng, no)
+    B = Vg.buffer(); Bo = np.array(Vo.buffer)
+    for j in range(1, m):
+        assert np.allclose(B[: j + 1, j], Bo[: j + 1, j], rtol=1e-5, atol=1e-5 if j > m // 2 else 1e-9), j
+    Q = Vg.dense()
+    if refine != 1:
+        assert np.abs(Q.T @ Q - np.eye(m)).max() < 1e-13
+
+
+def test_fused_gs_generic_agree(ctx, monkeypatch):
+    """The host-driven literal restatement (KSGPU_NO_FUSED_GS=1) and the fused kernels give the same result."""
+    import slepc_amd as ks
+    n, m = 2000, 10
+    Xh = np.random.default_rng(0).standard_normal((n, m))
+    outs = []
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("KSGPU_NO_FUSED_GS", "1")
+        V = ks.BV(ctx, n, m); V.set_dense(Xh)
+        nr = [V.OrthonormalizeColumn(j)[0] for j in range(m)]
+        outs.append((np.array(nr), V.dense(), V.buffer()))
+    monkeypatch.delenv("KSGPU_NO_FUSED_GS")
+    assert np.allclose(outs[0][0], outs[1][0], rtol=1e-13)
+    assert np.allclose(outs[0][1], outs[1][1], atol=1e-13)
+    assert np.allclose(np.triu(outs[0][2])[:, 1:], np.triu(outs[1][2])[:, 1:], atol=1e-12)
+
+
+def test_explicit_norm_fallback_and_zero_vector(ctx):
+    """norm^2 estimate <= 0 -> explicit BVNormColumn (bvorthog.c:126); exactly dependent column -> lindep."""
+    import slepc_amd as ks
+    n, m = 1000, 4
+    rng = np.random.default_rng(5)
+    Xh = rng.standard_normal((n, m))
+    Xh[:, 2] = 2.0 * Xh[:, 0] - 3.0 * Xh[:, 1]        # exactly in the span
+    Xh[:, 3] = 0.0
+    Vg = ks.BV(ctx, n, m); Vo = O.BV(n, m)
+    Vg.set_dense(Xh)
+    for j in range(m):
+        Vo.set_column(j, Xh[:, j])
+    for j in range(m):
+        ng, lg = Vg.OrthonormalizeColumn(j)
+        no, lo = Vo.OrthonormalizeColumn(j)
+        if j == 2:
+            # what is left of an exactly dependent column is rounding noise: only its size is comparable
+            assert ng < 1e-12 and no < 1e-12
+            continue
+        assert lg == lo, j
+        assert Vg.gs_passes()[1] == Vo.passes_last(), j
+    assert lg and ng == 0.0                             # zero column: norm 0, lindep (nrm==0)
+
+
+def test_invalid_inner_product_is_an_error(ctx):
+    """BV_SafeSqrt (bvimpl.h:137) raises PETSC_ERR_USER_INPUT when v'v is NaN/negative."""
+    import slepc_amd as ks
+    V = ks.BV(ctx, 100, 3)
+    V.set_column(0, np.full(100, np.nan))
+    with pytest.raises(ks.KsError) as e:
+        V.OrthogonalizeColumn(0)
+    assert e.value.rc == 71
+
+
+# ---- Lanczos / Arnoldi ---------------------------------------------------------------------------------------
+def _start(V):
+    V.SetRandomColumn(0)
+    _, nrm, _ = V.OrthogonalizeColumn(0)
+    V.ScaleColumn(0, 1.0 / nrm)
+
+
+@pytest.mark.parametrize("grid,m", [((30, 30), 12), ((50, 40), 30), ((21, 9), 20)])
+def test_lanczos_matches_oracle(ctx, grid, m):
+    import slepc_amd as ks
+    Ao = O.laplacian2d(*grid)
+    Ag = _mat(ctx, Ao)
+    Vo = O.BV(Ao.n, m + 1); Vg = ks.BV(ctx, Ao.n, m + 1)
+    _start(Vo); _start(Vg)
+    assert np.array_equal(Vo.column(0), Vg.column(0)) or np.allclose(Vo.column(0), Vg.column(0), rtol=1e-15)
+    To = np.zeros((m + 1, 3), order="F"); Tg = np.zeros((m + 1, 3), order="F")
+    ro = Vo.MatLanczos(Ao, To, 0, m); rg = Vg.MatLanczos(Ag, Tg, 0, m)
+    assert ro[0] == rg[0] and ro[2] == rg[2]
+    assert abs(ro[1] - rg[1]) < 1e-12
+    assert np.abs(To - Tg).max() < 1e-12
+    assert Vg.gs_passes()[0] == Vo.passes_total()
+    Vd = Vg.dense()
+    assert np.abs(Vd.T @ Vd - np.eye(m + 1)).max() < 1e-13
+    # three-term relation A V - V T = beta v e^T holds to rounding
+    Tm = np.diag(Tg[:m, 0]) + np.diag(Tg[: m - 1, 1], 1) + np.diag(Tg[: m - 1, 1], -1)
+    R = Ao.to_scipy() @ Vd[:, :m] - Vd[:, :m] @ Tm
+    R[:, m - 1] -= rg[1] * Vd[:, m]
+    assert np.abs(R).max() < 1e-12
+
+
+def test_lanczos_restart_from_k(ctx):
+    """k>0: the first k columns are locked and untouched (bvkrylov.c:30-33)."""
+    import slepc_amd as ks
+    Ao = O.laplacian2d(25)
+    Ag = _mat(ctx, Ao)
+    m = 10
+    Vg = ks.BV(ctx, Ao.n, m + 1); Vo = O.BV(Ao.n, m + 1)
+    _start(Vg); _start(Vo)
+    Tg = np.zeros((m + 1, 3), order="F"); To = np.zeros((m + 1, 3), order="F")
+    Vg.MatLanczos(Ag, Tg, 0, 4); Vo.MatLanczos(Ao, To, 0, 4)
+    before = Vg.dense()[:, :5].copy()
+    Vg.MatLanczos(Ag, Tg, 4, m); Vo.MatLanczos(Ao, To, 4, m)
+    assert np.array_equal(before, Vg.dense()[:, :5])
+    assert np.abs(Tg - To).max() < 1e-12
+
+
+def test_arnoldi_matches_oracle(ctx):
+    import scipy.sparse as sp
+    import slepc_amd as ks
+    n, m = 400, 16
+    S = (sp.random(n, n, density=0.03, random_state=11, format="csr") + sp.eye(n, format="csr") * 2).tocsr()
+    S.sort_indices()
+    Ao = O.CSR(n, S.indptr, S.indices, S.data)
+    Ag = _mat(ctx, Ao)
+    Vo = O.BV(n, m + 1); Vg = ks.BV(ctx, n, m + 1)
+    _start(Vo); _start(Vg)
+    Ho = np.zeros((m + 1, m + 1), order="F"); Hg = np.zeros((m + 1, m + 1), order="F")
+    ro = Vo.MatArnoldi(Ao, Ho, 0, m); rg = Vg.MatArnoldi(Ag, Hg, 0, m)
+    assert ro[0] == rg[0] and ro[2] == rg[2] and abs(ro[1] - rg[1]) < 1e-12
+    assert np.abs(Ho - Hg).max() < 1e-11
+    Vd = Vg.dense()
+    assert np.abs(S @ Vd[:, :m] - Vd @ Hg[: m + 1, :m]).max() < 1e-12
+    assert np.abs(np.tril(Hg[:m, :m], -2)).max() == 0.0
+
+
+def test_breakdown_halts_enqueued_run(ctx):
+    """Invariant subspace of dimension 3: the device-side halt must report m=3, breakdown, like the oracle."""
+    import slepc_amd as ks
+    n = 12
+    Ao = O.CSR(n, np.arange(n + 1), np.arange(n), np.arange(1, n + 1, dtype=float))
+    Ag = _mat(ctx, Ao)
+    v = np.zeros(n); v[[1, 4, 7]] = [1.0, 2.0, -1.0]; v /= np.linalg.norm(v)
+    Vg = ks.BV(ctx, n, 8); Vo = O.BV(n, 8)
+    Vg.set_column(0, v); Vo.set_column(0, v)
+    Tg = np.zeros((8, 3), order="F"); To = np.zeros((8, 3), order="F")
+    rg = Vg.MatLanczos(Ag, Tg, 0, 6); ro = Vo.MatLanczos(Ao, To, 0, 6)
+    assert rg[0] == ro[0] == 3 and rg[2] and ro[2]
+    assert np.allclose(Tg[:3], To[:3], atol=1e-12)
+
+
+def test_lanczos_argument_checks(ctx):
+    import slepc_amd as ks
+    Ao = O.laplacian1d(20); Ag = _mat(ctx, Ao)
+    V = ks.BV(ctx, 20, 6)
+    T = np.zeros((6, 3), order="F")
+    with pytest.raises(ks.KsError) as e:
+        V.MatLanczos(Ag, T, 3, 3)            # "Argument m should be at least equal to k+1"
+    assert e.value.rc == 63
+    with pytest.raises(ks.KsError) as e:
+        V.MatLanczos(Ag, T, 0, 6)            # needs m+1 columns
+    assert e.value.rc == 63
+
+
+# ---- EPS Krylov-Schur ----------------------------------------------------------------------------------------
+def _solve_gpu(ctx, A, nev, ncv=0, which="largest_magnitude", tol=0.0):
+    import slepc_amd as ks
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A); eps.SetDimensions(nev, ncv); eps.SetWhichEigenpairs(which); eps.SetTolerances(tol)
+    eps.Solve()
+    return eps
+
+
+def test_eps_ex2_golden_and_oracle(ctx):
+    """BASELINE config 1 anchor: ex2 -n 72 -eps_nev 4 -eps_ncv 20."""
+    import slepc_amd as ks
+    Ao = O.laplacian2d(72)
+    eps = _solve_gpu(ctx, ks.Mat.laplacian2d(ctx, 72), 4, 20)
+    r = O.eps_krylovschur_hep(Ao, 4, ncv=20)
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(4)])
+    ref = gi.eigenvalues_line(gi.read("eps/ex2_1.out")); alt = gi.eigenvalues_line(gi.read("eps/ex2_1_alt.out"))
+    assert all(min(abs(round(l, 5) - a), abs(round(l, 5) - b)) < 1.5e-5 for l, a, b in zip(lam, ref, alt))
+    assert np.allclose(lam, r.eigr[r.perm][:4], rtol=1e-10)
+    assert eps.GetConverged() == r.nconv and eps.GetIterationNumber() == r.its           # identical control flow
+    st = eps.GetStats()
+    assert st["arnoldi_steps"] == r.steps and st["gs_passes"] == r.passes
+    for i in range(4):
+        assert eps.ComputeError(i) < 1e-8
+        assert abs(eps.ComputeError(i) - O.eps_compute_error(Ao, r, i)) < 1e-10
+        x = eps.GetEigenvector(i)
+        assert abs(np.linalg.norm(x) - 1.0) < 1e-12
+
+
+def test_eps_config1_2d_100(ctx):
+    """BASELINE config 1: 2-D 5-pt Laplacian n=10000, nev=4, m=20."""
+    import slepc_amd as ks
+    Ao = O.laplacian2d(100)
+    eps = _solve_gpu(ctx, ks.Mat.laplacian2d(ctx, 100), 4, 20)
+    r = O.eps_krylovschur_hep(Ao, 4, ncv=20)
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(eps.GetConverged())])
+    assert eps.GetConverged() >= 4
+    assert np.allclose(lam[:4], r.eigr[r.perm][:4], rtol=1e-10)
+    exact = O.laplacian_eigenvalues([100, 100])
+    for l in lam[:4]:
+        assert np.min(np.abs(exact - l)) / l < 1e-10
+
+
+def test_eps_ex19_smallest_real(ctx):
+    import slepc_amd as ks
+    eps = _solve_gpu(ctx, ks.Mat.laplacian3d(ctx, 10, 10, 10), 8, 64 - 1, which="smallest_real")
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(8)])
+    ref = gi.eigenvalues_line(gi.read("eps/ex19_1.out"))
+    assert np.allclose(np.round(lam, 5), ref, atol=1.5e-5)
+    assert np.allclose(lam, O.laplacian_eigenvalues([10, 10, 10])[:8], rtol=1e-10)
+    assert np.all(np.diff(lam) >= 0)                         # final sort is exact
+
+
+def test_eps_test4_1d(ctx):
+    Ao = O.laplacian1d(30)
+    eps = _solve_gpu(ctx, _mat(ctx, Ao), 4)
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(4)])
+    assert np.allclose(np.round(lam, 5), gi.eigenvalues_line(gi.read("eps/eps_test4_1.out")), atol=1.5e-5)
+    assert eps.GetDimensions() == (4, 19, 19)                # ncv = max(2nev, nev+15)
+
+
+def test_eps_diagonal_test6(ctx):
+    n = 30
+    Ao = O.CSR(n, np.arange(n + 1), np.arange(n), np.arange(1, n + 1, dtype=float))
+    eps = _solve_gpu(ctx, _mat(ctx, Ao), 4)
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(4)])
+    assert np.allclose(lam, gi.eigenvalues_line(gi.read("eps/eps_test6_1.out")), atol=1e-9)
+
+
+@pytest.mark.parametrize("which", ["largest_magnitude", "smallest_real", "largest_real", "smallest_magnitude"])
+def test_eps_sorting_criteria_match_oracle(ctx, which):
+    Ao = O.laplacian2d(20)
+    eps = _solve_gpu(ctx, _mat(ctx, Ao), 5, which=which)
+    r = O.eps_krylovschur_hep(Ao, 5, which=which)
+    assert eps.GetConverged() == r.nconv and eps.GetIterationNumber() == r.its
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(r.nconv)])
+    assert np.allclose(lam, r.eigr[r.perm], rtol=1e-10)
+
+
+def test_eps_config2_1M(ctx):
+    """BASELINE config 2: 2-D Laplacian n=1e6 on one MI355X, Ritz values vs analytic spectrum + residuals."""
+    import slepc_amd as ks
+    eps = ks.EPS(ctx)
+    eps.SetOperators(ks.Mat.laplacian2d(ctx, 1000)); eps.SetDimensions(4, 20); eps.SetTolerances(1e-8, 400)
+    eps.Solve()
+    exact = O.laplacian_eigenvalues([1000, 1000])
+    nconv = eps.GetConverged()
+    assert eps.GetConvergedReason() in (1, -1)
+    for i in range(nconv):
+        lam = eps.GetEigenvalue(i)[0]
+        assert np.min(np.abs(exact - lam)) / lam < 1e-10
+        assert eps.ComputeError(i) < 1e-8
+
+
+def test_full_size_properties_config3(ctx):
+    """BASELINE config 3 size (216^3 = 10 077 696 rows): size-independent properties of one Lanczos run:
+    orthonormal basis, T symmetric-tridiagonal relation via Rayleigh quotients, Ritz values inside [0,12]."""
+    import slepc_amd as ks
+    N = 216
+    A = ks.Mat.laplacian3d(ctx, N, N, N)
+    assert A.n == 10077696 and A.nnz == 70263936
+    m = 30
+    V = ks.BV(ctx, A.n, m + 1)
+    _start(V)
+    T = np.zeros((m + 1, 3), order="F")
+    mm, beta, brk = V.MatLanczos(A, T, 0, m)
+    assert mm == m and not brk
+    M = np.zeros((m + 1, m + 1), order="F")
+    V.SetActiveColumns(0, m + 1)
+    V.Dot(V, M)
+    assert np.abs(M - np.eye(m + 1)).max() < 1e-12
+    # alpha_j = v_j' A v_j and beta_j = v_{j+1}' A v_j, checked with an independent SpMV + dot on 3 columns
+    W = ks.BV(ctx, A.n, 2)
+    for j in (0, 13, 29):
+        A.mult_dev(V.column_ptr(j), W.column_ptr(0))
+        V.SetActiveColumns(j, j + 2)
+        d = V.DotVec(W.column_ptr(0))
+        assert abs(d[0] - T[j, 0]) < 1e-11 and abs(d[1] - T[j, 1]) < 1e-11
+    Tm = np.diag(T[:m, 0]) + np.diag(T[: m - 1, 1], 1) + np.diag(T[: m - 1, 1], -1)
+    th = np.linalg.eigvalsh(Tm)
+    assert th.min() > 0 and th.max() < 12.0
+    assert V.gs_passes()[0] >= m

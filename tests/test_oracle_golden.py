@@ -1,0 +1,184 @@
+"""Pins the CPU oracle against the reference's own golden outputs (CPU only, no GPU needed)."""
+import numpy as np
+import pytest
+
+import golden_inputs as gi
+import scenarios as sc
+from oracle import oracle as O
+
+
+@pytest.fixture(scope="module")
+def be():
+    return sc.OracleBackend()
+
+
+def check_test1(out, txt):
+    """Compare a bv_test1 result with output/test1_1_bv_type-mat.out (16 significant digits)."""
+    assert np.array_equal(gi.section_after(txt, "After BVMult - ")[0], out["Mult"])
+    assert np.array_equal(gi.section_after(txt, "After BVMultVec")[0], out["MultVec"])
+    assert np.array_equal(gi.section_after(txt, "After BVDot - ")[0], out["Dot"])
+    assert np.array_equal(np.array([r[0] for r in gi.section_after(txt, "After BVDotVec")[0]]), out["DotVec"])
+    blocks = gi.section_after(txt, "After BVMultInPlace")
+    assert np.array_equal(blocks[0], out["MultInPlace"])
+    assert abs(out["NormColumn0"] - gi.value_after(txt, "2-Norm of X[0] =")) < 5e-5
+    assert abs(out["NormF"] - gi.value_after(txt, "Frobenius Norm of X =")) < 5e-4
+    assert np.array_equal(blocks[-1].ravel(), out["FirstRow"])
+
+
+def test_bv_test1_mat(be):
+    check_test1(sc.bv_test1(be), gi.read("bv/test1_1_bv_type-mat.out"))
+
+
+def test_bv_test1_testlda(be):
+    # test1_2 (-testlda) prints the same BV contents; its svec golden file lists values one per line
+    out = sc.bv_test1(be, testlda=True)
+    ref = sc.bv_test1(be, testlda=False)
+    for k in ref:
+        assert np.array_equal(np.asarray(out[k]), np.asarray(ref[k])), k
+
+
+def test_bv_test1_svec_gpu_file(be):
+    # output/test1_1_svec_gpu.out is what the reference's own HIP backend must print (requires: hip)
+    txt = gi.read("bv/test1_1_svec_gpu.out")
+    out = sc.bv_test1(be)
+    assert abs(out["NormColumn0"] - gi.value_after(txt, "2-Norm of X[0] =")) < 5e-5
+    assert abs(out["NormF"] - gi.value_after(txt, "Frobenius Norm of X =")) < 5e-4
+
+
+@pytest.mark.parametrize("otype", [O.CGS, O.MGS])
+@pytest.mark.parametrize("refine", [O.REFINE_IFNEEDED, O.REFINE_NEVER, O.REFINE_ALWAYS])
+def test_bv_test2(be, otype, refine):
+    txt = gi.read("bv/test2_1.out")
+    out = sc.bv_test2(be, otype, refine)
+    eps = np.finfo(float).eps
+    if refine != O.REFINE_NEVER:           # the reference runs test2 with the default refinement
+        assert out["level"] < 100 * eps
+    assert abs(out["norm_ones"] - gi.value_after(txt, "after orthogonalizing against X:")) < 5e-6
+
+
+def test_bv_test4(be):
+    txt = gi.read("bv/test4_1.out")
+    for trans in (False, True):
+        out = sc.bv_test4(be, trans=trans)
+        assert abs(out["NormColumn"] - gi.value_after(txt, "2-Norm of X[3] =")) < 5e-5
+        assert abs(out["NormF"] - gi.value_after(txt, "Frobenius Norm of X =")) < 5e-4
+
+
+def test_bv_test13(be):
+    txt = gi.read("bv/test13_1.out")
+    assert abs(sc.bv_test13(be)["NormF"] - gi.value_after(txt, "Frobenius Norm or X =")) < 5e-4
+
+
+def test_bv_test8(be):
+    txt = gi.read("bv/test8_1.out")
+    ref = np.array([r[0] for r in gi.numeric_blocks(txt)[-1]])
+    z = sc.bv_test8(be)["z"]
+    assert np.allclose(z, ref, atol=5e-7)
+    assert np.all(z[1::2] == 0.0)
+
+
+def test_bv_test7(be):
+    assert sc.bv_test7(be)["err"] < 1e-14           # output/test7_1.out: "Norm of error: 0."
+
+
+# ---- solver level ------------------------------------------------------------------------------------
+def test_eps_ex2_golden():
+    """ex2 -n 72 -eps_nev 4 -eps_ncv 20 -> 7.99630 (alt 7.99629), 7.99074, 7.98519, 7.98150."""
+    A = O.laplacian2d(72)
+    r = O.eps_krylovschur_hep(A, 4, ncv=20)
+    lam = r.eigr[r.perm][:4]
+    ref = gi.eigenvalues_line(gi.read("eps/ex2_1.out"))
+    alt = gi.eigenvalues_line(gi.read("eps/ex2_1_alt.out"))
+    assert r.nconv >= 4 and r.reason > 0
+    assert all(min(abs(round(l, 5) - a), abs(round(l, 5) - b)) < 1.5e-5 for l, a, b in zip(lam, ref, alt))
+    exact = O.laplacian_eigenvalues([72, 72])[::-1]
+    for i in range(4):
+        assert np.min(np.abs(exact - lam[i])) / lam[i] < 1e-10      # every returned value is a true eigenvalue
+        assert O.eps_compute_error(A, r, i) < 1e-8                   # EPSComputeError relative < tol
+
+
+def test_eps_test4_golden():
+    A = O.laplacian1d(30)
+    r = O.eps_krylovschur_hep(A, 4)
+    ref = gi.eigenvalues_line(gi.read("eps/eps_test4_1.out"))
+    assert np.allclose(np.round(r.eigr[r.perm][:4], 5), ref, atol=1.5e-5)
+
+
+def test_eps_ex19_golden():
+    A = O.laplacian3d(10, 10, 10)
+    r = O.eps_krylovschur_hep(A, 8, ncv=64, which="smallest_real")
+    ref = gi.eigenvalues_line(gi.read("eps/ex19_1.out"))
+    assert np.allclose(np.round(r.eigr[r.perm][:8], 5), ref, atol=1.5e-5)
+    exact = O.laplacian_eigenvalues([10, 10, 10])[:8]           # GetExactEigenvalues ex19.c:19-45
+    assert np.allclose(r.eigr[r.perm][:8], exact, rtol=1e-10)
+
+
+def test_eps_diagonal_test6():
+    n = 30
+    A = O.CSR(n, np.arange(n + 1), np.arange(n), np.arange(1, n + 1, dtype=float))
+    r = O.eps_krylovschur_hep(A, 4)
+    ref = gi.eigenvalues_line(gi.read("eps/eps_test6_1.out"))
+    assert np.allclose(r.eigr[r.perm][:4], ref, atol=1e-9)
+
+
+def test_sort_permutation_is_exact():
+    """DSSort / final sort are integer permutation work: the result must be exactly sorted by the criterion."""
+    A = O.laplacian2d(20)
+    for which in ("largest_magnitude", "smallest_real", "largest_real", "smallest_magnitude"):
+        r = O.eps_krylovschur_hep(A, 5, which=which)
+        lam = r.eigr[r.perm]
+        key = {"largest_magnitude": -np.abs(lam), "smallest_magnitude": np.abs(lam), "largest_real": -lam, "smallest_real": lam}[which]
+        assert np.all(np.diff(key) >= 0)
+        assert sorted(r.perm.tolist()) == list(range(r.nconv))
+
+
+def test_lanczos_relation_and_orthogonality():
+    """A V_m - V_m T = beta v_m e_m^T (bvkrylov.c:133) and V^T V = I."""
+    A = O.laplacian2d(15)
+    m = 14
+    V = O.BV(A.n, m + 1)
+    V.SetRandomColumn(0)
+    _, nrm, _ = V.OrthogonalizeColumn(0)
+    V.ScaleColumn(0, 1 / nrm)
+    T = np.zeros((m + 1, 3), order="F")
+    mm, beta, brk = V.MatLanczos(A, T, 0, m)
+    assert mm == m and not brk
+    Vd = V.dense()
+    Tm = np.diag(T[:m, 0]) + np.diag(T[: m - 1, 1], 1) + np.diag(T[: m - 1, 1], -1)
+    R = A.to_scipy() @ Vd[:, :m] - Vd[:, :m] @ Tm
+    R[:, m - 1] -= beta * Vd[:, m]
+    assert np.abs(R).max() < 1e-13
+    assert np.abs(Vd.T @ Vd - np.eye(m + 1)).max() < 1e-14
+    assert abs(T[m - 1, 1] - beta) == 0.0
+
+
+def test_arnoldi_relation():
+    rng = np.random.default_rng(3)
+    n, m = 60, 10
+    import scipy.sparse as sp
+    S = sp.random(n, n, density=0.1, random_state=5, format="csr") + sp.eye(n, format="csr") * 3
+    S.sort_indices()
+    A = O.CSR(n, S.indptr, S.indices, S.data)
+    V = O.BV(n, m + 1)
+    V.set_column(0, rng.standard_normal(n))
+    _, nrm, _ = V.OrthogonalizeColumn(0)
+    V.ScaleColumn(0, 1 / nrm)
+    H = np.zeros((m + 1, m + 1), order="F")
+    mm, beta, brk = V.MatArnoldi(A, H, 0, m)
+    Vd = V.dense()
+    R = S @ Vd[:, :m] - Vd[:, : m + 1] @ H[: m + 1, :m]
+    assert np.abs(R).max() < 1e-13
+    assert abs(H[m, m - 1] - beta) == 0.0
+    assert np.abs(np.tril(H[:m, :m], -2)).max() == 0.0
+
+
+def test_breakdown_sets_lindep():
+    """Invariant subspace: Lanczos on a start vector spanning 3 eigenvectors breaks down at step 3 (bvkrylov.c:92-97)."""
+    n = 12
+    A = O.CSR(n, np.arange(n + 1), np.arange(n), np.arange(1, n + 1, dtype=float))
+    V = O.BV(n, 8)
+    v = np.zeros(n); v[[1, 4, 7]] = [1.0, 2.0, -1.0]
+    V.set_column(0, v / np.linalg.norm(v))
+    T = np.zeros((8, 3), order="F")
+    mm, beta, brk = V.MatLanczos(A, T, 0, 6)
+    assert brk and mm == 3
