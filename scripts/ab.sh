@@ -1,0 +1,14 @@
+#!/bin/bash
+# usage: scripts/ab.sh "<ENV=1 ...>" ...   -> runs bench.py (150 steps) once per env-setting, prints value + per-class summary
+for envs in "$@"; do
+  echo "=== env: [$envs]"
+  env $envs python bench.py --steps 150 --warmup 30 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('steps/s %.1f  ms/step %.4f  kernel_ms/step %.4f' % (d['value'], d['ms_per_step'], d['step_traffic']['kernel_ms_per_step']))
+agg={}
+for k in d['kernels_untimed_instrumented_pass']:
+    a=agg.setdefault(k['class'],[0,0.0]); a[0]+=k['launches']; a[1]+=k['ms_total']
+for c,(n,ms) in sorted(agg.items(), key=lambda kv:-kv[1][1]): print('   %-22s n=%5d ms=%8.2f  ms/step=%.4f' % (c,n,ms,ms/150))
+"
+done

@@ -108,8 +108,14 @@ class Context:
         self.rank, self.size = rank, size
 
     # -- profiling
-    def prof_enable(self, on=True):
-        _lib.check(self.L.ks_prof_enable(self.h, int(on)))
+    def prof_enable(self, on=True, classes=None):
+        """classes: optional list of class names to time (fewer HIP events in a timed region); default all."""
+        v = int(bool(on))
+        if on and classes:
+            v = 0
+            for c in classes:
+                v |= 1 << (KCLASSES.index(c) + 1)
+        _lib.check(self.L.ks_prof_enable(self.h, v))
 
     def prof_reset(self):
         _lib.check(self.L.ks_prof_reset(self.h))

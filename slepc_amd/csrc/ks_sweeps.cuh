@@ -130,15 +130,17 @@ __global__ __launch_bounds__(SW_BLOCK) void k_multvec(const double *__restrict__
 __device__ __forceinline__ void reduce_partials_to_lds(const double *__restrict__ partials, int nblocks, int ncols, double *c_lds)
 {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  constexpr int PER_LANE = KS_MAX_BLOCKS / 64;
+  constexpr int PER_LANE = 16;
   for (int i = w; i < ncols; i += nw) {
     const double *p = partials + (size_t)i * nblocks;
-    double v[PER_LANE];
-#pragma unroll
-    for (int u = 0; u < PER_LANE; u++) { const int b = lane + 64 * u; v[u] = (b < nblocks) ? p[b] : 0.0; }
     double s = 0.0;
+    for (int b0 = 0; b0 < nblocks; b0 += 64 * PER_LANE) {
+      double v[PER_LANE];
 #pragma unroll
-    for (int u = 0; u < PER_LANE; u++) s += v[u];
+      for (int u = 0; u < PER_LANE; u++) { const int b = b0 + lane + 64 * u; v[u] = (b < nblocks) ? p[b] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < PER_LANE; u++) s += v[u];
+    }
     s = wave_sum(s);
     if (lane == 0) c_lds[i] = s;
   }

@@ -42,6 +42,7 @@ struct ks_ctx_s {
   KsComm comm;
   // profiling
   bool prof_on = false;
+  unsigned prof_mask = 0xffffffffu;   // classes that get HIP events when profiling is on
   KsProfSlot prof[KS_K_COUNT][KS_PROF_VARIANTS];
   std::vector<KsProfPending> pending;
   std::vector<hipEvent_t> event_pool;
@@ -54,7 +55,7 @@ int ks_prof_end(ks_ctx ctx);
 int ks_prof_flush(ks_ctx ctx);
 struct KsProfScope {
   ks_ctx ctx; bool on;
-  KsProfScope(ks_ctx c, int kclass, double bytes, int variant = 0, double hbm = -1.0) : ctx(c), on(c->prof_on) { if (on) ks_prof_begin(c, kclass, variant, bytes, hbm < 0 ? bytes : hbm); }
+  KsProfScope(ks_ctx c, int kclass, double bytes, int variant = 0, double hbm = -1.0) : ctx(c), on(c->prof_on && ((c->prof_mask >> kclass) & 1u)) { if (on) ks_prof_begin(c, kclass, variant, bytes, hbm < 0 ? bytes : hbm); }
   ~KsProfScope() { if (on) ks_prof_end(ctx); }
   // tag the record of a speculative Gram-Schmidt slot so it can be re-filed once pass counts are known
   void tag(int col, int slot, int k, long long n) { if (on && !ctx->pending.empty()) { auto &p = ctx->pending.back(); p.tag_col = col; p.tag_slot = slot; p.tag_k = k; p.tag_n = n; } }
@@ -74,6 +75,10 @@ struct ks_mat_s {
   // diagonal block (columns owned by this rank, LOCAL column indices)
   int *d_rowptr = nullptr; int *d_col = nullptr; double *d_val = nullptr; long long nnz_d = 0;
   int lanes_per_row = 8;
+  // sliced-ELL copy of the diagonal block (slice = 64 rows = one wavefront), chosen at assembly when the
+  // padding it needs is small; val/col stored column-major inside a slice: entry j of row 64s+lane at (sp[s]+j)*64+lane
+  bool use_sell = false;
+  int nslices = 0; int *s_ptr = nullptr; int *s_len = nullptr; int *s_col = nullptr; double *s_val = nullptr; long long s_entries = 0;
   // off-diagonal block (columns owned by other ranks), compressed to ghost indices [0,nghost)
   int *o_rowptr = nullptr; int *o_col = nullptr; double *o_val = nullptr; long long nnz_o = 0;
   int nghost = 0;
@@ -125,7 +130,7 @@ struct ks_bv_s {
 
 constexpr int KS_MAX_COLS   = 64;     // max columns handled by the register-tiled sweeps (k+1 <= 64)
 constexpr int KS_PSTRIDE    = 72;     // doubles per block in the partials array
-constexpr int KS_MAX_BLOCKS = 1024;
+constexpr int KS_MAX_BLOCKS = 4096;
 
 static inline double *ks_bv_col(ks_bv bv, int j) { return bv->array + (size_t)(bv->nc + j) * bv->ld; }
 
@@ -137,3 +142,5 @@ int ksk_scale(ks_ctx ctx, double *x, size_t n, double alpha);
 int ksk_copy(ks_ctx ctx, const double *src, double *dst, size_t n);
 
 int ks_mat_mult_internal(ks_mat A, const double *x, double *y);
+int ks_sweep_grid(ks_ctx ctx, int n, int vec);
+int ks_sweep_grid_for(ks_ctx ctx, int n, int vec, const void *kernel, int force_per_cu);   // resident-blocks grid of one kernel symbol   // blocks of a row sweep (shared by every sweep kernel so partials line up)
