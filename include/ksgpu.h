@@ -79,15 +79,27 @@ int ks_ctx_synchronize(ks_ctx ctx);
 int ks_ctx_device_info(ks_ctx ctx, char *arch, int arch_len, int *num_cu, size_t *mem_total);
 
 /* Row-wise distribution (PetscLayout, bvbasic.c:129-134).  Reductions inside BV ops
-   (bvblas.c:218,255; bvlapack.c:50) become an allreduce over all ranks.
-   Two providers: native RCCL (ks_comm_*) or a caller-supplied callback (e.g. GPU-aware MPI). */
+   (bvblas.c:218,255; bvlapack.c:50) become an allreduce over all ranks; MatMult exchanges the
+   boundary entries of x with the owning ranks (PETSc VecScatter inside MatMult_MPIAIJ).
+   Two providers: native RCCL over xGMI (ks_comm_init_rccl) or three caller-supplied operations
+   (ks_comm_set_ops; e.g. GPU-aware MPI: MPIU_Allreduce / MPI_Allgather / MPI_Isend+Irecv).      */
 #define KS_UNIQUE_ID_BYTES 128
 int ks_comm_get_unique_id(unsigned char id[KS_UNIQUE_ID_BYTES]);                       /* rank 0, then broadcast by the launcher */
 int ks_comm_init_rccl(ks_ctx ctx, int rank, int size, const unsigned char id[KS_UNIQUE_ID_BYTES]);
-typedef int (*ks_allreduce_fn)(void *user, double *dev_buf, int count, void *stream);  /* in-place SUM on device memory */
-typedef int (*ks_halo_fn)(void *user, const double *dev_send, double *dev_recv, void *stream);
-int ks_comm_set_callbacks(ks_ctx ctx, int rank, int size, ks_allreduce_fn allreduce, void *user);
+typedef struct ks_comm_ops {
+  /* in-place SUM of `count` doubles in DEVICE memory, ordered on `stream` */
+  int (*allreduce_sum)(void *user, double *dev_buf, int count, void *stream);
+  /* setup only: every rank contributes `bytes` HOST bytes; recv gets size*bytes, in rank order */
+  int (*allgather_host)(void *user, const void *send, int bytes, void *recv);
+  /* neighbour exchange on DEVICE buffers, ordered on `stream`: to/from peers[i], segments
+     [off[i], off[i]+cnt[i]) in units of elem_bytes */
+  int (*exchange)(void *user, int npeers, const int *peers, const void *dev_send, const int *send_off, const int *send_cnt,
+                  void *dev_recv, const int *recv_off, const int *recv_cnt, int elem_bytes, void *stream);
+} ks_comm_ops;
+int ks_comm_set_ops(ks_ctx ctx, int rank, int size, const ks_comm_ops *ops, void *user);
 int ks_comm_rank_size(ks_ctx ctx, int *rank, int *size);
+/* device<->host copy on the context's stream (synchronous); kind: 0 = host->device, 1 = device->host */
+int ks_ctx_memcpy(ks_ctx ctx, void *dst, const void *src, size_t bytes, int kind);
 
 /* ---- Mat: the MatMult(AIJ) slot ------------------------------------------------------------- */
 /* CSR arrays as in PETSc SeqAIJ (i,j,a): rowptr[n_local+1], col[nnz] (GLOBAL column indices),
@@ -112,6 +124,7 @@ int ks_bv_create(ks_ctx ctx, int n_local, int n_global, int m, int ld /*0: defau
 int ks_bv_destroy(ks_bv bv);                                                        /* ops->destroy */
 int ks_bv_duplicate(ks_bv bv, ks_bv *out);                                           /* ops->duplicate (storage only; no copy) */
 int ks_bv_get_sizes(ks_bv bv, int *n_local, int *n_global, int *m, int *ld);
+int ks_bv_set_ownership_start(ks_bv bv, int row_start);                             /* first global row of this rank (PetscLayout rstart); used by the reproducible random vectors */
 int ks_bv_set_active_columns(ks_bv bv, int l, int k);                               /* BVSetActiveColumns bvbasic.c:421 */
 int ks_bv_get_active_columns(ks_bv bv, int *l, int *k);
 int ks_bv_set_orthogonalization(ks_bv bv, int type, int refine, double eta);        /* BVSetOrthogonalization; eta<=0 keeps 0.7071 */

@@ -94,18 +94,35 @@ class Context:
         _lib.check(_lib.lib().ks_comm_get_unique_id(buf))
         return buf.raw
 
-    def set_allreduce_callback(self, rank, size, fn):
-        """fn(dev_ptr:int, count:int, stream:int) -> 0 ; in-place SUM allreduce on device memory."""
-        def tramp(user, buf, count, stream):
-            try:
-                return int(fn(buf, count, stream) or 0)
-            except Exception:       # noqa: BLE001 - must not unwind through C
-                import traceback
-                traceback.print_exc()
-                return 1
-        self._cb = _lib.ALLREDUCE_FN(tramp)
-        _lib.check(self.L.ks_comm_set_callbacks(self.h, rank, size, self._cb, None))
+    def set_comm_ops(self, rank, size, allreduce_sum, allgather_host, exchange):
+        """Caller-supplied communicator (what an MPI adapter would install). Python callables:
+             allreduce_sum(dev_ptr, count, stream) ; allgather_host(send_ptr, nbytes, recv_ptr) ;
+             exchange(peers, dev_send, send_off, send_cnt, dev_recv, recv_off, recv_cnt, elem_bytes, stream)
+           each returning 0 on success."""
+        def guard(f):
+            def g(*a):
+                try:
+                    return int(f(*a) or 0)
+                except Exception:       # noqa: BLE001 - must not unwind through C
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return g
+        ar = guard(lambda user, buf, count, stream: allreduce_sum(buf, count, stream))
+        ag = guard(lambda user, send, nbytes, recv: allgather_host(send, nbytes, recv))
+
+        def ex(user, npeers, peers, dsend, soff, scnt, drecv, roff, rcnt, eb, stream):
+            L = lambda p: [p[i] for i in range(npeers)]      # noqa: E731
+            return exchange(L(peers), dsend, L(soff), L(scnt), drecv, L(roff), L(rcnt), eb, stream)
+        self._ops = _lib.CommOps(_lib.ALLREDUCE_FN(ar), _lib.ALLGATHER_FN(ag), _lib.EXCHANGE_FN(guard(ex)))
+        _lib.check(self.L.ks_comm_set_ops(self.h, rank, size, C.byref(self._ops), None))
         self.rank, self.size = rank, size
+
+    def memcpy_h2d(self, dev_ptr, host_array):
+        _lib.check(self.L.ks_ctx_memcpy(self.h, C.c_void_p(dev_ptr), host_array.ctypes.data_as(C.c_void_p), host_array.nbytes, 0))
+
+    def memcpy_d2h(self, host_array, dev_ptr):
+        _lib.check(self.L.ks_ctx_memcpy(self.h, host_array.ctypes.data_as(C.c_void_p), C.c_void_p(dev_ptr), host_array.nbytes, 1))
 
     # -- profiling
     def prof_enable(self, on=True, classes=None):
@@ -203,6 +220,8 @@ class BV:
             _lib.check(L.ks_bv_create(ctx.h, n, n if N is None else N, m, ld, C.byref(h)))
             self.h = h
             self._own = True
+            if row_start:
+                _lib.check(L.ks_bv_set_ownership_start(self.h, row_start))
         else:
             self.h = _handle
             self._own = False

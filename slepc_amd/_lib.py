@@ -14,6 +14,12 @@ ip = C.POINTER(C.c_int)
 vp = C.c_void_p
 llp = C.POINTER(C.c_longlong)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_int, vp)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_int, vp)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, vp, C.c_int, ip, vp, ip, ip, vp, ip, ip, C.c_int, vp)
+
+
+class CommOps(C.Structure):
+    _fields_ = [("allreduce_sum", ALLREDUCE_FN), ("allgather_host", ALLGATHER_FN), ("exchange", EXCHANGE_FN)]
 
 
 class KsError(RuntimeError):
@@ -30,7 +36,8 @@ _SIG = {
     "ks_ctx_device_info": [vp, C.c_char_p, C.c_int, ip, C.POINTER(C.c_size_t)],
     "ks_comm_get_unique_id": [C.c_char_p],
     "ks_comm_init_rccl": [vp, C.c_int, C.c_int, C.c_char_p],
-    "ks_comm_set_callbacks": [vp, C.c_int, C.c_int, ALLREDUCE_FN, vp],
+    "ks_comm_set_ops": [vp, C.c_int, C.c_int, C.POINTER(CommOps), vp],
+    "ks_ctx_memcpy": [vp, vp, vp, C.c_size_t, C.c_int],
     "ks_comm_rank_size": [vp, ip, ip],
     # mat
     "ks_mat_create_csr": [vp, C.c_int, C.c_int, C.c_int, ip, ip, dp, C.POINTER(vp)],
@@ -45,6 +52,7 @@ _SIG = {
     "ks_bv_destroy": [vp],
     "ks_bv_duplicate": [vp, C.POINTER(vp)],
     "ks_bv_get_sizes": [vp, ip, ip, ip, ip],
+    "ks_bv_set_ownership_start": [vp, C.c_int],
     "ks_bv_set_active_columns": [vp, C.c_int, C.c_int],
     "ks_bv_get_active_columns": [vp, ip, ip],
     "ks_bv_set_orthogonalization": [vp, C.c_int, C.c_int, C.c_double],
@@ -115,7 +123,7 @@ def header_symbols():
     """Every function name declared in include/ksgpu.h."""
     txt = open(HEADER_PATH).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(ks_[a-z0-9_]+)\s*\(", txt)) - {"ks_allreduce_fn", "ks_halo_fn"})
+    return sorted(set(re.findall(r"\b(ks_[a-z0-9_]+)\s*\(", txt)) - {"ks_comm_ops"})
 
 
 def load():

@@ -272,6 +272,14 @@ extern "C" int ks_bv_get_sizes(ks_bv bv, int *n, int *N, int *m, int *ld)
   return KS_SUCCESS;
 }
 
+extern "C" int ks_bv_set_ownership_start(ks_bv bv, int row_start)
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  KS_CHECK(row_start >= 0 && row_start + bv->n <= bv->N, KS_ERR_ARG_OUTOFRANGE, "rows [%d,%d) outside the global size %d", row_start, row_start + bv->n, bv->N);
+  bv->row_start = row_start;
+  return KS_SUCCESS;
+}
+
 extern "C" int ks_bv_set_active_columns(ks_bv bv, int l, int k)   // bvbasic.c:421-440
 {
   KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");

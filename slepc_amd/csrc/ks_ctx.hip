@@ -212,7 +212,14 @@ struct NcclUniqueIdRaw { char internal[KS_UNIQUE_ID_BYTES]; };
 typedef int (*nccl_getuid_t)(NcclUniqueIdRaw *);
 typedef int (*nccl_initrank_t)(void **, int, NcclUniqueIdRaw, int);
 typedef int (*nccl_allreduce_t)(const void *, void *, size_t, int, int, void *, hipStream_t);
-typedef const char *(*nccl_errstr_t)(int);
+typedef int (*nccl_allgather_t)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef int (*nccl_send_t)(const void *, size_t, int, int, void *, hipStream_t);
+typedef int (*nccl_recv_t)(void *, size_t, int, int, void *, hipStream_t);
+typedef int (*nccl_group_t)();
+enum { NCCL_INT8 = 0, NCCL_INT32 = 2, NCCL_FLOAT64 = 8, NCCL_SUM = 0 };
+
+struct RcclFns { nccl_allreduce_t allreduce; nccl_allgather_t allgather; nccl_send_t send; nccl_recv_t recv; nccl_group_t gstart, gend; };
+static RcclFns g_rccl;
 
 static void *open_rccl()
 {
@@ -237,6 +244,40 @@ extern "C" int ks_comm_get_unique_id(unsigned char id[KS_UNIQUE_ID_BYTES])
   return KS_SUCCESS;
 }
 
+// RCCL implementations of the three provider operations; `user` is the ks_ctx
+static int rccl_allreduce_sum(void *user, double *dev_buf, int count, void *stream)
+{
+  ks_ctx ctx = (ks_ctx)user;
+  return g_rccl.allreduce(dev_buf, dev_buf, (size_t)count, NCCL_FLOAT64, NCCL_SUM, ctx->comm.nccl_comm, (hipStream_t)stream);
+}
+static int rccl_allgather_host(void *user, const void *send, int bytes, void *recv)
+{
+  ks_ctx ctx = (ks_ctx)user;
+  char *d = nullptr;
+  if (hipMalloc(&d, (size_t)bytes * (ctx->comm.size + 1)) != hipSuccess) return 1;
+  int rc = 0;
+  if (hipMemcpyAsync(d + (size_t)bytes * ctx->comm.size, send, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = 2;
+  if (!rc) rc = g_rccl.allgather(d + (size_t)bytes * ctx->comm.size, d, (size_t)bytes, NCCL_INT8, ctx->comm.nccl_comm, ctx->stream);
+  if (!rc && hipMemcpyAsync(recv, d, (size_t)bytes * ctx->comm.size, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = 3;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = 4;
+  hipFree(d);
+  return rc;
+}
+static int rccl_exchange(void *user, int npeers, const int *peers, const void *dev_send, const int *send_off, const int *send_cnt,
+                         void *dev_recv, const int *recv_off, const int *recv_cnt, int elem_bytes, void *stream)
+{
+  ks_ctx ctx = (ks_ctx)user;
+  const int dt = elem_bytes == 8 ? NCCL_FLOAT64 : (elem_bytes == 4 ? NCCL_INT32 : NCCL_INT8);
+  const size_t mul = (dt == NCCL_INT8) ? (size_t)elem_bytes : 1;
+  int rc = g_rccl.gstart();
+  for (int i = 0; i < npeers && !rc; i++) {
+    if (send_cnt[i]) rc = g_rccl.send((const char *)dev_send + (size_t)send_off[i] * elem_bytes, (size_t)send_cnt[i] * mul, dt, peers[i], ctx->comm.nccl_comm, (hipStream_t)stream);
+    if (!rc && recv_cnt[i]) rc = g_rccl.recv((char *)dev_recv + (size_t)recv_off[i] * elem_bytes, (size_t)recv_cnt[i] * mul, dt, peers[i], ctx->comm.nccl_comm, (hipStream_t)stream);
+  }
+  int rc2 = g_rccl.gend();
+  return rc ? rc : rc2;
+}
+
 extern "C" int ks_comm_init_rccl(ks_ctx ctx, int rank, int size, const unsigned char id[KS_UNIQUE_ID_BYTES])
 {
   KS_CHECK(ctx && id, KS_ERR_ARG_NULL, "ctx or id is NULL");
@@ -245,22 +286,33 @@ extern "C" int ks_comm_init_rccl(ks_ctx ctx, int rank, int size, const unsigned 
   void *h = open_rccl();
   KS_CHECK(h, KS_ERR_LIB, "cannot open librccl: %s", dlerror());
   nccl_initrank_t f = (nccl_initrank_t)dlsym(h, "ncclCommInitRank");
-  KS_CHECK(f, KS_ERR_LIB, "ncclCommInitRank not found");
+  g_rccl.allreduce = (nccl_allreduce_t)dlsym(h, "ncclAllReduce");
+  g_rccl.allgather = (nccl_allgather_t)dlsym(h, "ncclAllGather");
+  g_rccl.send = (nccl_send_t)dlsym(h, "ncclSend");
+  g_rccl.recv = (nccl_recv_t)dlsym(h, "ncclRecv");
+  g_rccl.gstart = (nccl_group_t)dlsym(h, "ncclGroupStart");
+  g_rccl.gend = (nccl_group_t)dlsym(h, "ncclGroupEnd");
+  KS_CHECK(f && g_rccl.allreduce && g_rccl.allgather && g_rccl.send && g_rccl.recv && g_rccl.gstart && g_rccl.gend, KS_ERR_LIB, "RCCL symbols not found");
   NcclUniqueIdRaw raw; memcpy(raw.internal, id, KS_UNIQUE_ID_BYTES);
   void *comm = nullptr;
   int rc = f(&comm, size, raw, rank);
   KS_CHECK(rc == 0, KS_ERR_LIB, "ncclCommInitRank failed (%d)", rc);
   ctx->comm.rccl_lib = h; ctx->comm.nccl_comm = comm; ctx->comm.rank = rank; ctx->comm.size = size;
-  ctx->comm.cb_allreduce = nullptr;
+  ctx->comm.ops.allreduce_sum = rccl_allreduce_sum; ctx->comm.ops.allgather_host = rccl_allgather_host; ctx->comm.ops.exchange = rccl_exchange;
+  ctx->comm.user = ctx;
+  ctx->comm.force_collectives = getenv("KSGPU_FORCE_MULTI") != nullptr;
   return KS_SUCCESS;
 }
 
-extern "C" int ks_comm_set_callbacks(ks_ctx ctx, int rank, int size, ks_allreduce_fn allreduce, void *user)
+extern "C" int ks_comm_set_ops(ks_ctx ctx, int rank, int size, const ks_comm_ops *ops, void *user)
 {
   KS_CHECK(ctx, KS_ERR_ARG_NULL, "ctx is NULL");
   KS_CHECK(size >= 1 && rank >= 0 && rank < size, KS_ERR_ARG_OUTOFRANGE, "bad rank/size %d/%d", rank, size);
-  KS_CHECK(size == 1 || allreduce, KS_ERR_ARG_NULL, "allreduce callback required when size>1");
-  ctx->comm.rank = rank; ctx->comm.size = size; ctx->comm.cb_allreduce = allreduce; ctx->comm.cb_user = user;
+  KS_CHECK(size == 1 || (ops && ops->allreduce_sum && ops->allgather_host && ops->exchange), KS_ERR_ARG_NULL, "all three operations are required when size>1");
+  ctx->comm.rank = rank; ctx->comm.size = size;
+  if (ops) ctx->comm.ops = *ops;
+  ctx->comm.user = user;
+  ctx->comm.force_collectives = ops && ops->allreduce_sum && getenv("KSGPU_FORCE_MULTI") != nullptr;
   return KS_SUCCESS;
 }
 
@@ -272,22 +324,41 @@ extern "C" int ks_comm_rank_size(ks_ctx ctx, int *rank, int *size)
   return KS_SUCCESS;
 }
 
+extern "C" int ks_ctx_memcpy(ks_ctx ctx, void *dst, const void *src, size_t bytes, int kind)
+{
+  KS_CHECK(ctx && (bytes == 0 || (dst && src)), KS_ERR_ARG_NULL, "NULL argument");
+  KS_HIP(hipSetDevice(ctx->device));
+  if (bytes) KS_HIP(hipMemcpyAsync(dst, src, bytes, kind == 0 ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, ctx->stream));
+  KS_HIP(hipStreamSynchronize(ctx->stream));
+  return KS_SUCCESS;
+}
+
 // In-place SUM allreduce of `count` doubles in device memory, stream-ordered (bvblas.c:255 MPIU_Allreduce).
 int ks_allreduce_sum(ks_ctx ctx, double *dev_buf, int count)
 {
-  if (ctx->comm.size <= 1 || count <= 0) return KS_SUCCESS;
+  if (!ks_is_multi(ctx) || count <= 0) return KS_SUCCESS;
+  KS_CHECK(ctx->comm.ops.allreduce_sum, KS_ERR_ORDER, "size>1 but no communicator: call ks_comm_init_rccl or ks_comm_set_ops");
   KsProfScope ps(ctx, KS_K_ALLREDUCE, 8.0 * count);
-  if (ctx->comm.cb_allreduce) {
-    int rc = ctx->comm.cb_allreduce(ctx->comm.cb_user, dev_buf, count, (void *)ctx->stream);
-    KS_CHECK(rc == 0, KS_ERR_LIB, "allreduce callback failed (%d)", rc);
-    return KS_SUCCESS;
-  }
-  KS_CHECK(ctx->comm.nccl_comm, KS_ERR_ORDER, "size>1 but no communicator: call ks_comm_init_rccl or ks_comm_set_callbacks");
-  static nccl_allreduce_t f = nullptr;
-  if (!f) f = (nccl_allreduce_t)dlsym(ctx->comm.rccl_lib, "ncclAllReduce");
-  KS_CHECK(f, KS_ERR_LIB, "ncclAllReduce not found");
-  const int ncclFloat64 = 8, ncclSum = 0;
-  int rc = f(dev_buf, dev_buf, (size_t)count, ncclFloat64, ncclSum, ctx->comm.nccl_comm, ctx->stream);
-  KS_CHECK(rc == 0, KS_ERR_LIB, "ncclAllReduce failed (%d)", rc);
+  int rc = ctx->comm.ops.allreduce_sum(ctx->comm.user, dev_buf, count, (void *)ctx->stream);
+  KS_CHECK(rc == 0, KS_ERR_LIB, "allreduce failed (%d)", rc);
+  return KS_SUCCESS;
+}
+
+int ks_comm_allgather_host(ks_ctx ctx, const void *send, int bytes, void *recv)
+{
+  if (ctx->comm.size == 1) { memcpy(recv, send, bytes); return KS_SUCCESS; }
+  KS_CHECK(ctx->comm.ops.allgather_host, KS_ERR_ORDER, "no communicator");
+  int rc = ctx->comm.ops.allgather_host(ctx->comm.user, send, bytes, recv);
+  KS_CHECK(rc == 0, KS_ERR_LIB, "allgather failed (%d)", rc);
+  return KS_SUCCESS;
+}
+
+int ks_comm_exchange(ks_ctx ctx, int npeers, const int *peers, const void *dev_send, const int *send_off, const int *send_cnt,
+                     void *dev_recv, const int *recv_off, const int *recv_cnt, int elem_bytes)
+{
+  if (npeers == 0) return KS_SUCCESS;
+  KS_CHECK(ctx->comm.ops.exchange, KS_ERR_ORDER, "no communicator");
+  int rc = ctx->comm.ops.exchange(ctx->comm.user, npeers, peers, dev_send, send_off, send_cnt, dev_recv, recv_off, recv_cnt, elem_bytes, (void *)ctx->stream);
+  KS_CHECK(rc == 0, KS_ERR_LIB, "neighbour exchange failed (%d)", rc);
   return KS_SUCCESS;
 }

@@ -227,7 +227,7 @@ int sweep_grid(ks_ctx ctx, int n, int vec) { return ks_sweep_grid(ctx, n, vec); 
 int launch_finish(ks_bv bv, const GsArgs &a)
 {
   ks_ctx ctx = bv->ctx;
-  const bool multi = ctx->comm.size > 1;
+  const bool multi = ks_is_multi(ctx);
   KsProfScope ps(ctx, KS_K_GSFIN, 8.0 * bv->last_grid * (a.k + 1));
   ps.tag(a.k, a.slot, a.k, bv->n);
   if (!multi) hipLaunchKernelGGL((k_gs_finish<true, true>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, bv->last_grid, a, bv->buffer, bv->gs, bv->recs);

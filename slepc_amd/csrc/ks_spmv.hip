@@ -20,7 +20,6 @@
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <numeric>
-#include <dlfcn.h>
 
 namespace {
 
@@ -264,25 +263,6 @@ int exclusive_scan_int(hipStream_t st, const int *in, int *out, long long nitems
   return KS_SUCCESS;
 }
 
-// RCCL point-to-point symbols for the halo exchange
-typedef int (*nccl_send_t)(const void *, size_t, int, int, void *, hipStream_t);
-typedef int (*nccl_recv_t)(void *, size_t, int, int, void *, hipStream_t);
-typedef int (*nccl_group_t)();
-typedef int (*nccl_allgather_t)(const void *, void *, size_t, int, void *, hipStream_t);
-
-struct RcclP2P { nccl_send_t send; nccl_recv_t recv; nccl_group_t gstart, gend; nccl_allgather_t allgather; };
-int get_p2p(ks_ctx ctx, RcclP2P *p)
-{
-  KS_CHECK(ctx->comm.rccl_lib && ctx->comm.nccl_comm, KS_ERR_ORDER, "multi-rank Mat needs the RCCL provider (ks_comm_init_rccl)");
-  p->send = (nccl_send_t)dlsym(ctx->comm.rccl_lib, "ncclSend");
-  p->recv = (nccl_recv_t)dlsym(ctx->comm.rccl_lib, "ncclRecv");
-  p->gstart = (nccl_group_t)dlsym(ctx->comm.rccl_lib, "ncclGroupStart");
-  p->gend = (nccl_group_t)dlsym(ctx->comm.rccl_lib, "ncclGroupEnd");
-  p->allgather = (nccl_allgather_t)dlsym(ctx->comm.rccl_lib, "ncclAllGather");
-  KS_CHECK(p->send && p->recv && p->gstart && p->gend && p->allgather, KS_ERR_LIB, "RCCL p2p symbols not found");
-  return KS_SUCCESS;
-}
-
 // Build the halo plan from the sorted list of needed global columns (garray, host).
 // Owners are found from the allgathered row_start array; every rank tells its owners which rows it needs.
 int build_halo_plan(ks_mat A, const std::vector<int> &garray)
@@ -291,29 +271,17 @@ int build_halo_plan(ks_mat A, const std::vector<int> &garray)
   const int size = ctx->comm.size, rank = ctx->comm.rank;
   A->nghost = (int)garray.size();
   if (size == 1) { KS_CHECK(garray.empty(), KS_ERR_ARG_OUTOFRANGE, "column index outside [0,n) on a single rank"); return KS_SUCCESS; }
-  RcclP2P p2p; KS_CALL(get_p2p(ctx, &p2p));
-  const int ncclInt32 = 2;
   // 1. ownership ranges
-  int *d_tmp = nullptr; KS_HIP(hipMalloc(&d_tmp, sizeof(int) * (size + 1) * 2));
-  KS_HIP(hipMemcpyAsync(d_tmp + size, &A->row_start, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  KS_CHECK(p2p.allgather(d_tmp + size, d_tmp, 1, ncclInt32, ctx->comm.nccl_comm, ctx->stream) == 0, KS_ERR_LIB, "ncclAllGather failed");
   std::vector<int> starts(size + 1);
-  KS_HIP(hipMemcpyAsync(starts.data(), d_tmp, sizeof(int) * size, hipMemcpyDeviceToHost, ctx->stream));
-  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_CALL(ks_comm_allgather_host(ctx, &A->row_start, sizeof(int), starts.data()));
   starts[size] = A->n_global;
-  // 2. recv counts per owner
-  std::vector<int> recv_cnt(size, 0), send_cnt(size, 0);
+  for (int p = 0; p < size; p++) KS_CHECK(starts[p] <= starts[p + 1], KS_ERR_ARG_WRONG, "row blocks must be contiguous and ordered by rank");
+  // 2. how many entries I need from every owner; 3. everybody learns everybody's needs
+  std::vector<int> recv_cnt(size, 0), all_cnt((size_t)size * size, 0), send_cnt(size, 0);
   { int p = 0; for (int g : garray) { while (p + 1 < size && g >= starts[p + 1]) p++; KS_CHECK(p != rank, KS_ERR_PLIB, "ghost column owned by self"); recv_cnt[p]++; } }
-  // 3. exchange counts (all-to-all of one int)
-  int *d_cnt = nullptr; KS_HIP(hipMalloc(&d_cnt, sizeof(int) * size * 2));
-  KS_HIP(hipMemcpyAsync(d_cnt, recv_cnt.data(), sizeof(int) * size, hipMemcpyHostToDevice, ctx->stream));
-  p2p.gstart();
-  for (int p = 0; p < size; p++) if (p != rank) { p2p.send(d_cnt + p, 1, ncclInt32, p, ctx->comm.nccl_comm, ctx->stream); p2p.recv(d_cnt + size + p, 1, ncclInt32, p, ctx->comm.nccl_comm, ctx->stream); }
-  KS_CHECK(p2p.gend() == 0, KS_ERR_LIB, "ncclGroupEnd failed (counts)");
-  KS_HIP(hipMemcpyAsync(send_cnt.data(), d_cnt + size, sizeof(int) * size, hipMemcpyDeviceToHost, ctx->stream));
-  KS_HIP(hipStreamSynchronize(ctx->stream));
-  send_cnt[rank] = 0;
-  // 4. exchange index lists: I send my garray segments (global ids) to owners; owners receive the ids they must send me
+  KS_CALL(ks_comm_allgather_host(ctx, recv_cnt.data(), (int)(sizeof(int) * size), all_cnt.data()));
+  for (int p = 0; p < size; p++) send_cnt[p] = (p == rank) ? 0 : all_cnt[(size_t)p * size + rank];
+  // 4. exchange index lists: I send my garray segments (global ids) to their owners and receive the ids I must serve
   int nsend = 0; for (int p = 0; p < size; p++) nsend += send_cnt[p];
   int *d_g = nullptr, *d_sidx = nullptr;
   KS_HIP(hipMalloc(&d_g, sizeof(int) * std::max<size_t>(garray.size(), 1)));
@@ -321,15 +289,14 @@ int build_halo_plan(ks_mat A, const std::vector<int> &garray)
   KS_HIP(hipMemcpyAsync(d_g, garray.data(), sizeof(int) * garray.size(), hipMemcpyHostToDevice, ctx->stream));
   A->peers.clear(); A->send_cnt.clear(); A->recv_cnt.clear(); A->send_off.clear(); A->recv_off.clear();
   int roff = 0, soff = 0;
-  p2p.gstart();
   for (int p = 0; p < size; p++) {
     if (p == rank || (recv_cnt[p] == 0 && send_cnt[p] == 0)) continue;
     A->peers.push_back(p); A->recv_cnt.push_back(recv_cnt[p]); A->send_cnt.push_back(send_cnt[p]); A->recv_off.push_back(roff); A->send_off.push_back(soff);
-    if (recv_cnt[p]) p2p.send(d_g + roff, recv_cnt[p], ncclInt32, p, ctx->comm.nccl_comm, ctx->stream);
-    if (send_cnt[p]) p2p.recv(d_sidx + soff, send_cnt[p], ncclInt32, p, ctx->comm.nccl_comm, ctx->stream);
     roff += recv_cnt[p]; soff += send_cnt[p];
   }
-  KS_CHECK(p2p.gend() == 0, KS_ERR_LIB, "ncclGroupEnd failed (index lists)");
+  // in this exchange the roles are swapped: what I will RECEIVE during SpMV (ghost segments) is what I SEND now (their ids)
+  KS_CALL(ks_comm_exchange(ctx, (int)A->peers.size(), A->peers.data(), d_g, A->recv_off.data(), A->recv_cnt.data(),
+                           d_sidx, A->send_off.data(), A->send_cnt.data(), (int)sizeof(int)));
   std::vector<int> sidx(std::max(nsend, 1));
   KS_HIP(hipMemcpyAsync(sidx.data(), d_sidx, sizeof(int) * nsend, hipMemcpyDeviceToHost, ctx->stream));
   KS_HIP(hipStreamSynchronize(ctx->stream));
@@ -338,7 +305,7 @@ int build_halo_plan(ks_mat A, const std::vector<int> &garray)
   A->send_idx = d_sidx; A->nsend = nsend;
   KS_HIP(hipMalloc(&A->send_buf, sizeof(double) * std::max(nsend, 1)));
   KS_HIP(hipMalloc(&A->ghost, sizeof(double) * std::max(A->nghost, 1)));
-  hipFree(d_tmp); hipFree(d_cnt); hipFree(d_g);
+  hipFree(d_g);
   return KS_SUCCESS;
 }
 
@@ -542,15 +509,9 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
   const bool multi = ctx->comm.size > 1 && (A->nsend > 0 || A->nghost > 0);
   if (multi) {
     KsProfScope ps(ctx, KS_K_HALO, 8.0 * (A->nsend + A->nghost));
-    RcclP2P p2p; KS_CALL(get_p2p(ctx, &p2p));
-    const int ncclFloat64 = 8;
     if (A->nsend) hipLaunchKernelGGL(k_pack, dim3((A->nsend + 255) / 256), dim3(256), 0, ctx->stream, A->nsend, A->send_idx, x, A->send_buf);
-    p2p.gstart();
-    for (size_t i = 0; i < A->peers.size(); i++) {
-      if (A->send_cnt[i]) p2p.send(A->send_buf + A->send_off[i], A->send_cnt[i], ncclFloat64, A->peers[i], ctx->comm.nccl_comm, ctx->stream);
-      if (A->recv_cnt[i]) p2p.recv(A->ghost + A->recv_off[i], A->recv_cnt[i], ncclFloat64, A->peers[i], ctx->comm.nccl_comm, ctx->stream);
-    }
-    KS_CHECK(p2p.gend() == 0, KS_ERR_LIB, "ncclGroupEnd failed (halo)");
+    KS_CALL(ks_comm_exchange(ctx, (int)A->peers.size(), A->peers.data(), A->send_buf, A->send_off.data(), A->send_cnt.data(),
+                             A->ghost, A->recv_off.data(), A->recv_cnt.data(), (int)sizeof(double)));
   }
   {
     KsProfScope ps(ctx, KS_K_SPMV, 12.0 * A->nnz + 4.0 * (A->n + 1) + 16.0 * A->n);

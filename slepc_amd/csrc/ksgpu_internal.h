@@ -24,12 +24,13 @@ struct KsProfPending { hipEvent_t e0, e1; int kclass; int variant; double bytes;
 // ---- communicator -------------------------------------------------------------------------------
 struct KsComm {
   int rank = 0, size = 1;
+  bool force_collectives = false;   // KSGPU_FORCE_MULTI=1: take the multi-rank code path even with one rank (tests)
   // native RCCL (resolved with dlopen so that a process that already holds librccl reuses it)
   void *rccl_lib = nullptr;
   void *nccl_comm = nullptr;
-  // callback provider
-  ks_allreduce_fn cb_allreduce = nullptr;
-  void *cb_user = nullptr;
+  // active provider (RCCL fills these with its own implementations)
+  ks_comm_ops ops = {nullptr, nullptr, nullptr};
+  void *user = nullptr;
 };
 
 struct ks_ctx_s {
@@ -64,6 +65,10 @@ struct KsStepRec;
 void ks_prof_resolve_gs(ks_ctx ctx, const KsStepRec *recs, int col0, int col1);   // re-file tagged records of columns [col0,col1]
 
 int ks_allreduce_sum(ks_ctx ctx, double *dev_buf, int count);   // no-op when size==1
+int ks_comm_allgather_host(ks_ctx ctx, const void *send, int bytes, void *recv);
+int ks_comm_exchange(ks_ctx ctx, int npeers, const int *peers, const void *dev_send, const int *send_off, const int *send_cnt,
+                     void *dev_recv, const int *recv_off, const int *recv_cnt, int elem_bytes);
+static inline bool ks_is_multi(ks_ctx ctx) { return ctx->comm.size > 1 || ctx->comm.force_collectives; }
 
 // ---- Mat ----------------------------------------------------------------------------------------
 struct ks_mat_s {
