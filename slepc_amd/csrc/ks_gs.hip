@@ -34,6 +34,7 @@ struct GsArgs {
   int normalize;   // BVOrthonormalizeColumn: scale by 1/nrm
   int krylov;      // inside BVMatLanczos/Arnoldi: lindep halts the rest of the run
   int ldb;         // leading dimension of the coefficient buffer (nc+m)
+  int spec_last;   // this is the last slot of the optimistic program: unfinished business halts the run for the host
   double eta, deftol;
 };
 
@@ -108,6 +109,10 @@ __device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict_
   }
   st->nrm = nrm; st->onrm = onrm;
   st->do_update = upd; st->fuse_dot = fuse; st->scale_now = scal;
+  // Optimistic program: only the slots of the common case (two passes) are enqueued. If this column still needs
+  // a pass or an explicit norm after them, stop every later kernel of the run and tell the host which column to
+  // complete (the pending update itself still runs: it gates on do_update only).
+  if (a.spec_last && (st->more_ || st->expl)) { st->active = 0; st->halt_col = k; }
 }
 
 // REDUCE: sum block partials -> c (LDS, and global scratch = buffer column 0).  BOOK: run the bookkeeping.
@@ -218,7 +223,8 @@ __global__ void k_scale_if(double *__restrict__ x, int n, const KsGsState *__res
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= alpha;
 }
 
-__global__ void k_gs_begin_run(KsGsState *st) { st->active = 1; st->err = 0; st->do_update = 0; st->more_ = 0; st->expl = 0; st->pending_scale = 0; }
+__global__ void k_gs_begin_run(KsGsState *st) { st->active = 1; st->err = 0; st->do_update = 0; st->more_ = 0; st->expl = 0; st->pending_scale = 0; st->halt_col = -1; }
+__global__ void k_gs_resume(KsGsState *st) { st->active = 1; st->halt_col = -1; }
 
 bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -265,31 +271,58 @@ int launch_update(ks_bv bv, int k, double *v, int slot)
   return KS_SUCCESS;
 }
 
-// Enqueue the complete fused CGS of column j (against columns 0..j-1) on the stream. No host sync.
-int enqueue_fused_gs(ks_bv bv, int j, int normalize, int krylov)
+// Slot programs of one column (no host sync inside):
+//   optimistic:  dot, [finish p, update p] for p = 1..2              (IFNEEDED / ALWAYS: the common CGS2 case)
+//   completion:  [finish p, update p] for the remaining passes, the explicit-norm resolution slot and the
+//                stand-alone scaling - enqueued by the host only for a column the device flagged (halt_col)
+//   NEVER refinement always needs the resolution slot, so its whole program is enqueued at once.
+int spec_slots(ks_bv bv) { return bv->orthog_ref == KS_BV_ORTHOG_REFINE_NEVER ? 1 : 2; }
+int total_slots(ks_bv bv) { return bv->orthog_ref == KS_BV_ORTHOG_REFINE_IFNEEDED ? 3 : (bv->orthog_ref == KS_BV_ORTHOG_REFINE_ALWAYS ? 2 : 1); }
+
+int enqueue_gs_slots(ks_bv bv, int j, int normalize, int krylov, int first, int last, bool halt_at_last, bool resolution_and_scale)
 {
   ks_ctx ctx = bv->ctx;
-  KS_CHECK(j + 1 <= KS_MAX_COLS, KS_ERR_SUP, "fused Gram-Schmidt supports at most %d columns", KS_MAX_COLS);
   GsArgs a; a.k = j; a.refine = bv->orthog_ref; a.normalize = normalize; a.krylov = krylov; a.ldb = bv->nc + bv->m; a.eta = bv->orthog_eta; a.deftol = bv->deftol;
   double *v = ks_bv_col(bv, j);
-  // h = V(:,0:j+1)^T v  (BVDotColumnInc bvorthog.c:32-47: k+1 dots including (v,v))
-  KS_CALL(ksk_dot(bv, ks_bv_col(bv, 0), bv->ld, j + 1, v, krylov != 0));
-  const int nslots = (bv->orthog_ref == KS_BV_ORTHOG_REFINE_IFNEEDED) ? 3 : (bv->orthog_ref == KS_BV_ORTHOG_REFINE_ALWAYS ? 2 : 1);
-  for (int p = 1; p <= nslots; p++) {
-    a.slot = p;
+  for (int p = first; p <= last; p++) {
+    a.slot = p; a.spec_last = (halt_at_last && p == last) ? 1 : 0;
     KS_CALL(launch_finish(bv, a));
     KS_CALL(launch_update(bv, j, v, p));
   }
-  a.slot = nslots + 1;                  // resolves an explicit-norm request of the last update
-  KS_CALL(launch_finish(bv, a));
-  if (normalize) {
-    KsProfScope ps(ctx, KS_K_SCALE, 0.0);
-    ps.tag(j, 0, j, bv->n);
-    const int grid = std::max(1, std::min((bv->n + 255) / 256, ctx->num_cu * 4));
-    hipLaunchKernelGGL(k_scale_if, dim3(grid), dim3(256), 0, ctx->stream, v, bv->n, bv->gs);
-    KS_HIP(hipGetLastError());
+  if (resolution_and_scale) {
+    a.slot = last + 1; a.spec_last = 0;     // resolves an explicit-norm request of the last update
+    KS_CALL(launch_finish(bv, a));
+    if (normalize) {
+      KsProfScope ps(ctx, KS_K_SCALE, 0.0);
+      ps.tag(j, 0, j, bv->n);
+      const int grid = std::max(1, std::min((bv->n + 255) / 256, ctx->num_cu * 4));
+      hipLaunchKernelGGL(k_scale_if, dim3(grid), dim3(256), 0, ctx->stream, v, bv->n, bv->gs);
+      KS_HIP(hipGetLastError());
+    }
   }
   return KS_SUCCESS;
+}
+
+// Optimistic program of column j (against columns 0..j-1).
+int enqueue_fused_gs(ks_bv bv, int j, int normalize, int krylov)
+{
+  KS_CHECK(j + 1 <= KS_MAX_COLS, KS_ERR_SUP, "fused Gram-Schmidt supports at most %d columns", KS_MAX_COLS);
+  // h = V(:,0:j+1)^T v  (BVDotColumnInc bvorthog.c:32-47: k+1 dots including (v,v))
+  KS_CALL(ksk_dot(bv, ks_bv_col(bv, 0), bv->ld, j + 1, ks_bv_col(bv, j), krylov != 0));
+  const int ns = spec_slots(bv), nt = total_slots(bv);
+  const bool whole = (ns >= nt) && bv->orthog_ref == KS_BV_ORTHOG_REFINE_NEVER;
+  static const bool optimistic = !getenv("KSGPU_NO_OPTIMISTIC");
+  if (whole || !optimistic) return enqueue_gs_slots(bv, j, normalize, krylov, 1, nt, false, true);
+  return enqueue_gs_slots(bv, j, normalize, krylov, 1, ns, true, false);
+}
+
+// Completion program of the column the device flagged: remaining passes + resolution + scaling.
+int enqueue_gs_completion(ks_bv bv, int j, int normalize, int krylov)
+{
+  hipLaunchKernelGGL(k_gs_resume, dim3(1), dim3(1), 0, bv->ctx->stream, bv->gs);
+  KS_HIP(hipGetLastError());
+  const int ns = spec_slots(bv), nt = total_slots(bv);
+  return enqueue_gs_slots(bv, j, normalize, krylov, ns + 1, nt, false, true);
 }
 
 int begin_run(ks_bv bv)
@@ -453,6 +486,11 @@ int orthogonalize_column(ks_bv bv, int j, int normalize, double *H, double *norm
     KS_CALL(enqueue_fused_gs(bv, j, normalize, 0));
     KsGsState st; KsStepRec rec;
     KS_CALL(fetch_state(bv, &st, &rec, j, j));
+    if (st.halt_col == j) {                       // rare: third pass and/or explicit norm needed
+      if (ctx->prof_on) { KsStepRec tmp = rec; tmp.passes = st.pass + 1; tmp.expl = 0; ks_prof_resolve_gs(ctx, &tmp, j, j); }
+      KS_CALL(enqueue_gs_completion(bv, j, normalize, 0));
+      KS_CALL(fetch_state(bv, &st, &rec, j, j));
+    }
     ks_prof_resolve_gs(ctx, &rec, j, j);
     bv->passes_last_host = rec.passes; bv->passes_total_host += rec.passes;
     if (norm) *norm = rec.nrm;
@@ -571,26 +609,51 @@ static int krylov_run(ks_bv V, ks_mat A, int k, int *m, double *beta, int *break
   int lin = 0;
   double nrm_last = 0.0;
   if (use_fused(V) && m0 < V->N) {
-    // the whole run is enqueued; a device-side breakdown turns the remaining steps into no-ops
-    KS_CALL(begin_run(V));
-    for (int j = k; j < m0; j++) {
-      KS_CALL(ks_mat_mult_internal(A, ks_bv_col(V, j), ks_bv_col(V, j + 1)));    // BVMatMultColumn (not gated: harmless after a halt)
-      KS_CALL(enqueue_fused_gs(V, j + 1, 1, 1));
-    }
-    KsGsState st; std::vector<KsStepRec> recs(m0 - k);
-    KS_CALL(fetch_state(V, &st, recs.data(), k + 1, m0));
-    if (ctx->prof_on) {
-      // records of columns after a device-side halt were never written: treat them as 0 passes (all gated off)
-      std::vector<KsStepRec> rr(recs); bool halted = false;
-      for (int j = k; j < m0; j++) { if (halted) { rr[j - k].passes = 0; rr[j - k].expl = 0; } if (rr[j - k].lindep) halted = true; }
-      ks_prof_resolve_gs(ctx, rr.data(), k + 1, m0);
-    }
-    int mm = m0;
-    for (int j = k; j < m0; j++) {
-      const KsStepRec &r = recs[j - k];
-      V->passes_last_host = r.passes; V->passes_total_host += r.passes;
-      nrm_last = r.nrm;
-      if (r.lindep) { lin = 1; mm = j + 1; break; }
+    // The whole run is enqueued with the optimistic two-pass program per step; a device-side breakdown, or a
+    // column that needs more than the optimistic program, turns the remaining steps into no-ops. In the second
+    // case the host completes that one column and re-enqueues the rest of the run.
+    int mm = m0, j0 = k;
+    while (j0 < m0 && !lin) {
+      KS_CALL(begin_run(V));
+      for (int j = j0; j < m0; j++) {
+        KS_CALL(ks_mat_mult_internal(A, ks_bv_col(V, j), ks_bv_col(V, j + 1)));    // BVMatMultColumn (not gated: harmless after a halt)
+        KS_CALL(enqueue_fused_gs(V, j + 1, 1, 1));
+      }
+      KsGsState st; std::vector<KsStepRec> recs(m0 - j0);
+      KS_CALL(fetch_state(V, &st, recs.data(), j0 + 1, m0));
+      const int hc = st.halt_col;                    // column awaiting completion, or -1
+      if (ctx->prof_on) {
+        // columns after a halt never ran (0 passes, everything gated off); the flagged column ran both optimistic
+        // slots in the fused form
+        std::vector<KsStepRec> rr(recs); bool halted = false;
+        for (int j = j0; j < m0; j++) {
+          KsStepRec &r = rr[j - j0];
+          if (halted) { r.passes = 0; r.expl = 0; r.lindep = 0; }
+          else if (j + 1 == hc) { r.passes = st.pass + 1; r.expl = 0; r.lindep = 0; halted = true; }
+          else if (r.lindep) halted = true;
+        }
+        ks_prof_resolve_gs(ctx, rr.data(), j0 + 1, m0);
+      }
+      int next = m0;
+      for (int j = j0; j < m0; j++) {
+        if (j + 1 == hc) {
+          // rare path: finish column hc on the device (remaining passes, explicit norm, scaling), then go on
+          KsStepRec rec;
+          KS_CALL(enqueue_gs_completion(V, hc, 1, 1));
+          KS_CALL(fetch_state(V, &st, &rec, hc, hc));
+          ks_prof_resolve_gs(ctx, &rec, hc, hc);
+          V->passes_last_host = rec.passes; V->passes_total_host += rec.passes;
+          nrm_last = rec.nrm;
+          if (rec.lindep) { lin = 1; mm = j + 1; }
+          next = j + 1;
+          break;
+        }
+        const KsStepRec &r = recs[j - j0];
+        V->passes_last_host = r.passes; V->passes_total_host += r.passes;
+        nrm_last = r.nrm;
+        if (r.lindep) { lin = 1; mm = j + 1; break; }
+      }
+      j0 = next;
     }
     *m = mm;
   } else {

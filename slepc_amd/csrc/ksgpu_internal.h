@@ -109,6 +109,8 @@ struct KsGsState {
   int err;            // sticky error (KS_ERR_USER_INPUT: invalid inner product)
   int lindep;         // result for the current column
   int more_;          // another pass follows the pending update (bvorthog.c:179 loop condition)
+  int halt_col;       // >=0: column whose orthogonalization needs slots beyond the optimistic program (host completes it)
+  int pad2_;
   double onrm, nrm, alpha;
   long long passes_total;
 };

@@ -180,4 +180,4 @@ def test_native_rccl_provider_single_rank_forced_collectives():
     p.join(120)
     assert "error" not in out, out.get("error")
     assert out["ok"]
-    assert out["allreduces"] >= 4 * out["steps"]          # one ncclAllReduce per Gram-Schmidt slot went through RCCL
+    assert out["allreduces"] >= 2 * out["steps"]          # one ncclAllReduce per executed Gram-Schmidt pass went through RCCL
