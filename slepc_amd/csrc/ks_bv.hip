@@ -147,7 +147,7 @@ int ksk_dot(ks_bv bv, const double *A, int lda, int ncols, const double *y, bool
   KS_CHECK(ncols >= 1 && ncols <= KS_MAX_COLS, KS_ERR_PLIB, "dot sweep with %d columns", ncols);
   const bool v2 = (lda % 2 == 0) && aligned16(A) && aligned16(y);
   int grid = 1;
-  static const int dot_per_cu = getenv("KSGPU_DOT_PERCU") ? atoi(getenv("KSGPU_DOT_PERCU")) : 0;
+  static const int dot_per_cu = getenv("KSGPU_DOT_PERCU") ? atoi(getenv("KSGPU_DOT_PERCU")) : 4;   // measured best (2: -25 %, 3: -6 %, 6: +-0, 8: -10 %)
   const KsGsState *g = gate ? bv->gs : nullptr;
   KsProfScope ps(ctx, KS_K_DOT, 8.0 * bv->n * (ncols + (y >= A && y < A + (size_t)ncols * lda ? 0 : 1)), ks_kt_for(ncols));
 #define LAUNCH_DOT(KT)                                                                                                                        \
@@ -251,7 +251,7 @@ extern "C" int ks_bv_destroy(ks_bv bv)
   if (!bv) return KS_SUCCESS;
   hipSetDevice(bv->ctx->device);
   hipStreamSynchronize(bv->ctx->stream);
-  hipFree(bv->array); hipFree(bv->buffer); hipFree(bv->partials); hipFree(bv->coef); hipFree(bv->hc); hipFree(bv->gs); hipFree(bv->recs);
+  hipFree(bv->array); hipFree(bv->buffer); hipFree(bv->partials); hipFree(bv->coef); hipFree(bv->hc); hipFree(bv->gs); hipFree(bv->recs); hipFree(bv->panel);
   delete bv;
   return KS_SUCCESS;
 }
@@ -363,6 +363,9 @@ static int panel_mult(ks_ctx ctx, int kclass, const double *A, int lda, int n, i
 {
   if (n == 0 || nout == 0) return KS_SUCCESS;
   KS_CHECK(kin >= 1 && kin <= KS_MAX_COLS, KS_ERR_SUP, "panel product with %d inner columns (max %d)", kin, KS_MAX_COLS);
+  static const bool use_mfma = !getenv("KSGPU_NO_MFMA");
+  if (use_mfma && nout <= 64 && lda % 2 == 0 && aligned16(A))       // FP64 matrix cores; the VALU kernel below is the unaligned fallback
+    return ksp_mult_mfma(ctx, kclass, A, lda, n, kin, Qdev, transq ? ldq : 1, transq ? 1 : ldq, nout, alpha, beta, C, ldc);
   const int grid = (int)std::min<long long>(((long long)n + SW_BLOCK - 1) / SW_BLOCK, (long long)ctx->num_cu * 8);
   KsProfScope ps(ctx, kclass, 8.0 * n * (kin + nout * (beta == 0.0 ? 1 : 2)));
 #define LAUNCH_PM(KT)                                                                                                                      \
@@ -505,7 +508,11 @@ extern "C" int ks_bv_dot(ks_bv X, ks_bv Y, double *M, int ldm)   // bvglobal.c:8
   KS_CHECK(my <= KS_MAX_COLS, KS_ERR_SUP, "BVDot with more than %d active columns in Y", KS_MAX_COLS);
   KS_CHECK((size_t)my * nx <= X->coef_len, KS_ERR_ARG_SIZ, "result block too large");
   const double *py = Y->array + (size_t)(Y->nc + Y->l) * Y->ld;
-  {
+  static const bool use_mfma = !getenv("KSGPU_NO_MFMA");
+  const double *px0 = X->array + (size_t)(X->nc + X->l) * X->ld;
+  if (use_mfma && X->n > 0 && nx <= 64 && X->ld % 2 == 0 && Y->ld % 2 == 0 && aligned16(py) && aligned16(px0)) {
+    KS_CALL(ksp_dot_mfma(X, py, Y->ld, my, px0, X->ld, nx, X->n, X->coef));      // one sweep over both panels on the matrix cores
+  } else {
     KsProfScope ps(ctx, KS_K_BVDOT, 8.0 * X->n * (my + nx));
     const bool save = ctx->prof_on; ctx->prof_on = false;       // account the whole panel product as one class
     for (int jx = 0; jx < nx; jx++) {

@@ -254,7 +254,11 @@ int launch_update(ks_bv bv, int k, double *v, int slot)
   int grid = 1;
   const int kk = std::max(k, 1);
   static const bool snake = !getenv("KSGPU_NO_SNAKE");
-  static const int upd_per_cu = getenv("KSGPU_UPD_PERCU") ? atoi(getenv("KSGPU_UPD_PERCU")) : 0;
+  // blocks per CU of the update sweep: measured on MI355X at n = 1e7, k = 16..30: 1 block (4 waves, k KiB in flight each)
+  // per CU is fastest (fewer concurrent DRAM streams), as long as every block still gets many tiles
+  static const int upd_env = getenv("KSGPU_UPD_PERCU") ? atoi(getenv("KSGPU_UPD_PERCU")) : 0;
+  const long long ntl = ((long long)bv->n + 511) / 512;
+  const int upd_per_cu = upd_env ? upd_env : (ntl >= 16LL * ctx->num_cu ? 1 : (ntl >= 8LL * ctx->num_cu ? 2 : 0));
   const int rev = (snake && (slot & 1)) ? 1 : 0;     // dot: forward, update 1: backward, update 2: forward, update 3: backward
   KsProfScope ps(ctx, KS_K_UPD_FUSED, 8.0 * bv->n * (k + 2), ks_kt_for(kk));
   ps.tag(k, slot, k, bv->n);

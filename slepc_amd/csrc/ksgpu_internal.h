@@ -133,6 +133,7 @@ struct ks_bv_s {
   long long passes_total_host = 0; int passes_last_host = 0;
   int row_start = 0;            // first global row (reproducible random)
   int last_grid = 1;            // grid size of the sweep that last wrote `partials`
+  double *panel = nullptr; size_t panel_len = 0;   // block partials of the MFMA panel dot (grid x 64 x 64 max)
 };
 
 constexpr int KS_MAX_COLS   = 64;     // max columns handled by the register-tiled sweeps (k+1 <= 64)
@@ -149,5 +150,9 @@ int ksk_scale(ks_ctx ctx, double *x, size_t n, double alpha);
 int ksk_copy(ks_ctx ctx, const double *src, double *dst, size_t n);
 
 int ks_mat_mult_internal(ks_mat A, const double *x, double *y);
+// MFMA f64 panel contractions (ks_panel.hip)
+int ksp_dot_mfma(ks_bv bv, const double *Y, int ldy, int my, const double *X, int ldx, int nx, int n, double *M_dev);
+int ksp_mult_mfma(ks_ctx ctx, int kclass, const double *A, int lda, int n, int kin, const double *Qdev, int qsk, int qsi, int nout,
+                  double alpha, double beta, double *C, int ldc);
 int ks_sweep_grid(ks_ctx ctx, int n, int vec);
 int ks_sweep_grid_for(ks_ctx ctx, int n, int vec, const void *kernel, int force_per_cu);   // resident-blocks grid of one kernel symbol   // blocks of a row sweep (shared by every sweep kernel so partials line up)

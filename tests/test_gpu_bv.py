@@ -163,3 +163,46 @@ def test_empty_active_window_is_noop(ctx, gpu):
     assert np.all(M == 7.0)
     X.Scale(5.0)
     assert np.all(X.dense() == 1.0)
+
+
+@pytest.mark.parametrize("mfma", [True, False])
+@pytest.mark.parametrize("n,my,nx", [(1, 1, 1), (130, 5, 3), (4097, 17, 31), (20000, 31, 31), (9000, 64, 33), (3000, 48, 64)])
+def test_panel_contractions_mfma_and_valu(ctx, gpu, cpu, monkeypatch, mfma, n, my, nx):
+    """BVDot / BVMult / BVMultInPlace on the FP64 matrix cores (v_mfma_f64_16x16x4) and on the VALU fallback
+    against the oracle; tile edges (1..64 columns, ragged row tiles)."""
+    if not mfma:
+        monkeypatch.setenv("KSGPU_NO_MFMA", "1")
+    import importlib
+    rng = np.random.default_rng(n + my + nx)
+    Xh = rng.standard_normal((n, nx)); Yh = rng.standard_normal((n, my))
+    Q = np.asfortranarray(rng.standard_normal((nx, my)))
+    QQ = np.asfortranarray(rng.standard_normal((nx, nx)))
+    res = []
+    for be in (gpu, cpu):
+        X = be.bv(n, nx); Y = be.bv(n, my)
+        be.fill(X, Xh); be.fill(Y, Yh)
+        out = {}
+        M = np.zeros((my, nx), order="F"); X.Dot(Y, M); out["dot"] = M.copy()
+        Y.Mult(0.5, -1.5, X, Q); out["mult"] = Y.dense()
+        Y.Mult(2.0, 0.0, X, Q); out["mult_beta0"] = Y.dense()
+        s, e = (1, nx - 1) if nx > 2 else (0, nx)
+        X.MultInPlace(QQ, s, e); out["mip"] = X.dense()
+        X.MultInPlace(QQ, 0, nx, trans=True); out["mip_t"] = X.dense()
+        res.append(out)
+    a, b = res
+    for key in b:
+        tol = 1e-13 * max(1.0, np.abs(b[key]).max()) * max(1.0, np.sqrt(n))
+        assert np.allclose(a[key], b[key], rtol=0, atol=tol), (key, np.abs(a[key] - b[key]).max())
+
+
+def test_panel_dot_exact_on_integers(ctx, gpu):
+    """A = I check with an asymmetric operand: catches a transposed or mis-mapped MFMA accumulator layout."""
+    n, k = 64, 33
+    Xh = np.zeros((n, k)); Yh = np.zeros((n, k))
+    for j in range(k):
+        Yh[j, j] = 1.0
+        Xh[:k, j] = np.arange(k) * 3 + 7 * j          # asymmetric integer block
+    X = gpu.bv(n, k); Y = gpu.bv(n, k)
+    gpu.fill(X, Xh); gpu.fill(Y, Yh)
+    M = np.zeros((k, k), order="F"); X.Dot(Y, M)
+    assert np.array_equal(M, Xh[:k, :k])
