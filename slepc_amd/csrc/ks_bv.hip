@@ -363,7 +363,7 @@ static int panel_mult(ks_ctx ctx, int kclass, const double *A, int lda, int n, i
 {
   if (n == 0 || nout == 0) return KS_SUCCESS;
   KS_CHECK(kin >= 1 && kin <= KS_MAX_COLS, KS_ERR_SUP, "panel product with %d inner columns (max %d)", kin, KS_MAX_COLS);
-  static const bool use_mfma = !getenv("KSGPU_NO_MFMA");
+  const bool use_mfma = !getenv("KSGPU_NO_MFMA");
   if (use_mfma && nout <= 64 && lda % 2 == 0 && aligned16(A))       // FP64 matrix cores; the VALU kernel below is the unaligned fallback
     return ksp_mult_mfma(ctx, kclass, A, lda, n, kin, Qdev, transq ? ldq : 1, transq ? 1 : ldq, nout, alpha, beta, C, ldc);
   const int grid = (int)std::min<long long>(((long long)n + SW_BLOCK - 1) / SW_BLOCK, (long long)ctx->num_cu * 8);
@@ -508,7 +508,7 @@ extern "C" int ks_bv_dot(ks_bv X, ks_bv Y, double *M, int ldm)   // bvglobal.c:8
   KS_CHECK(my <= KS_MAX_COLS, KS_ERR_SUP, "BVDot with more than %d active columns in Y", KS_MAX_COLS);
   KS_CHECK((size_t)my * nx <= X->coef_len, KS_ERR_ARG_SIZ, "result block too large");
   const double *py = Y->array + (size_t)(Y->nc + Y->l) * Y->ld;
-  static const bool use_mfma = !getenv("KSGPU_NO_MFMA");
+  const bool use_mfma = !getenv("KSGPU_NO_MFMA");
   const double *px0 = X->array + (size_t)(X->nc + X->l) * X->ld;
   if (use_mfma && X->n > 0 && nx <= 64 && X->ld % 2 == 0 && Y->ld % 2 == 0 && aligned16(py) && aligned16(px0)) {
     KS_CALL(ksp_dot_mfma(X, py, Y->ld, my, px0, X->ld, nx, X->n, X->coef));      // one sweep over both panels on the matrix cores

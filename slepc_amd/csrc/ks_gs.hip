@@ -169,7 +169,7 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long lo
       double2 s = *reinterpret_cast<const double2 *>(v + r);
       double2 xv[KT];
 #pragma unroll
-      for (int i = 0; i < KT; i++) { const int ii = i < k ? i : (k > 0 ? k - 1 : 0); xv[i] = *reinterpret_cast<const double2 *>(V + (long long)ii * ld + r); }
+      for (int i = 0; i < KT; i++) { const int ii = i < k ? i : (k > 0 ? k - 1 : 0); xv[i] = ldcol2(V + (long long)ii * ld + r); }
 #pragma unroll
       for (int i = 0; i < KT; i++) { s.x = fma(cc[i], xv[i].x, s.x); s.y = fma(cc[i], xv[i].y, s.y); }
       if (scal) { s.x *= alpha; s.y *= alpha; }

@@ -13,7 +13,7 @@
 // (a wave-instruction moves 128 rows of ONE column = 1 KiB contiguous), stored column-major with a row pitch of
 // 130 doubles. With that pitch the MFMA operand reads - 16 different columns x 4 consecutive rows per wave
 // (Dot), or 16 consecutive rows x 4 columns (Mult) - are bank-conflict free for ds_read_b64.
-#include "ksgpu_internal.h"
+#include "ks_sweeps.cuh"
 #include <algorithm>
 
 namespace {
@@ -30,7 +30,7 @@ __device__ __forceinline__ double2 load_column(const double *__restrict__ src, l
   const long long r = r0 + 2 * lane;
   double2 v; v.x = 0.0; v.y = 0.0;
   if (src) {
-    if (r + 1 < n) v = *reinterpret_cast<const double2 *>(src + r);
+    if (r + 1 < n) v = ksk::ldcol2(src + r);
     else if (r < n) v.x = src[r];
   }
   return v;

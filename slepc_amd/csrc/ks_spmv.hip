@@ -16,7 +16,7 @@
 // DPP/shuffle butterflies inside the group. Each thread keeps UNROLL independent rows in flight
 // so that rowptr -> (col,val) -> x[col] dependent chains of different rows overlap.
 // Algorithmic bytes per call: 12*nnz + 4*(n+1) + 16*n.
-#include "ksgpu_internal.h"
+#include "ks_sweeps.cuh"
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <numeric>
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_sell(int nrows, int nslices
     for (int j = 0; j < w; j += UNR) {          // fully predicated batches: all loads of a batch are independent
       int c[UNR]; double a[UNR], xv[UNR];
 #pragma unroll
-      for (int u = 0; u < UNR; u++) { const bool ok = j + u < len; c[u] = ok ? col[base + (long long)(j + u) * 64] : -1; a[u] = ok ? val[base + (long long)(j + u) * 64] : 0.0; }
+      for (int u = 0; u < UNR; u++) { const bool ok = j + u < len; c[u] = ok ? ksk::ldstream(col + base + (long long)(j + u) * 64) : -1; a[u] = ok ? ksk::ldstream(val + base + (long long)(j + u) * 64) : 0.0; }
 #pragma unroll
       for (int u = 0; u < UNR; u++) xv[u] = c[u] >= 0 ? x[c[u]] : 0.0;
 #pragma unroll
