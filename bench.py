@@ -98,6 +98,11 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="disable the per-kernel HIP-event timing")
     args = ap.parse_args()
 
+    # RCCL / the HIP runtime may print banners on stdout: park stdout on stderr until the one JSON line is due
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import slepc_amd as ks
 
@@ -110,13 +115,15 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("BENCH_FORCE_DIST") == "1"     # rehearse the N>1 code path (RCCL comm, slab grid) on one GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     ctx = ks.Context(local_rank)
-    if world > 1:
+    if world > 1 or force_dist:
         idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             idt.copy_(torch.frombuffer(bytearray(ks.Context.get_unique_id()), dtype=torch.uint8))
@@ -124,7 +131,7 @@ def main():
         ctx.init_rccl(rank, world, bytes(idt.cpu().numpy().tobytes()))
 
     side = args.side
-    if world == 1:
+    if world == 1 and not force_dist:
         nx = ny = nz = side
         A = ks.Mat.laplacian3d(ctx, nx, ny, nz)
         workload = "3-D 7-pt Laplacian %d^3 (BASELINE config 3), Krylov-Schur nev=%d m=%d" % (side, NEV, NCV)
@@ -136,6 +143,7 @@ def main():
         workload = "3-D 7-pt Laplacian %dx%dx%d in %d z-slabs of %d planes (BASELINE config 4 at N=8), Krylov-Schur nev=%d m=%d" % (nx, ny, nz, world, planes, NEV, NCV)
 
     def barrier():
+        ctx.synchronize()                 # the library's own stream
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -191,7 +199,7 @@ def main():
         if prof:
             kernels = []
             for (name, var), v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
-                sym = ks.KSYMBOL.get(name, name).replace("{KT}", str(var)).replace("{G}", "8")
+                sym = ks.kernel_symbol(name, var)
                 kernels.append({"class": name, "variant": var, "kernel": sym, "launches": v["launches"], "ms_total": round(v["ms"], 3),
                                 "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
                                 "alg_GBps": round(v["alg_bytes"] / v["ms"] / 1e6, 1) if v["ms"] > 0 else 0.0,
@@ -241,7 +249,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(side)
             except Exception as e:       # noqa: BLE001 - the baseline must not take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -30,10 +30,22 @@ WHICH = {"largest_magnitude": 1, "smallest_magnitude": 2, "largest_real": 3, "sm
 
 KCLASSES = ["spmv_csr", "bv_dot_sweep", "gs_bookkeeping", "gs_update_fused_dot", "gs_update", "bv_scale", "bv_multinplace",
             "bv_copy", "bv_mult", "bv_dot_panel", "bv_norm", "halo_exchange", "allreduce", "gated_noop", "other"]
-# kernel symbol behind each (class, variant) as rocprofv3 --kernel-trace names it (VEC=2 forms)
-KSYMBOL = {"spmv_csr": "k_spmv_csr<{G}, 4, false, false>", "bv_dot_sweep": "k_dot_sweep<{KT}, 2>",
-           "gs_update_fused_dot": "k_gs_update<{KT}, 2>", "gs_update": "k_gs_update<{KT}, 2>",
-           "gs_bookkeeping": "k_gs_finish<true, true>", "bv_multinplace": "k_panel_mult<{KT}, false>"}
+# kernel symbol behind each (class, variant) as rocprofv3 --kernel-trace names it (16-byte-load forms)
+def kernel_symbol(name, var):
+    if name == "spmv_csr":
+        return "k_spmv_sell<8>" if var == 8 else "k_spmv_csr<G, 4, false, false>"
+    if name == "bv_dot_sweep":
+        return "k_dot_sweep<%d, 2>" % var
+    if name in ("gs_update_fused_dot", "gs_update") or (name == "gated_noop" and var > 0):
+        return "k_gs_update<%d, 2>" % var
+    if name == "gs_bookkeeping":
+        return "k_gs_finish<true, true>"
+    if name in ("bv_multinplace", "bv_mult"):
+        return "k_panel_mult_mfma<%d, NT>" % (var // 4) if var else "k_panel_mult<KT, false>"
+    if name == "bv_dot_panel":
+        return "k_panel_dot_mfma<MT, NT>"
+    return name
+
 
 _dp = _lib.dp
 _ip = _lib.ip

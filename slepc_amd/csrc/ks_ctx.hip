@@ -112,18 +112,19 @@ static int get_event(ks_ctx ctx, hipEvent_t *e)
 int ks_prof_begin(ks_ctx ctx, int kclass, int variant, double bytes, double hbm)
 {
   KsProfPending p; p.kclass = kclass; p.variant = (variant >= 0 && variant / 4 < KS_PROF_VARIANTS) ? variant / 4 : 0; p.bytes = bytes; p.hbm = hbm;
-  p.tag_col = -1; p.tag_slot = 0; p.tag_k = 0; p.tag_n = 0;
+  p.tag_col = -1; p.tag_slot = 0; p.tag_k = 0; p.tag_n = 0; p.done = false;
+  if (ctx->pending.size() > 400000) { ctx->prof_on = false; return KS_ERR_MEM; }   // runaway instrumentation: stop recording, keep running
   KS_CALL(get_event(ctx, &p.e0)); KS_CALL(get_event(ctx, &p.e1));
   KS_HIP(hipEventRecord(p.e0, ctx->stream));
   ctx->pending.push_back(p);
   return KS_SUCCESS;
 }
 
-int ks_prof_end(ks_ctx ctx)
+int ks_prof_end(ks_ctx ctx, size_t index)
 {
-  if (ctx->pending.empty()) return KS_SUCCESS;
-  KS_HIP(hipEventRecord(ctx->pending.back().e1, ctx->stream));
-  if (ctx->pending.size() > 60000) KS_CALL(ks_prof_flush(ctx));
+  if (index >= ctx->pending.size()) return KS_SUCCESS;
+  ctx->pending[index].done = true;
+  KS_HIP(hipEventRecord(ctx->pending[index].e1, ctx->stream));
   return KS_SUCCESS;
 }
 
@@ -133,7 +134,9 @@ int ks_prof_flush(ks_ctx ctx)
   KS_HIP(hipStreamSynchronize(ctx->stream));
   for (auto &p : ctx->pending) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+    if (!p.done) { (void)hipGetLastError(); }
+    else if (hipEventElapsedTime(&ms, p.e0, p.e1) != hipSuccess) { (void)hipGetLastError(); }     // never leave a sticky error behind for the host application
+    else {
       KsProfSlot &sl = ctx->prof[p.kclass][p.variant];
       sl.launches++; sl.ms += ms; sl.bytes += p.bytes; sl.hbm += p.hbm;
     }

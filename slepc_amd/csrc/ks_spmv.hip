@@ -514,7 +514,7 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
                              A->ghost, A->recv_off.data(), A->recv_cnt.data(), (int)sizeof(double)));
   }
   {
-    KsProfScope ps(ctx, KS_K_SPMV, 12.0 * A->nnz + 4.0 * (A->n + 1) + 16.0 * A->n);
+    KsProfScope ps(ctx, KS_K_SPMV, 12.0 * A->nnz + 4.0 * (A->n + 1) + 16.0 * A->n, A->use_sell ? 8 : 0);   // variant 8: k_spmv_sell<8>, 0: k_spmv_csr
     if (A->use_sell) {
       static const int remap = getenv("KSGPU_SELL_REMAP") ? 1 : 0;
       const long long groups = ((long long)A->nslices + 3) / 4;

@@ -19,7 +19,7 @@ void ks_set_error(const char *fmt, ...);
 
 // ---- profiling ----------------------------------------------------------------------------------
 struct KsProfSlot { long long launches = 0; double ms = 0.0; double bytes = 0.0; double hbm = 0.0; };
-struct KsProfPending { hipEvent_t e0, e1; int kclass; int variant; double bytes; double hbm; int tag_col; int tag_slot; int tag_k; long long tag_n; };
+struct KsProfPending { hipEvent_t e0, e1; int kclass; int variant; double bytes; double hbm; int tag_col; int tag_slot; int tag_k; long long tag_n; bool done; };
 
 // ---- communicator -------------------------------------------------------------------------------
 struct KsComm {
@@ -52,14 +52,16 @@ struct ks_ctx_s {
 };
 
 int ks_prof_begin(ks_ctx ctx, int kclass, int variant, double alg_bytes, double hbm_bytes);   // records start event when profiling
-int ks_prof_end(ks_ctx ctx);
+int ks_prof_end(ks_ctx ctx, size_t index);
 int ks_prof_flush(ks_ctx ctx);
-struct KsProfScope {
-  ks_ctx ctx; bool on;
-  KsProfScope(ks_ctx c, int kclass, double bytes, int variant = 0, double hbm = -1.0) : ctx(c), on(c->prof_on && ((c->prof_mask >> kclass) & 1u)) { if (on) ks_prof_begin(c, kclass, variant, bytes, hbm < 0 ? bytes : hbm); }
-  ~KsProfScope() { if (on) ks_prof_end(ctx); }
+struct KsProfScope {      // scopes may nest (an allreduce inside a bookkeeping slot): each remembers its own record
+  ks_ctx ctx; bool on; size_t index = 0;
+  KsProfScope(ks_ctx c, int kclass, double bytes, int variant = 0, double hbm = -1.0) : ctx(c), on(c->prof_on && ((c->prof_mask >> kclass) & 1u)) {
+    if (on) { on = ks_prof_begin(c, kclass, variant, bytes, hbm < 0 ? bytes : hbm) == KS_SUCCESS; index = c->pending.empty() ? 0 : c->pending.size() - 1; }
+  }
+  ~KsProfScope() { if (on) ks_prof_end(ctx, index); }
   // tag the record of a speculative Gram-Schmidt slot so it can be re-filed once pass counts are known
-  void tag(int col, int slot, int k, long long n) { if (on && !ctx->pending.empty()) { auto &p = ctx->pending.back(); p.tag_col = col; p.tag_slot = slot; p.tag_k = k; p.tag_n = n; } }
+  void tag(int col, int slot, int k, long long n) { if (on && index < ctx->pending.size()) { auto &p = ctx->pending[index]; p.tag_col = col; p.tag_slot = slot; p.tag_k = k; p.tag_n = n; } }
 };
 struct KsStepRec;
 void ks_prof_resolve_gs(ks_ctx ctx, const KsStepRec *recs, int col0, int col1);   // re-file tagged records of columns [col0,col1]
