@@ -65,7 +65,12 @@ typedef struct ks_eps_s *ks_eps;   /* Krylov-Schur eigensolver driver           
 enum { KS_BV_ORTHOG_CGS = 0, KS_BV_ORTHOG_MGS = 1 };
 enum { KS_BV_ORTHOG_REFINE_IFNEEDED = 0, KS_BV_ORTHOG_REFINE_NEVER = 1, KS_BV_ORTHOG_REFINE_ALWAYS = 2 };
 enum { KS_NORM_1 = 0, KS_NORM_2 = 1, KS_NORM_FROBENIUS = 2, KS_NORM_INFINITY = 3 };
-enum { KS_EPS_LARGEST_MAGNITUDE = 1, KS_EPS_SMALLEST_MAGNITUDE = 2, KS_EPS_LARGEST_REAL = 3, KS_EPS_SMALLEST_REAL = 4 };
+/* EPSWhich, include/slepceps.h:109-119 (same numbering; TARGET_IMAGINARY and ALL are not offered) */
+enum { KS_EPS_LARGEST_MAGNITUDE = 1, KS_EPS_SMALLEST_MAGNITUDE = 2, KS_EPS_LARGEST_REAL = 3, KS_EPS_SMALLEST_REAL = 4,
+       KS_EPS_LARGEST_IMAGINARY = 5, KS_EPS_SMALLEST_IMAGINARY = 6, KS_EPS_TARGET_MAGNITUDE = 7, KS_EPS_TARGET_REAL = 8,
+       KS_EPS_WHICH_USER = 11 };
+/* SlepcEigenvalueComparisonFn (include/slepcsc.h): *res < 0 if a is preferred to b, > 0 if b is preferred, 0 if equal */
+typedef int (*ks_eig_compare_fn)(double ar, double ai, double br, double bi, int *res, void *ctx);
 enum { KS_EPS_HEP = 1, KS_EPS_NHEP = 3 };
 enum { KS_EPS_ERROR_ABSOLUTE = 0, KS_EPS_ERROR_RELATIVE = 1 };
 enum { KS_EPS_CONVERGED_TOL = 1, KS_EPS_CONVERGED_USER = 2, KS_EPS_DIVERGED_ITS = -1, KS_EPS_DIVERGED_BREAKDOWN = -2,
@@ -179,6 +184,8 @@ int ks_eps_set_problem_type(ks_eps eps, int type);                         /* KS
 int ks_eps_set_dimensions(ks_eps eps, int nev, int ncv /*<=0: default*/, int mpd /*<=0: default*/);
 int ks_eps_set_tolerances(ks_eps eps, double tol /*<=0: 1e-8*/, int max_it /*<=0: default*/);
 int ks_eps_set_which_eigenpairs(ks_eps eps, int which);
+int ks_eps_set_target(ks_eps eps, double target);                            /* EPSSetTarget epsopts.c:604 (sorting only: no spectral transformation) */
+int ks_eps_set_eigenvalue_comparison(ks_eps eps, ks_eig_compare_fn fn, void *ctx);   /* EPSSetEigenvalueComparison epsopts.c:563 */
 int ks_eps_set_krylovschur_restart(ks_eps eps, double keep);               /* EPSKrylovSchurSetRestart, default 0.5 */
 int ks_eps_set_random_seed(ks_eps eps, uint64_t seed);
 int ks_eps_set_initial_vector(ks_eps eps, const double *v_host);           /* EPSSetInitialSpace with one vector */
@@ -190,6 +197,9 @@ int ks_eps_get_converged_reason(ks_eps eps, int *reason);
 int ks_eps_get_dimensions(ks_eps eps, int *nev, int *ncv, int *mpd);
 int ks_eps_get_eigenvalue(ks_eps eps, int i, double *eigr, double *eigi);
 int ks_eps_get_eigenvector_host(ks_eps eps, int i, double *xr_host);       /* n_local doubles */
+/* EPSGetEigenpair epssolve.c:405: conjugate pairs come as (xr,xi) of the first and (xr,-xi) of the second member
+   (BV_GetEigenvector bvimpl.h:423-446); any of the four outputs may be NULL */
+int ks_eps_get_eigenpair_host(ks_eps eps, int i, double *eigr, double *eigi, double *xr_host, double *xi_host);
 int ks_eps_get_error_estimate(ks_eps eps, int i, double *errest);
 int ks_eps_compute_error(ks_eps eps, int i, int type, double *error);      /* EPSComputeError epssolve.c:742 */
 int ks_eps_get_bv(ks_eps eps, ks_bv *V);

@@ -408,7 +408,17 @@ WHICH = {
     "smallest_magnitude": lambda ar, ai, br, bi: -_cmp(np.hypot(ar, ai), np.hypot(br, bi)),
     "largest_real": lambda ar, ai, br, bi: _cmp(ar, br),
     "smallest_real": lambda ar, ai, br, bi: -_cmp(ar, br),
+    "largest_imaginary": lambda ar, ai, br, bi: _cmp(abs(ai), abs(bi)),
+    "smallest_imaginary": lambda ar, ai, br, bi: -_cmp(abs(ai), abs(bi)),
 }
+
+
+def which_target_magnitude(t):         # SlepcCompareTargetMagnitude slepcsc.c:233-247
+    return lambda ar, ai, br, bi: -_cmp(np.hypot(ar - t, ai), np.hypot(br - t, bi))
+
+
+def which_target_real(t):              # SlepcCompareTargetReal slepcsc.c:249-263
+    return lambda ar, ai, br, bi: -_cmp(abs(ar - t), abs(br - t))
 
 DS_STATE_RAW, DS_STATE_INTERMEDIATE, DS_STATE_CONDENSED, DS_STATE_TRUNCATED = 0, 1, 2, 3
 
@@ -580,7 +590,7 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
     assert ncv <= nev + mpd
     if max_it is None:
         max_it = max(100, 2 * n // ncv)
-    compare = WHICH[which]
+    compare = which if callable(which) else WHICH[which]
 
     V = BV(n, ncv + 1, omp=omp)
     V.SetOrthogonalization(*orthog)
@@ -698,3 +708,322 @@ def eps_compute_error(A, res, i, relative=True):
     if relative:
         err /= abs(kr) * 1.0        # vecnorm = 1 for non-GHEP (epssolve.c:758,774)
     return err
+
+
+# ================================================================================================
+# Non-symmetric problems: DS NHEP + the Arnoldi variant of the Krylov-Schur driver
+# ================================================================================================
+def markov_matrix(m):
+    """MatMarkovModel (src/eps/tutorials/ex5.c:137-170): random walk on a triangular grid, N = m(m+1)/2."""
+    import scipy.sparse as sp
+    cst = 0.5 / (m - 1)
+    rows, cols, vals = [], [], []
+    ix = 0
+    for i in range(1, m + 1):
+        jmax = m - i + 1
+        for j in range(1, jmax + 1):
+            ix += 1
+            if j != jmax:
+                pd = cst * (i + j - 1)
+                rows.append(ix - 1); cols.append(ix); vals.append(2 * pd if i == 1 else pd)                   # north
+                rows.append(ix - 1); cols.append(ix + jmax - 1); vals.append(2 * pd if j == 1 else pd)        # east
+            pu = 0.5 - cst * (i + j - 3)
+            if j > 1:
+                rows.append(ix - 1); cols.append(ix - 2); vals.append(pu)                                     # south
+            if i > 1:
+                rows.append(ix - 1); cols.append(ix - jmax - 2); vals.append(pu)                              # west
+    N = m * (m + 1) // 2
+    S = sp.csr_matrix((vals, (rows, cols)), shape=(N, N))
+    S.sort_indices()
+    return CSR(N, S.indptr, S.indices, S.data)
+
+
+class DSNHEP:
+    """DS type NHEP with extra row (krylovschur.c:153-159). A is ld x ld column-major; row n holds the extra row."""
+
+    def __init__(self, ld, compare):
+        self.ld = ld
+        self.A = np.zeros((ld, ld), order="F")
+        self.Q = np.zeros((ld, ld), order="F")
+        self.X = np.zeros((ld, ld), order="F")
+        self.n = self.l = self.k = self.t = 0
+        self.state = DS_STATE_RAW
+        self.compare = compare
+
+    def SetDimensions(self, n, l, k):
+        self.n = n; self.t = n; self.l = l; self.k = k
+
+    def SetState(self, st):
+        self.state = st
+
+    def _eig_from_T(self, wr, wi, j0, j1):
+        """recover eigenvalues of the diagonal blocks j0..j1-1 of the quasi-triangular A (dsutil.c:65-79,160-170)"""
+        A, n = self.A, self.n
+        j = j0
+        while j < j1:
+            if j == n - 1 or A[j + 1, j] == 0.0:
+                wr[j] = A[j, j]; wi[j] = 0.0
+            else:
+                wr[j] = A[j, j]; wr[j + 1] = A[j, j]
+                wi[j] = np.sqrt(abs(A[j + 1, j])) * np.sqrt(abs(A[j, j + 1])); wi[j + 1] = -wi[j]
+                j += 1
+            j += 1
+
+    def Solve(self, wr, wi):               # DSSolve_NHEP_Private dsutil.c:21-91
+        if self.state >= DS_STATE_CONDENSED:
+            return
+        n, ld, l = self.n, self.ld, self.l
+        A, Q = self.A, self.Q
+        Q[:, :] = 0.0
+        for i in range(n):
+            Q[i, i] = 1.0
+        if n == 1:
+            wr[0] = A[0, 0]; wi[0] = 0.0
+            self.state = DS_STATE_CONDENSED
+            return
+        ilo = l + 1
+        lwork = 6 * ld
+        work = np.zeros(lwork); tau = np.zeros(ld); info = C.c_int(0)
+        if self.state < DS_STATE_INTERMEDIATE:
+            _L("dgehrd")(_i(n), _i(ilo), _i(n), _p(A), _i(ld), _p(tau), _p(work), _i(lwork), C.byref(info))
+            assert info.value == 0
+            for j in range(n - 1):
+                for i in range(j + 2, n):
+                    Q[i, j] = A[i, j]; A[i, j] = 0.0
+            _L("dorghr")(_i(n), _i(ilo), _i(n), _p(Q), _i(ld), _p(tau), _p(work), _i(lwork), C.byref(info))
+            assert info.value == 0
+        wrr = np.zeros(ld); wii = np.zeros(ld)
+        _L("dhseqr")(b"S", b"V", _i(n), _i(ilo), _i(n), _p(A), _i(ld), _p(wrr), _p(wii), _p(Q), _i(ld), _p(work), _i(lwork), C.byref(info))
+        assert info.value == 0, info.value
+        wr[:n] = wrr[:n]; wi[:n] = wii[:n]
+        self._eig_from_T(wr, wi, 0, l)
+        self.state = DS_STATE_CONDENSED
+
+    def Sort(self, wr, wi):                # DSSort_NHEP_Total dsutil.c:93-175
+        n, ld, l = self.n, self.ld, self.l
+        A, Q = self.A, self.Q
+        work = np.zeros(ld); info = C.c_int(0)
+        i = l
+        while i < n - 1:
+            re, im = wr[i], wi[i]
+            pos = 0
+            j = i + 2 if im != 0 else i + 1
+            while j < n:
+                if self.compare(re, im, wr[j], wi[j]) > 0:
+                    re, im = wr[j], wi[j]; pos = j
+                if wi[j] != 0:
+                    j += 1
+                j += 1
+            if pos:
+                ifst = C.c_int(pos + 1); ilst = C.c_int(i + 1)
+                _L("dtrexc")(b"V", _i(n), _p(A), _i(ld), _p(Q), _i(ld), C.byref(ifst), C.byref(ilst), _p(work), C.byref(info))
+                assert info.value == 0, info.value
+                self._eig_from_T(wr, wi, i, n)
+            if wi[i] != 0:
+                i += 1
+            i += 1
+
+    def UpdateExtraRow(self):              # DSUpdateExtraRow_NHEP dsnhep.c:318-341
+        n = self.n
+        x = self.A[n, :n].copy()
+        self.A[n, :n] = self.Q[:n, :n].T @ x
+        self.k = n
+
+    def Vectors(self, k):
+        """DSVectors_NHEP_Eigen_Some dsnhep.c:101-167: k-th eigenvector of A (through Q), returns (newk, rnorm)."""
+        n, ld = self.n, self.ld
+        A = self.A
+        iscomplex = (k < n - 1 and A[k + 1, k] != 0.0)
+        mm = 2 if iscomplex else 1
+        select = np.zeros(ld, dtype=np.int32); select[k] = 1
+        if iscomplex:
+            select[k + 1] = 1
+        Y = np.zeros((ld, 2), order="F")
+        work = np.zeros(3 * ld); mout = C.c_int(0); info = C.c_int(0)
+        _L("dtrevc")(b"R", b"S", select.ctypes.data_as(_ip), _i(n), _p(A), _i(ld), _p(Y), _i(ld), _p(Y), _i(ld), _i(mm), C.byref(mout), _p(work), C.byref(info))
+        assert info.value == 0 and mout.value == mm
+        Z = self.Q[:n, :n] @ Y[:n, :mm]
+        norm = np.linalg.norm(Z[:, 0])
+        if iscomplex:
+            norm = np.hypot(norm, np.linalg.norm(Z[:, 1]))
+        Z /= norm
+        self.X[:n, k:k + mm] = Z
+        rnorm = np.hypot(Z[n - 1, 0], Z[n - 1, 1]) if iscomplex else abs(Z[n - 1, 0])
+        return (k + 1 if iscomplex else k), rnorm
+
+    def VectorsAll(self):
+        """DSVectors_NHEP_Eigen_All dsnhep.c:169-232 (state CONDENSED or later: back-transform with Q)."""
+        n = self.n
+        k = 0
+        while k < n:
+            newk, _ = self.Vectors(k)
+            k = newk + 1
+        return self.X[:n, :n]
+
+    def GetTruncateSize(self, l, n, k):    # DSGetTruncateSize_Default dsops.c:329-345
+        if self.A[l + k, l + k - 1] != 0.0:
+            k = k + 1 if l + k < n - 1 else k - 1
+        return k
+
+    def Truncate(self, n, trim):           # DSTruncate_NHEP dsnhep.c:385-415
+        A, l = self.A, self.l
+        if trim:
+            A[self.n, l:self.n] = 0.0
+            self.l = 0; self.k = 0; self.n = n; self.t = n
+            self.state = DS_STATE_RAW
+        else:
+            if self.k == self.n:
+                A[n, l:n] = A[self.n, l:n]
+                A[self.n, l:self.n] = 0.0
+            self.k = n; self.t = self.n; self.n = n
+            self.state = DS_STATE_TRUNCATED
+
+    def Qmat(self):
+        rows = self.t if self.state == DS_STATE_TRUNCATED else self.n
+        return self.Q[:rows, : self.n]
+
+
+def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which="largest_magnitude", keep=0.5,
+                         seed=0x12345678, v0=None, max_steps=None):
+    """EPSSolve_KrylovSchur_Default with the Arnoldi expansion (krylovschur.c:227-337, non-Hermitian branch),
+    EPSKrylovConvergence for conjugate pairs (epskrylov.c:262-287), EPSComputeVectors_Schur (epsdefault.c:105-169)."""
+    n = A.n
+    if ncv is None:
+        ncv = min(n, nev + mpd) if mpd is not None else (min(n, max(2 * nev, nev + 15)) if nev < 500 else min(n, nev + 500))
+    if mpd is None:
+        mpd = ncv
+    if max_it is None:
+        max_it = max(100, 2 * n // ncv)
+    compare = which if callable(which) else WHICH[which]
+    V = BV(n, ncv + 1)
+    ds = DSNHEP(ncv + 1, compare)
+    eigr = np.zeros(ncv + 1); eigi = np.zeros(ncv + 1); errest = np.zeros(ncv + 1)
+
+    def start_vector(i):
+        if v0 is not None and i == 0:
+            V.set_column(0, v0)
+        else:
+            V.SetRandomColumn(i, seed)
+        _, norm, lindep = V.OrthogonalizeColumn(i)
+        if not (lindep or norm == 0.0):
+            V.ScaleColumn(i, 1.0 / norm)
+        return lindep or norm == 0.0
+
+    assert not start_vector(0)
+    l = 0; nconv = 0; its = 0; reason = 0; steps = 0
+    while reason == 0:
+        its += 1
+        nv = min(nconv + mpd, ncv)
+        if max_steps is not None and steps + (nv - (nconv + l)) > max_steps:
+            nv = nconv + l + (max_steps - steps)
+        ds.SetDimensions(nv, nconv, nconv + l)
+        k0 = nconv + l
+        H = ds.A[: nv + 1, :nv]                       # DSGetMat(DS_MAT_A): (n+1) x n with the extra row
+        Hs = np.asfortranarray(ds.A)                  # BVMatArnoldi writes through ld = ds.ld
+        nv, beta, breakdown = V.MatArnoldi(A, Hs, k0, nv)
+        ds.A[:, :] = Hs
+        steps += nv - k0
+        ds.SetDimensions(nv, nconv, nconv + l)
+        ds.SetState(DS_STATE_RAW if l else DS_STATE_INTERMEDIATE)
+        V.SetActiveColumns(nconv, nv)
+        ds.Solve(eigr, eigi)
+        ds.Sort(eigr, eigi)
+        ds.UpdateExtraRow()
+        # EPSKrylovConvergence
+        marker = -1
+        k = nconv
+        while k < nv:
+            re, im = eigr[k], eigi[k]
+            newk, resnorm = ds.Vectors(k)
+            resnorm *= beta
+            w = np.hypot(re, im)
+            errest[k] = resnorm / w if w != 0.0 else np.finfo(float).max
+            if marker == -1 and errest[k] >= tol:
+                marker = k
+            if newk == k + 1:
+                errest[k + 1] = errest[k]; k += 1
+            if marker != -1:
+                break
+            k += 1
+        k = marker if marker != -1 else nv
+        if k >= nev:
+            reason = 2
+        elif its >= max_it:
+            reason = -1
+        if max_steps is not None and steps >= max_steps and reason == 0:
+            reason = -99
+        if reason != 0 or breakdown or k == nv:
+            l = 0
+        else:
+            l = max(1, int((nv - k) * keep))
+            l = ds.GetTruncateSize(k, nv, l)
+        if reason == 0:
+            if breakdown or k == nv:
+                if k < nev and start_vector(k):
+                    reason = -2
+            else:
+                ds.Truncate(k + l, False)
+        V.MultInPlace(ds.Qmat(), nconv, k + l)
+        if reason == 0 and not breakdown:
+            V.CopyColumn(nv, k + l)
+        nconv = k
+    ds.Truncate(nconv, True)
+    # EPSComputeVectors_Schur: X = V * Z, Z = eigenvectors of the truncated T
+    V.SetActiveColumns(0, nconv)
+    ds.state = DS_STATE_RAW            # after trimming, the eigenvectors are those of T itself (no back-transform)
+    Qsave = ds.Q.copy(); ds.Q[:, :] = np.eye(ds.ld)
+    Z = np.asfortranarray(ds.VectorsAll().copy()) if nconv else np.zeros((0, 0), order="F")
+    ds.Q[:, :] = Qsave
+    if nconv:
+        V.MultInPlace(Z, 0, nconv)
+    # conjugate pairs: positive imaginary part first (epssolve.c:163-175) - trexc already orders them so
+    # final sort keeping pairs together (slepcsc.c:89-140)
+    perm = list(range(nconv))
+    i = nconv - 1
+    while i >= 0:
+        re = eigr[perm[i]]; im = eigi[perm[i]]
+        j = i + 1
+        if im != 0:
+            i -= 1
+            im = eigi[perm[i]]
+        while j < nconv:
+            if compare(re, im, eigr[perm[j]], eigi[perm[j]]) <= 0:
+                break
+            if not im:
+                if eigi[perm[j]] == 0.0:
+                    perm[j - 1], perm[j] = perm[j], perm[j - 1]; j += 1
+                else:
+                    tmp = perm[j - 1]; perm[j - 1] = perm[j]; perm[j] = perm[j + 1]; perm[j + 1] = tmp; j += 2
+            else:
+                if eigi[perm[j]] == 0.0:
+                    tmp = perm[j - 2]; perm[j - 2] = perm[j]; perm[j] = perm[j - 1]; perm[j - 1] = tmp; j += 1
+                else:
+                    perm[j - 2], perm[j] = perm[j], perm[j - 2]
+                    perm[j - 1], perm[j + 1] = perm[j + 1], perm[j - 1]; j += 2
+        i -= 1
+    res = EPSResult()
+    res.nconv = nconv; res.its = its; res.reason = reason; res.steps = steps
+    res.eigr = eigr[:nconv].copy(); res.eigi = eigi[:nconv].copy(); res.perm = np.array(perm, dtype=np.int64)
+    res.errest = errest[:nconv].copy(); res.V = V; res.passes = V.passes_total(); res.ncv = ncv
+    return res
+
+
+def eps_compute_error_nhep(A, res, i):
+    """EPSComputeError relative, real-arithmetic pair form (epssolve.c:666-718)."""
+    j = int(res.perm[i])
+    kr, ki = res.eigr[j], res.eigi[j]
+    S = A.to_scipy()
+    if ki == 0 or abs(ki) < abs(kr * np.finfo(float).eps):
+        x = np.array(res.V.column(j))
+        u = S @ x - kr * x
+        nrm = np.linalg.norm(u)
+    else:
+        jr = j if ki > 0 else j - 1                 # BV_GetEigenvector bvimpl.h:423-446
+        xr = np.array(res.V.column(jr)); xi = np.array(res.V.column(jr + 1))
+        if ki < 0:
+            xi = -xi
+        u = S @ xr - kr * xr + ki * xi
+        nr = np.linalg.norm(u)
+        u = S @ xi - kr * xi - ki * xr
+        nrm = np.hypot(nr, np.linalg.norm(u))
+    return nrm / np.hypot(kr, ki)

@@ -26,7 +26,9 @@ EPS_LARGEST_MAGNITUDE, EPS_SMALLEST_MAGNITUDE, EPS_LARGEST_REAL, EPS_SMALLEST_RE
 EPS_HEP, EPS_NHEP = 1, 3
 EPS_ERROR_ABSOLUTE, EPS_ERROR_RELATIVE = 0, 1
 EPS_CONVERGED_TOL, EPS_CONVERGED_USER, EPS_DIVERGED_ITS, EPS_DIVERGED_BREAKDOWN = 1, 2, -1, -2
-WHICH = {"largest_magnitude": 1, "smallest_magnitude": 2, "largest_real": 3, "smallest_real": 4}
+WHICH = {"largest_magnitude": 1, "smallest_magnitude": 2, "largest_real": 3, "smallest_real": 4,
+         "largest_imaginary": 5, "smallest_imaginary": 6, "target_magnitude": 7, "target_real": 8, "user": 11}
+EIG_COMPARE_FN = C.CFUNCTYPE(C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_void_p)
 
 KCLASSES = ["spmv_csr", "bv_dot_sweep", "gs_bookkeeping", "gs_update_fused_dot", "gs_update", "bv_scale", "bv_multinplace",
             "bv_copy", "bv_mult", "bv_dot_panel", "bv_norm", "halo_exchange", "allreduce", "gated_noop", "other"]
@@ -449,6 +451,17 @@ class EPS:
     def SetWhichEigenpairs(self, which):
         _lib.check(self.ctx.L.ks_eps_set_which_eigenpairs(self.h, WHICH.get(which, which)))
 
+    def SetTarget(self, target):
+        _lib.check(self.ctx.L.ks_eps_set_target(self.h, target))
+
+    def SetEigenvalueComparison(self, func):
+        """func(ar, ai, br, bi) -> negative if a is preferred, positive if b is (SlepcEigenvalueComparisonFn)."""
+        def tramp(ar, ai, br, bi, res, _ctx):
+            res[0] = int(func(ar, ai, br, bi))
+            return 0
+        self._cmp_cb = EIG_COMPARE_FN(tramp)          # keep the trampoline alive as long as the solver
+        _lib.check(self.ctx.L.ks_eps_set_eigenvalue_comparison(self.h, C.cast(self._cmp_cb, C.c_void_p), None))
+
     def KrylovSchurSetRestart(self, keep):
         _lib.check(self.ctx.L.ks_eps_set_krylovschur_restart(self.h, keep))
 
@@ -487,6 +500,13 @@ class EPS:
         x = np.empty(self._A.n)
         _lib.check(self.ctx.L.ks_eps_get_eigenvector_host(self.h, i, _p(x)))
         return x
+
+    def GetEigenpair(self, i):
+        """EPSGetEigenpair: (kr, ki, xr, xi) with the reference's conjugate-pair convention."""
+        r = C.c_double(); im = C.c_double()
+        xr = np.empty(self._A.n); xi = np.empty(self._A.n)
+        _lib.check(self.ctx.L.ks_eps_get_eigenpair_host(self.h, i, C.byref(r), C.byref(im), _p(xr), _p(xi)))
+        return r.value, im.value, xr, xi
 
     def GetErrorEstimate(self, i):
         v = C.c_double(); _lib.check(self.ctx.L.ks_eps_get_error_estimate(self.h, i, C.byref(v))); return v.value

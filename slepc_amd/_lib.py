@@ -96,6 +96,8 @@ _SIG = {
     "ks_eps_set_dimensions": [vp, C.c_int, C.c_int, C.c_int],
     "ks_eps_set_tolerances": [vp, C.c_double, C.c_int],
     "ks_eps_set_which_eigenpairs": [vp, C.c_int],
+    "ks_eps_set_target": [vp, C.c_double],
+    "ks_eps_set_eigenvalue_comparison": [vp, C.c_void_p, vp],
     "ks_eps_set_krylovschur_restart": [vp, C.c_double],
     "ks_eps_set_random_seed": [vp, C.c_uint64],
     "ks_eps_set_initial_vector": [vp, dp],
@@ -107,6 +109,7 @@ _SIG = {
     "ks_eps_get_dimensions": [vp, ip, ip, ip],
     "ks_eps_get_eigenvalue": [vp, C.c_int, dp, dp],
     "ks_eps_get_eigenvector_host": [vp, C.c_int, dp],
+    "ks_eps_get_eigenpair_host": [vp, C.c_int, dp, dp, dp, dp],
     "ks_eps_get_error_estimate": [vp, C.c_int, dp],
     "ks_eps_compute_error": [vp, C.c_int, C.c_int, dp],
     "ks_eps_get_bv": [vp, C.POINTER(vp)],

@@ -1,0 +1,29 @@
+// Small dense kernels for the projected (m x m, m <= 64) non-symmetric eigenproblem: the LAPACK routines the
+// reference's DS NHEP calls (gehrd/orghr, hseqr, trexc, trevc; src/sys/classes/ds/impls/dsutil.c:21-175,
+// src/sys/classes/ds/impls/nhep/dsnhep.c:101-167) written out for the host, since LAPACK is not part of this
+// image's C toolchain. Column-major, 0-based indices, leading dimension ld.
+#pragma once
+
+namespace ksd {
+
+// A(ilo:n, ilo:n) -> upper Hessenberg by Householder similarity (dgehd2), Q <- accumulated reflectors (dorghr);
+// rows/columns below ilo are assumed already upper triangular. Q must come in as the identity.
+void hess_reduce(int n, int ilo, double *A, int ld, double *Q);
+
+// Real Schur form of the upper Hessenberg A (active window ilo..n-1): A <- T quasi-triangular with standardised
+// 2x2 blocks, Q <- Q*Z, eigenvalues in wr/wi (dhseqr 'S','V' contract, algorithm of dlahqr). Returns 0 or the
+// 1-based index where the QR iteration failed.
+int real_schur(int n, int ilo, double *A, int ld, double *wr, double *wi, double *Q);
+
+// Standardise a real 2x2 block (dlanv2).
+void lanv2(double &a, double &b, double &c, double &d, double &rt1r, double &rt1i, double &rt2r, double &rt2i, double &cs, double &sn);
+
+// Move the diagonal block starting at row ifst up to row ilst (ilst <= ifst) by adjacent swaps, updating Q
+// (dtrexc 'V' for the upward direction used by DSSort_NHEP_Total). Returns 0, or 1 if a swap was rejected.
+int trexc_up(int n, double *T, int ld, double *Q, int ifst, int ilst);
+
+// Right eigenvector of the quasi-triangular T for the block starting at column k (dtrevc 'R','S'): xr (and xi for a
+// complex pair; the pair is (k,k+1)) of length n, not back-transformed. Returns 1 for a complex pair, 0 for real.
+int trevc_one(int n, const double *T, int ld, int k, double *xr, double *xi);
+
+} // namespace ksd

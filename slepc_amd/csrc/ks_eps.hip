@@ -17,6 +17,7 @@
 // iteration written out below (same algorithm family as steqr; eigenvalues returned ascending as steqr
 // does, so that the insertion sort of DSSort sees the same input order).
 #include "ksgpu_internal.h"
+#include "ks_dense.h"
 #include <algorithm>
 #include <limits>
 
@@ -94,15 +95,26 @@ int tridiag_ql(int n, double *d, double *e, double *Z, int ldz, int nz)
   return 0;
 }
 
-// SlepcCompare* (src/sys/slepcsc.c:152-213), real scalars
-int compare_eig(int which, double ar, double ai, double br, double bi)
+// SlepcCompare* (src/sys/slepcsc.c:152-300), real scalars; EPS_WHICH_USER calls the function installed with
+// ks_eps_set_eigenvalue_comparison (EPSSetEigenvalueComparison epsopts.c:563)
+struct KsCompare {
+  int which = KS_EPS_LARGEST_MAGNITUDE;
+  double target = 0.0;
+  ks_eig_compare_fn fn = nullptr; void *fn_ctx = nullptr;
+};
+int compare_eig(const KsCompare &cmp, double ar, double ai, double br, double bi)
 {
   double a, b;
-  switch (which) {
+  switch (cmp.which) {
     case KS_EPS_LARGEST_MAGNITUDE:  a = hypot(ar, ai); b = hypot(br, bi); return a < b ? 1 : (a > b ? -1 : 0);
     case KS_EPS_SMALLEST_MAGNITUDE: a = hypot(ar, ai); b = hypot(br, bi); return a > b ? 1 : (a < b ? -1 : 0);
     case KS_EPS_LARGEST_REAL:       return ar < br ? 1 : (ar > br ? -1 : 0);
     case KS_EPS_SMALLEST_REAL:      return ar > br ? 1 : (ar < br ? -1 : 0);
+    case KS_EPS_LARGEST_IMAGINARY:  a = fabs(ai); b = fabs(bi); return a < b ? 1 : (a > b ? -1 : 0);
+    case KS_EPS_SMALLEST_IMAGINARY: a = fabs(ai); b = fabs(bi); return a > b ? 1 : (a < b ? -1 : 0);
+    case KS_EPS_TARGET_MAGNITUDE:   a = hypot(ar - cmp.target, ai); b = hypot(br - cmp.target, bi); return a > b ? 1 : (a < b ? -1 : 0);
+    case KS_EPS_TARGET_REAL:        a = fabs(ar - cmp.target); b = fabs(br - cmp.target); return a > b ? 1 : (a < b ? -1 : 0);
+    case KS_EPS_WHICH_USER: { int r = 0; cmp.fn(ar, ai, br, bi, &r, cmp.fn_ctx); return r; }
   }
   return 0;
 }
@@ -111,7 +123,7 @@ enum { DS_RAW = 0, DS_INTERMEDIATE = 1, DS_CONDENSED = 2, DS_TRUNCATED = 3 };
 
 // DS type HEP, compact storage with extra row (krylovschur.c:160-168)
 struct DsHep {
-  int ld = 0, n = 0, l = 0, k = 0, t = 0, state = DS_RAW, which = KS_EPS_LARGEST_MAGNITUDE;
+  int ld = 0, n = 0, l = 0, k = 0, t = 0, state = DS_RAW; KsCompare which;
   std::vector<double> T, Q; std::vector<int> perm;
   void allocate(int ld_) { ld = ld_; T.assign((size_t)3 * ld, 0.0); Q.assign((size_t)ld * ld, 0.0); perm.assign(ld, 0); }
   double *d() { return T.data(); }
@@ -206,6 +218,106 @@ struct DsHep {
   }
 };
 
+// DS type NHEP with extra row (krylovschur.c:153-159): A is ld x ld column-major, row n holds the extra row.
+// Restates DSSolve_NHEP_Private / DSSort_NHEP_Total (src/sys/classes/ds/impls/dsutil.c:21-175),
+// DSVectors_NHEP_Eigen_Some (nhep/dsnhep.c:101-167), DSUpdateExtraRow_NHEP (:318-341), DSTruncate_NHEP (:385-415),
+// DSGetTruncateSize_Default (interface/dsops.c:329-345) on top of the host kernels of ks_dense.cpp.
+struct DsNhep {
+  int ld = 0, n = 0, l = 0, k = 0, t = 0, state = DS_RAW; KsCompare which;
+  std::vector<double> A, Q, X;
+  void allocate(int ld_) { ld = ld_; A.assign((size_t)ld * ld, 0.0); Q.assign((size_t)ld * ld, 0.0); X.assign((size_t)ld * ld, 0.0); }
+  double &a(int i, int j) { return A[(size_t)i + (size_t)j * ld]; }
+  double &q(int i, int j) { return Q[(size_t)i + (size_t)j * ld]; }
+  void set_dimensions(int n_, int l_, int k_) { n = n_; t = n_; l = l_; k = k_; }
+
+  void eig_from_T(double *wr, double *wi, int j0, int j1)                                    // dsutil.c:65-79,160-170
+  {
+    for (int j = j0; j < j1; j++) {
+      if (j == n - 1 || a(j + 1, j) == 0.0) { wr[j] = a(j, j); wi[j] = 0.0; }
+      else {
+        wr[j] = a(j, j); wr[j + 1] = a(j, j);
+        wi[j] = sqrt(fabs(a(j + 1, j))) * sqrt(fabs(a(j, j + 1))); wi[j + 1] = -wi[j];
+        j++;
+      }
+    }
+  }
+
+  int solve(double *wr, double *wi)                                                          // dsutil.c:21-91
+  {
+    if (state >= DS_CONDENSED) return 0;
+    std::fill(Q.begin(), Q.end(), 0.0);
+    for (int i = 0; i < n; i++) q(i, i) = 1.0;
+    if (n == 1) { wr[0] = a(0, 0); wi[0] = 0.0; state = DS_CONDENSED; return 0; }
+    if (state < DS_INTERMEDIATE) ksd::hess_reduce(n, l, A.data(), ld, Q.data());             // gehrd + orghr
+    const int info = ksd::real_schur(n, l, A.data(), ld, wr, wi, Q.data());                  // hseqr 'S','V'
+    if (info) return info;
+    eig_from_T(wr, wi, 0, l);
+    state = DS_CONDENSED;
+    return 0;
+  }
+
+  int sort(double *wr, double *wi)                                                           // dsutil.c:93-175
+  {
+    for (int i = l; i < n - 1; i++) {
+      double re = wr[i], im = wi[i];
+      int pos = 0;
+      for (int j = (im != 0.0) ? i + 2 : i + 1; j < n; j++) {
+        if (compare_eig(which, re, im, wr[j], wi[j]) > 0) { re = wr[j]; im = wi[j]; pos = j; }
+        if (wi[j] != 0.0) j++;
+      }
+      if (pos) {
+        if (ksd::trexc_up(n, A.data(), ld, Q.data(), pos, i)) return 1;                      // trexc 'V', ifst=pos+1, ilst=i+1
+        eig_from_T(wr, wi, i, n);
+      }
+      if (wi[i] != 0.0) i++;
+    }
+    return 0;
+  }
+
+  void update_extra_row()                                                                    // dsnhep.c:318-341
+  {
+    std::vector<double> x(n);
+    for (int j = 0; j < n; j++) x[j] = a(n, j);
+    for (int j = 0; j < n; j++) { double s = 0.0; for (int i = 0; i < n; i++) s += q(i, j) * x[i]; a(n, j) = s; }
+    k = n;
+  }
+
+  // k-th eigenvector of A back-transformed with Q (or not), normalised, into X(:,k[,k+1]); returns the index of the
+  // last column written; rnorm = |last component| (dsnhep.c:101-167)
+  int vectors(int kk, bool back, double *rnorm)
+  {
+    double xr[KS_MAX_COLS + 1], xi[KS_MAX_COLS + 1], zr[KS_MAX_COLS + 1], zi[KS_MAX_COLS + 1];
+    const bool cplx = ksd::trevc_one(n, A.data(), ld, kk, xr, xi) != 0;
+    for (int i = 0; i < n; i++) {
+      if (back) { double sr = 0.0, si = 0.0; for (int j = 0; j < n; j++) { sr += q(i, j) * xr[j]; si += q(i, j) * xi[j]; } zr[i] = sr; zi[i] = si; }
+      else { zr[i] = xr[i]; zi[i] = xi[i]; }
+    }
+    double nr = 0.0, ni = 0.0;
+    for (int i = 0; i < n; i++) { nr = hypot(nr, zr[i]); ni = hypot(ni, zi[i]); }
+    const double norm = cplx ? hypot(nr, ni) : nr;
+    for (int i = 0; i < n; i++) { X[(size_t)i + (size_t)kk * ld] = zr[i] / norm; if (cplx) X[(size_t)i + (size_t)(kk + 1) * ld] = zi[i] / norm; }
+    if (rnorm) *rnorm = cplx ? hypot(zr[n - 1] / norm, zi[n - 1] / norm) : fabs(zr[n - 1] / norm);
+    return cplx ? kk + 1 : kk;
+  }
+
+  int get_truncate_size(int ll, int nn, int kk)                                              // dsops.c:329-345
+  {
+    if (a(ll + kk, ll + kk - 1) != 0.0) kk = (ll + kk < nn - 1) ? kk + 1 : kk - 1;
+    return kk;
+  }
+
+  void truncate(int nn, bool trim)                                                           // dsnhep.c:385-415
+  {
+    if (trim) {
+      for (int j = l; j < n; j++) a(n, j) = 0.0;
+      l = 0; k = 0; n = nn; t = nn; state = DS_RAW;
+    } else {
+      if (k == n) { for (int j = l; j < nn; j++) a(nn, j) = a(n, j); for (int j = l; j < n; j++) a(n, j) = 0.0; }
+      k = nn; t = n; n = nn; state = DS_TRUNCATED;
+    }
+  }
+};
+
 } // namespace
 
 struct ks_eps_s {
@@ -215,7 +327,7 @@ struct ks_eps_s {
   int problem_type = KS_EPS_HEP;
   int nev = 1, ncv = 0, mpd = 0, ncv_user = 0, mpd_user = 0;
   double tol = 1e-8; int max_it = 0, max_it_user = 0;
-  int which = KS_EPS_LARGEST_MAGNITUDE;
+  KsCompare which;
   double keep = 0.5;
   uint64_t seed = 0x12345678ULL;
   std::vector<double> v0; bool have_v0 = false;
@@ -226,6 +338,7 @@ struct ks_eps_s {
   long long steps = 0, passes = 0; int restarts = 0;
   bool solved = false;
   DsHep ds;
+  DsNhep dsn;
 };
 
 extern "C" int ks_eps_create(ks_ctx ctx, ks_eps *out)
@@ -254,8 +367,8 @@ extern "C" int ks_eps_set_operators(ks_eps eps, ks_mat A, ks_mat B)   // epssetu
 extern "C" int ks_eps_set_problem_type(ks_eps eps, int type)
 {
   KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
-  KS_CHECK(type == KS_EPS_HEP, KS_ERR_SUP, "only EPS_HEP (symmetric, Lanczos) is driven end to end in this build; use ks_bv_matarnoldi for the non-symmetric expansion");
-  eps->problem_type = type; return KS_SUCCESS;
+  KS_CHECK(type == KS_EPS_HEP || type == KS_EPS_NHEP, KS_ERR_SUP, "only EPS_HEP (Lanczos) and EPS_NHEP (Arnoldi) are driven by this build; generalized problems are out of scope");
+  eps->problem_type = type; eps->solved = false; return KS_SUCCESS;
 }
 extern "C" int ks_eps_set_dimensions(ks_eps eps, int nev, int ncv, int mpd)
 {
@@ -274,8 +387,23 @@ extern "C" int ks_eps_set_tolerances(ks_eps eps, double tol, int max_it)
 extern "C" int ks_eps_set_which_eigenpairs(ks_eps eps, int which)
 {
   KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
-  KS_CHECK(which >= KS_EPS_LARGEST_MAGNITUDE && which <= KS_EPS_SMALLEST_REAL, KS_ERR_ARG_OUTOFRANGE, "Invalid 'which' value");
-  eps->which = which; return KS_SUCCESS;
+  switch (which) {                                    // epsopts.c:478-510
+    case KS_EPS_LARGEST_MAGNITUDE: case KS_EPS_SMALLEST_MAGNITUDE: case KS_EPS_LARGEST_REAL: case KS_EPS_SMALLEST_REAL:
+    case KS_EPS_LARGEST_IMAGINARY: case KS_EPS_SMALLEST_IMAGINARY: case KS_EPS_TARGET_MAGNITUDE: case KS_EPS_TARGET_REAL:
+    case KS_EPS_WHICH_USER: break;
+    default: KS_FAIL(KS_ERR_ARG_OUTOFRANGE, "Invalid 'which' value");
+  }
+  eps->which.which = which; eps->solved = false; return KS_SUCCESS;
+}
+extern "C" int ks_eps_set_target(ks_eps eps, double target)                     // EPSSetTarget epsopts.c:604
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  eps->which.target = target; eps->solved = false; return KS_SUCCESS;
+}
+extern "C" int ks_eps_set_eigenvalue_comparison(ks_eps eps, ks_eig_compare_fn fn, void *fctx)   // epsopts.c:563
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  eps->which.fn = fn; eps->which.fn_ctx = fctx; eps->which.which = KS_EPS_WHICH_USER; eps->solved = false; return KS_SUCCESS;
 }
 extern "C" int ks_eps_set_krylovschur_restart(ks_eps eps, double keep)   // krylovschur.c:339-350
 {
@@ -309,12 +437,114 @@ static int start_vector(ks_eps eps, int i, bool *breakdown)
   return KS_SUCCESS;
 }
 
+// Non-Hermitian branch of EPSSolve_KrylovSchur_Default (krylovschur.c:227-337 with BVMatArnoldi), the conjugate-pair
+// handling of EPSKrylovConvergence (epskrylov.c:262-287), EPSComputeVectors_Schur (epsdefault.c:105-169) and the
+// pair-aware SlepcSortEigenvalues (slepcsc.c:89-140).
+static int solve_nhep(ks_eps eps, long long passes0)
+{
+  ks_mat A = eps->A; ks_bv V = eps->V;
+  const int nev = eps->nev, ncv = eps->ncv, mpd = eps->mpd;
+  DsNhep &ds = eps->dsn;
+  ds.allocate(ncv + 1); ds.which = eps->which; ds.state = DS_RAW;
+  KS_CALL(start_vector(eps, 0, nullptr));
+  int l = 0;
+  while (eps->reason == KS_EPS_CONVERGED_ITERATING) {
+    eps->its++;
+    int nv = std::min(eps->nconv + mpd, ncv);
+    if (eps->max_steps && eps->steps + (nv - (eps->nconv + l)) > eps->max_steps) nv = eps->nconv + l + (int)(eps->max_steps - eps->steps);
+    ds.set_dimensions(nv, eps->nconv, eps->nconv + l);
+    double beta = 0.0; int breakdown = 0;
+    const int k0 = eps->nconv + l;
+    KS_CALL(ks_bv_matarnoldi(V, A, ds.A.data(), ds.ld, k0, &nv, &beta, &breakdown));
+    eps->steps += nv - k0;
+    ds.set_dimensions(nv, eps->nconv, eps->nconv + l);
+    ds.state = l ? DS_RAW : DS_INTERMEDIATE;
+    KS_CALL(ks_bv_set_active_columns(V, eps->nconv, nv));
+
+    int info = ds.solve(eps->eigr.data(), eps->eigi.data());
+    KS_CHECK(info == 0, KS_ERR_LIB, "Hessenberg QR iteration failed to converge (info=%d)", info);
+    info = ds.sort(eps->eigr.data(), eps->eigi.data());
+    KS_CHECK(info == 0, KS_ERR_LIB, "reordering of the Schur form failed: blocks too close to swap");
+    ds.update_extra_row();
+
+    // EPSKrylovConvergence(eps,FALSE,nconv,nv-nconv,beta,0.0,1.0,&k)
+    int marker = -1, k;
+    for (k = eps->nconv; k < nv; k++) {
+      const double re = eps->eigr[k], im = eps->eigi[k];
+      double resnorm = 0.0;
+      const int newk = ds.vectors(k, true, &resnorm);
+      resnorm *= beta;
+      const double w = hypot(re, im);
+      eps->errest[k] = (w != 0.0) ? resnorm / w : std::numeric_limits<double>::max();
+      if (marker == -1 && eps->errest[k] >= eps->tol) marker = k;
+      if (newk == k + 1) { eps->errest[k + 1] = eps->errest[k]; k++; }
+      if (marker != -1) break;
+    }
+    k = (marker != -1) ? marker : nv;
+    if (k >= nev) eps->reason = KS_EPS_CONVERGED_TOL;
+    else if (eps->its >= eps->max_it) eps->reason = KS_EPS_DIVERGED_ITS;
+    if (eps->reason == KS_EPS_CONVERGED_ITERATING && eps->max_steps && eps->steps >= eps->max_steps) eps->reason = KS_EPS_CONVERGED_USER;
+
+    if (eps->reason != KS_EPS_CONVERGED_ITERATING || breakdown || k == nv) l = 0;
+    else {
+      l = std::max(1, (int)((nv - k) * eps->keep));
+      l = ds.get_truncate_size(k, nv, l);                      // do not split a 2x2 block (krylovschur.c:300)
+    }
+    if (eps->reason == KS_EPS_CONVERGED_ITERATING) {
+      if (breakdown || k == nv) {
+        if (k < nev) {
+          bool brk = false;
+          KS_CALL(start_vector(eps, k, &brk));
+          if (brk) eps->reason = KS_EPS_DIVERGED_BREAKDOWN;
+        }
+      } else ds.truncate(k + l, false);
+    }
+    KS_CALL(ks_bv_multinplace(V, ds.Q.data(), ds.ld, eps->nconv, k + l));
+    if (eps->reason == KS_EPS_CONVERGED_ITERATING && !breakdown) KS_CALL(ks_bv_copycolumn(V, nv, k + l));
+    eps->nconv = k;
+    eps->restarts++;
+  }
+  ds.truncate(eps->nconv, true);
+
+  // EPSComputeVectors_Schur: X = V*Z with Z the (normalised) eigenvectors of the trimmed quasi-triangular T
+  const int nc = eps->nconv;
+  KS_CALL(ks_bv_set_active_columns(V, 0, nc));
+  if (nc) {
+    for (int k = 0; k < nc; k++) k = ds.vectors(k, false, nullptr);
+    KS_CALL(ks_bv_multinplace(V, ds.X.data(), ds.ld, 0, nc));
+  }
+  // SlepcSortEigenvalues keeping conjugate pairs together
+  std::vector<int> &perm = eps->perm;
+  const double *eigr = eps->eigr.data(), *eigi = eps->eigi.data();
+  for (int i = 0; i <= ncv; i++) perm[i] = i;
+  for (int i = nc - 1; i >= 0; i--) {
+    const double re = eigr[perm[i]]; double im = eigi[perm[i]];
+    int j = i + 1;
+    if (im != 0.0) { i--; im = eigi[perm[i]]; }                // complex eigenvalue: positive imaginary part first
+    while (j < nc) {
+      if (compare_eig(eps->which, re, im, eigr[perm[j]], eigi[perm[j]]) <= 0) break;
+      if (im == 0.0) {
+        if (eigi[perm[j]] == 0.0) { std::swap(perm[j - 1], perm[j]); j++; }
+        else { const int tmp = perm[j - 1]; perm[j - 1] = perm[j]; perm[j] = perm[j + 1]; perm[j + 1] = tmp; j += 2; }
+      } else {
+        if (eigi[perm[j]] == 0.0) { const int tmp = perm[j - 2]; perm[j - 2] = perm[j]; perm[j] = perm[j - 1]; perm[j - 1] = tmp; j++; }
+        else { std::swap(perm[j - 2], perm[j]); std::swap(perm[j - 1], perm[j + 1]); j += 2; }
+      }
+    }
+  }
+  long long passes1 = 0; ks_bv_gs_passes(V, &passes1, nullptr);
+  eps->passes = passes1 - passes0;
+  eps->solved = true;
+  return KS_SUCCESS;
+}
+
 extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve_KrylovSchur_Default krylovschur.c:227
 {
   KS_CHECK(eps && eps->A, KS_ERR_ORDER, "EPSSetOperators must be called first");
   ks_mat A = eps->A;
   const int n = A->n_global;
   // ---- EPSSetUp ----
+  KS_CHECK(eps->which.which != KS_EPS_WHICH_USER || eps->which.fn, KS_ERR_ORDER, "Must call EPSSetEigenvalueComparison() first");   // epssetup.c:311
   int nev = eps->nev, ncv = eps->ncv_user, mpd = eps->mpd_user;
   if (ncv) { KS_CHECK(ncv >= nev + 1 || (ncv == nev && ncv == n), KS_ERR_USER_INPUT, "The value of ncv must be at least nev+1"); }
   else if (mpd) ncv = std::min(n, nev + mpd);
@@ -326,7 +556,7 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   eps->max_it = eps->max_it_user ? eps->max_it_user : std::max(100, 2 * n / ncv);
   if (eps->V) { int vm = 0; ks_bv_get_sizes(eps->V, nullptr, nullptr, &vm, nullptr); if (vm != ncv + 1) { ks_bv_destroy(eps->V); eps->V = nullptr; } }
   if (!eps->V) { KS_CALL(ks_bv_create(eps->ctx, A->n, A->n_global, ncv + 1, 0, &eps->V)); eps->V->row_start = A->row_start; }   // EPSAllocateSolution(eps,1)
-  if (!eps->W) { KS_CALL(ks_bv_create(eps->ctx, A->n, A->n_global, 2, 0, &eps->W)); }
+  if (!eps->W) { KS_CALL(ks_bv_create(eps->ctx, A->n, A->n_global, 3, 0, &eps->W)); }
   eps->eigr.assign(ncv + 1, 0.0); eps->eigi.assign(ncv + 1, 0.0); eps->errest.assign(ncv + 1, 0.0);
   eps->perm.resize(ncv + 1); for (int i = 0; i <= ncv; i++) eps->perm[i] = i;
   DsHep &ds = eps->ds;
@@ -335,6 +565,8 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   long long passes0 = 0; ks_bv_gs_passes(eps->V, &passes0, nullptr);
   ks_bv V = eps->V;
   KS_CALL(ks_bv_set_active_columns(V, 0, ncv + 1));
+
+  if (eps->problem_type == KS_EPS_NHEP) return solve_nhep(eps, passes0);
 
   // ---- EPSSolve_KrylovSchur_Default ----
   KS_CALL(start_vector(eps, 0, nullptr));
@@ -430,7 +662,7 @@ extern "C" int ks_eps_get_eigenvalue(ks_eps eps, int i, double *eigr, double *ei
   KS_CHECK(i < eps->nconv, KS_ERR_ARG_OUTOFRANGE, "The index can be nconv-1 at most, see EPSGetConverged()");
   const int k = eps->perm[i];
   if (eigr) *eigr = eps->eigr[k];
-  if (eigi) *eigi = 0.0;
+  if (eigi) *eigi = eps->eigi[k];
   return KS_SUCCESS;
 }
 extern "C" int ks_eps_get_eigenvector_host(ks_eps eps, int i, double *xr)
@@ -438,7 +670,25 @@ extern "C" int ks_eps_get_eigenvector_host(ks_eps eps, int i, double *xr)
   KS_CHECK(eps && xr, KS_ERR_ARG_NULL, "NULL argument");
   KS_CHECK(eps->solved, KS_ERR_ARG_WRONGSTATE, "Must call EPSSolve() first");
   KS_CHECK(i >= 0 && i < eps->nconv, KS_ERR_ARG_OUTOFRANGE, "The index can be nconv-1 at most, see EPSGetConverged()");
-  return ks_bv_get_column_host(eps->V, eps->perm[i], xr);      // EPSComputeVectors_Hermitian: V already holds the Ritz vectors
+  const int k = eps->perm[i];
+  // EPSComputeVectors_Hermitian: V already holds the Ritz vectors; pairs: BV_GetEigenvector bvimpl.h:423-446
+  return ks_bv_get_column_host(eps->V, eps->eigi[k] < 0.0 ? k - 1 : k, xr);
+}
+extern "C" int ks_eps_get_eigenpair_host(ks_eps eps, int i, double *eigr, double *eigi, double *xr, double *xi)   // EPSGetEigenpair epssolve.c:405
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  KS_CHECK(eps->solved, KS_ERR_ARG_WRONGSTATE, "Must call EPSSolve() first");
+  KS_CHECK(i >= 0 && i < eps->nconv, KS_ERR_ARG_OUTOFRANGE, "The index can be nconv-1 at most, see EPSGetConverged()");
+  const int k = eps->perm[i], nloc = eps->V->n;
+  const double im = eps->eigi[k];
+  if (eigr) *eigr = eps->eigr[k];
+  if (eigi) *eigi = im;
+  if (im > 0.0) { if (xr) KS_CALL(ks_bv_get_column_host(eps->V, k, xr)); if (xi) KS_CALL(ks_bv_get_column_host(eps->V, k + 1, xi)); }
+  else if (im < 0.0) {
+    if (xr) KS_CALL(ks_bv_get_column_host(eps->V, k - 1, xr));
+    if (xi) { KS_CALL(ks_bv_get_column_host(eps->V, k, xi)); for (int r = 0; r < nloc; r++) xi[r] = -xi[r]; }
+  } else { if (xr) KS_CALL(ks_bv_get_column_host(eps->V, k, xr)); if (xi) for (int r = 0; r < nloc; r++) xi[r] = 0.0; }
+  return KS_SUCCESS;
 }
 extern "C" int ks_eps_get_error_estimate(ks_eps eps, int i, double *errest)
 {
@@ -455,19 +705,38 @@ extern "C" int ks_eps_compute_error(ks_eps eps, int i, int type, double *error) 
   KS_CHECK(eps->solved, KS_ERR_ARG_WRONGSTATE, "Must call EPSSolve() first");
   KS_CHECK(i >= 0 && i < eps->nconv, KS_ERR_ARG_OUTOFRANGE, "The index can be nconv-1 at most, see EPSGetConverged()");
   const int j = eps->perm[i];
-  const double kr = eps->eigr[j];
+  const double kr = eps->eigr[j], ki = eps->eigi[j];
   ks_bv W = eps->W, V = eps->V;
-  // W0 = x ; W1 = u = A*x ; u -= kr*x ; ||u||
-  KS_CALL(ksk_copy(eps->ctx, ks_bv_col(V, j), ks_bv_col(W, 0), V->n));
-  KS_CALL(ks_mat_mult_internal(eps->A, ks_bv_col(W, 0), ks_bv_col(W, 1)));
-  if (fabs(kr) > std::numeric_limits<double>::epsilon()) {
-    KS_CALL(ks_bv_set_active_columns(W, 0, 1));
-    const double q = -kr;                                   // VecAXPY(u,-kr,w)
-    KS_CALL(ks_bv_multvec(W, 1.0, 1.0, ks_bv_col(W, 1), &q));
-  }
   double nrm = 0.0;
-  KS_CALL(ks_bv_normcolumn(W, 1, KS_NORM_2, &nrm));
-  if (type == KS_EPS_ERROR_RELATIVE) nrm /= fabs(kr) * 1.0;  // vecnorm = 1 (not GHEP)
+  if (ki == 0.0 || fabs(ki) < fabs(kr * std::numeric_limits<double>::epsilon())) {
+    // W0 = x ; W2 = u = A*x ; u -= kr*x ; ||u||
+    KS_CALL(ksk_copy(eps->ctx, ks_bv_col(V, j), ks_bv_col(W, 0), V->n));
+    KS_CALL(ks_mat_mult_internal(eps->A, ks_bv_col(W, 0), ks_bv_col(W, 2)));
+    if (fabs(kr) > std::numeric_limits<double>::epsilon()) {
+      KS_CALL(ks_bv_set_active_columns(W, 0, 1));
+      const double q = -kr;                                   // VecAXPY(u,-kr,w)
+      KS_CALL(ks_bv_multvec(W, 1.0, 1.0, ks_bv_col(W, 2), &q));
+    }
+    KS_CALL(ks_bv_normcolumn(W, 2, KS_NORM_2, &nrm));
+  } else {
+    // real arithmetic, complex pair (epssolve.c:690-712): W0 = xr, W1 = xi (sign per BV_GetEigenvector)
+    const int jr = ki > 0.0 ? j : j - 1;
+    KS_CALL(ksk_copy(eps->ctx, ks_bv_col(V, jr), ks_bv_col(W, 0), V->n));
+    KS_CALL(ksk_copy(eps->ctx, ks_bv_col(V, jr + 1), ks_bv_col(W, 1), V->n));
+    if (ki < 0.0) KS_CALL(ks_bv_scalecolumn(W, 1, -1.0));
+    KS_CALL(ks_bv_set_active_columns(W, 0, 2));
+    double q[2], nr = 0.0, ni = 0.0;
+    KS_CALL(ks_mat_mult_internal(eps->A, ks_bv_col(W, 0), ks_bv_col(W, 2)));      // u = A*xr - kr*xr + ki*xi
+    q[0] = -kr; q[1] = ki;
+    KS_CALL(ks_bv_multvec(W, 1.0, 1.0, ks_bv_col(W, 2), q));
+    KS_CALL(ks_bv_normcolumn(W, 2, KS_NORM_2, &nr));
+    KS_CALL(ks_mat_mult_internal(eps->A, ks_bv_col(W, 1), ks_bv_col(W, 2)));      // u = A*xi - kr*xi - ki*xr
+    q[0] = -ki; q[1] = -kr;
+    KS_CALL(ks_bv_multvec(W, 1.0, 1.0, ks_bv_col(W, 2), q));
+    KS_CALL(ks_bv_normcolumn(W, 2, KS_NORM_2, &ni));
+    nrm = hypot(nr, ni);
+  }
+  if (type == KS_EPS_ERROR_RELATIVE) nrm /= hypot(kr, ki) * 1.0;  // vecnorm = 1 (not GHEP)
   else KS_CHECK(type == KS_EPS_ERROR_ABSOLUTE, KS_ERR_ARG_OUTOFRANGE, "Invalid error type");
   *error = nrm;
   return KS_SUCCESS;

@@ -1,0 +1,55 @@
+"""Shared inputs for the non-symmetric (EPS_NHEP, Arnoldi) cases: the reference's ex5 / test9 set-ups and a
+seeded random matrix whose dominant eigenvalues include complex-conjugate pairs."""
+import numpy as np
+
+from oracle import oracle as O
+
+SQRT_EPS = np.sqrt(np.finfo(float).eps)
+
+
+def my_eigen_sort(ar, ai, br, bi, origin=0.0):
+    """MyEigenSort of src/eps/tests/test9.c:195-204: closest to the origin, ties broken towards the right."""
+    da, db = np.hypot(ar - origin, ai), np.hypot(br - origin, bi)
+    d = (db - da) / max(da, db)
+    if d > SQRT_EPS:
+        return 1
+    if d < -SQRT_EPS:
+        return -1
+    return 1 if br >= 0 else -1          # PetscSign(PetscRealPart(br))
+
+
+def test9_v0(n):
+    v0 = np.zeros(n)
+    v0[0] = -1.5; v0[1] = 2.1            # test9.c:126-130
+    return v0
+
+
+def random_nonsymmetric(n, nnz_row=8, seed=7):
+    """Sparse matrix with i.i.d. N(0, 1/nnz_row) entries: the spectrum fills the unit disk (circular law), so every
+    extreme part of it is made of clustered complex-conjugate pairs and Krylov-Schur needs tens of restarts."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    rows = np.repeat(np.arange(n), nnz_row)
+    cols = rng.integers(0, n, n * nnz_row)
+    vals = rng.standard_normal(n * nnz_row) / np.sqrt(nnz_row)
+    S = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr(); S.sum_duplicates(); S.sort_indices()
+    return O.CSR(n, S.indptr, S.indices, S.data)
+
+
+def planted_pairs(n, nnz_row=6, seed=7, rot=0.9):
+    """Diagonal in [0,1] + small random off-diagonals + three 2x2 rotation blocks (radii 2.5, 2.2, 1.9) and two real
+    outliers (2.35, -2.05): well-separated exterior eigenvalues, converges in one or two restarts."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    rows = np.repeat(np.arange(n), nnz_row)
+    cols = rng.integers(0, n, n * nnz_row)
+    vals = rng.uniform(-1, 1, n * nnz_row) * 0.05
+    A = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tolil()
+    A.setdiag(rng.uniform(0, 1, n))
+    for b, (rad, th) in enumerate([(2.5, 0.6), (2.2, 1.3), (1.9, 2.2)]):
+        i = 2 * b
+        A[i, i] = rad * np.cos(th); A[i + 1, i + 1] = rad * np.cos(th)
+        A[i, i + 1] = rad * np.sin(th) * rot; A[i + 1, i] = -rad * np.sin(th) / rot
+    A[6, 6] = 2.35; A[7, 7] = -2.05
+    S = A.tocsr(); S.sum_duplicates(); S.sort_indices()
+    return O.CSR(n, S.indptr, S.indices, S.data)

@@ -1,0 +1,145 @@
+"""Non-symmetric Krylov-Schur (EPS_NHEP: BVMatArnoldi + DS NHEP on the host) on the GPU versus the CPU oracle
+(which drives LAPACK) and the reference's golden outputs for ex5 / test9.
+
+Tolerances: eigenvalues within 1e-10 relative of the oracle; EPSComputeError below the solver tolerance; iteration,
+step and Gram-Schmidt pass counts IDENTICAL to the oracle (integer control flow)."""
+import numpy as np
+import pytest
+
+import golden_inputs as gi
+import nhep_cases as nc
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(ctx, Ao, nev, ncv=0, which="largest_magnitude", tol=0.0, max_it=0, v0=None, cmp=None):
+    import slepc_amd as ks
+    A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A); eps.SetProblemType(ks.EPS_NHEP); eps.SetDimensions(nev, ncv); eps.SetTolerances(tol, max_it)
+    if cmp is not None:
+        eps.SetEigenvalueComparison(cmp)
+    else:
+        eps.SetWhichEigenpairs(which)
+    if v0 is not None:
+        eps.SetInitialVector(v0)
+    eps.Solve()
+    return eps
+
+
+def _check_against_oracle(eps, r, Ao, tol=1e-8):
+    assert eps.GetConverged() == r.nconv and eps.GetIterationNumber() == r.its and eps.GetConvergedReason() == r.reason
+    st = eps.GetStats()
+    assert st["arnoldi_steps"] == r.steps and st["gs_passes"] == r.passes
+    S = Ao.to_scipy()
+    for i in range(r.nconv):
+        kr, ki = eps.GetEigenvalue(i)
+        j = r.perm[i]
+        assert abs(kr - r.eigr[j]) <= 1e-10 * np.hypot(r.eigr[j], r.eigi[j])
+        assert abs(ki - r.eigi[j]) <= 1e-10 * np.hypot(r.eigr[j], r.eigi[j])
+        err = eps.ComputeError(i)
+        assert err < tol and abs(err - O.eps_compute_error_nhep(Ao, r, i)) < 1e-10
+        k2, k3, xr, xi = eps.GetEigenpair(i)
+        assert (k2, k3) == (kr, ki)
+        x = xr + 1j * xi
+        assert abs(np.linalg.norm(x) - 1.0) < 1e-12                       # test9.c CheckNormalizedVectors
+        lam = kr + 1j * ki
+        assert np.linalg.norm(S @ x - lam * x) / abs(lam) < tol
+
+
+def test_eps_ex5_markov_golden(ctx):
+    Ao = O.markov_matrix(15)
+    eps = _solve(ctx, Ao, 4, which="largest_real")
+    r = O.eps_krylovschur_nhep(Ao, 4, which="largest_real")
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(4)])
+    assert np.allclose(np.round(lam, 5), gi.eigenvalues_line(gi.read("eps/ex5_1.out")), atol=1.5e-5)
+    _check_against_oracle(eps, r, Ao)
+
+
+def test_eps_test9_user_comparison_golden(ctx):
+    Ao = O.markov_matrix(15)
+    v0 = nc.test9_v0(Ao.n)
+    eps = _solve(ctx, Ao, 4, ncv=8, tol=0.5e-10, max_it=300, v0=v0, cmp=nc.my_eigen_sort)
+    r = O.eps_krylovschur_nhep(Ao, 4, ncv=8, max_it=300, tol=0.5e-10, which=nc.my_eigen_sort, v0=v0)
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(4)])
+    assert np.allclose(np.round(lam, 5), gi.eigenvalues_line(gi.read("eps/eps_test9_1.out")), atol=1.5e-5)
+    _check_against_oracle(eps, r, Ao, tol=1e-9)
+
+
+@pytest.mark.parametrize("which", ["largest_magnitude", "largest_real", "largest_imaginary"])
+def test_eps_complex_pairs(ctx, which):
+    Ao = nc.random_nonsymmetric(500)
+    eps = _solve(ctx, Ao, 6, ncv=24, which=which)
+    r = O.eps_krylovschur_nhep(Ao, 6, ncv=24, which=which)
+    assert np.count_nonzero(r.eigi[r.perm][:6]) >= 2
+    _check_against_oracle(eps, r, Ao)
+    lam = np.array([complex(*eps.GetEigenvalue(i)) for i in range(r.nconv)])
+    k = 0
+    while k < r.nconv:                                   # pairs adjacent, positive imaginary part first
+        if lam[k].imag != 0:
+            assert lam[k].imag > 0 and lam[k + 1] == np.conj(lam[k])
+            k += 1
+        k += 1
+
+
+def test_eps_planted_pairs_larger(ctx):
+    """n = 200000 rows: the sweeps run multi-block; well-separated pairs, so the restart path is rounding-insensitive."""
+    Ao = nc.planted_pairs(200000)
+    eps = _solve(ctx, Ao, 8, ncv=20)
+    r = O.eps_krylovschur_nhep(Ao, 8, ncv=20)
+    assert np.count_nonzero(r.eigi[r.perm][:8]) == 6
+    _check_against_oracle(eps, r, Ao)
+
+
+def test_eps_many_restarts_large(ctx):
+    """Circular-law matrix, n = 3000, largest real part: >100 restarts. Rounding may shift a convergence decision by
+    a restart, so only the results are compared: true eigenvalues, small residuals, exact ordering."""
+    Ao = nc.random_nonsymmetric(3000)
+    eps = _solve(ctx, Ao, 6, ncv=24, which="largest_real")
+    r = O.eps_krylovschur_nhep(Ao, 6, ncv=24, which="largest_real")
+    assert eps.GetConverged() >= 6 and eps.GetConvergedReason() > 0
+    lam = np.array([complex(*eps.GetEigenvalue(i)) for i in range(6)])
+    ref = (r.eigr + 1j * r.eigi)[r.perm][:6]
+    assert np.allclose(lam, ref, rtol=1e-8)
+    assert np.all(np.diff(lam.real) <= 0)
+    for i in range(6):
+        assert eps.ComputeError(i) < 1e-8
+
+
+def test_eps_target_magnitude(ctx):
+    """EPS_TARGET_MAGNITUDE without a spectral transformation only changes the ordering; interior convergence is slow,
+    so target the well-separated planted eigenvalue 2.35."""
+    import slepc_amd as ks
+    Ao = nc.planted_pairs(2000)
+    A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A); eps.SetProblemType(ks.EPS_NHEP); eps.SetDimensions(1, 24)
+    eps.SetWhichEigenpairs("target_magnitude"); eps.SetTarget(2.35)
+    eps.Solve()
+    r = O.eps_krylovschur_nhep(Ao, 1, ncv=24, which=O.which_target_magnitude(2.35))
+    _check_against_oracle(eps, r, Ao)
+    assert abs(eps.GetEigenvalue(0)[0] - 2.35) < 1e-2
+
+
+def test_nhep_on_symmetric_matches_hep(ctx):
+    """Arnoldi + NHEP on a symmetric matrix finds the same eigenvalues as Lanczos + HEP."""
+    import slepc_amd as ks
+    A = ks.Mat.laplacian2d(ctx, 40)
+    out = []
+    for t in (ks.EPS_HEP, ks.EPS_NHEP):
+        eps = ks.EPS(ctx)
+        eps.SetOperators(A); eps.SetProblemType(t); eps.SetDimensions(4, 20)
+        eps.Solve()
+        assert eps.GetConverged() >= 4
+        out.append([eps.GetEigenvalue(i) for i in range(4)])
+    assert np.allclose(np.array(out[0]), np.array(out[1]), rtol=1e-10, atol=1e-14)
+
+
+def test_user_comparison_required(ctx):
+    import slepc_amd as ks
+    eps = ks.EPS(ctx)
+    eps.SetOperators(ks.Mat.laplacian2d(ctx, 8))
+    eps.SetWhichEigenpairs("user")
+    with pytest.raises(ks.KsError):
+        eps.Solve()

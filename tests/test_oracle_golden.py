@@ -182,3 +182,51 @@ def test_breakdown_sets_lindep():
     T = np.zeros((8, 3), order="F")
     mm, beta, brk = V.MatLanczos(A, T, 0, 6)
     assert brk and mm == 3
+
+
+# ---- non-symmetric path (Arnoldi + DS NHEP) -----------------------------------------------------------------------
+def test_eps_ex5_golden():
+    """ex5 -eps_largest_real -eps_nev 4 (Markov model m=15, EPS_NHEP) -> 1.00000, 0.97137, 0.90423, 0.85714."""
+    A = O.markov_matrix(15)
+    r = O.eps_krylovschur_nhep(A, 4, which="largest_real")
+    ref = gi.eigenvalues_line(gi.read("eps/ex5_1.out"))
+    lam = r.eigr[r.perm][:4]
+    assert r.nconv >= 4 and r.reason > 0 and np.all(r.eigi[r.perm][:4] == 0)
+    assert np.allclose(np.round(lam, 5), ref, atol=1.5e-5)
+    for i in range(4):
+        assert O.eps_compute_error_nhep(A, r, i) < 1e-8
+
+
+def test_eps_test9_golden():
+    """test9 -eps_nev 4 -eps_ncv 8 -eps_max_it 300: user comparison MyEigenSort (largest distance from the origin, ties
+    towards the right), tol = 0.5*PETSC_SMALL, initial vector from the test -> 1.00000, -1.00000, 0.97137, -0.97137."""
+    import nhep_cases as nc
+    A = O.markov_matrix(15)
+    r = O.eps_krylovschur_nhep(A, 4, ncv=8, max_it=300, tol=0.5e-10, which=nc.my_eigen_sort, v0=nc.test9_v0(A.n))
+    ref = gi.eigenvalues_line(gi.read("eps/eps_test9_1.out"))
+    assert r.nconv >= 4 and r.reason > 0
+    assert np.allclose(np.round(r.eigr[r.perm][:4], 5), ref, atol=1.5e-5)
+    for i in range(4):
+        assert O.eps_compute_error_nhep(A, r, i) < 1e-9
+
+
+def test_eps_nhep_complex_pairs():
+    """Conjugate pairs: kept together by DSSort/trexc, by the restart size (DSGetTruncateSize) and by the final sort;
+    eigenvalues are true eigenvalues and the real-arithmetic residual of EPSComputeError is below tol."""
+    import nhep_cases as nc
+    A = nc.random_nonsymmetric(500)
+    r = O.eps_krylovschur_nhep(A, 6, ncv=24)
+    lam = (r.eigr + 1j * r.eigi)[r.perm]
+    assert r.nconv >= 6 and np.count_nonzero(r.eigi[r.perm][:6]) >= 4
+    exact = np.linalg.eigvals(A.to_scipy().toarray())
+    for i in range(r.nconv):
+        assert np.min(np.abs(exact - lam[i])) < 1e-6 * abs(lam[i])        # non-normal: error <= cond * residual
+        assert O.eps_compute_error_nhep(A, r, i) < 1e-8
+    mags = np.abs(lam)
+    assert np.all(np.diff(mags) <= 1e-9)                       # largest magnitude first
+    k = 0
+    while k < r.nconv:                                          # pairs adjacent, positive imaginary part first
+        if lam[k].imag != 0:
+            assert lam[k].imag > 0 and lam[k + 1] == np.conj(lam[k]) and r.perm[k + 1] == r.perm[k] + 1
+            k += 1
+        k += 1
