@@ -652,11 +652,11 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
         k = marker if marker != -1 else nv
         # EPSStoppingBasic
         if k >= nev:
-            reason = 2      # EPS_CONVERGED_TOL
+            reason = 1      # EPS_CONVERGED_TOL (slepceps.h)
         elif its >= max_it:
             reason = -1     # EPS_DIVERGED_ITS
         if max_steps is not None and steps >= max_steps and reason == 0:
-            reason = -99
+            reason = 2      # EPS_CONVERGED_USER (step cap of the bench harness)
         # update l
         if reason != 0 or breakdown or k == nv:
             l = 0
@@ -947,11 +947,11 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
             k += 1
         k = marker if marker != -1 else nv
         if k >= nev:
-            reason = 2
+            reason = 1      # EPS_CONVERGED_TOL
         elif its >= max_it:
             reason = -1
         if max_steps is not None and steps >= max_steps and reason == 0:
-            reason = -99
+            reason = 2      # EPS_CONVERGED_USER (step cap of the bench harness)
         if reason != 0 or breakdown or k == nv:
             l = 0
         else:

@@ -104,7 +104,7 @@ def test_eps_many_restarts_large(ctx):
     assert np.allclose(lam, ref, rtol=1e-8)
     assert np.all(np.diff(lam.real) <= 0)
     for i in range(6):
-        assert eps.ComputeError(i) < 1e-8
+        assert eps.ComputeError(i) < 1e-7        # convergence is decided on the estimate; non-normal: true residual ~ tol
 
 
 def test_eps_target_magnitude(ctx):
