@@ -42,6 +42,7 @@ extern "C" {
 #define KS_ERR_SUP             56
 #define KS_ERR_ORDER           58
 #define KS_ERR_ARG_SIZ         60
+#define KS_ERR_ARG_IDN         61
 #define KS_ERR_ARG_WRONG       62
 #define KS_ERR_ARG_OUTOFRANGE  63
 #define KS_ERR_USER_INPUT      71   /* BV_SafeSqrt "Invalid inner product" bvimpl.h:137 */
@@ -51,11 +52,13 @@ extern "C" {
 #define KS_ERR_PLIB            77
 #define KS_ERR_CONV_FAILED     82
 #define KS_ERR_ARG_NULL        85
+#define KS_ERR_NOT_CONVERGED   91   /* inner linear solve (KSPSetErrorIfNotConverged, stsles.c:58) */
 #define KS_ERR_GPU             97   /* no usable gfx950 device */
 
 const char *ks_error_string(int rc);
 const char *ks_last_error_message(void);     /* detail of the last failure on this thread */
 
+typedef struct ks_st_s  *ks_st;    /* spectral transformation: the operator of the Krylov expansion */
 typedef struct ks_ctx_s *ks_ctx;   /* device + stream + communicator + profiling state            */
 typedef struct ks_mat_s *ks_mat;   /* sparse operator (CSR / AIJ), row block owned by this rank   */
 typedef struct ks_bv_s  *ks_bv;    /* basis vectors                                               */
@@ -71,7 +74,8 @@ enum { KS_EPS_LARGEST_MAGNITUDE = 1, KS_EPS_SMALLEST_MAGNITUDE = 2, KS_EPS_LARGE
        KS_EPS_WHICH_USER = 11 };
 /* SlepcEigenvalueComparisonFn (include/slepcsc.h): *res < 0 if a is preferred to b, > 0 if b is preferred, 0 if equal */
 typedef int (*ks_eig_compare_fn)(double ar, double ai, double br, double bi, int *res, void *ctx);
-enum { KS_EPS_HEP = 1, KS_EPS_NHEP = 3 };
+enum { KS_EPS_HEP = 1, KS_EPS_NHEP = 3, KS_EPS_GNHEP = 4 };   /* EPSProblemType, slepceps.h */
+enum { KS_ST_SHIFT = 0, KS_ST_SINVERT = 1 };                 /* STType "shift", "sinvert" */
 enum { KS_EPS_ERROR_ABSOLUTE = 0, KS_EPS_ERROR_RELATIVE = 1 };
 enum { KS_EPS_CONVERGED_TOL = 1, KS_EPS_CONVERGED_USER = 2, KS_EPS_DIVERGED_ITS = -1, KS_EPS_DIVERGED_BREAKDOWN = -2,
        KS_EPS_DIVERGED_SYMMETRY_LOST = -3, KS_EPS_CONVERGED_ITERATING = 0 };
@@ -117,6 +121,12 @@ int ks_mat_create_csr(ks_ctx ctx, int n_local, int row_start, int n_global,
    2-D 5-pt Laplacian of ex2.c:44-51.                                                           */
 int ks_mat_create_laplacian3d(ks_ctx ctx, int nx, int ny, int nz, int z0, int nz_local, ks_mat *A);
 int ks_mat_create_laplacian2d(ks_ctx ctx, int n, int m, ks_mat *A);
+/* MatCreateShell + MATOP_MULT (the matrix-free route of src/eps/tutorials/ex3.c): y = mult(user, x) on device
+   pointers of n_local doubles; the callback must order its work after everything already enqueued on the context's
+   stream (enqueue on that stream, or synchronise) and leave y complete in that order.          */
+typedef int (*ks_shell_mult_fn)(void *user, const double *x_dev, double *y_dev);
+int ks_mat_create_shell(ks_ctx ctx, int n_local, int row_start, int n_global, ks_shell_mult_fn mult, void *user, ks_mat *A);
+int ks_mat_get_diagonal(ks_mat A, double *d_dev);                      /* MatGetDiagonal (local diagonal block) */
 int ks_mat_destroy(ks_mat A);
 int ks_mat_get_sizes(ks_mat A, int *n_local, int *n_global, long long *nnz_local);
 /* MatMult: y = A x on device pointers (x, y: n_local doubles owned by this rank).
@@ -184,6 +194,7 @@ int ks_eps_set_problem_type(ks_eps eps, int type);                         /* KS
 int ks_eps_set_dimensions(ks_eps eps, int nev, int ncv /*<=0: default*/, int mpd /*<=0: default*/);
 int ks_eps_set_tolerances(ks_eps eps, double tol /*<=0: 1e-8*/, int max_it /*<=0: default*/);
 int ks_eps_set_which_eigenpairs(ks_eps eps, int which);
+int ks_eps_get_st(ks_eps eps, ks_st *st);                                    /* EPSGetST: borrowed, owned by the EPS */
 int ks_eps_set_target(ks_eps eps, double target);                            /* EPSSetTarget epsopts.c:604 (sorting only: no spectral transformation) */
 int ks_eps_set_eigenvalue_comparison(ks_eps eps, ks_eig_compare_fn fn, void *ctx);   /* EPSSetEigenvalueComparison epsopts.c:563 */
 int ks_eps_set_krylovschur_restart(ks_eps eps, double keep);               /* EPSKrylovSchurSetRestart, default 0.5 */
@@ -204,6 +215,22 @@ int ks_eps_get_error_estimate(ks_eps eps, int i, double *errest);
 int ks_eps_compute_error(ks_eps eps, int i, int type, double *error);      /* EPSComputeError epssolve.c:742 */
 int ks_eps_get_bv(ks_eps eps, ks_bv *V);
 int ks_eps_get_stats(ks_eps eps, long long *arnoldi_steps, long long *gs_passes, int *restarts);
+
+/* ---- ST: spectral transformation (slepcst.h) ---------------------------------------------------
+   STSHIFT and STSINVERT in matrix mode "shell" (A - sigma*B is applied, never assembled); the linear solves are
+   GMRES(restart) + Jacobi, the KSP that mode defaults to (stsles.c:51-53), run on the BV kernels of this library.
+   An EPS owns one ST (ks_eps_get_st = EPSGetST); ks_st_create makes a stand-alone one. */
+int ks_st_create(ks_ctx ctx, ks_st *st);
+int ks_st_destroy(ks_st st);
+int ks_st_set_type(ks_st st, int type);                                   /* STSetType */
+int ks_st_set_shift(ks_st st, double sigma);                              /* STSetShift */
+int ks_st_get_shift(ks_st st, double *sigma);
+int ks_st_set_matrices(ks_st st, ks_mat A, ks_mat B /* may be NULL */);   /* STSetMatrices */
+int ks_st_set_ksp(ks_st st, double rtol, int max_it, int restart);        /* KSPSetTolerances / KSPGMRESSetRestart on STGetKSP; 0 keeps */
+int ks_st_setup(ks_st st);                                                /* STSetUp */
+int ks_st_apply(ks_st st, const double *x_dev, double *y_dev);            /* STApply stsolve.c:44 */
+int ks_st_backtransform(ks_st st, int n, double *eigr, double *eigi);     /* STBackTransform stsolve.c:563 */
+int ks_st_get_ksp_stats(ks_st st, long long *solves, long long *iterations, double *last_rnorm);
 
 /* ---- profiling: HIP-event timing per kernel class, on the context's stream -------------------- */
 /* A class is one __global__ kernel template; `variant` is its compile-time column tile KT (0 when

@@ -354,6 +354,22 @@ class BV:
         _chk(self._lib.orc_bv_matarnoldi(self._h, A._h, _p(H), H.shape[0], k, C.byref(mm), C.byref(beta), C.byref(brk)))
         return mm.value, beta.value, bool(brk.value)
 
+    def MatArnoldiOp(self, op, H, k, m):
+        """BVMatArnoldi (bvkrylov.c:56-113) with the operator given as a callable y = op(x) (an ST operator)."""
+        brk = False; beta = 0.0
+        for j in range(k, m):
+            self.set_column(j + 1, op(np.array(self.column(j))))
+            beta, brk = self.OrthonormalizeColumn(j + 1)
+            if brk:
+                m = j + 1
+                break
+        for j in range(k, m - 1):
+            H[: j + 2, j] = self.buffer[: j + 2, j + 1]
+        H[:m, m - 1] = self.buffer[:m, m]
+        if H.shape[0] > m:
+            H[m, m - 1] = self.buffer[m, m]
+        return m, beta, brk
+
 
 # ------------------------------------------------------------------------------------------------
 # LAPACK entry points (the very routines the reference calls), taken from scipy's bundled LAPACK
@@ -883,10 +899,52 @@ class DSNHEP:
         return self.Q[:rows, : self.n]
 
 
+class ST:
+    """Spectral transformation, types shift and sinvert (src/sys/classes/st/impls/shift/shift.c:16-97,
+    sinvert/sinvert.c:16-77). Operator per STApply_Generic (stsolve.c:16-25): y = P^-1 M x with
+        shift:   nmat=1  M = A - sigma I, P = none      nmat=2  M = A - sigma B, P = B
+        sinvert: nmat=1  M = none,        P = A - sigma I   nmat=2  M = B,       P = A - sigma B
+    The linear solves use the reference's default KSP, preonly + LU (stsles.c:54-56), here SuperLU through scipy."""
+
+    def __init__(self, A, B=None, kind="shift", sigma=0.0):
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spl
+        self.kind = kind; self.sigma = float(sigma); self.n = A.n
+        Sa = A.to_scipy().tocsc()
+        Sb = B.to_scipy().tocsc() if B is not None else None
+        Ib = Sb if Sb is not None else sp.identity(A.n, format="csc")
+        T = (Sa - self.sigma * Ib).tocsc() if self.sigma != 0.0 else Sa
+        if kind == "shift":
+            self.M = T.tocsr(); self.lu = spl.splu(Sb) if Sb is not None else None
+        elif kind == "sinvert":
+            self.M = Sb.tocsr() if Sb is not None else None; self.lu = spl.splu(T)
+        else:
+            raise ValueError(kind)
+        self.solves = 0
+
+    def apply(self, x):
+        y = self.M @ x if self.M is not None else x
+        if self.lu is not None:
+            y = self.lu.solve(np.ascontiguousarray(y)); self.solves += 1
+        return y
+
+    def backtransform(self, re, im):
+        if self.kind == "shift":                       # shift.c:49-56
+            return re + self.sigma, im
+        if im == 0.0:                                  # sinvert.c:16-40 (real scalars)
+            return 1.0 / re + self.sigma, 0.0
+        t = re * re + im * im
+        return re / t + self.sigma, -im / t
+
+
 def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which="largest_magnitude", keep=0.5,
-                         seed=0x12345678, v0=None, max_steps=None):
+                         seed=0x12345678, v0=None, max_steps=None, st=None):
     """EPSSolve_KrylovSchur_Default with the Arnoldi expansion (krylovschur.c:227-337, non-Hermitian branch),
-    EPSKrylovConvergence for conjugate pairs (epskrylov.c:262-287), EPSComputeVectors_Schur (epsdefault.c:105-169)."""
+    EPSKrylovConvergence for conjugate pairs (epskrylov.c:262-287), EPSComputeVectors_Schur (epsdefault.c:105-169).
+    With st (an ST): the Krylov operator is st.apply, the DS sorts through the back-transformation
+    (EPSSetUpSort_Default epssetup.c:222-240, SlepcSCCompare slepcsc.c:41-62), convergence is tested on the
+    transformed eigenvalue except for STSHIFT (epskrylov.c:253), and EPSComputeValues maps the eigenvalues back
+    (epssolve.c:27-41) before the conjugate-pair fix-up and the final sort (epssolve.c:160-178)."""
     n = A.n
     if ncv is None:
         ncv = min(n, nev + mpd) if mpd is not None else (min(n, max(2 * nev, nev + 15)) if nev < 500 else min(n, nev + 500))
@@ -895,8 +953,14 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
     if max_it is None:
         max_it = max(100, 2 * n // ncv)
     compare = which if callable(which) else WHICH[which]
+    if st is not None:
+        def ds_compare(ar, ai, br, bi):
+            ar, ai = st.backtransform(ar, ai); br, bi = st.backtransform(br, bi)
+            return compare(ar, ai, br, bi)
+    else:
+        ds_compare = compare
     V = BV(n, ncv + 1)
-    ds = DSNHEP(ncv + 1, compare)
+    ds = DSNHEP(ncv + 1, ds_compare)
     eigr = np.zeros(ncv + 1); eigi = np.zeros(ncv + 1); errest = np.zeros(ncv + 1)
 
     def start_vector(i):
@@ -920,7 +984,10 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
         k0 = nconv + l
         H = ds.A[: nv + 1, :nv]                       # DSGetMat(DS_MAT_A): (n+1) x n with the extra row
         Hs = np.asfortranarray(ds.A)                  # BVMatArnoldi writes through ld = ds.ld
-        nv, beta, breakdown = V.MatArnoldi(A, Hs, k0, nv)
+        if st is None:
+            nv, beta, breakdown = V.MatArnoldi(A, Hs, k0, nv)
+        else:
+            nv, beta, breakdown = V.MatArnoldiOp(st.apply, Hs, k0, nv)
         ds.A[:, :] = Hs
         steps += nv - k0
         ds.SetDimensions(nv, nconv, nconv + l)
@@ -934,6 +1001,8 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
         k = nconv
         while k < nv:
             re, im = eigr[k], eigi[k]
+            if st is not None and st.kind == "shift":
+                re, im = st.backtransform(re, im)
             newk, resnorm = ds.Vectors(k)
             resnorm *= beta
             w = np.hypot(re, im)
@@ -976,7 +1045,19 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
     ds.Q[:, :] = Qsave
     if nconv:
         V.MultInPlace(Z, 0, nconv)
-    # conjugate pairs: positive imaginary part first (epssolve.c:163-175) - trexc already orders them so
+    if st is not None:                 # EPSComputeValues -> EPSBackTransform_Default
+        for i in range(nconv):
+            eigr[i], eigi[i] = st.backtransform(eigr[i], eigi[i])
+    # conjugate pairs: positive imaginary part first (epssolve.c:163-175); trexc orders them so, but the inversion
+    # of sinvert flips the sign of the imaginary parts
+    i = 0
+    while i < nconv - 1:
+        if eigi[i] != 0:
+            if eigi[i] < 0:
+                eigi[i] = -eigi[i]; eigi[i + 1] = -eigi[i + 1]
+                V.ScaleColumn(i + 1, -1.0)
+            i += 1
+        i += 1
     # final sort keeping pairs together (slepcsc.c:89-140)
     perm = list(range(nconv))
     i = nconv - 1
@@ -1008,22 +1089,23 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
     return res
 
 
-def eps_compute_error_nhep(A, res, i):
-    """EPSComputeError relative, real-arithmetic pair form (epssolve.c:666-718)."""
+def eps_compute_error_nhep(A, res, i, B=None):
+    """EPSComputeError relative, real-arithmetic pair form (epssolve.c:666-718): ||A x - k B x|| / |k|."""
     j = int(res.perm[i])
     kr, ki = res.eigr[j], res.eigi[j]
     S = A.to_scipy()
+    Bm = (lambda v: B.to_scipy() @ v) if B is not None else (lambda v: v)
     if ki == 0 or abs(ki) < abs(kr * np.finfo(float).eps):
         x = np.array(res.V.column(j))
-        u = S @ x - kr * x
+        u = S @ x - kr * Bm(x)
         nrm = np.linalg.norm(u)
     else:
         jr = j if ki > 0 else j - 1                 # BV_GetEigenvector bvimpl.h:423-446
         xr = np.array(res.V.column(jr)); xi = np.array(res.V.column(jr + 1))
         if ki < 0:
             xi = -xi
-        u = S @ xr - kr * xr + ki * xi
+        u = S @ xr - kr * Bm(xr) + ki * Bm(xi)
         nr = np.linalg.norm(u)
-        u = S @ xi - kr * xi - ki * xr
+        u = S @ xi - kr * Bm(xi) - ki * Bm(xr)
         nrm = np.hypot(nr, np.linalg.norm(u))
     return nrm / np.hypot(kr, ki)

@@ -23,11 +23,13 @@ CGS, MGS = 0, 1
 REFINE_IFNEEDED, REFINE_NEVER, REFINE_ALWAYS = 0, 1, 2
 NORM_1, NORM_2, NORM_FROBENIUS, NORM_INFINITY = 0, 1, 2, 3
 EPS_LARGEST_MAGNITUDE, EPS_SMALLEST_MAGNITUDE, EPS_LARGEST_REAL, EPS_SMALLEST_REAL = 1, 2, 3, 4
-EPS_HEP, EPS_NHEP = 1, 3
+EPS_HEP, EPS_NHEP, EPS_GNHEP = 1, 3, 4
 EPS_ERROR_ABSOLUTE, EPS_ERROR_RELATIVE = 0, 1
 EPS_CONVERGED_TOL, EPS_CONVERGED_USER, EPS_DIVERGED_ITS, EPS_DIVERGED_BREAKDOWN = 1, 2, -1, -2
 WHICH = {"largest_magnitude": 1, "smallest_magnitude": 2, "largest_real": 3, "smallest_real": 4,
          "largest_imaginary": 5, "smallest_imaginary": 6, "target_magnitude": 7, "target_real": 8, "user": 11}
+SHELL_MULT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+ST_SHIFT, ST_SINVERT = 0, 1
 EIG_COMPARE_FN = C.CFUNCTYPE(C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_void_p)
 
 KCLASSES = ["spmv_csr", "bv_dot_sweep", "gs_bookkeeping", "gs_update_fused_dot", "gs_update", "bv_scale", "bv_multinplace",
@@ -196,6 +198,28 @@ class Mat:
         h = C.c_void_p()
         _lib.check(ctx.L.ks_mat_create_laplacian2d(ctx.h, n, n if m is None else m, C.byref(h)))
         return cls(ctx, h)
+
+    @classmethod
+    def shell(cls, ctx, n, mult, row_start=0, n_global=None):
+        """MatCreateShell + MATOP_MULT: mult(x_ptr, y_ptr) works on device pointers (n doubles each)."""
+        def tramp(_user, x, y):
+            try:
+                mult(x, y)
+                return 0
+            except KsError as e:
+                return e.rc
+        cb = SHELL_MULT_FN(tramp)
+        h = C.c_void_p()
+        _lib.check(ctx.L.ks_mat_create_shell(ctx.h, n, row_start, n if n_global is None else n_global, C.cast(cb, C.c_void_p), None, C.byref(h)))
+        m = cls(ctx, h)
+        m._cb = cb                      # keep the trampoline alive as long as the matrix
+        return m
+
+    def get_diagonal(self):
+        """MatGetDiagonal of the local diagonal block, as a host array (test convenience)."""
+        V = BV(self.ctx, self.n, 1)
+        _lib.check(self.ctx.L.ks_mat_get_diagonal(self.h, C.c_void_p(V.column_ptr(0))))
+        return V.column(0)
 
     def destroy(self):
         if self.h and self.ctx.h:      # a closed context already released the device; never touch it again
@@ -414,6 +438,65 @@ class BV:
         return mm.value, beta.value, bool(brk.value)
 
 
+class ST:
+    """Spectral transformation (STSHIFT / STSINVERT, shell matrix mode, GMRES + Jacobi inner solves)."""
+
+    def __init__(self, ctx, _handle=None):
+        self.ctx = ctx
+        self._owned = _handle is None
+        if _handle is None:
+            _handle = C.c_void_p(); _lib.check(ctx.L.ks_st_create(ctx.h, C.byref(_handle)))
+        self.h = _handle
+
+    def destroy(self):
+        if self._owned and self.h and self.ctx.h:
+            self.ctx.L.ks_st_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def SetType(self, t):
+        _lib.check(self.ctx.L.ks_st_set_type(self.h, {"shift": ST_SHIFT, "sinvert": ST_SINVERT}.get(t, t)))
+
+    def SetShift(self, sigma):
+        _lib.check(self.ctx.L.ks_st_set_shift(self.h, sigma))
+
+    def GetShift(self):
+        v = C.c_double(); _lib.check(self.ctx.L.ks_st_get_shift(self.h, C.byref(v))); return v.value
+
+    def SetMatrices(self, A, B=None):
+        _lib.check(self.ctx.L.ks_st_set_matrices(self.h, A.h, None if B is None else B.h))
+        self._A, self._B = A, B
+
+    def SetKSP(self, rtol=0.0, max_it=0, restart=0):
+        _lib.check(self.ctx.L.ks_st_set_ksp(self.h, rtol, max_it, restart))
+
+    def SetUp(self):
+        _lib.check(self.ctx.L.ks_st_setup(self.h))
+
+    def Apply(self, x):
+        """y = Op x with host vectors (test convenience, single rank)."""
+        x = _f64(x)
+        W = BV(self.ctx, len(x), 2)
+        W.set_column(0, x)
+        _lib.check(self.ctx.L.ks_st_apply(self.h, C.c_void_p(W.column_ptr(0)), C.c_void_p(W.column_ptr(1))))
+        return W.column(1)
+
+    def BackTransform(self, eigr, eigi):
+        r = _f64(np.atleast_1d(eigr)).copy(); i = _f64(np.atleast_1d(eigi)).copy()
+        _lib.check(self.ctx.L.ks_st_backtransform(self.h, len(r), _p(r), _p(i)))
+        return r, i
+
+    def GetKSPStats(self):
+        s = C.c_longlong(); it = C.c_longlong(); r = C.c_double()
+        _lib.check(self.ctx.L.ks_st_get_ksp_stats(self.h, C.byref(s), C.byref(it), C.byref(r)))
+        return {"solves": s.value, "iterations": it.value, "last_rnorm": r.value}
+
+
 class EPS:
     """EPSCreate/EPSSetOperators/EPSSolve... for the default Krylov-Schur solver (symmetric problems)."""
 
@@ -437,7 +520,11 @@ class EPS:
 
     def SetOperators(self, A, B=None):
         _lib.check(self.ctx.L.ks_eps_set_operators(self.h, A.h, None if B is None else B.h))
-        self._A = A
+        self._A = A; self._B = B
+
+    def GetST(self):
+        h = C.c_void_p(); _lib.check(self.ctx.L.ks_eps_get_st(self.h, C.byref(h)))
+        return ST(self.ctx, _handle=h)
 
     def SetProblemType(self, t):
         _lib.check(self.ctx.L.ks_eps_set_problem_type(self.h, t))

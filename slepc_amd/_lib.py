@@ -44,6 +44,8 @@ _SIG = {
     "ks_mat_create_laplacian3d": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
     "ks_mat_create_laplacian2d": [vp, C.c_int, C.c_int, C.POINTER(vp)],
     "ks_mat_destroy": [vp],
+    "ks_mat_create_shell": [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(vp)],
+    "ks_mat_get_diagonal": [vp, vp],
     "ks_mat_get_sizes": [vp, ip, ip, llp],
     "ks_mat_mult": [vp, vp, vp],
     "ks_mat_mult_host": [vp, dp, dp],
@@ -114,6 +116,18 @@ _SIG = {
     "ks_eps_compute_error": [vp, C.c_int, C.c_int, dp],
     "ks_eps_get_bv": [vp, C.POINTER(vp)],
     "ks_eps_get_stats": [vp, llp, llp, ip],
+    "ks_eps_get_st": [vp, C.POINTER(vp)],
+    "ks_st_create": [vp, C.POINTER(vp)],
+    "ks_st_destroy": [vp],
+    "ks_st_set_type": [vp, C.c_int],
+    "ks_st_set_shift": [vp, C.c_double],
+    "ks_st_get_shift": [vp, dp],
+    "ks_st_set_matrices": [vp, vp, vp],
+    "ks_st_set_ksp": [vp, C.c_double, C.c_int, C.c_int],
+    "ks_st_setup": [vp],
+    "ks_st_apply": [vp, vp, vp],
+    "ks_st_backtransform": [vp, C.c_int, dp, dp],
+    "ks_st_get_ksp_stats": [vp, llp, llp, dp],
     # profiling
     "ks_prof_enable": [vp, C.c_int],
     "ks_prof_reset": [vp],

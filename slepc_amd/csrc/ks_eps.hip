@@ -98,13 +98,15 @@ int tridiag_ql(int n, double *d, double *e, double *Z, int ldz, int nz)
 // SlepcCompare* (src/sys/slepcsc.c:152-300), real scalars; EPS_WHICH_USER calls the function installed with
 // ks_eps_set_eigenvalue_comparison (EPSSetEigenvalueComparison epsopts.c:563)
 struct KsCompare {
-  int which = KS_EPS_LARGEST_MAGNITUDE;
+  int which = 0;                      // 0 = not set: resolved at set-up (EPSSetWhichEigenpairs_Default epsdefault.c:209-219)
   double target = 0.0;
   ks_eig_compare_fn fn = nullptr; void *fn_ctx = nullptr;
+  ks_st map = nullptr;                // SlepcMap_ST: compare the back-transformed values (SlepcSCCompare slepcsc.c:41-62)
 };
 int compare_eig(const KsCompare &cmp, double ar, double ai, double br, double bi)
 {
   double a, b;
+  if (cmp.map) { ks_st_backtransform_internal(cmp.map, 1, &ar, &ai); ks_st_backtransform_internal(cmp.map, 1, &br, &bi); }
   switch (cmp.which) {
     case KS_EPS_LARGEST_MAGNITUDE:  a = hypot(ar, ai); b = hypot(br, bi); return a < b ? 1 : (a > b ? -1 : 0);
     case KS_EPS_SMALLEST_MAGNITUDE: a = hypot(ar, ai); b = hypot(br, bi); return a > b ? 1 : (a < b ? -1 : 0);
@@ -322,12 +324,15 @@ struct DsNhep {
 
 struct ks_eps_s {
   ks_ctx ctx = nullptr;
-  ks_mat A = nullptr;
-  ks_bv V = nullptr, W = nullptr;      // basis (ncv+1 columns), work vectors (2 columns)
+  ks_mat A = nullptr, B = nullptr;
+  ks_mat op = nullptr;                 // operator of the expansion: A itself, or the ST's shell matrix
+  ks_st st = nullptr;                  // owned (EPSGetST)
+  ks_bv V = nullptr, W = nullptr;      // basis (ncv+1 columns), work vectors (3 columns)
   int problem_type = KS_EPS_HEP;
   int nev = 1, ncv = 0, mpd = 0, ncv_user = 0, mpd_user = 0;
   double tol = 1e-8; int max_it = 0, max_it_user = 0;
-  KsCompare which;
+  KsCompare which;                     // user settings; cmp_ds / cmp_final are what a solve uses
+  KsCompare cmp_ds, cmp_final;
   double keep = 0.5;
   uint64_t seed = 0x12345678ULL;
   std::vector<double> v0; bool have_v0 = false;
@@ -352,6 +357,7 @@ extern "C" int ks_eps_destroy(ks_eps eps)
 {
   if (!eps) return KS_SUCCESS;
   ks_bv_destroy(eps->V); ks_bv_destroy(eps->W);
+  ks_st_destroy(eps->st);
   delete eps;
   return KS_SUCCESS;
 }
@@ -359,15 +365,23 @@ extern "C" int ks_eps_destroy(ks_eps eps)
 extern "C" int ks_eps_set_operators(ks_eps eps, ks_mat A, ks_mat B)   // epssetup.c:450
 {
   KS_CHECK(eps && A, KS_ERR_ARG_NULL, "NULL argument");
-  KS_CHECK(!B, KS_ERR_SUP, "generalized problems (B != NULL) are outside this build's scope");
+  KS_CHECK(!B || (B->n == A->n && B->n_global == A->n_global), KS_ERR_ARG_INCOMP, "Mismatching dimensions of A (%d) and B (%d)", A->n, B ? B->n : 0);
   if (eps->V && eps->A && eps->A->n != A->n) { ks_bv_destroy(eps->V); ks_bv_destroy(eps->W); eps->V = eps->W = nullptr; }
-  eps->A = A; eps->solved = false;
+  eps->A = A; eps->B = B; eps->solved = false;
+  if (eps->st) KS_CALL(ks_st_set_matrices(eps->st, A, B));
+  return KS_SUCCESS;
+}
+extern "C" int ks_eps_get_st(ks_eps eps, ks_st *st)                     // EPSGetST epsbasic.c
+{
+  KS_CHECK(eps && st, KS_ERR_ARG_NULL, "NULL argument");
+  if (!eps->st) { KS_CALL(ks_st_create(eps->ctx, &eps->st)); if (eps->A) KS_CALL(ks_st_set_matrices(eps->st, eps->A, eps->B)); }
+  *st = eps->st; eps->solved = false;
   return KS_SUCCESS;
 }
 extern "C" int ks_eps_set_problem_type(ks_eps eps, int type)
 {
   KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
-  KS_CHECK(type == KS_EPS_HEP || type == KS_EPS_NHEP, KS_ERR_SUP, "only EPS_HEP (Lanczos) and EPS_NHEP (Arnoldi) are driven by this build; generalized problems are out of scope");
+  KS_CHECK(type == KS_EPS_HEP || type == KS_EPS_NHEP || type == KS_EPS_GNHEP, KS_ERR_SUP, "EPS_HEP (Lanczos), EPS_NHEP and EPS_GNHEP (Arnoldi) are driven by this build; GHEP needs the B-inner product, which is not built");
   eps->problem_type = type; eps->solved = false; return KS_SUCCESS;
 }
 extern "C" int ks_eps_set_dimensions(ks_eps eps, int nev, int ncv, int mpd)
@@ -398,7 +412,9 @@ extern "C" int ks_eps_set_which_eigenpairs(ks_eps eps, int which)
 extern "C" int ks_eps_set_target(ks_eps eps, double target)                     // EPSSetTarget epsopts.c:604
 {
   KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
-  eps->which.target = target; eps->solved = false; return KS_SUCCESS;
+  eps->which.target = target; eps->solved = false;
+  if (eps->st && !eps->st->sigma_set) { eps->st->sigma = target; eps->st->ready = false; }   // STSetDefaultShift (epsbasic.c:386)
+  return KS_SUCCESS;
 }
 extern "C" int ks_eps_set_eigenvalue_comparison(ks_eps eps, ks_eig_compare_fn fn, void *fctx)   // epsopts.c:563
 {
@@ -442,10 +458,12 @@ static int start_vector(ks_eps eps, int i, bool *breakdown)
 // pair-aware SlepcSortEigenvalues (slepcsc.c:89-140).
 static int solve_nhep(ks_eps eps, long long passes0)
 {
-  ks_mat A = eps->A; ks_bv V = eps->V;
+  ks_mat A = eps->op; ks_bv V = eps->V;
   const int nev = eps->nev, ncv = eps->ncv, mpd = eps->mpd;
+  ks_st map = eps->cmp_ds.map;
+  const bool isshift = !map || map->type == KS_ST_SHIFT;
   DsNhep &ds = eps->dsn;
-  ds.allocate(ncv + 1); ds.which = eps->which; ds.state = DS_RAW;
+  ds.allocate(ncv + 1); ds.which = eps->cmp_ds; ds.state = DS_RAW;
   KS_CALL(start_vector(eps, 0, nullptr));
   int l = 0;
   while (eps->reason == KS_EPS_CONVERGED_ITERATING) {
@@ -470,7 +488,8 @@ static int solve_nhep(ks_eps eps, long long passes0)
     // EPSKrylovConvergence(eps,FALSE,nconv,nv-nconv,beta,0.0,1.0,&k)
     int marker = -1, k;
     for (k = eps->nconv; k < nv; k++) {
-      const double re = eps->eigr[k], im = eps->eigi[k];
+      double re = eps->eigr[k], im = eps->eigi[k];
+      if (isshift && map) ks_st_backtransform_internal(map, 1, &re, &im);          // epskrylov.c:253
       double resnorm = 0.0;
       const int newk = ds.vectors(k, true, &resnorm);
       resnorm *= beta;
@@ -513,6 +532,15 @@ static int solve_nhep(ks_eps eps, long long passes0)
     for (int k = 0; k < nc; k++) k = ds.vectors(k, false, nullptr);
     KS_CALL(ks_bv_multinplace(V, ds.X.data(), ds.ld, 0, nc));
   }
+  // EPSComputeValues (epssolve.c:27-41), then conjugate pairs with the positive imaginary part first (:160-175):
+  // the inversion of sinvert flips the sign
+  if (map) ks_st_backtransform_internal(map, nc, eps->eigr.data(), eps->eigi.data());
+  for (int i = 0; i < nc - 1; i++) {
+    if (eps->eigi[i] != 0.0) {
+      if (eps->eigi[i] < 0.0) { eps->eigi[i] = -eps->eigi[i]; eps->eigi[i + 1] = -eps->eigi[i + 1]; KS_CALL(ks_bv_scalecolumn(V, i + 1, -1.0)); }
+      i++;
+    }
+  }
   // SlepcSortEigenvalues keeping conjugate pairs together
   std::vector<int> &perm = eps->perm;
   const double *eigr = eps->eigr.data(), *eigi = eps->eigi.data();
@@ -522,7 +550,7 @@ static int solve_nhep(ks_eps eps, long long passes0)
     int j = i + 1;
     if (im != 0.0) { i--; im = eigi[perm[i]]; }                // complex eigenvalue: positive imaginary part first
     while (j < nc) {
-      if (compare_eig(eps->which, re, im, eigr[perm[j]], eigi[perm[j]]) <= 0) break;
+      if (compare_eig(eps->cmp_final, re, im, eigr[perm[j]], eigi[perm[j]]) <= 0) break;
       if (im == 0.0) {
         if (eigi[perm[j]] == 0.0) { std::swap(perm[j - 1], perm[j]); j++; }
         else { const int tmp = perm[j - 1]; perm[j - 1] = perm[j]; perm[j] = perm[j + 1]; perm[j + 1] = tmp; j += 2; }
@@ -543,8 +571,26 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   KS_CHECK(eps && eps->A, KS_ERR_ORDER, "EPSSetOperators must be called first");
   ks_mat A = eps->A;
   const int n = A->n_global;
-  // ---- EPSSetUp ----
+  // ---- EPSSetUp (epssetup.c:286-420) ----
   KS_CHECK(eps->which.which != KS_EPS_WHICH_USER || eps->which.fn, KS_ERR_ORDER, "Must call EPSSetEigenvalueComparison() first");   // epssetup.c:311
+  int ptype = eps->problem_type;
+  if (!eps->B && ptype == KS_EPS_GNHEP) ptype = KS_EPS_NHEP;          // "reverting to a standard eigenproblem" (epssetup.c:324-327)
+  KS_CHECK(!eps->B || ptype == KS_EPS_GNHEP, KS_ERR_ARG_INCOMP, "Inconsistent EPS state: the problem type does not match the number of matrices");
+  ks_st st = eps->st;
+  const bool sinvert = st && st->type == KS_ST_SINVERT;
+  if (st && !st->sigma_set) { if (st->sigma != eps->which.target) st->ready = false; st->sigma = eps->which.target; }   // shift defaults to the target (sinvert.c:62)
+  KsCompare cmp = eps->which;
+  if (!cmp.which) cmp.which = sinvert ? KS_EPS_TARGET_MAGNITUDE : KS_EPS_LARGEST_MAGNITUDE;   // epsdefault.c:209-219
+  KS_CHECK(!sinvert || cmp.which == KS_EPS_TARGET_MAGNITUDE || cmp.which == KS_EPS_TARGET_REAL || cmp.which == KS_EPS_WHICH_USER, KS_ERR_USER_INPUT,
+           "Shift-and-invert requires a target 'which' (see EPSSetWhichEigenpairs), for instance -st_type sinvert -eps_target 0 -eps_target_magnitude");   // epssetup.c:117-120
+  eps->cmp_final = cmp;                                              // EPSSetUpSort_Basic: eps->sc, no map
+  eps->cmp_ds = cmp;                                                 // EPSSetUpSort_Default: DS sc with map = SlepcMap_ST
+  if (eps->B || !ks_st_is_plain(st)) {
+    if (!st) { KS_CALL(ks_eps_get_st(eps, &st)); }
+    KS_CALL(ks_st_set_matrices(st, A, eps->B)); st->ready = false;
+    KS_CALL(ks_st_setup_internal(st));
+    eps->op = st->op; eps->cmp_ds.map = st;
+  } else eps->op = A;
   int nev = eps->nev, ncv = eps->ncv_user, mpd = eps->mpd_user;
   if (ncv) { KS_CHECK(ncv >= nev + 1 || (ncv == nev && ncv == n), KS_ERR_USER_INPUT, "The value of ncv must be at least nev+1"); }
   else if (mpd) ncv = std::min(n, nev + mpd);
@@ -560,13 +606,14 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   eps->eigr.assign(ncv + 1, 0.0); eps->eigi.assign(ncv + 1, 0.0); eps->errest.assign(ncv + 1, 0.0);
   eps->perm.resize(ncv + 1); for (int i = 0; i <= ncv; i++) eps->perm[i] = i;
   DsHep &ds = eps->ds;
-  ds.allocate(ncv + 1); ds.which = eps->which; ds.state = DS_RAW;
+  ds.allocate(ncv + 1); ds.which = eps->cmp_ds; ds.state = DS_RAW;
   eps->nconv = 0; eps->its = 0; eps->reason = KS_EPS_CONVERGED_ITERATING; eps->steps = 0; eps->restarts = 0; eps->solved = false;
   long long passes0 = 0; ks_bv_gs_passes(eps->V, &passes0, nullptr);
   ks_bv V = eps->V;
   KS_CALL(ks_bv_set_active_columns(V, 0, ncv + 1));
 
-  if (eps->problem_type == KS_EPS_NHEP) return solve_nhep(eps, passes0);
+  if (ptype != KS_EPS_HEP) return solve_nhep(eps, passes0);
+  const bool isshift = !st || st->type == KS_ST_SHIFT;
 
   // ---- EPSSolve_KrylovSchur_Default ----
   KS_CALL(start_vector(eps, 0, nullptr));
@@ -578,7 +625,7 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
     ds.set_dimensions(nv, eps->nconv, eps->nconv + l);
     double beta = 0.0; int breakdown = 0;
     const int k0 = eps->nconv + l;
-    KS_CALL(ks_bv_matlanczos(V, A, ds.T.data(), ds.ld, k0, &nv, &beta, &breakdown));
+    KS_CALL(ks_bv_matlanczos(V, eps->op, ds.T.data(), ds.ld, k0, &nv, &beta, &breakdown));
     eps->steps += nv - k0;
     ds.set_dimensions(nv, eps->nconv, eps->nconv + l);
     ds.state = l ? DS_RAW : DS_INTERMEDIATE;
@@ -593,7 +640,8 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
     // EPSKrylovConvergence(eps,FALSE,nconv,nv-nconv,beta,0.0,1.0,&k)
     int marker = -1, k;
     for (k = eps->nconv; k < nv; k++) {
-      const double re = eps->eigr[k];              // shift ST with sigma=0: STBackTransform is the identity (shift.c:49)
+      double re = eps->eigr[k], im0 = 0.0;
+      if (isshift && eps->cmp_ds.map) ks_st_backtransform_internal(eps->cmp_ds.map, 1, &re, &im0);   // epskrylov.c:253 (identity for sigma = 0)
       const double resnorm = ds.vectors_resnorm(k) * beta * 1.0;
       const double w = fabs(re);
       eps->errest[k] = (w != 0.0) ? resnorm / w : std::numeric_limits<double>::max();     // EPSConvergedRelative
@@ -628,14 +676,16 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
 
   // ---- EPSSolve epilogue ----
   KS_CALL(ks_bv_set_active_columns(V, 0, eps->nconv));
-  // SlepcSortEigenvalues slepcsc.c:89-140 (all eigenvalues real here)
+  // EPSComputeValues (epssolve.c:27-41): map the eigenvalues back through the ST
   const int nc = eps->nconv;
+  if (eps->cmp_ds.map) ks_st_backtransform_internal(eps->cmp_ds.map, nc, eps->eigr.data(), eps->eigi.data());
+  // SlepcSortEigenvalues slepcsc.c:89-140 (all eigenvalues real here)
   for (int i = 0; i <= ncv; i++) eps->perm[i] = i;
   for (int i = nc - 1; i >= 0; i--) {
     const double re = eps->eigr[eps->perm[i]];
     int j = i + 1;
     while (j < nc) {
-      if (compare_eig(eps->which, re, 0.0, eps->eigr[eps->perm[j]], 0.0) <= 0) break;
+      if (compare_eig(eps->cmp_final, re, 0.0, eps->eigr[eps->perm[j]], 0.0) <= 0) break;
       std::swap(eps->perm[j - 1], eps->perm[j]); j++;
     }
   }
@@ -706,34 +756,36 @@ extern "C" int ks_eps_compute_error(ks_eps eps, int i, int type, double *error) 
   KS_CHECK(i >= 0 && i < eps->nconv, KS_ERR_ARG_OUTOFRANGE, "The index can be nconv-1 at most, see EPSGetConverged()");
   const int j = eps->perm[i];
   const double kr = eps->eigr[j], ki = eps->eigi[j];
-  ks_bv W = eps->W, V = eps->V;
+  ks_bv W = eps->W, V = eps->V; ks_ctx ctx = eps->ctx; ks_mat A = eps->A, B = eps->B;
+  const long long n = V->n;
+  double *u = ks_bv_col(W, 0);
   double nrm = 0.0;
+  // EPSComputeResidualNorm_Private epssolve.c:666-718 (STGetMatrix 0/1 = the user's A and B)
   if (ki == 0.0 || fabs(ki) < fabs(kr * std::numeric_limits<double>::epsilon())) {
-    // W0 = x ; W2 = u = A*x ; u -= kr*x ; ||u||
-    KS_CALL(ksk_copy(eps->ctx, ks_bv_col(V, j), ks_bv_col(W, 0), V->n));
-    KS_CALL(ks_mat_mult_internal(eps->A, ks_bv_col(W, 0), ks_bv_col(W, 2)));
+    const double *x = ks_bv_col(V, j);
+    KS_CALL(ks_mat_mult_internal(A, x, u));                                         // u = A*x
     if (fabs(kr) > std::numeric_limits<double>::epsilon()) {
-      KS_CALL(ks_bv_set_active_columns(W, 0, 1));
-      const double q = -kr;                                   // VecAXPY(u,-kr,w)
-      KS_CALL(ks_bv_multvec(W, 1.0, 1.0, ks_bv_col(W, 2), &q));
+      const double *w = x;
+      if (B) { KS_CALL(ks_mat_mult_internal(B, x, ks_bv_col(W, 2))); w = ks_bv_col(W, 2); }   // w = B*x
+      KS_CALL(ksk_lincomb(ctx, n, nullptr, 1.0, u, -kr, w, u));                      // u = A*x - k*B*x
     }
-    KS_CALL(ks_bv_normcolumn(W, 2, KS_NORM_2, &nrm));
+    KS_CALL(ks_bv_normcolumn(W, 0, KS_NORM_2, &nrm));
   } else {
-    // real arithmetic, complex pair (epssolve.c:690-712): W0 = xr, W1 = xi (sign per BV_GetEigenvector)
+    // complex pair in real arithmetic: xr = V(:,jr), xi = sg*V(:,jr+1) (BV_GetEigenvector bvimpl.h:423-446)
     const int jr = ki > 0.0 ? j : j - 1;
-    KS_CALL(ksk_copy(eps->ctx, ks_bv_col(V, jr), ks_bv_col(W, 0), V->n));
-    KS_CALL(ksk_copy(eps->ctx, ks_bv_col(V, jr + 1), ks_bv_col(W, 1), V->n));
-    if (ki < 0.0) KS_CALL(ks_bv_scalecolumn(W, 1, -1.0));
-    KS_CALL(ks_bv_set_active_columns(W, 0, 2));
-    double q[2], nr = 0.0, ni = 0.0;
-    KS_CALL(ks_mat_mult_internal(eps->A, ks_bv_col(W, 0), ks_bv_col(W, 2)));      // u = A*xr - kr*xr + ki*xi
-    q[0] = -kr; q[1] = ki;
-    KS_CALL(ks_bv_multvec(W, 1.0, 1.0, ks_bv_col(W, 2), q));
-    KS_CALL(ks_bv_normcolumn(W, 2, KS_NORM_2, &nr));
-    KS_CALL(ks_mat_mult_internal(eps->A, ks_bv_col(W, 1), ks_bv_col(W, 2)));      // u = A*xi - kr*xi - ki*xr
-    q[0] = -ki; q[1] = -kr;
-    KS_CALL(ks_bv_multvec(W, 1.0, 1.0, ks_bv_col(W, 2), q));
-    KS_CALL(ks_bv_normcolumn(W, 2, KS_NORM_2, &ni));
+    const double sg = ki > 0.0 ? 1.0 : -1.0;
+    const double *xr = ks_bv_col(V, jr), *xi = ks_bv_col(V, jr + 1);
+    const double *v = xr, *w = xi;                                                   // v = B*xr, w = B*(V(:,jr+1))
+    if (B) { KS_CALL(ks_mat_mult_internal(B, xr, ks_bv_col(W, 1))); KS_CALL(ks_mat_mult_internal(B, xi, ks_bv_col(W, 2))); v = ks_bv_col(W, 1); w = ks_bv_col(W, 2); }
+    double nr = 0.0, ni = 0.0;
+    KS_CALL(ks_mat_mult_internal(A, xr, u));                                        // u = A*xr - kr*B*xr + ki*B*xi
+    KS_CALL(ksk_lincomb(ctx, n, nullptr, 1.0, u, -kr, v, u));
+    KS_CALL(ksk_lincomb(ctx, n, nullptr, 1.0, u, ki * sg, w, u));
+    KS_CALL(ks_bv_normcolumn(W, 0, KS_NORM_2, &nr));
+    KS_CALL(ks_mat_mult_internal(A, xi, u));                                        // u = A*xi - kr*B*xi - ki*B*xr
+    KS_CALL(ksk_lincomb(ctx, n, nullptr, sg, u, -kr * sg, w, u));
+    KS_CALL(ksk_lincomb(ctx, n, nullptr, 1.0, u, -ki, v, u));
+    KS_CALL(ks_bv_normcolumn(W, 0, KS_NORM_2, &ni));
     nrm = hypot(nr, ni);
   }
   if (type == KS_EPS_ERROR_RELATIVE) nrm /= hypot(kr, ki) * 1.0;  // vecnorm = 1 (not GHEP)

@@ -506,6 +506,7 @@ extern "C" int ks_mat_get_sizes(ks_mat A, int *n_local, int *n_global, long long
 int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
 {
   ks_ctx ctx = A->ctx;
+  if (A->shell_mult) return A->shell_mult(A->shell_user, x, y);
   const bool multi = ctx->comm.size > 1 && (A->nsend > 0 || A->nghost > 0);
   if (multi) {
     KsProfScope ps(ctx, KS_K_HALO, 8.0 * (A->nsend + A->nghost));
@@ -532,6 +533,53 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
       launch_spmv<true, true>(ctx->stream, ctx->num_cu, 2, A->n_orows, A->o_rowptr, A->o_col, A->o_val, A->ghost, y, A->o_rows);
   }
   KS_HIP(hipGetLastError());
+  return KS_SUCCESS;
+}
+
+// MatGetDiagonal: entries (i,i) of the diagonal block, 0 where the pattern has none
+__global__ void k_diag_csr(int n, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val, double *__restrict__ d)
+{
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  double v = 0.0;
+  for (int p = rp[r]; p < rp[r + 1]; p++) if (col[p] == r) v += val[p];
+  d[r] = v;
+}
+__global__ void k_diag_sell(int n, const int *__restrict__ sp, const int *__restrict__ rlen, const int *__restrict__ col, const double *__restrict__ val, double *__restrict__ d)
+{
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const long long s = r >> 6, base = (long long)sp[s] * 64 + (r & 63);
+  double v = 0.0;
+  for (int j = 0; j < rlen[r]; j++) if (col[base + (long long)j * 64] == r) v += val[base + (long long)j * 64];
+  d[r] = v;
+}
+int ks_mat_get_diagonal_internal(ks_mat A, double *d)
+{
+  ks_ctx ctx = A->ctx;
+  KS_CHECK(!A->shell_mult, KS_ERR_SUP, "a matrix-free operator has no stored diagonal");
+  if (A->n == 0) return KS_SUCCESS;
+  const unsigned nb = (unsigned)((A->n + 255) / 256);
+  if (A->use_sell) hipLaunchKernelGGL(k_diag_sell, dim3(nb), dim3(256), 0, ctx->stream, A->n, A->s_ptr, A->s_len, A->s_col, A->s_val, d);
+  else hipLaunchKernelGGL(k_diag_csr, dim3(nb), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, d);
+  KS_HIP(hipGetLastError());
+  return KS_SUCCESS;
+}
+extern "C" int ks_mat_get_diagonal(ks_mat A, double *d_dev)
+{
+  KS_CHECK(A && d_dev, KS_ERR_ARG_NULL, "NULL argument");
+  KS_HIP(hipSetDevice(A->ctx->device));
+  return ks_mat_get_diagonal_internal(A, d_dev);
+}
+
+// MatCreateShell + MatShellSetOperation(MATOP_MULT) (the matrix-free route of src/eps/tutorials/ex3.c)
+extern "C" int ks_mat_create_shell(ks_ctx ctx, int n_local, int row_start, int n_global, ks_shell_mult_fn mult, void *user, ks_mat *out)
+{
+  KS_CHECK(ctx && out && mult, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(n_local >= 0 && n_global >= n_local && row_start >= 0, KS_ERR_ARG_OUTOFRANGE, "bad sizes n_local=%d n_global=%d row_start=%d", n_local, n_global, row_start);
+  ks_mat A = new ks_mat_s(); A->ctx = ctx; A->n = n_local; A->row_start = row_start; A->n_global = n_global;
+  A->shell_mult = mult; A->shell_user = user;
+  *out = A;
   return KS_SUCCESS;
 }
 

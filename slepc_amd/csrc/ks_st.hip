@@ -1,0 +1,258 @@
+// Spectral transformation: the operator the Krylov expansion multiplies by (the caller side of MatMult on the path).
+//
+// Restates STSHIFT and STSINVERT (src/sys/classes/st/impls/shift/shift.c:16-97, sinvert/sinvert.c:16-77) with
+// STApply_Generic (src/sys/classes/st/interface/stsolve.c:16-25):  y = P^-1 M x,
+//     shift:    nmat=1  M = A - sigma I, P none          nmat=2  M = A - sigma B, P = B
+//     sinvert:  nmat=1  M none,          P = A - sigma I nmat=2  M = B,           P = A - sigma B
+// in the reference's ST_MATMODE_SHELL form: A - sigma B is never assembled, it is applied as two SpMVs and an
+// axpy (stshellmat.c), and its diagonal is diag(A) - sigma diag(B). The linear solves are the KSP that mode
+// defaults to (stsles.c:51-53): GMRES(30) with a Jacobi preconditioner on the left, relative tolerance
+// SLEPC_DEFAULT_TOL on the preconditioned residual (stsles.c:407), zero initial guess, failure to converge is an
+// error (KSPSetErrorIfNotConverged, stsles.c:58). PETSc's KSP itself is external to the reference; this GMRES runs on
+// the same device kernels as the outer iteration: the Krylov basis is a BV, its Gram-Schmidt is the fused CGS of
+// ks_gs.hip, the update x += K y is BVMultVec.
+#include "ksgpu_internal.h"
+#include <algorithm>
+
+namespace {
+
+// out = s .* (a*u + b*v)   (s, v may be NULL: s = 1, v ignored)
+__global__ void k_lincomb(long long n, const double *__restrict__ s, double a, const double *__restrict__ u, double b, const double *__restrict__ v, double *__restrict__ out)
+{
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    double t = a * u[i];
+    if (v) t += b * v[i];
+    out[i] = s ? s[i] * t : t;
+  }
+}
+// d = 1 / (a*da + b*db), db NULL = identity; a zero diagonal entry leaves the row unscaled (PCJacobi does the same)
+__global__ void k_jacobi_setup(long long n, double a, const double *__restrict__ da, double b, const double *__restrict__ db, double *__restrict__ d)
+{
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double t = (da ? a * da[i] : 0.0) + b * (db ? db[i] : 1.0);
+    d[i] = (t != 0.0) ? 1.0 / t : 1.0;
+  }
+}
+
+} // namespace
+int ksk_lincomb(ks_ctx ctx, long long n, const double *s, double a, const double *u, double b, const double *v, double *out)
+{
+  if (n == 0) return KS_SUCCESS;
+  const unsigned nb = (unsigned)std::min<long long>((n + 255) / 256, (long long)ctx->num_cu * 16);
+  hipLaunchKernelGGL(k_lincomb, dim3(nb), dim3(256), 0, ctx->stream, n, s, a, u, b, v, out);
+  KS_HIP(hipGetLastError());
+  return KS_SUCCESS;
+}
+namespace {
+inline int lincomb(ks_ctx ctx, long long n, const double *s, double a, const double *u, double b, const double *v, double *out) { return ksk_lincomb(ctx, n, s, a, u, b, v, out); }
+
+// out = s .* (a*A*x + b*(B*x | x)); tmp is scratch of n doubles (used when both terms are present)
+int linop_apply(ks_st st, double a, ks_mat A, double b, ks_mat B, bool identity_term, const double *s, const double *x, double *out, double *tmp)
+{
+  ks_ctx ctx = st->ctx;
+  const long long n = st->n;
+  if (A) {
+    KS_CALL(ks_mat_mult_internal(A, x, out));
+    if (B) { KS_CALL(ks_mat_mult_internal(B, x, tmp)); return lincomb(ctx, n, s, a, out, b, tmp, out); }
+    if (identity_term) return lincomb(ctx, n, s, a, out, b, x, out);
+    if (s || a != 1.0) return lincomb(ctx, n, s, a, out, 0.0, nullptr, out);
+    return KS_SUCCESS;
+  }
+  if (B) { KS_CALL(ks_mat_mult_internal(B, x, out)); if (s || b != 1.0) return lincomb(ctx, n, s, b, out, 0.0, nullptr, out); return KS_SUCCESS; }
+  return lincomb(ctx, n, s, b, x, 0.0, nullptr, out);
+}
+
+// the matrix P of the table above, y = s .* P x
+int apply_P(ks_st st, const double *s, const double *x, double *out, double *tmp)
+{
+  if (st->type == KS_ST_SINVERT) return linop_apply(st, 1.0, st->A, -st->sigma, st->B, !st->B, s, x, out, tmp);
+  return linop_apply(st, 0.0, nullptr, 1.0, st->B, false, s, x, out, tmp);           // shift, nmat=2: P = B
+}
+
+// Left-preconditioned restarted GMRES for P y = rhs (KSPGMRES defaults: restart 30, classical Gram-Schmidt)
+int gmres_solve(ks_st st, const double *rhs, double *y)
+{
+  ks_ctx ctx = st->ctx; ks_bv K = st->K;
+  const int m = st->restart;
+  const long long n = st->n;
+  double *t1 = ks_bv_col(st->W, 1), *t2 = ks_bv_col(st->W, 2);
+  std::vector<double> H((size_t)(m + 1) * m, 0.0), g(m + 1, 0.0), cs(m, 0.0), sn(m, 0.0), h(m + 1, 0.0), yc(m, 0.0);
+  st->solves++;
+  KS_HIP(hipMemsetAsync(y, 0, sizeof(double) * std::max<long long>(n, 1), ctx->stream));
+  KS_CALL(lincomb(ctx, n, st->dinv, 1.0, rhs, 0.0, nullptr, ks_bv_col(K, 0)));
+  double beta = 0.0;
+  KS_CALL(ks_bv_normcolumn(K, 0, KS_NORM_2, &beta));
+  st->last_rnorm = beta;
+  if (beta == 0.0) return KS_SUCCESS;
+  const double tol = std::max(st->rtol * beta, 1e-50);
+  int its = 0;
+  for (;;) {
+    KS_CALL(ks_bv_scalecolumn(K, 0, 1.0 / beta));
+    std::fill(g.begin(), g.end(), 0.0); g[0] = beta;
+    int jj = 0; double res = beta;
+    for (int j = 0; j < m; j++) {
+      KS_CALL(apply_P(st, st->dinv, ks_bv_col(K, j), ks_bv_col(K, j + 1), t1));
+      double hn = 0.0; int lindep = 0;
+      KS_CALL(ks_bv_orthogonalizecolumn(K, j + 1, h.data(), &hn, &lindep));
+      its++; st->its++;
+      h[j + 1] = hn;
+      for (int i = 0; i < j; i++) { const double t = cs[i] * h[i] + sn[i] * h[i + 1]; h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1]; h[i] = t; }
+      const double r = hypot(h[j], h[j + 1]);
+      if (r == 0.0) { cs[j] = 1.0; sn[j] = 0.0; } else { cs[j] = h[j] / r; sn[j] = h[j + 1] / r; }
+      h[j] = r; h[j + 1] = 0.0;
+      g[j + 1] = -sn[j] * g[j]; g[j] = cs[j] * g[j];
+      for (int i = 0; i <= j; i++) H[(size_t)i + (size_t)j * (m + 1)] = h[i];
+      res = fabs(g[j + 1]); jj = j + 1;
+      if (res <= tol || its >= st->max_it || lindep || hn == 0.0) break;
+      KS_CALL(ks_bv_scalecolumn(K, j + 1, 1.0 / hn));
+    }
+    for (int i = jj - 1; i >= 0; i--) {                     // back substitution R yc = g
+      double t = g[i];
+      for (int c = i + 1; c < jj; c++) t -= H[(size_t)i + (size_t)c * (m + 1)] * yc[c];
+      const double d = H[(size_t)i + (size_t)i * (m + 1)];
+      yc[i] = (d != 0.0) ? t / d : 0.0;
+    }
+    KS_CALL(ks_bv_set_active_columns(K, 0, jj));
+    KS_CALL(ks_bv_multvec(K, 1.0, 1.0, y, yc.data()));
+    st->last_rnorm = res;
+    if (res <= tol) break;
+    KS_CHECK(its < st->max_it, KS_ERR_NOT_CONVERGED, "KSPSolve has not converged: GMRES reached %d iterations, preconditioned residual %g > %g", its, res, tol);
+    // restart from the true preconditioned residual
+    KS_CALL(apply_P(st, nullptr, y, t1, t2));
+    KS_CALL(lincomb(ctx, n, st->dinv, 1.0, rhs, -1.0, t1, ks_bv_col(K, 0)));
+    KS_CALL(ks_bv_normcolumn(K, 0, KS_NORM_2, &beta));
+    st->last_rnorm = beta;
+    if (beta <= tol) break;
+  }
+  return KS_SUCCESS;
+}
+
+int st_shell_mult(void *user, const double *x, double *y) { return ks_st_apply_internal((ks_st)user, x, y); }
+
+} // namespace
+
+bool ks_st_is_plain(ks_st st) { return !st || (st->type == KS_ST_SHIFT && st->sigma == 0.0 && !st->B); }
+
+int ks_st_setup_internal(ks_st st)
+{
+  KS_CHECK(st && st->A, KS_ERR_ORDER, "STSetMatrices must be called first");
+  if (st->ready) return KS_SUCCESS;
+  ks_ctx ctx = st->ctx; ks_mat A = st->A, B = st->B;
+  KS_CHECK(!B || (B->n == A->n && B->n_global == A->n_global), KS_ERR_ARG_INCOMP, "Mismatching dimensions of A (%d) and B (%d)", A->n, B ? B->n : 0);
+  KS_HIP(hipSetDevice(ctx->device));
+  st->n = A->n;
+  const bool need_solve = (st->type == KS_ST_SINVERT) || (st->type == KS_ST_SHIFT && B);
+  if (st->W) { int wn = 0; ks_bv_get_sizes(st->W, &wn, nullptr, nullptr, nullptr); if (wn != A->n) { ks_bv_destroy(st->W); ks_bv_destroy(st->K); st->W = st->K = nullptr; if (st->dinv) hipFree(st->dinv); st->dinv = nullptr; } }
+  if (!st->W) KS_CALL(ks_bv_create(ctx, A->n, A->n_global, 3, 0, &st->W));
+  if (need_solve) {
+    if (st->K) { int km = 0; ks_bv_get_sizes(st->K, nullptr, nullptr, &km, nullptr); if (km != st->restart + 1) { ks_bv_destroy(st->K); st->K = nullptr; } }
+    if (!st->K) { KS_CALL(ks_bv_create(ctx, A->n, A->n_global, st->restart + 1, 0, &st->K)); st->K->row_start = A->row_start; }
+    if (!st->dinv) KS_HIP(hipMalloc(&st->dinv, sizeof(double) * std::max(A->n, 1)));
+    // Jacobi: diag(P)
+    double *da = ks_bv_col(st->W, 1), *db = ks_bv_col(st->W, 2);
+    const unsigned nb = (unsigned)std::max<long long>(1, std::min<long long>(((long long)A->n + 255) / 256, (long long)ctx->num_cu * 16));
+    if (st->type == KS_ST_SINVERT) {
+      KS_CALL(ks_mat_get_diagonal_internal(A, da));
+      if (B) KS_CALL(ks_mat_get_diagonal_internal(B, db));
+      hipLaunchKernelGGL(k_jacobi_setup, dim3(nb), dim3(256), 0, ctx->stream, (long long)A->n, 1.0, da, -st->sigma, B ? db : nullptr, st->dinv);
+    } else {
+      KS_CALL(ks_mat_get_diagonal_internal(B, db));
+      hipLaunchKernelGGL(k_jacobi_setup, dim3(nb), dim3(256), 0, ctx->stream, (long long)A->n, 0.0, (const double *)nullptr, 1.0, db, st->dinv);
+    }
+    KS_HIP(hipGetLastError());
+  }
+  if (!st->op) KS_CALL(ks_mat_create_shell(ctx, A->n, A->row_start, A->n_global, st_shell_mult, st, &st->op));
+  st->op->n = A->n; st->op->row_start = A->row_start; st->op->n_global = A->n_global;
+  st->ready = true;
+  return KS_SUCCESS;
+}
+
+int ks_st_apply_internal(ks_st st, const double *x, double *y)     // STApply_Generic stsolve.c:16-25
+{
+  if (!st->ready) KS_CALL(ks_st_setup_internal(st));
+  double *w = ks_bv_col(st->W, 0), *t1 = ks_bv_col(st->W, 1);
+  if (st->type == KS_ST_SINVERT) {
+    if (st->B) { KS_CALL(ks_mat_mult_internal(st->B, x, w)); return gmres_solve(st, w, y); }
+    return gmres_solve(st, x, y);
+  }
+  // shift
+  if (st->B) { KS_CALL(linop_apply(st, 1.0, st->A, -st->sigma, st->B, false, nullptr, x, w, t1)); return gmres_solve(st, w, y); }
+  return linop_apply(st, 1.0, st->A, -st->sigma, nullptr, st->sigma != 0.0, nullptr, x, y, t1);
+}
+
+void ks_st_backtransform_internal(ks_st st, int n, double *eigr, double *eigi)
+{
+  if (!st) return;
+  for (int j = 0; j < n; j++) {
+    if (st->type == KS_ST_SHIFT) eigr[j] += st->sigma;                                  // shift.c:49-56
+    else if (eigi[j] == 0.0) eigr[j] = 1.0 / eigr[j] + st->sigma;                        // sinvert.c:16-40
+    else { const double t = eigr[j] * eigr[j] + eigi[j] * eigi[j]; eigr[j] = eigr[j] / t + st->sigma; eigi[j] = -eigi[j] / t; }
+  }
+}
+
+extern "C" int ks_st_create(ks_ctx ctx, ks_st *out)
+{
+  KS_CHECK(ctx && out, KS_ERR_ARG_NULL, "ctx/out is NULL");
+  ks_st st = new ks_st_s(); st->ctx = ctx; *out = st;
+  return KS_SUCCESS;
+}
+extern "C" int ks_st_destroy(ks_st st)
+{
+  if (!st) return KS_SUCCESS;
+  ks_bv_destroy(st->K); ks_bv_destroy(st->W);
+  if (st->dinv) hipFree(st->dinv);
+  if (st->op) ks_mat_destroy(st->op);
+  delete st;
+  return KS_SUCCESS;
+}
+extern "C" int ks_st_set_type(ks_st st, int type)                    // STSetType
+{
+  KS_CHECK(st, KS_ERR_ARG_NULL, "ST is NULL");
+  KS_CHECK(type == KS_ST_SHIFT || type == KS_ST_SINVERT, KS_ERR_SUP, "only STSHIFT and STSINVERT are built");
+  if (st->type != type) { st->type = type; st->ready = false; }
+  return KS_SUCCESS;
+}
+extern "C" int ks_st_set_shift(ks_st st, double sigma)               // STSetShift stfunc.c
+{
+  KS_CHECK(st, KS_ERR_ARG_NULL, "ST is NULL");
+  if (st->sigma != sigma || !st->sigma_set) { st->sigma = sigma; st->ready = false; }
+  st->sigma_set = true;
+  return KS_SUCCESS;
+}
+extern "C" int ks_st_get_shift(ks_st st, double *sigma) { KS_CHECK(st && sigma, KS_ERR_ARG_NULL, "NULL argument"); *sigma = st->sigma; return KS_SUCCESS; }
+extern "C" int ks_st_set_matrices(ks_st st, ks_mat A, ks_mat B)      // STSetMatrices (n = 1 or 2)
+{
+  KS_CHECK(st && A, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(!A->shell_mult && (!B || !B->shell_mult), KS_ERR_SUP, "ST needs assembled matrices (their diagonals feed the Jacobi preconditioner)");
+  st->A = A; st->B = B; st->ready = false;
+  return KS_SUCCESS;
+}
+extern "C" int ks_st_set_ksp(ks_st st, double rtol, int max_it, int restart)   // KSPSetTolerances / KSPGMRESSetRestart on STGetKSP
+{
+  KS_CHECK(st, KS_ERR_ARG_NULL, "ST is NULL");
+  if (rtol > 0.0) st->rtol = rtol;
+  if (max_it > 0) st->max_it = max_it;
+  if (restart > 0) { KS_CHECK(restart + 1 <= KS_MAX_COLS, KS_ERR_ARG_OUTOFRANGE, "GMRES restart %d exceeds %d", restart, KS_MAX_COLS - 1); if (restart != st->restart) { st->restart = restart; st->ready = false; } }
+  return KS_SUCCESS;
+}
+extern "C" int ks_st_setup(ks_st st) { KS_CHECK(st, KS_ERR_ARG_NULL, "ST is NULL"); return ks_st_setup_internal(st); }
+extern "C" int ks_st_apply(ks_st st, const double *x_dev, double *y_dev)        // STApply stsolve.c:44
+{
+  KS_CHECK(st && x_dev && y_dev, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(x_dev != y_dev, KS_ERR_ARG_IDN, "x and y must be different vectors");
+  KS_CHECK(st->A, KS_ERR_ORDER, "STSetMatrices must be called first");
+  KS_HIP(hipSetDevice(st->ctx->device));
+  return ks_st_apply_internal(st, x_dev, y_dev);
+}
+extern "C" int ks_st_backtransform(ks_st st, int n, double *eigr, double *eigi) // STBackTransform stsolve.c:563
+{
+  KS_CHECK(st && (n == 0 || (eigr && eigi)), KS_ERR_ARG_NULL, "NULL argument");
+  ks_st_backtransform_internal(st, n, eigr, eigi);
+  return KS_SUCCESS;
+}
+extern "C" int ks_st_get_ksp_stats(ks_st st, long long *solves, long long *iterations, double *last_rnorm)
+{
+  KS_CHECK(st, KS_ERR_ARG_NULL, "ST is NULL");
+  if (solves) *solves = st->solves; if (iterations) *iterations = st->its; if (last_rnorm) *last_rnorm = st->last_rnorm;
+  return KS_SUCCESS;
+}

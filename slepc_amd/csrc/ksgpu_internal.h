@@ -95,7 +95,30 @@ struct ks_mat_s {
   std::vector<int> peers, send_cnt, recv_cnt, send_off, recv_off;
   int *send_idx = nullptr; int nsend = 0;     // local row indices to pack
   double *send_buf = nullptr;
+  // matrix-free operator (MATSHELL with MATOP_MULT): y = shell_mult(user, x); may synchronise the host
+  int (*shell_mult)(void *user, const double *x_dev, double *y_dev) = nullptr;
+  void *shell_user = nullptr;
 };
+int ks_mat_get_diagonal_internal(ks_mat A, double *d_dev);
+
+// ---- ST: spectral transformation (ks_st.hip) ----------------------------------------------------
+struct ks_st_s {
+  ks_ctx ctx = nullptr;
+  int type = KS_ST_SHIFT;
+  double sigma = 0.0; bool sigma_set = false;
+  ks_mat A = nullptr, B = nullptr;            // borrowed
+  double rtol = 1e-8; int max_it = 10000, restart = 30;   // KSP: SLEPC_DEFAULT_TOL (stsles.c:407), PETSc defaults
+  ks_bv K = nullptr, W = nullptr;             // GMRES basis (restart+1 columns), work vectors (3 columns)
+  double *dinv = nullptr;                     // Jacobi: 1/diag(P)
+  ks_mat op = nullptr;                        // shell matrix whose MatMult is STApply
+  int n = 0; bool ready = false;
+  long long solves = 0, its = 0; double last_rnorm = 0.0;
+};
+bool ks_st_is_plain(ks_st st);                // shift with sigma = 0 on a standard problem: Op = A itself
+int ks_st_setup_internal(ks_st st);
+int ks_st_apply_internal(ks_st st, const double *x, double *y);
+void ks_st_backtransform_internal(ks_st st, int n, double *eigr, double *eigi);
+int ksk_lincomb(ks_ctx ctx, long long n, const double *s, double a, const double *u, double b, const double *v, double *out);   // out = s.*(a*u + b*v)   // diagonal of the local diagonal block (MatGetDiagonal)
 
 // ---- BV -----------------------------------------------------------------------------------------
 // Device-resident Gram-Schmidt state (one per BV).  Written by the 1-block bookkeeping kernel,

@@ -53,3 +53,38 @@ def planted_pairs(n, nnz_row=6, seed=7, rot=0.9):
     A[6, 6] = 2.35; A[7, 7] = -2.05
     S = A.tocsr(); S.sum_duplicates(); S.sort_indices()
     return O.CSR(n, S.indptr, S.indices, S.data)
+
+
+def config5_pencil(n, mean_nnz=32, seed=42):
+    """BASELINE config 5 at reduced n: A = random nonsymmetric CSR, row lengths Poisson(mean) clipped to
+    [1, 2*mean], columns uniform without replacement, values uniform(-1,1), diagonal += 40; B = tridiagonal
+    (1/6, 2/3, 1/6), the 1-D mass matrix. Returns (A, B)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    lens = np.clip(rng.poisson(mean_nnz, n), 1, min(2 * mean_nnz, n))
+    rowptr = np.concatenate([[0], np.cumsum(lens)])
+    cols = np.concatenate([rng.choice(n, l, replace=False) for l in lens])
+    vals = rng.uniform(-1, 1, rowptr[-1])
+    A = sp.csr_matrix((vals, cols, rowptr), shape=(n, n)) + 40.0 * sp.identity(n, format="csr")
+    A.sum_duplicates(); A.sort_indices()
+    B = sp.diags([np.full(n - 1, 1 / 6), np.full(n, 2 / 3), np.full(n - 1, 1 / 6)], [-1, 0, 1], format="csr")
+    B.sort_indices()
+    return (O.CSR(n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data),
+            O.CSR(n, B.indptr.astype(np.int32), B.indices.astype(np.int32), B.data))
+
+
+def config5_pencil_fast(n, mean_nnz=32, seed=42):
+    """Vectorised variant for large n: columns drawn WITH replacement (a repeated (i,j) stays as two CSR entries, which
+    MatMult and MatGetDiagonal sum), not sorted inside a row; same value distribution, diagonal + 40, same B."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    lens = np.clip(rng.poisson(mean_nnz, n), 1, 2 * mean_nnz).astype(np.int64)
+    rowptr = np.concatenate([[0], np.cumsum(lens + 1)]).astype(np.int32)        # + the diagonal entry
+    nnz = int(rowptr[-1])
+    col = rng.integers(0, n, nnz, dtype=np.int32)
+    val = rng.uniform(-1, 1, nnz)
+    col[rowptr[:-1]] = np.arange(n, dtype=np.int32); val[rowptr[:-1]] = 40.0   # first entry of each row: the diagonal
+    A = O.CSR(n, rowptr, col, val)
+    B = sp.diags([np.full(n - 1, 1 / 6), np.full(n, 2 / 3), np.full(n - 1, 1 / 6)], [-1, 0, 1], format="csr")
+    B.sort_indices()
+    return A, O.CSR(n, B.indptr.astype(np.int32), B.indices.astype(np.int32), B.data)
