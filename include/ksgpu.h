@@ -67,6 +67,8 @@ typedef struct ks_eps_s *ks_eps;   /* Krylov-Schur eigensolver driver           
 /* enums mirror include/slepcbv.h, include/slepceps.h, PETSc NormType */
 enum { KS_BV_ORTHOG_CGS = 0, KS_BV_ORTHOG_MGS = 1 };
 enum { KS_BV_ORTHOG_REFINE_IFNEEDED = 0, KS_BV_ORTHOG_REFINE_NEVER = 1, KS_BV_ORTHOG_REFINE_ALWAYS = 2 };
+/* BVOrthogBlockType, include/slepcbv.h */
+enum { KS_BV_ORTHOG_BLOCK_GS = 0, KS_BV_ORTHOG_BLOCK_CHOL = 1, KS_BV_ORTHOG_BLOCK_TSQR = 2, KS_BV_ORTHOG_BLOCK_TSQRCHOL = 3, KS_BV_ORTHOG_BLOCK_SVQB = 4 };
 enum { KS_NORM_1 = 0, KS_NORM_2 = 1, KS_NORM_FROBENIUS = 2, KS_NORM_INFINITY = 3 };
 /* EPSWhich, include/slepceps.h:109-119 (same numbering; TARGET_IMAGINARY and ALL are not offered) */
 enum { KS_EPS_LARGEST_MAGNITUDE = 1, KS_EPS_SMALLEST_MAGNITUDE = 2, KS_EPS_LARGEST_REAL = 3, KS_EPS_SMALLEST_REAL = 4,
@@ -176,6 +178,13 @@ int ks_bv_matmultcolumn(ks_bv V, ks_mat A, int j);                              
 int ks_bv_orthogonalizecolumn(ks_bv bv, int j, double *H, double *norm, int *lindep);            /* BVOrthogonalizeColumn bvorthog.c:315 */
 int ks_bv_orthonormalizecolumn(ks_bv bv, int j, int replace, double *norm, int *lindep);         /* BVOrthonormalizeColumn bvorthog.c:380 */
 int ks_bv_orthogonalizevec(ks_bv bv, double *v_dev, double *H, double *norm, int *lindep);       /* BVOrthogonalizeVec bvorthog.c:247 */
+/* BVOrthogonalize bvorthog.c:729: QR of the active columns, V0 = V R, leading columns untouched. R (host, column-major,
+   ldr >= k) may be NULL; only its columns l..k-1 are written (upper triangular except for SVQB). The block method is the
+   fourth argument of BVSetOrthogonalization.                                                                          */
+int ks_bv_set_orthog_block(ks_bv bv, int block);
+int ks_bv_orthogonalize(ks_bv V, double *R, int ldr);
+int ks_bv_matproject(ks_bv X, ks_mat A /* NULL: identity */, ks_bv Y, double *M, int ldm);   /* BVMatProject bvglobal.c:1014: M = Y^H A X */
+int ks_bv_normalize(ks_bv V, const double *eigi /* may be NULL */);                          /* BVNormalize bvglobal.c:855 */
 int ks_bv_orthogonalizesomecolumn(ks_bv bv, int j, const int *which, double *H, double *norm, int *lindep); /* bvorthog.c:432 (MGS) */
 int ks_bv_gs_passes(ks_bv bv, long long *passes_total, int *passes_last);                        /* instrumentation */
 

@@ -354,6 +354,64 @@ class BV:
         _chk(self._lib.orc_bv_matarnoldi(self._h, A._h, _p(H), H.shape[0], k, C.byref(mm), C.byref(beta), C.byref(brk)))
         return mm.value, beta.value, bool(brk.value)
 
+    def Orthogonalize(self, R=None, block="gs"):
+        """BVOrthogonalize (bvorthog.c:729-767) with the block methods of bvorthog.c:510-690 and the LAPACK kernels of
+        bvlapack.c:136-451 (potrf/trtri, syev, geqrf/orgqr through scipy.linalg.lapack; single process, so TSQR is one
+        geqrf). R: Fortran-ordered (>=k, >=k) array or None; columns l..k-1 are written."""
+        import scipy.linalg.lapack as la
+        l, k, n = self.l, self.k, self.n
+        A = self.array
+        if k <= l:
+            return
+        if block == "gs":
+            for j in range(l, k):
+                self.SetActiveColumns(0, k)                     # V->l = -V->nc around BV_StoreCoefficients (:536-539)
+                H, norm, _ = self.OrthogonalizeColumn(j)
+                self.SetActiveColumns(l, k)
+                if R is not None:
+                    R[:j, j] = H[:j]; R[j, j] = norm
+                if norm == 0.0:
+                    raise RuntimeError("Breakdown in BVOrthogonalize due to a linearly dependent column")
+                self.ScaleColumn(j, 1.0 / norm)
+            return
+        Rb = np.zeros((k, k), order="F")
+        if l:                                                   # BVOrthogonalize_BlockGS :492-505
+            Rb[:l, l:k] = A[:n, :l].T @ A[:n, l:k]
+            A[:n, l:k] -= A[:n, :l] @ Rb[:l, l:k]
+        V2 = A[:n, l:k]
+        if block == "chol":
+            G = V2.T @ V2
+            c, info = la.dpotrf(G, lower=0)
+            if info:                                            # bvlapack.c:177-185
+                c, info = la.dpotrf(G + 50.0 * np.finfo(float).eps * np.eye(k - l), lower=0)
+                assert info == 0
+            c = np.triu(c)
+            S, info = la.dtrtri(c, lower=0); assert info == 0
+            A[:n, l:k] = V2 @ np.triu(S)
+            Rb[l:k, l:k] = c; tri = True
+        elif block == "svqb":
+            G = V2.T @ V2
+            D = 1.0 / np.sqrt(np.diag(G))
+            w, U, info = la.dsyev(G * D[:, None] * D[None, :], lower=1); assert info == 0
+            A[:n, l:k] = V2 @ (D[:, None] * U / np.sqrt(w)[None, :])
+            Rb[l:k, l:k] = np.sqrt(w)[:, None] * U.T / D[None, :]; tri = False
+        elif block in ("tsqr", "tsqrchol"):
+            qr, tau, _, info = la.dgeqrf(np.asfortranarray(V2)); assert info == 0
+            Rr = np.triu(qr[: k - l, :])
+            if block == "tsqr":
+                Q, _, info = la.dorgqr(qr[:, : k - l], tau); assert info == 0
+                A[:n, l:k] = Q[:, : k - l]
+            else:
+                S, info = la.dtrtri(Rr, lower=0); assert info == 0
+                A[:n, l:k] = V2 @ np.triu(S)
+            Rb[l:k, l:k] = Rr; tri = True
+        else:
+            raise ValueError(block)
+        if R is not None:                                       # BV_StoreCoeffsBlock_Default :576-596
+            for j in range(l, k):
+                rows = j + 1 if tri else k
+                R[:rows, j] = Rb[:rows, j]
+
     def MatArnoldiOp(self, op, H, k, m):
         """BVMatArnoldi (bvkrylov.c:56-113) with the operator given as a callable y = op(x) (an ST operator)."""
         brk = False; beta = 0.0

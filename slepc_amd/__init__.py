@@ -28,6 +28,7 @@ EPS_ERROR_ABSOLUTE, EPS_ERROR_RELATIVE = 0, 1
 EPS_CONVERGED_TOL, EPS_CONVERGED_USER, EPS_DIVERGED_ITS, EPS_DIVERGED_BREAKDOWN = 1, 2, -1, -2
 WHICH = {"largest_magnitude": 1, "smallest_magnitude": 2, "largest_real": 3, "smallest_real": 4,
          "largest_imaginary": 5, "smallest_imaginary": 6, "target_magnitude": 7, "target_real": 8, "user": 11}
+BLOCK = {"gs": 0, "chol": 1, "tsqr": 2, "tsqrchol": 3, "svqb": 4}
 SHELL_MULT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 ST_SHIFT, ST_SINVERT = 0, 1
 EIG_COMPARE_FN = C.CFUNCTYPE(C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_void_p)
@@ -402,6 +403,22 @@ class BV:
         H = np.zeros(max(j - self.l, 0) + 1)
         _lib.check(self.ctx.L.ks_bv_orthogonalizecolumn(self.h, j, _p(H), C.byref(nrm), C.byref(lin)))
         return H[: max(j - self.l, 0)], nrm.value, bool(lin.value)
+
+    def SetOrthogBlock(self, block):
+        _lib.check(self.ctx.L.ks_bv_set_orthog_block(self.h, BLOCK.get(block, block)))
+
+    def Orthogonalize(self, R=None):
+        """BVOrthogonalize: R (Fortran-ordered, at least k x k) receives the triangular factor in its columns l..k-1."""
+        if R is not None:
+            assert R.flags.f_contiguous
+        _lib.check(self.ctx.L.ks_bv_orthogonalize(self.h, _p(R) if R is not None else None, R.shape[0] if R is not None else 0))
+
+    def MatProject(self, A, Y, M):
+        assert M.flags.f_contiguous
+        _lib.check(self.ctx.L.ks_bv_matproject(self.h, None if A is None else A.h, Y.h, _p(M), M.shape[0]))
+
+    def Normalize(self, eigi=None):
+        _lib.check(self.ctx.L.ks_bv_normalize(self.h, _p(_f64(eigi)) if eigi is not None else None))
 
     def OrthonormalizeColumn(self, j, replace=False):
         nrm = C.c_double(); lin = C.c_int()

@@ -88,6 +88,10 @@ _SIG = {
     "ks_bv_orthogonalizevec": [vp, vp, dp, dp, ip],
     "ks_bv_orthogonalizesomecolumn": [vp, C.c_int, ip, dp, dp, ip],
     "ks_bv_gs_passes": [vp, llp, ip],
+    "ks_bv_set_orthog_block": [vp, C.c_int],
+    "ks_bv_orthogonalize": [vp, dp, C.c_int],
+    "ks_bv_matproject": [vp, vp, vp, dp, C.c_int],
+    "ks_bv_normalize": [vp, dp],
     "ks_bv_matarnoldi": [vp, vp, dp, C.c_int, C.c_int, ip, dp, ip],
     "ks_bv_matlanczos": [vp, vp, dp, C.c_int, C.c_int, ip, dp, ip],
     # eps

@@ -496,27 +496,25 @@ extern "C" int ks_bv_dotcolumn(ks_bv X, int j, double *q)   // bvglobal.c:302-32
   return rc;
 }
 
-extern "C" int ks_bv_dot(ks_bv X, ks_bv Y, double *M, int ldm)   // bvglobal.c:86-116, svec.c:89-107: M = Y^H X
+// M(ys:ye, xs:xe) = Y(:,ys:ye)^H X(:,xs:xe); X and Y may be the same BV
+int ksb_dot_range(ks_bv X, int xs, int xe, ks_bv Y, int ys, int ye, double *M, int ldm)
 {
-  KS_CHECK(X && Y && M, KS_ERR_ARG_NULL, "NULL argument");
-  KS_CHECK(ldm >= Y->k, KS_ERR_ARG_SIZ, "Mat argument has %d rows, should have at least %d", ldm, Y->k);
-  KS_CHECK(X->n == Y->n, KS_ERR_ARG_INCOMP, "Mismatching local dimension X %d, Y %d", X->n, Y->n);
-  if (X->l == X->k || Y->l == Y->k) return KS_SUCCESS;
+  if (xs >= xe || ys >= ye) return KS_SUCCESS;
   ks_ctx ctx = X->ctx;
   KS_HIP(hipSetDevice(ctx->device));
-  const int my = Y->k - Y->l, nx = X->k - X->l;
+  const int my = ye - ys, nx = xe - xs;
   KS_CHECK(my <= KS_MAX_COLS, KS_ERR_SUP, "BVDot with more than %d active columns in Y", KS_MAX_COLS);
   KS_CHECK((size_t)my * nx <= X->coef_len, KS_ERR_ARG_SIZ, "result block too large");
-  const double *py = Y->array + (size_t)(Y->nc + Y->l) * Y->ld;
+  const double *py = Y->array + (size_t)(Y->nc + ys) * Y->ld;
   const bool use_mfma = !getenv("KSGPU_NO_MFMA");
-  const double *px0 = X->array + (size_t)(X->nc + X->l) * X->ld;
+  const double *px0 = X->array + (size_t)(X->nc + xs) * X->ld;
   if (use_mfma && X->n > 0 && nx <= 64 && X->ld % 2 == 0 && Y->ld % 2 == 0 && aligned16(py) && aligned16(px0)) {
     KS_CALL(ksp_dot_mfma(X, py, Y->ld, my, px0, X->ld, nx, X->n, X->coef));      // one sweep over both panels on the matrix cores
   } else {
     KsProfScope ps(ctx, KS_K_BVDOT, 8.0 * X->n * (my + nx));
     const bool save = ctx->prof_on; ctx->prof_on = false;       // account the whole panel product as one class
     for (int jx = 0; jx < nx; jx++) {
-      const double *xcol = X->array + (size_t)(X->nc + X->l + jx) * X->ld;
+      const double *xcol = X->array + (size_t)(X->nc + xs + jx) * X->ld;
       if (X->n > 0) { KS_CALL(ksk_dot(X, py, Y->ld, my, xcol, false)); KS_CALL(ksk_reduce_partials(X, my, X->coef + (size_t)jx * my)); }
       else KS_HIP(hipMemsetAsync(X->coef + (size_t)jx * my, 0, sizeof(double) * my, ctx->stream));
     }
@@ -526,9 +524,30 @@ extern "C" int ks_bv_dot(ks_bv X, ks_bv Y, double *M, int ldm)   // bvglobal.c:8
   std::vector<double> tmp((size_t)my * nx);
   KS_HIP(hipMemcpyAsync(tmp.data(), X->coef, sizeof(double) * my * nx, hipMemcpyDeviceToHost, ctx->stream));
   KS_HIP(hipStreamSynchronize(ctx->stream));
-  double *C = M + (size_t)X->l * ldm + Y->l;
+  double *C = M + (size_t)xs * ldm + ys;
   for (int j = 0; j < nx; j++) memcpy(C + (size_t)j * ldm, tmp.data() + (size_t)j * my, sizeof(double) * my);
   return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_dot(ks_bv X, ks_bv Y, double *M, int ldm)   // bvglobal.c:86-116, svec.c:89-107: M = Y^H X
+{
+  KS_CHECK(X && Y && M, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(ldm >= Y->k, KS_ERR_ARG_SIZ, "Mat argument has %d rows, should have at least %d", ldm, Y->k);
+  KS_CHECK(X->n == Y->n, KS_ERR_ARG_INCOMP, "Mismatching local dimension X %d, Y %d", X->n, Y->n);
+  return ksb_dot_range(X, X->l, X->k, Y, Y->l, Y->k, M, ldm);
+}
+
+// Y(:,ys:ye) = beta*Y(:,ys:ye) + alpha*X(:,xs:xe)*Q(xs:xe, ys:ye); X and Y may be the same BV when the ranges are disjoint
+int ksb_mult_range(ks_bv Y, int ys, int ye, double alpha, double beta, ks_bv X, int xs, int xe, const double *Q, int ldq)
+{
+  const int ny = ye - ys, kx = xe - xs;
+  if (ny <= 0 || kx <= 0) return KS_SUCCESS;
+  ks_ctx ctx = Y->ctx;
+  KS_HIP(hipSetDevice(ctx->device));
+  double *qdev = nullptr;
+  KS_CALL(stage_coefs(Y, Q, (size_t)ldq * ye, &qdev));
+  return panel_mult(ctx, KS_K_MULT, X->array + (size_t)(X->nc + xs) * X->ld, X->ld, Y->n, kx, qdev + (size_t)ys * ldq + xs, ldq, false, ny, alpha, beta,
+                    Y->array + (size_t)(Y->nc + ys) * Y->ld, Y->ld);
 }
 
 // ---- ops->scale / norm / copy ------------------------------------------------------------------------

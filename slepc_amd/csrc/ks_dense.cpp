@@ -426,6 +426,86 @@ int trevc_one(int n, const double *T, int ld, int k, double *xr, double *xi)
   return pair ? 1 : 0;
 }
 
+int potrf_upper(int n, double *A, int ld)
+{
+  for (int j = 0; j < n; j++) {
+    double d = AT(A, j, j);
+    for (int k = 0; k < j; k++) d -= AT(A, k, j) * AT(A, k, j);
+    if (!(d > 0.0)) return j + 1;                       // also catches NaN
+    d = std::sqrt(d); AT(A, j, j) = d;
+    for (int c = j + 1; c < n; c++) {
+      double t = AT(A, j, c);
+      for (int k = 0; k < j; k++) t -= AT(A, k, j) * AT(A, k, c);
+      AT(A, j, c) = t / d;
+    }
+  }
+  return 0;
+}
+
+int trtri_upper(int n, double *A, int ld)
+{
+  for (int j = 0; j < n; j++) if (AT(A, j, j) == 0.0) return j + 1;
+  for (int j = 0; j < n; j++) {                        // dtrti2: column j of the inverse from the leading j x j inverse
+    AT(A, j, j) = 1.0 / AT(A, j, j);
+    const double ajj = -AT(A, j, j);
+    for (int i = 0; i < j; i++) {                      // x = inv(A(0:j,0:j)) * A(0:j,j) (upper triangular mat-vec, in place top-down)
+      double t = 0.0;
+      for (int k = i; k < j; k++) t += AT(A, i, k) * AT(A, k, j);
+      AT(A, i, j) = t;
+    }
+    for (int i = 0; i < j; i++) AT(A, i, j) *= ajj;
+  }
+  return 0;
+}
+
+int sym_eig(int n, double *A, int ld, double *w)
+{
+  if (n <= 0) return 0;
+  double S[64 * 64], V[64 * 64];
+  if (n > 64) return -1;
+  for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) { S[i + j * n] = (i >= j) ? AT(A, i, j) : AT(A, j, i); V[i + j * n] = (i == j) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0.0, dg = 0.0;
+    for (int j = 0; j < n; j++) { dg += S[j + j * n] * S[j + j * n]; for (int i = j + 1; i < n; i++) off += S[i + j * n] * S[i + j * n]; }
+    if (off <= 1e-34 * dg || off == 0.0) break;
+    for (int p = 0; p < n - 1; p++)
+      for (int q = p + 1; q < n; q++) {
+        const double apq = S[p + q * n];
+        if (apq == 0.0) continue;
+        const double app = S[p + p * n], aqq = S[q + q * n];
+        if (std::fabs(apq) < 1e-300) continue;
+        const double theta = (aqq - app) / (2.0 * apq);
+        const double t = sgn(1.0, theta) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s2 = t * c;
+        for (int k = 0; k < n; k++) { const double skp = S[k + p * n], skq = S[k + q * n]; S[k + p * n] = c * skp - s2 * skq; S[k + q * n] = s2 * skp + c * skq; }
+        for (int k = 0; k < n; k++) { const double spk = S[p + k * n], sqk = S[q + k * n]; S[p + k * n] = c * spk - s2 * sqk; S[q + k * n] = s2 * spk + c * sqk; }
+        for (int k = 0; k < n; k++) { const double vkp = V[k + p * n], vkq = V[k + q * n]; V[k + p * n] = c * vkp - s2 * vkq; V[k + q * n] = s2 * vkp + c * vkq; }
+      }
+  }
+  int idx[64];
+  for (int i = 0; i < n; i++) idx[i] = i;
+  std::sort(idx, idx + n, [&](int a, int b) { return S[a + a * n] < S[b + b * n]; });
+  for (int j = 0; j < n; j++) { w[j] = S[idx[j] + idx[j] * n]; for (int i = 0; i < n; i++) AT(A, i, j) = V[i + idx[j] * n]; }
+  return 0;
+}
+
+void tsqr_combine(int n, double *R1, int ld1, double *R2, int ld2)
+{
+  // eliminate R2 row by row: row i of R2 is annihilated against rows i..n-1 of R1 (entries left of the diagonal are zero)
+  for (int i = 0; i < n; i++)
+    for (int j = i; j < n; j++) {
+      double &a = R1[(size_t)j + (size_t)j * ld1], &b = R2[(size_t)i + (size_t)j * ld2];
+      if (b == 0.0) continue;
+      double c, s, r;
+      lartg(a, b, c, s, r);
+      a = r; b = 0.0;
+      for (int k = j + 1; k < n; k++) {
+        double &x = R1[(size_t)j + (size_t)k * ld1], &y = R2[(size_t)i + (size_t)k * ld2];
+        const double t = c * x + s * y; y = c * y - s * x; x = t;
+      }
+    }
+}
+
 } // namespace ksd
 
 // ---- C hooks for the CPU unit tests (tests/test_dense_host.py builds this file alone with g++) ----------------
@@ -435,5 +515,9 @@ void ksd_hess_reduce(int n, int ilo, double *A, int ld, double *Q) { ksd::hess_r
 int ksd_real_schur(int n, int ilo, double *A, int ld, double *wr, double *wi, double *Q) { return ksd::real_schur(n, ilo, A, ld, wr, wi, Q); }
 int ksd_trexc_up(int n, double *T, int ld, double *Q, int ifst, int ilst) { return ksd::trexc_up(n, T, ld, Q, ifst, ilst); }
 int ksd_trevc_one(int n, const double *T, int ld, int k, double *xr, double *xi) { return ksd::trevc_one(n, T, ld, k, xr, xi); }
+int ksd_potrf_upper(int n, double *A, int ld) { return ksd::potrf_upper(n, A, ld); }
+int ksd_trtri_upper(int n, double *A, int ld) { return ksd::trtri_upper(n, A, ld); }
+int ksd_sym_eig(int n, double *A, int ld, double *w) { return ksd::sym_eig(n, A, ld, w); }
+void ksd_tsqr_combine(int n, double *R1, int ld1, double *R2, int ld2) { ksd::tsqr_combine(n, R1, ld1, R2, ld2); }
 }
 #endif

@@ -26,4 +26,17 @@ int trexc_up(int n, double *T, int ld, double *Q, int ifst, int ilst);
 // complex pair; the pair is (k,k+1)) of length n, not back-transformed. Returns 1 for a complex pair, 0 for real.
 int trevc_one(int n, const double *T, int ld, int k, double *xr, double *xi);
 
+// ---- symmetric / triangular kernels of the block orthogonalisations (bvlapack.c:136-341) ----
+// Upper Cholesky factor of the symmetric positive definite A (upper triangle referenced), in place (dpotrf 'U').
+// Returns 0, or the 1-based order of the leading minor that is not positive definite.
+int potrf_upper(int n, double *A, int ld);
+// Inverse of an upper triangular matrix, in place (dtrtri 'U','N'). Returns 0, or the 1-based index of a zero pivot.
+int trtri_upper(int n, double *A, int ld);
+// Eigendecomposition of a symmetric matrix (lower triangle referenced): A <- eigenvectors (columns), w ascending
+// (dsyev 'V','L' contract; cyclic Jacobi rotations, which are as accurate as QR for these n <= 64 Gram matrices).
+int sym_eig(int n, double *A, int ld, double *w);
+// R factor of the QR factorisation of the stacked upper triangles [R1; R2] (both n x n, column-major, ld), by Givens
+// rotations, into R1 (the reduction operator of the parallel TSQR, SlepcGivensPacked bvlapack.c:456-478).
+void tsqr_combine(int n, double *R1, int ld1, double *R2, int ld2);
+
 } // namespace ksd

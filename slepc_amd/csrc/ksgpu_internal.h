@@ -144,7 +144,7 @@ struct KsStepRec { double nrm, onrm; int passes, lindep, expl, col; };
 struct ks_bv_s {
   ks_ctx ctx = nullptr;
   int n = 0, N = 0, m = 0, l = 0, k = 0, nc = 0, ld = 0;
-  int orthog_type = KS_BV_ORTHOG_CGS, orthog_ref = KS_BV_ORTHOG_REFINE_IFNEEDED;
+  int orthog_type = KS_BV_ORTHOG_CGS, orthog_ref = KS_BV_ORTHOG_REFINE_IFNEEDED, orthog_block = KS_BV_ORTHOG_BLOCK_GS;
   double orthog_eta = 0.7071;
   double deftol = 10 * 2.220446049250313e-16;
   double *array = nullptr;      // m*ld
@@ -175,6 +175,8 @@ int ksk_scale(ks_ctx ctx, double *x, size_t n, double alpha);
 int ksk_copy(ks_ctx ctx, const double *src, double *dst, size_t n);
 
 int ks_mat_mult_internal(ks_mat A, const double *x, double *y);
+int ksb_dot_range(ks_bv X, int xs, int xe, ks_bv Y, int ys, int ye, double *M, int ldm);          // M(ys:ye,xs:xe) = Y(:,ys:ye)^T X(:,xs:xe)
+int ksb_mult_range(ks_bv Y, int ys, int ye, double alpha, double beta, ks_bv X, int xs, int xe, const double *Q, int ldq);
 // MFMA f64 panel contractions (ks_panel.hip)
 int ksp_dot_mfma(ks_bv bv, const double *Y, int ldy, int my, const double *X, int ldx, int nx, int n, double *M_dev);
 int ksp_mult_mfma(ks_ctx ctx, int kclass, const double *A, int lda, int n, int kin, const double *Qdev, int qsk, int qsi, int nout,

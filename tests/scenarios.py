@@ -171,3 +171,76 @@ def bv_test7(be, n=30, k=6):
     V.MatMult(A, W)
     ref = A1.to_scipy() @ Vh
     return {"err": np.abs(W.dense() - ref).max()}
+
+
+def _test11_X(n, k):
+    X = np.zeros((n, k))
+    for j in range(k):
+        for i in range(n // 2 + 1):
+            if i + j < n:
+                X[i + j, j] = (3.0 * i + j - 2) / (2 * (i + j + 1))
+    return X
+
+
+def _orthogonalize(bv, R, block):
+    """one call signature for both backends (the oracle takes the method per call, the library per BV)"""
+    if hasattr(bv, "SetOrthogBlock"):
+        bv.SetOrthogBlock(block); bv.Orthogonalize(R)
+    else:
+        bv.Orthogonalize(R, block)
+
+
+def bv_test11(be, block, n=20, l=2, k=8, resid=True, X0=None):
+    """test11.c: BVOrthogonalize of the leading columns, then of the active ones; levels of orthogonality
+    ||M(l:k,l:k) - I||_F (MyMatNorm) and residuals ||X - Q R||_F as the program prints them."""
+    X0 = _test11_X(n, k) if X0 is None else X0
+    X = be.bv(n, k); Y = be.bv(n, k)
+    be.fill(X, X0); be.fill(Y, X0)
+    M = np.zeros((k, k), order="F")
+    R = np.zeros((k, k), order="F") if resid else None
+    out = {}
+
+    def level(a, b):
+        Y.Dot(Y, M)
+        D = M[a:b, a:b] - np.eye(b - a)
+        return np.sqrt((D * D).sum())
+
+    if l > 0:
+        Y.SetActiveColumns(0, l); X.SetActiveColumns(0, l)
+        _orthogonalize(Y, R, block)
+        out["Q1"] = level(0, l)
+        if resid:
+            out["res1"] = np.linalg.norm(X0[:, :l] - Y.dense()[:, :l] @ R[:l, :l])
+    Y.SetActiveColumns(l, k); X.SetActiveColumns(l, k)
+    _orthogonalize(Y, R, block)
+    if l > 0:
+        out["Q2"] = level(l, k)
+    Y.SetActiveColumns(0, k); X.SetActiveColumns(0, k)
+    out["Q"] = level(0, k)
+    if resid:
+        out["res"] = np.linalg.norm(X0 - Y.dense() @ R)
+        out["R"] = R.copy()
+    out["Y"] = Y.dense()
+    return out
+
+
+def bv_test12(be, block="gs", n=20, k=8):
+    """test12.c: BVOrthogonalize of a basis with two linearly dependent columns (GS)."""
+    X0 = np.zeros((n, k))
+    full = _test11_X(n, k)
+    j = 0
+    while j < k // 2:
+        X0[:, j] = full[:, j]; j += 1
+    X0[:, j] = X0[:, 0] + 0.5 * X0[:, 1]; j += 1
+    while j < k - 1:
+        X0[:, j] = full[:, j]; j += 1
+    X0[:, j] = X0[:, 1] - 1.2 * X0[:, k // 2 + 1]
+    X = be.bv(n, k); be.fill(X, X0)
+    R = np.zeros((k, k), order="F")
+    _orthogonalize(X, R, block)
+    M = np.eye(k, order="F") if True else None
+    M = np.asfortranarray(M)
+    X.Dot(X, M)
+    level = np.abs(M - np.eye(k)).sum(axis=0).max()                   # MatShift(-1); MatNorm(NORM_1)
+    res = np.linalg.norm(X0 - X.dense() @ R)
+    return {"level": level, "res": res, "R": R.copy()}

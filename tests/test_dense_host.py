@@ -24,6 +24,11 @@ def lib():
     lib.ksd_real_schur.argtypes = [C.c_int, C.c_int, P, C.c_int, P, P, P]
     lib.ksd_trexc_up.argtypes = [C.c_int, P, C.c_int, P, C.c_int, C.c_int]
     lib.ksd_trevc_one.argtypes = [C.c_int, P, C.c_int, C.c_int, P, P]
+    lib.ksd_potrf_upper.argtypes = [C.c_int, P, C.c_int]
+    lib.ksd_trtri_upper.argtypes = [C.c_int, P, C.c_int]
+    lib.ksd_sym_eig.argtypes = [C.c_int, P, C.c_int, P]
+    lib.ksd_tsqr_combine.argtypes = [C.c_int, P, C.c_int, P, C.c_int]
+    lib.ksd_tsqr_combine.restype = None
     return lib
 
 
@@ -148,3 +153,38 @@ def test_reorder_matches_lapack(lib):
         i += 1
     assert np.allclose(wr, er[:n], atol=1e-10) and np.allclose(wi, ei[:n], atol=1e-10)
     assert np.all(np.diff(wr) <= 1e-12)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 17, 40, 64])
+def test_cholesky_inverse_symmetric_eig_tsqr_combine(lib, n):
+    """The k x k kernels of the block orthogonalisations (bvlapack.c:136-341,456-478) against LAPACK."""
+    import scipy.linalg.lapack as la
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((3 * n + 2, n)); G = X.T @ X
+    eps = np.finfo(float).eps
+    A = np.asfortranarray(G.copy())
+    assert lib.ksd_potrf_upper(n, p(A), n) == 0
+    c, info = la.dpotrf(G, lower=0)
+    assert np.abs(np.triu(A) - np.triu(c)).max() <= 50 * n * eps * np.abs(c).max()
+    Ri = np.asfortranarray(np.triu(A))
+    assert lib.ksd_trtri_upper(n, p(Ri), n) == 0
+    assert np.abs(np.triu(Ri) @ np.triu(A) - np.eye(n)).max() < 1e3 * n * eps * np.linalg.cond(np.triu(A))
+    E = np.asfortranarray(G.copy()); w = np.zeros(n)
+    assert lib.ksd_sym_eig(n, p(E), n, p(w)) == 0
+    assert np.all(np.diff(w) >= 0)                                        # ascending, as dsyev
+    assert np.abs(w - np.linalg.eigvalsh(G)).max() <= 200 * n * eps * w.max()
+    assert np.abs(E.T @ E - np.eye(n)).max() <= 100 * n * eps and np.abs(E @ np.diag(w) @ E.T - G).max() <= 200 * n * eps * np.abs(G).max()
+    R1 = np.asfortranarray(np.triu(rng.standard_normal((n, n)))); R2 = np.asfortranarray(np.triu(rng.standard_normal((n, n))))
+    S = np.vstack([R1, R2])
+    lib.ksd_tsqr_combine(n, p(R1), n, p(R2), n)
+    assert np.all(np.tril(R1, -1) == 0)
+    assert np.abs(R1.T @ R1 - S.T @ S).max() <= 100 * n * eps * np.abs(S.T @ S).max()
+    Rref = np.linalg.qr(S, mode="r")
+    assert np.abs(np.abs(R1) - np.abs(Rref)).max() <= 1e3 * n * eps * np.abs(Rref).max()      # equal up to row signs
+
+
+def test_cholesky_reports_indefinite(lib):
+    B = np.asfortranarray(np.array([[1.0, 2.0], [2.0, 1.0]]))
+    assert lib.ksd_potrf_upper(2, p(B), 2) == 2
+    Z = np.asfortranarray(np.array([[1.0, 2.0], [0.0, 0.0]]))
+    assert lib.ksd_trtri_upper(2, p(Z), 2) == 2

@@ -1,0 +1,130 @@
+"""BVOrthogonalize (GS / CHOL / TSQR / TSQRCHOL / SVQB), BVMatProject and BVNormalize on the GPU: the reference's
+test11 / test12 programs against their golden outputs and the CPU oracle, then size-independent properties
+(orthogonality, V0 = Q R, triangularity, untouched leading columns) at sizes where the panel kernels run multi-block."""
+import numpy as np
+import pytest
+
+import golden_inputs as gi
+import scenarios as sc
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(float).eps
+BLOCKS = ["gs", "chol", "tsqr", "tsqrchol", "svqb"]
+
+
+@pytest.fixture(scope="module")
+def gpu(ctx):
+    return sc.GpuBackend(ctx)
+
+
+@pytest.fixture(scope="module")
+def cpu():
+    return sc.OracleBackend()
+
+
+@pytest.mark.parametrize("block", BLOCKS)
+def test_bv_test11_golden_and_oracle(gpu, cpu, block):
+    txt = gi.read("bv/test11_6.out")
+    assert "Level of orthogonality of Q < 100*eps" in txt and "Residual ||X-Q*R|| < 100*eps" in txt
+    a, b = sc.bv_test11(gpu, block), sc.bv_test11(cpu, block)
+    for key in ("Q1", "Q2", "Q", "res1", "res"):
+        assert a[key] < 100 * EPS, (block, key, a[key])
+    if block != "svqb":
+        assert np.all(np.tril(a["R"], -1) == 0)
+    if block in ("gs", "chol"):                       # unique factorisation with a positive diagonal: compare entrywise
+        assert np.allclose(a["R"], b["R"], rtol=0, atol=1e-13) and np.allclose(a["Y"], b["Y"], rtol=0, atol=1e-13)
+    if block in ("tsqr", "tsqrchol"):                 # Householder R: rows defined up to sign
+        assert np.allclose(np.abs(a["R"]), np.abs(b["R"]), rtol=0, atol=1e-13)
+    if block == "svqb":                               # eigenvector signs are free; the Gram factor R'R is not
+        assert np.allclose(a["R"][:, 2:].T @ a["R"][:, 2:], b["R"][:, 2:].T @ b["R"][:, 2:], rtol=0, atol=1e-12)
+
+
+def test_bv_test12_dependent_columns(gpu, cpu):
+    txt = gi.read("bv/test12_1.out")
+    assert "Level of orthogonality < 100*eps" in txt and "Residual ||X-QR|| < 100*eps" in txt
+    a = sc.bv_test12(gpu)
+    assert a["level"] < 100 * EPS and a["res"] < 100 * EPS
+
+
+@pytest.mark.parametrize("block", BLOCKS)
+@pytest.mark.parametrize("n,l,k", [(5000, 0, 7), (100003, 3, 20), (1000000, 5, 37), (70000, 0, 64)])
+def test_orthogonalize_properties(ctx, block, n, l, k):
+    import slepc_amd as ks
+    rng = np.random.default_rng(n + k)
+    X0 = rng.standard_normal((n, k))
+    X0[:, :l] = np.linalg.qr(X0[:, :l])[0] if l else X0[:, :l]        # leading columns come orthonormal
+    V = ks.BV(ctx, n, k)
+    V.set_dense(X0)
+    V.SetActiveColumns(l, k); V.SetOrthogBlock(block)
+    R = np.zeros((k, k), order="F")
+    V.Orthogonalize(R)
+    Q = V.dense()
+    assert np.array_equal(Q[:, :l], X0[:, :l])                          # leading columns untouched
+    G = Q.T @ Q
+    assert np.abs(G - np.eye(k)).max() < 200 * EPS * np.sqrt(k)
+    Rfull = R.copy(); Rfull[:l, :l] = np.eye(l)                        # leading block of R is not referenced
+    assert np.abs(X0[:, l:] - Q @ Rfull[:, l:]).max() < 1e3 * EPS * np.abs(X0).max() * np.sqrt(k)
+    if block != "svqb":
+        assert np.all(np.tril(R, -1)[:, l:] == 0)
+    if block in ("gs", "chol"):
+        assert np.all(np.diag(R)[l:] > 0)
+    V.Orthogonalize(None)                                              # R is optional; an orthonormal basis stays one
+    assert np.abs(V.dense().T @ V.dense() - np.eye(k)).max() < 200 * EPS * np.sqrt(k)
+
+
+@pytest.mark.parametrize("block", ["tsqr", "tsqrchol", "chol"])
+def test_ill_conditioned_basis(ctx, block):
+    """cond(V) = 1e6: TSQR keeps Q orthonormal to working precision (its second pass); V inv(R) from one pass
+    (TSQRCHOL) or from the Gram matrix (CHOL, cond squared) loses orthogonality as the theory says."""
+    import slepc_amd as ks
+    n, k = 20000, 12
+    rng = np.random.default_rng(5)
+    U = np.linalg.qr(rng.standard_normal((n, k)))[0]; W = np.linalg.qr(rng.standard_normal((k, k)))[0]
+    X0 = U @ np.diag(np.logspace(0, -6, k)) @ W.T
+    V = ks.BV(ctx, n, k); V.set_dense(X0); V.SetOrthogBlock(block)
+    R = np.zeros((k, k), order="F")
+    V.Orthogonalize(R)
+    Q = V.dense()
+    lvl = np.abs(Q.T @ Q - np.eye(k)).max()
+    assert np.abs(X0 - Q @ R).max() < 1e-13
+    assert lvl < {"tsqr": 1e-13, "tsqrchol": 1e-8, "chol": 1e-2}[block]
+
+
+def test_breakdown_is_an_error_for_gs(ctx):
+    import slepc_amd as ks
+    V = ks.BV(ctx, 50, 3)
+    X0 = np.zeros((50, 3)); X0[0, 0] = 1.0; X0[1, 2] = 1.0           # column 1 is exactly zero
+    V.set_dense(X0)
+    with pytest.raises(ks.KsError) as e:
+        V.Orthogonalize(None)
+    assert e.value.rc == 82
+
+
+def test_matproject_and_normalize(ctx):
+    import slepc_amd as ks
+    Ao = O.laplacian2d(40)
+    A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
+    n = Ao.n
+    rng = np.random.default_rng(9)
+    X0 = rng.standard_normal((n, 9)); Y0 = rng.standard_normal((n, 6))
+    X = ks.BV(ctx, n, 9); Y = ks.BV(ctx, n, 6); X.set_dense(X0); Y.set_dense(Y0)
+    X.SetActiveColumns(2, 8); Y.SetActiveColumns(1, 5)
+    M = np.full((6, 9), 7.0, order="F")
+    X.MatProject(A, Y, M)
+    S = Ao.to_scipy()
+    want = Y0[:, 1:5].T @ (S @ X0[:, 2:8])
+    assert np.allclose(M[1:5, 2:8], want, rtol=1e-12, atol=1e-11)
+    M2 = M.copy(); M2[1:5, 2:8] = 7.0
+    assert np.all(M2 == 7.0)                                           # nothing outside the active block is written
+    X.MatProject(None, Y, M)
+    assert np.allclose(M[1:5, 2:8], Y0[:, 1:5].T @ X0[:, 2:8], rtol=1e-12, atol=1e-11)
+    # BVNormalize: plain, and pairwise for complex-conjugate pairs
+    X.SetActiveColumns(0, 9); X.Normalize()
+    assert np.allclose(np.linalg.norm(X.dense(), axis=0), 1.0, rtol=1e-14)
+    X.set_dense(X0); X.SetActiveColumns(1, 6)
+    X.Normalize(np.array([0.0, 0.3, -0.3, 0.0, 0.0]))
+    D = X.dense()
+    assert abs(np.linalg.norm(D[:, 1]) - 1) < 1e-14 and abs(np.linalg.norm(D[:, 4]) - 1) < 1e-14 and abs(np.linalg.norm(D[:, 5]) - 1) < 1e-14
+    assert abs(np.hypot(np.linalg.norm(D[:, 2]), np.linalg.norm(D[:, 3])) - 1) < 1e-14
+    assert np.array_equal(D[:, 0], X0[:, 0]) and np.array_equal(D[:, 6:], X0[:, 6:])

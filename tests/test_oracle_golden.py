@@ -230,3 +230,27 @@ def test_eps_nhep_complex_pairs():
             assert lam[k].imag > 0 and lam[k + 1] == np.conj(lam[k]) and r.perm[k + 1] == r.perm[k] + 1
             k += 1
         k += 1
+
+
+# ---- block orthogonalisation (BV test11 / test12) ----------------------------------------------------------------
+@pytest.mark.parametrize("block", ["gs", "chol", "tsqr", "tsqrchol", "svqb"])
+def test_bv_test11(be, block):
+    """output/test11_1.out and test11_6.out: every level and residual prints as '< 100*eps'."""
+    txt = gi.read("bv/test11_6.out")
+    for line in ("Level of orthogonality of Q1 < 100*eps", "Residual ||X1-Q1*R11|| < 100*eps", "Level of orthogonality of Q2 < 100*eps",
+                 "Level of orthogonality of Q < 100*eps", "Residual ||X-Q*R|| < 100*eps"):
+        assert line in txt
+    out = sc.bv_test11(be, block)
+    tol = 100 * np.finfo(float).eps
+    for key in ("Q1", "Q2", "Q", "res1", "res"):
+        assert out[key] < tol, (block, key, out[key])
+    if block != "svqb":
+        assert np.all(np.tril(out["R"], -1) == 0)
+
+
+def test_bv_test12(be):
+    """output/test12_1.out: GS with two dependent columns still ends below 100*eps."""
+    txt = gi.read("bv/test12_1.out")
+    assert "Level of orthogonality < 100*eps" in txt and "Residual ||X-QR|| < 100*eps" in txt
+    out = sc.bv_test12(be)
+    assert out["level"] < 100 * np.finfo(float).eps and out["res"] < 100 * np.finfo(float).eps
