@@ -43,6 +43,8 @@ extern "C" {
 #define KS_ERR_ORDER           58
 #define KS_ERR_ARG_SIZ         60
 #define KS_ERR_ARG_IDN         61
+#define KS_ERR_FILE_OPEN       65
+#define KS_ERR_FILE_UNEXPECTED 79
 #define KS_ERR_ARG_WRONG       62
 #define KS_ERR_ARG_OUTOFRANGE  63
 #define KS_ERR_USER_INPUT      71   /* BV_SafeSqrt "Invalid inner product" bvimpl.h:137 */
@@ -123,6 +125,9 @@ int ks_mat_create_csr(ks_ctx ctx, int n_local, int row_start, int n_global,
    2-D 5-pt Laplacian of ex2.c:44-51.                                                           */
 int ks_mat_create_laplacian3d(ks_ctx ctx, int nx, int ny, int nz, int z0, int nz_local, ks_mat *A);
 int ks_mat_create_laplacian2d(ks_ctx ctx, int n, int m, ks_mat *A);
+/* MatLoad from a PETSc binary viewer file (the .petsc files under share/slepc/datafiles/matrices, as ex4.c and ex7.c read them); every
+   rank takes the row block PETSC_DECIDE would give it */
+int ks_mat_load_petsc_binary(ks_ctx ctx, const char *path, ks_mat *A);
 /* MatCreateShell + MATOP_MULT (the matrix-free route of src/eps/tutorials/ex3.c): y = mult(user, x) on device
    pointers of n_local doubles; the callback must order its work after everything already enqueued on the context's
    stream (enqueue on that stream, or synchronise) and leave y complete in that order.          */

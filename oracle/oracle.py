@@ -787,6 +787,20 @@ def eps_compute_error(A, res, i, relative=True):
 # ================================================================================================
 # Non-symmetric problems: DS NHEP + the Arnoldi variant of the Krylov-Schur driver
 # ================================================================================================
+def load_petsc_binary(path):
+    """MatLoad of a PETSc binary viewer file: big-endian int32 {1211216, rows, cols, nnz}, row lengths, column indices,
+    float64 values (the format of share/slepc/datafiles/matrices/*.petsc)."""
+    raw = open(path, "rb").read()
+    hdr = np.frombuffer(raw, dtype=">i4", count=4)
+    assert hdr[0] == 1211216 and hdr[1] == hdr[2], hdr
+    n, nnz = int(hdr[1]), int(hdr[3])
+    lens = np.frombuffer(raw, dtype=">i4", count=n, offset=16).astype(np.int64)
+    col = np.frombuffer(raw, dtype=">i4", count=nnz, offset=16 + 4 * n).astype(np.int32)
+    val = np.frombuffer(raw, dtype=">f8", count=nnz, offset=16 + 4 * n + 4 * nnz).astype(np.float64)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    return CSR(n, rowptr, col, val)
+
+
 def markov_matrix(m):
     """MatMarkovModel (src/eps/tutorials/ex5.c:137-170): random walk on a triangular grid, N = m(m+1)/2."""
     import scipy.sparse as sp

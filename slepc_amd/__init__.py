@@ -13,6 +13,7 @@ Device memory belongs to the library; host<->device staging uses numpy arrays. t
 plumbing (streams, torch.distributed bootstrap of the RCCL communicator) and is imported lazily.
 The library is gfx950-only and has NO CPU fallback: creating a Context without an MI355X raises.
 """
+import os
 import ctypes as C
 import numpy as np
 
@@ -198,6 +199,13 @@ class Mat:
     def laplacian2d(cls, ctx, n, m=None):
         h = C.c_void_p()
         _lib.check(ctx.L.ks_mat_create_laplacian2d(ctx.h, n, n if m is None else m, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def load(cls, ctx, path):
+        """MatLoad of a PETSc binary file."""
+        h = C.c_void_p()
+        _lib.check(ctx.L.ks_mat_load_petsc_binary(ctx.h, os.fsencode(path), C.byref(h)))
         return cls(ctx, h)
 
     @classmethod

@@ -29,6 +29,8 @@ extern "C" const char *ks_error_string(int rc)
     case KS_ERR_PLIB: return "internal library error";
     case KS_ERR_CONV_FAILED: return "convergence failed";
     case KS_ERR_ARG_NULL: return "null argument";
+    case KS_ERR_FILE_OPEN: return "unable to open file";
+    case KS_ERR_FILE_UNEXPECTED: return "unexpected data in file";
     case KS_ERR_ARG_IDN: return "two arguments must be different";
     case KS_ERR_NOT_CONVERGED: return "linear solve did not converge";
     case KS_ERR_GPU: return "no usable gfx950 GPU";

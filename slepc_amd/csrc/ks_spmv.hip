@@ -572,6 +572,42 @@ extern "C" int ks_mat_get_diagonal(ks_mat A, double *d_dev)
   return ks_mat_get_diagonal_internal(A, d_dev);
 }
 
+// MatLoad of a PETSc binary viewer file (the format of share/slepc/datafiles/matrices/*.petsc): big-endian int32
+// header {MAT_FILE_CLASSID = 1211216, rows, cols, nnz}, int32 row lengths, int32 column indices, float64 values.
+// Each rank keeps the row block PETSC_DECIDE would give it (n/size rows, the first n%size ranks one more).
+namespace {
+inline uint32_t be32(const unsigned char *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]; }
+inline double be64f(const unsigned char *p) { uint64_t v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | p[i]; double d; memcpy(&d, &v, 8); return d; }
+}
+extern "C" int ks_mat_load_petsc_binary(ks_ctx ctx, const char *path, ks_mat *out)
+{
+  KS_CHECK(ctx && path && out, KS_ERR_ARG_NULL, "NULL argument");
+  FILE *f = fopen(path, "rb");
+  KS_CHECK(f, KS_ERR_FILE_OPEN, "Cannot open file %s", path);
+  std::vector<unsigned char> buf;
+  fseek(f, 0, SEEK_END); const long sz = ftell(f); fseek(f, 0, SEEK_SET);
+  buf.resize(sz > 0 ? (size_t)sz : 0);
+  const size_t got = buf.empty() ? 0 : fread(buf.data(), 1, buf.size(), f);
+  fclose(f);
+  KS_CHECK(got == buf.size() && buf.size() >= 16, KS_ERR_FILE_UNEXPECTED, "Short read on %s", path);
+  KS_CHECK(be32(buf.data()) == 1211216u, KS_ERR_FILE_UNEXPECTED, "Not a Mat object in %s (classid %u)", path, be32(buf.data()));
+  const long long rows = (int32_t)be32(buf.data() + 4), cols = (int32_t)be32(buf.data() + 8), nnz = (int32_t)be32(buf.data() + 12);
+  KS_CHECK(rows >= 0 && cols == rows && nnz >= 0, KS_ERR_FILE_UNEXPECTED, "Unsupported matrix shape %lld x %lld (nnz %lld) in %s: square sparse matrices only", rows, cols, nnz, path);
+  KS_CHECK((long long)buf.size() >= 16 + 4 * rows + 12 * nnz, KS_ERR_FILE_UNEXPECTED, "File %s is truncated", path);
+  const unsigned char *pl = buf.data() + 16, *pc = pl + 4 * rows, *pv = pc + 4 * nnz;
+  std::vector<long long> start(rows + 1, 0);
+  for (long long i = 0; i < rows; i++) start[i + 1] = start[i] + (int32_t)be32(pl + 4 * i);
+  KS_CHECK(start[rows] == nnz, KS_ERR_FILE_UNEXPECTED, "Row lengths of %s do not add up to its nnz", path);
+  const int size = ctx->comm.size, rank = ctx->comm.rank;
+  const long long base = rows / size, rem = rows % size;
+  const long long r0 = rank * base + std::min<long long>(rank, rem), nloc = base + (rank < rem ? 1 : 0);
+  std::vector<int> rp(nloc + 1), ci((size_t)(start[r0 + nloc] - start[r0]));
+  std::vector<double> va(ci.size());
+  for (long long i = 0; i <= nloc; i++) rp[i] = (int)(start[r0 + i] - start[r0]);
+  for (size_t e = 0; e < ci.size(); e++) { ci[e] = (int32_t)be32(pc + 4 * (start[r0] + e)); va[e] = be64f(pv + 8 * (start[r0] + e)); }
+  return ks_mat_create_csr(ctx, (int)nloc, (int)r0, (int)rows, rp.data(), ci.data(), va.data(), out);
+}
+
 // MatCreateShell + MatShellSetOperation(MATOP_MULT) (the matrix-free route of src/eps/tutorials/ex3.c)
 extern "C" int ks_mat_create_shell(ks_ctx ctx, int n_local, int row_start, int n_global, ks_shell_mult_fn mult, void *user, ks_mat *out)
 {

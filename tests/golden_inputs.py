@@ -54,6 +54,34 @@ def eigenvalues_line(text):
     raise ValueError("no eigenvalue line")
 
 
+def complex_eigenvalues_line(text):
+    """The -terse eigenvalue line when it holds conjugate pairs: '-243874.97870+6999.66927i, ..., -212991.49278'."""
+    pat = re.compile(r"^\s*(" + _NUM + r")(?:([-+]\d+\.?\d*)i)?\s*$")
+    for line in text.splitlines():
+        toks = [t.strip() for t in line.split(",")]
+        if len(toks) >= 2 and all(pat.match(t) for t in toks) and "." in toks[0]:
+            out = []
+            for t in toks:
+                m = pat.match(t)
+                out.append(complex(float(m.group(1)), float(m.group(2)) if m.group(2) else 0.0))
+            return np.array(out)
+    raise ValueError("no eigenvalue line")
+
+
+def matrix_path(name):
+    return os.path.join(GOLDEN, "matrices", name)
+
+
+def table_first_column(text):
+    """First numeric column of an EPSErrorView-style table (test29_1.out)."""
+    vals = []
+    for line in text.splitlines():
+        toks = line.split()
+        if toks and re.fullmatch(_NUM, toks[0]) and len(toks) >= 2 and "." in toks[0]:
+            vals.append(float(toks[0]))
+    return np.array(vals)
+
+
 # ---- inputs (src/sys/classes/bv/tests/test1.c:60-99, test2.c:58-69, test4.c, test13.c) -----------------
 def test1_X(n=10, k=5):
     X = np.zeros((n, k))

@@ -143,3 +143,68 @@ def test_user_comparison_required(ctx):
     eps.SetWhichEigenpairs("user")
     with pytest.raises(ks.KsError):
         eps.Solve()
+
+
+# ---- the reference's own matrix files (PETSc binary) through MatLoad: ex4, ex7, test29 ----------------------------
+def test_matload_and_ex4_rdb200(ctx):
+    import slepc_amd as ks
+    A = ks.Mat.load(ctx, gi.matrix_path("rdb200.petsc"))
+    Ao = O.load_petsc_binary(gi.matrix_path("rdb200.petsc"))
+    assert (A.n, A.N, A.nnz) == (200, 200, 1120)
+    x = np.random.default_rng(0).standard_normal(200)
+    assert np.allclose(A.mult(x), Ao.mult(x), rtol=0, atol=1e-12)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A); eps.SetProblemType(ks.EPS_NHEP); eps.SetDimensions(4)
+    eps.Solve()
+    txt = gi.read("eps/ex4_1.out")
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(4)])
+    assert np.allclose(np.round(lam, 5), gi.eigenvalues_line(txt), atol=1.5e-5)
+    assert eps.GetIterationNumber() == int(gi.value_after(txt, "Number of iterations of the method:"))
+    _check_against_oracle(eps, O.eps_krylovschur_nhep(Ao, 4), Ao)
+    with pytest.raises(ks.KsError) as e:
+        ks.Mat.load(ctx, gi.matrix_path("does_not_exist.petsc"))
+    assert e.value.rc == 65
+    with pytest.raises(ks.KsError) as e:
+        ks.Mat.load(ctx, __file__)                      # not a PETSc binary Mat
+    assert e.value.rc == 79
+
+
+def _bfw(ctx):
+    import slepc_amd as ks
+    return (ks.Mat.load(ctx, gi.matrix_path("bfw62a.petsc")), ks.Mat.load(ctx, gi.matrix_path("bfw62b.petsc")),
+            O.load_petsc_binary(gi.matrix_path("bfw62a.petsc")), O.load_petsc_binary(gi.matrix_path("bfw62b.petsc")))
+
+
+def test_ex7_generalized_golden(ctx):
+    """ex7: (bfw62a, bfw62b), GNHEP with the default ST (shift): Op = B^-1 A. B is 62 x 62 symmetric indefinite, so the
+    GMRES restart is raised to the dimension, where it is exact."""
+    import slepc_amd as ks
+    A, B, Ao, Bo = _bfw(ctx)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A, B); eps.SetProblemType(ks.EPS_GNHEP); eps.SetDimensions(4)
+    eps.GetST().SetKSP(rtol=1e-14, restart=62)
+    eps.Solve()
+    txt = gi.read("eps/ex7_1.out")
+    lam = np.array([complex(*eps.GetEigenvalue(i)) for i in range(4)])
+    ref = gi.complex_eigenvalues_line(txt)
+    assert np.allclose(np.round(lam.real, 5), ref.real, atol=1.5e-5) and np.allclose(np.round(lam.imag, 5), ref.imag, atol=1.5e-5)
+    assert eps.GetIterationNumber() == int(gi.value_after(txt, "Number of iterations of the method:"))
+    r = O.eps_krylovschur_nhep(Ao, 4, st=O.ST(Ao, Bo, "shift", 0.0))
+    assert eps.GetConverged() == r.nconv and eps.GetStats()["arnoldi_steps"] == r.steps
+    for i in range(r.nconv):
+        j = r.perm[i]
+        assert abs(complex(*eps.GetEigenvalue(i)) - complex(r.eigr[j], r.eigi[j])) <= 1e-9 * abs(complex(r.eigr[j], r.eigi[j]))
+        assert eps.ComputeError(i) < 1e-8
+
+
+def test_test29_sinvert_golden(ctx):
+    import slepc_amd as ks
+    A, B, Ao, Bo = _bfw(ctx)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A, B); eps.SetProblemType(ks.EPS_GNHEP); eps.SetDimensions(4); eps.SetTarget(-190000.0)
+    st = eps.GetST(); st.SetType("sinvert"); st.SetKSP(rtol=1e-14, restart=62)
+    eps.Solve()
+    ref = gi.table_first_column(gi.read("eps/eps_test29_1.out"))
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(4)])
+    assert np.allclose(lam, ref, rtol=1e-10)
+    assert st.GetShift() == -190000.0

@@ -254,3 +254,35 @@ def test_bv_test12(be):
     assert "Level of orthogonality < 100*eps" in txt and "Residual ||X-QR|| < 100*eps" in txt
     out = sc.bv_test12(be)
     assert out["level"] < 100 * np.finfo(float).eps and out["res"] < 100 * np.finfo(float).eps
+
+
+# ---- matrices from the reference's data files (PETSc binary), ex4 / ex7 / test29 ----------------------------------
+def test_eps_ex4_rdb200_golden():
+    """ex4 -file rdb200.petsc -eps_nev 4: -35.00752, -34.10419, -33.20131, -32.68111 in 5 iterations."""
+    A = O.load_petsc_binary(gi.matrix_path("rdb200.petsc"))
+    assert A.n == 200 and len(A.val) == 1120
+    txt = gi.read("eps/ex4_1.out")
+    r = O.eps_krylovschur_nhep(A, 4)
+    assert np.allclose(np.round(r.eigr[r.perm][:4], 5), gi.eigenvalues_line(txt), atol=1.5e-5) and np.all(r.eigi[r.perm][:4] == 0)
+    assert r.its == int(gi.value_after(txt, "Number of iterations of the method:"))
+
+
+def test_eps_ex7_generalized_golden():
+    """ex7 -f1 bfw62a.petsc -f2 bfw62b.petsc -eps_nev 4 (GNHEP, default ST = shift: Op = B^-1 A, 4 iterations)."""
+    A = O.load_petsc_binary(gi.matrix_path("bfw62a.petsc")); B = O.load_petsc_binary(gi.matrix_path("bfw62b.petsc"))
+    txt = gi.read("eps/ex7_1.out")
+    r = O.eps_krylovschur_nhep(A, 4, st=O.ST(A, B, "shift", 0.0))
+    lam = (r.eigr + 1j * r.eigi)[r.perm][:4]
+    ref = gi.complex_eigenvalues_line(txt)
+    assert np.allclose(np.round(lam.real, 5), ref.real, atol=1.5e-5) and np.allclose(np.round(lam.imag, 5), ref.imag, atol=1.5e-5)
+    assert r.its == int(gi.value_after(txt, "Number of iterations of the method:"))
+    for i in range(4):
+        assert O.eps_compute_error_nhep(A, r, i, B) < 1e-8
+
+
+def test_eps_test29_sinvert_golden():
+    """test29 -eps_nev 4 -st_type sinvert -eps_target -190000 on (bfw62a, bfw62b)."""
+    A = O.load_petsc_binary(gi.matrix_path("bfw62a.petsc")); B = O.load_petsc_binary(gi.matrix_path("bfw62b.petsc"))
+    r = O.eps_krylovschur_nhep(A, 4, which=O.which_target_magnitude(-190000.0), st=O.ST(A, B, "sinvert", -190000.0))
+    ref = gi.table_first_column(gi.read("eps/eps_test29_1.out"))
+    assert len(ref) == 4 and np.allclose(r.eigr[r.perm][:4], ref, rtol=1e-11)
