@@ -18,6 +18,17 @@ def my_eigen_sort(ar, ai, br, bi, origin=0.0):
     return 1 if br >= 0 else -1          # PetscSign(PetscRealPart(br))
 
 
+def right_of(target):
+    """MyEigenSort of src/eps/tests/test11.c:150-176: closest to the target, but on its right side first."""
+    def cmp(ar, ai, br, bi):
+        aright, bright = target < ar, target < br
+        if aright == bright:
+            da, db = np.hypot(ar - target, ai), np.hypot(br - target, bi)
+            return -1 if da < db else (1 if da > db else 0)
+        return -1 if aright else 1
+    return cmp
+
+
 def test9_v0(n):
     v0 = np.zeros(n)
     v0[0] = -1.5; v0[1] = 2.1            # test9.c:126-130

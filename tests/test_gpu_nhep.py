@@ -208,3 +208,4 @@ def test_test29_sinvert_golden(ctx):
     lam = np.array([eps.GetEigenvalue(i)[0] for i in range(4)])
     assert np.allclose(lam, ref, rtol=1e-10)
     assert st.GetShift() == -190000.0
+

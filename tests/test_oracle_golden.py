@@ -286,3 +286,13 @@ def test_eps_test29_sinvert_golden():
     r = O.eps_krylovschur_nhep(A, 4, which=O.which_target_magnitude(-190000.0), st=O.ST(A, B, "sinvert", -190000.0))
     ref = gi.table_first_column(gi.read("eps/eps_test29_1.out"))
     assert len(ref) == 4 and np.allclose(r.eigr[r.perm][:4], ref, rtol=1e-11)
+
+
+def test_eps_test11_sinvert_user_sort_golden():
+    """test11 -eps_nev 4 -st_type sinvert: Markov matrix, shift 0.5, user ordering 'closest to the right of 0.5',
+    tol = PETSC_SMALL, initial vector of ones -> 0.51928, 0.55740, 0.57028, 0.57143."""
+    import nhep_cases as nc
+    A = O.markov_matrix(15)
+    r = O.eps_krylovschur_nhep(A, 4, tol=1e-10, which=nc.right_of(0.5), st=O.ST(A, None, "sinvert", 0.5), v0=np.ones(A.n))
+    ref = gi.eigenvalues_line(gi.read("eps/eps_test11_1.out"))
+    assert r.nconv >= 4 and np.allclose(np.round(r.eigr[r.perm][:4], 5), ref, atol=1.5e-5)
