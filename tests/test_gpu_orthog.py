@@ -128,3 +128,60 @@ def test_matproject_and_normalize(ctx):
     assert abs(np.linalg.norm(D[:, 1]) - 1) < 1e-14 and abs(np.linalg.norm(D[:, 4]) - 1) < 1e-14 and abs(np.linalg.norm(D[:, 5]) - 1) < 1e-14
     assert abs(np.hypot(np.linalg.norm(D[:, 2]), np.linalg.norm(D[:, 3])) - 1) < 1e-14
     assert np.array_equal(D[:, 0], X0[:, 0]) and np.array_equal(D[:, 6:], X0[:, 6:])
+
+
+def test_bv_test9_matproject_golden(ctx):
+    """test9.c: H0 = Y' G X by BVMatProject equals H1 = Y' Z with Z = G X stored by BVMatMult ("||H0-H1|| < 10*eps");
+    integer data, so the two must agree exactly, and with a host evaluation."""
+    import slepc_amd as ks
+    assert "||H0-H1|| < 10*eps" in gi.read("bv/test9_1.out")
+    n, kx, lx, ky, ly = 20, 6, 3, 5, 2
+    rows, cols, vals = [], [], []
+    for i in range(n):                                   # non-symmetric Toeplitz G: -1 1 1 1 1 on diagonals -1..3
+        for d, v in zip(range(-1, 4), [-1.0, 1.0, 1.0, 1.0, 1.0]):
+            if 0 <= i + d < n:
+                rows.append(i); cols.append(i + d); vals.append(v)
+    import scipy.sparse as sp
+    S = sp.csr_matrix((vals, (rows, cols)), shape=(n, n)); S.sort_indices()
+    G = ks.Mat.from_csr(ctx, S.indptr, S.indices, S.data)
+    X0 = np.zeros((n, kx + 2))
+    for j in range(kx + 2):
+        for i in range(4):
+            if i + j < n:
+                X0[i + j, j] = 3 * i + j - 2
+    Y0 = np.tile((np.arange(ky + 1) + 1) / 4.0, (n, 1))
+    X = ks.BV(ctx, n, kx + 2); Z = ks.BV(ctx, n, kx + 2); Y = ks.BV(ctx, n, ky + 1)
+    X.set_dense(X0); Y.set_dense(Y0)
+    X.SetActiveColumns(0, kx); Z.SetActiveColumns(0, kx)
+    X.MatMult(G, Z)
+    X.SetActiveColumns(lx, kx); Z.SetActiveColumns(lx, kx); Y.SetActiveColumns(ly, ky)
+    H0 = np.zeros((ky, kx), order="F"); H1 = np.zeros((ky, kx), order="F")
+    X.MatProject(G, Y, H0)
+    Z.MatProject(None, Y, H1)
+    assert np.array_equal(H0, H1)
+    want = np.zeros((ky, kx)); want[ly:ky, lx:kx] = Y0[:, ly:ky].T @ (S @ X0[:, lx:kx])
+    assert np.array_equal(H0, want)
+
+
+def test_bv_test18_normalize_golden(ctx):
+    """test18.c parts 1 and 3 (the B-norm part needs BVSetMatrix, which is not built): 15 columns of length 250."""
+    import slepc_amd as ks
+    txt = gi.read("bv/test18_1.out")
+    assert "Deviation from normalized vectors < 100*eps" in txt and "Deviation from normalized conjugate vectors < 100*eps" in txt
+    n, k, l = 250, 15, 3
+    X0 = sc._test11_X(n, k)
+    X = ks.BV(ctx, n, k); X.set_dense(X0); X.SetActiveColumns(l, k)
+    X.Normalize()
+    assert max(abs(X.NormColumn(j) - 1.0) for j in range(l, k)) < 100 * EPS
+    assert np.array_equal(X.dense()[:, :l], X0[:, :l])
+    # conjugate pairs: eigi = (r, -r) for columns (l, l+1), (l+2, l+3), ... as the test draws them
+    Z = ks.BV(ctx, n, k); Z.set_dense(X0); Z.SetActiveColumns(l, k)
+    eigi = np.zeros(k - l)
+    rng = np.random.default_rng(1)
+    for j in range(0, k - l - 1, 2):
+        eigi[j] = rng.uniform(0.1, 1.0); eigi[j + 1] = -eigi[j]
+    Z.Normalize(eigi)
+    err = 0.0
+    for j in range(l, k - 1, 2):
+        err = max(err, abs(np.hypot(Z.NormColumn(j), Z.NormColumn(j + 1)) - 1.0))
+    assert err < 100 * EPS
