@@ -212,6 +212,7 @@ int ks_eps_get_st(ks_eps eps, ks_st *st);                                    /* 
 int ks_eps_set_target(ks_eps eps, double target);                            /* EPSSetTarget epsopts.c:604 (sorting only: no spectral transformation) */
 int ks_eps_set_eigenvalue_comparison(ks_eps eps, ks_eig_compare_fn fn, void *ctx);   /* EPSSetEigenvalueComparison epsopts.c:563 */
 int ks_eps_set_krylovschur_restart(ks_eps eps, double keep);               /* EPSKrylovSchurSetRestart, default 0.5 */
+int ks_eps_set_krylovschur_locking(ks_eps eps, int lock);               /* EPSKrylovSchurSetLocking: 0 = non-locking variant (krylovschur.c:294) */
 int ks_eps_set_random_seed(ks_eps eps, uint64_t seed);
 int ks_eps_set_initial_vector(ks_eps eps, const double *v_host);           /* EPSSetInitialSpace with one vector */
 int ks_eps_set_max_steps(ks_eps eps, long long max_steps);                 /* bench harness: stop after this many Arnoldi steps (0 = off) */

@@ -644,7 +644,7 @@ class EPSResult:
 
 def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which="largest_magnitude",
                         keep=0.5, seed=0x12345678, omp=False, v0=None, orthog=(CGS, REFINE_IFNEEDED, 0.7071),
-                        max_steps=None, monitor=None):
+                        max_steps=None, monitor=None, lock=True):
     """EPSSolve for a standard symmetric problem with the default Krylov-Schur solver.
 
     EPSSetUp_KrylovSchur krylovschur.c:93-194 (EPS_KS_SYMM), EPSSetDimensions_Default epssetup.c:654-678,
@@ -736,6 +736,8 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
             l = 0
         else:
             l = max(1, int((nv - k) * keep))
+        if not lock and l > 0:                 # non-locking variant (krylovschur.c:294)
+            l += k; k = 0
         if reason == 0:
             if breakdown or k == nv:
                 if k < nev:
@@ -1010,7 +1012,7 @@ class ST:
 
 
 def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which="largest_magnitude", keep=0.5,
-                         seed=0x12345678, v0=None, max_steps=None, st=None):
+                         seed=0x12345678, v0=None, max_steps=None, st=None, lock=True):
     """EPSSolve_KrylovSchur_Default with the Arnoldi expansion (krylovschur.c:227-337, non-Hermitian branch),
     EPSKrylovConvergence for conjugate pairs (epskrylov.c:262-287), EPSComputeVectors_Schur (epsdefault.c:105-169).
     With st (an ST): the Krylov operator is st.apply, the DS sorts through the back-transformation
@@ -1098,6 +1100,8 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
         else:
             l = max(1, int((nv - k) * keep))
             l = ds.GetTruncateSize(k, nv, l)
+        if not lock and l > 0:                 # non-locking variant (krylovschur.c:294)
+            l += k; k = 0
         if reason == 0:
             if breakdown or k == nv:
                 if k < nev and start_vector(k):

@@ -574,6 +574,9 @@ class EPS:
         self._cmp_cb = EIG_COMPARE_FN(tramp)          # keep the trampoline alive as long as the solver
         _lib.check(self.ctx.L.ks_eps_set_eigenvalue_comparison(self.h, C.cast(self._cmp_cb, C.c_void_p), None))
 
+    def KrylovSchurSetLocking(self, lock):
+        _lib.check(self.ctx.L.ks_eps_set_krylovschur_locking(self.h, int(bool(lock))))
+
     def KrylovSchurSetRestart(self, keep):
         _lib.check(self.ctx.L.ks_eps_set_krylovschur_restart(self.h, keep))
 

@@ -104,6 +104,7 @@ _SIG = {
     "ks_eps_set_tolerances": [vp, C.c_double, C.c_int],
     "ks_eps_set_which_eigenpairs": [vp, C.c_int],
     "ks_eps_set_target": [vp, C.c_double],
+    "ks_eps_set_krylovschur_locking": [vp, C.c_int],
     "ks_eps_set_eigenvalue_comparison": [vp, C.c_void_p, vp],
     "ks_eps_set_krylovschur_restart": [vp, C.c_double],
     "ks_eps_set_random_seed": [vp, C.c_uint64],

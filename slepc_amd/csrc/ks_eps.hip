@@ -333,7 +333,7 @@ struct ks_eps_s {
   double tol = 1e-8; int max_it = 0, max_it_user = 0;
   KsCompare which;                     // user settings; cmp_ds / cmp_final are what a solve uses
   KsCompare cmp_ds, cmp_final;
-  double keep = 0.5;
+  double keep = 0.5; bool lock = true;   // EPSKrylovSchurSetRestart / SetLocking
   uint64_t seed = 0x12345678ULL;
   std::vector<double> v0; bool have_v0 = false;
   long long max_steps = 0;
@@ -427,6 +427,11 @@ extern "C" int ks_eps_set_krylovschur_restart(ks_eps eps, double keep)   // kryl
   KS_CHECK(keep >= 0.1 && keep <= 0.9, KS_ERR_ARG_OUTOFRANGE, "The keep argument %g must be in the range [.1,.9]", keep);
   eps->keep = keep; return KS_SUCCESS;
 }
+extern "C" int ks_eps_set_krylovschur_locking(ks_eps eps, int lock)     // EPSKrylovSchurSetLocking krylovschur.c:388-423
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  eps->lock = lock != 0; eps->solved = false; return KS_SUCCESS;
+}
 extern "C" int ks_eps_set_random_seed(ks_eps eps, uint64_t seed) { KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL"); eps->seed = seed; return KS_SUCCESS; }
 extern "C" int ks_eps_set_initial_vector(ks_eps eps, const double *v)
 {
@@ -509,6 +514,7 @@ static int solve_nhep(ks_eps eps, long long passes0)
       l = std::max(1, (int)((nv - k) * eps->keep));
       l = ds.get_truncate_size(k, nv, l);                      // do not split a 2x2 block (krylovschur.c:300)
     }
+    if (!eps->lock && l > 0) { l += k; k = 0; }                // non-locking variant (krylovschur.c:294)
     if (eps->reason == KS_EPS_CONVERGED_ITERATING) {
       if (breakdown || k == nv) {
         if (k < nev) {
@@ -657,6 +663,7 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
     // update l
     if (eps->reason != KS_EPS_CONVERGED_ITERATING || breakdown || k == nv) l = 0;
     else l = std::max(1, (int)((nv - k) * eps->keep));
+    if (!eps->lock && l > 0) { l += k; k = 0; }      // non-locking variant: reset no. of converged pairs (krylovschur.c:294)
     if (eps->reason == KS_EPS_CONVERGED_ITERATING) {
       if (breakdown || k == nv) {
         if (k < nev) {

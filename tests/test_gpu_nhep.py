@@ -209,3 +209,28 @@ def test_test29_sinvert_golden(ctx):
     assert np.allclose(lam, ref, rtol=1e-10)
     assert st.GetShift() == -190000.0
 
+
+
+@pytest.mark.parametrize("ptype", ["hep", "nhep"])
+def test_non_locking_variant(ctx, ptype):
+    """-eps_krylovschur_locking 0 (krylovschur.c:294): converged pairs stay in the active window; same eigenvalues, the
+    oracle's restart/step/pass counts."""
+    import slepc_amd as ks
+    if ptype == "hep":
+        Ao = O.laplacian2d(72); r = O.eps_krylovschur_hep(Ao, 4, ncv=20, lock=False)
+    else:
+        Ao = nc.random_nonsymmetric(500); r = O.eps_krylovschur_nhep(Ao, 6, ncv=24, lock=False)
+    A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A); eps.SetProblemType(ks.EPS_HEP if ptype == "hep" else ks.EPS_NHEP)
+    eps.SetDimensions(4, 20) if ptype == "hep" else eps.SetDimensions(6, 24)
+    eps.KrylovSchurSetLocking(False)
+    eps.Solve()
+    assert eps.GetConverged() == r.nconv and eps.GetIterationNumber() == r.its
+    st = eps.GetStats()
+    assert st["arnoldi_steps"] == r.steps and st["gs_passes"] == r.passes
+    for i in range(r.nconv):
+        j = r.perm[i]
+        ref = complex(r.eigr[j], r.eigi[j] if ptype == "nhep" else 0.0)
+        assert abs(complex(*eps.GetEigenvalue(i)) - ref) <= 1e-10 * abs(ref)
+        assert eps.ComputeError(i) < 1e-8

@@ -185,10 +185,12 @@ def test_breakdown_sets_lindep():
 
 
 # ---- non-symmetric path (Arnoldi + DS NHEP) -----------------------------------------------------------------------
-def test_eps_ex5_golden():
-    """ex5 -eps_largest_real -eps_nev 4 (Markov model m=15, EPS_NHEP) -> 1.00000, 0.97137, 0.90423, 0.85714."""
+@pytest.mark.parametrize("lock", [True, False])
+def test_eps_ex5_golden(lock):
+    """ex5 -eps_largest_real -eps_nev 4 -eps_krylovschur_locking {{0 1}} (Markov model m=15, EPS_NHEP)
+    -> 1.00000, 0.97137, 0.90423, 0.85714."""
     A = O.markov_matrix(15)
-    r = O.eps_krylovschur_nhep(A, 4, which="largest_real")
+    r = O.eps_krylovschur_nhep(A, 4, which="largest_real", lock=lock)
     ref = gi.eigenvalues_line(gi.read("eps/ex5_1.out"))
     lam = r.eigr[r.perm][:4]
     assert r.nconv >= 4 and r.reason > 0 and np.all(r.eigi[r.perm][:4] == 0)
