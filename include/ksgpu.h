@@ -78,7 +78,7 @@ enum { KS_EPS_LARGEST_MAGNITUDE = 1, KS_EPS_SMALLEST_MAGNITUDE = 2, KS_EPS_LARGE
        KS_EPS_WHICH_USER = 11 };
 /* SlepcEigenvalueComparisonFn (include/slepcsc.h): *res < 0 if a is preferred to b, > 0 if b is preferred, 0 if equal */
 typedef int (*ks_eig_compare_fn)(double ar, double ai, double br, double bi, int *res, void *ctx);
-enum { KS_EPS_HEP = 1, KS_EPS_NHEP = 3, KS_EPS_GNHEP = 4 };   /* EPSProblemType, slepceps.h */
+enum { KS_EPS_HEP = 1, KS_EPS_GHEP = 2, KS_EPS_NHEP = 3, KS_EPS_GNHEP = 4 };   /* EPSProblemType, slepceps.h */
 enum { KS_ST_SHIFT = 0, KS_ST_SINVERT = 1 };                 /* STType "shift", "sinvert" */
 enum { KS_EPS_ERROR_ABSOLUTE = 0, KS_EPS_ERROR_RELATIVE = 1 };
 enum { KS_EPS_CONVERGED_TOL = 1, KS_EPS_CONVERGED_USER = 2, KS_EPS_DIVERGED_ITS = -1, KS_EPS_DIVERGED_BREAKDOWN = -2,
@@ -187,6 +187,10 @@ int ks_bv_orthogonalizevec(ks_bv bv, double *v_dev, double *H, double *norm, int
    ldr >= k) may be NULL; only its columns l..k-1 are written (upper triangular except for SVQB). The block method is the
    fourth argument of BVSetOrthogonalization.                                                                          */
 int ks_bv_set_orthog_block(ks_bv bv, int block);
+/* BVSetMatrix(bv,B,PETSC_FALSE) bvfunc.c:200: inner products, norms of columns and every orthogonalisation use y^H B x
+   (B symmetric positive definite; borrowed; NULL restores the standard inner product) */
+int ks_bv_set_matrix(ks_bv bv, ks_mat B);
+int ks_bv_get_matrix(ks_bv bv, ks_mat *B);
 int ks_bv_orthogonalize(ks_bv V, double *R, int ldr);
 int ks_bv_matproject(ks_bv X, ks_mat A /* NULL: identity */, ks_bv Y, double *M, int ldm);   /* BVMatProject bvglobal.c:1014: M = Y^H A X */
 int ks_bv_normalize(ks_bv V, const double *eigi /* may be NULL */);                          /* BVNormalize bvglobal.c:855 */

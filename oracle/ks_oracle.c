@@ -35,6 +35,12 @@ enum { ORC_CGS = 0, ORC_MGS = 1 };                               /* BVOrthogType
 enum { ORC_REFINE_IFNEEDED = 0, ORC_REFINE_NEVER = 1, ORC_REFINE_ALWAYS = 2 }; /* BVOrthogRefineType */
 enum { ORC_NORM_1 = 0, ORC_NORM_2 = 1, ORC_NORM_FROBENIUS = 2, ORC_NORM_INFINITY = 3 }; /* PETSc NormType */
 
+/* CSR matrix (PETSc SeqAIJ layout: i = rowptr, j = col, a = val) */
+typedef struct {
+  int n, ncols; int nnz;
+  const int *rowptr; const int *col; const double *val;
+} orc_csr;
+
 /* struct _p_BV (include/slepc/private/bvimpl.h:63-113), the fields the path uses */
 typedef struct {
   int     n, N;          /* local/global rows (single rank in the oracle: n == N) */
@@ -51,13 +57,9 @@ typedef struct {
   double *work;  int lwork;
   int     passes_last;   /* instrumentation: number of GS passes of the last orthogonalization */
   long    passes_total;
+  const orc_csr *matrix; /* inner-product matrix B of BVSetMatrix (positive definite; indef = FALSE), or NULL */
+  double *Bx;            /* B*x of the vector last used in an inner product (BV_IPMatMult bvimpl.h:147-158) */
 } orc_bv;
-
-/* CSR matrix (PETSc SeqAIJ layout: i = rowptr, j = col, a = val) */
-typedef struct {
-  int n, ncols; int nnz;
-  const int *rowptr; const int *col; const double *val;
-} orc_csr;
 
 /* ------------------------------------------------------------------------------------------- */
 /* BV lifecycle                                                                                 */
@@ -77,7 +79,13 @@ orc_bv *orc_bv_create(int n, int m, int ld)
   bv->h = (double*)calloc(m,sizeof(double)); bv->c = (double*)calloc(m,sizeof(double));
   return bv;
 }
-void orc_bv_destroy(orc_bv *bv) { if (!bv) return; free(bv->array); free(bv->buffer); free(bv->h); free(bv->c); free(bv->work); free(bv); }
+void orc_bv_destroy(orc_bv *bv) { if (!bv) return; free(bv->array); free(bv->buffer); free(bv->h); free(bv->c); free(bv->work); free(bv->Bx); free(bv); }
+void orc_csr_mult(int n,const int *rowptr,const int *col,const double *val,const double *x,double *y);
+/* BVSetMatrix bvfunc.c:200-250 (indef = PETSC_FALSE) */
+void orc_bv_set_matrix(orc_bv *bv,const orc_csr *B) { bv->matrix=B; if (B && !bv->Bx) bv->Bx=(double*)calloc((size_t)bv->n+1,sizeof(double)); }
+/* BV_IPMatMult bvimpl.h:147-158 (no caching by vector id: recomputed on every use) */
+static const double *orc_ipmatmult(orc_bv *bv,const double *x)
+{ if (!bv->matrix) return x; orc_csr_mult(bv->matrix->n,bv->matrix->rowptr,bv->matrix->col,bv->matrix->val,x,bv->Bx); return bv->Bx; }
 double *orc_bv_array(orc_bv *bv)  { return bv->array; }
 double *orc_bv_buffer(orc_bv *bv) { return bv->buffer; }
 double *orc_bv_column(orc_bv *bv,int j) { return bv->array + (size_t)(bv->nc+j)*bv->ld; }   /* svec.c:292-303 */
@@ -223,6 +231,12 @@ int orc_bv_dot(orc_bv *X,orc_bv *Y,double *M,int ldm)
 {
   if (X->n!=Y->n) return ORC_ERR_ARG;
   if (X->l==X->k || Y->l==Y->k) return ORC_OK;
+  if (X->matrix) {                                       /* bvglobal.c:103-107: cached = B*X, M = Y^H cached */
+    int j,nx=X->k-X->l; double *W=(double*)malloc((size_t)X->n*nx*sizeof(double)+8);
+    for (j=0;j<nx;j++) orc_csr_mult(X->matrix->n,X->matrix->rowptr,X->matrix->col,X->matrix->val,X->array+(size_t)(X->nc+X->l+j)*X->ld,W+(size_t)j*X->n);
+    orc_gemm_tn(Y->k-Y->l,nx,X->n,Y->array+(size_t)(Y->nc+Y->l)*Y->ld,Y->ld,W,X->n,M+(size_t)X->l*ldm+Y->l,ldm);
+    free(W); return ORC_OK;
+  }
   orc_gemm_tn(Y->k-Y->l,X->k-X->l,X->n,Y->array+(size_t)(Y->nc+Y->l)*Y->ld,Y->ld,X->array+(size_t)(X->nc+X->l)*X->ld,X->ld,M+(size_t)X->l*ldm+Y->l,ldm);
   return ORC_OK;
 }
@@ -231,7 +245,8 @@ int orc_bv_dot(orc_bv *X,orc_bv *Y,double *M,int ldm)
 int orc_bv_dotvec(orc_bv *X,const double *y,double *m)
 {
   double *qq = m ? m : X->buffer;
-  orc_gemv_t(X->n,X->k-X->l,X->array+(size_t)(X->nc+X->l)*X->ld,X->ld,y,qq);
+  const double *z = orc_ipmatmult(X,y);                  /* svec.c:117-120: z = B*y when a matrix is set */
+  orc_gemv_t(X->n,X->k-X->l,X->array+(size_t)(X->nc+X->l)*X->ld,X->ld,z,qq);
   return ORC_OK;
 }
 
@@ -253,9 +268,11 @@ int orc_bv_scale(orc_bv *bv,int j,double alpha)
 }
 
 /* BVNorm / BVNormColumn (bvglobal.c:498,662; BVNorm_Svec svec.c:164-176; BVNorm_LAPACK_Private bvlapack.c:37-83) */
+static int orc_norm_vec_or_column(orc_bv *bv,int j,double *v,double *nrm);
 int orc_bv_norm(orc_bv *bv,int j,int type,double *val)
 {
   const double *A; int ncols,i,c,n=bv->n,lda=bv->ld;
+  if (bv->matrix && j>=0) { if (j>=bv->m) return ORC_ERR_ARG; return orc_norm_vec_or_column(bv,j,NULL,val); }   /* bvglobal.c:683-687 */
   if (j<0) { A=bv->array+(size_t)(bv->nc+bv->l)*bv->ld; ncols=bv->k-bv->l; }
   else { if (j>=bv->m) return ORC_ERR_ARG; A=orc_bv_column(bv,j); ncols=1; }
   if (type==ORC_NORM_FROBENIUS || type==ORC_NORM_2) {
@@ -350,8 +367,14 @@ static int orc_dotcolumn_inc(orc_bv *X,int j,double *q)
 { int ksave=X->k,ierr; X->k=j+1; ierr=orc_bv_dotvec(X,orc_bv_column(X,j),q); X->k=ksave; return ierr; }
 
 /* BV_NormVecOrColumn bvorthog.c:20-26 */
+static int orc_safe_sqrt(orc_bv *bv,double alpha,double *res);
 static int orc_norm_vec_or_column(orc_bv *bv,int j,double *v,double *nrm)
 {
+  if (bv->matrix) {                                      /* BVNorm_Private bvglobal.c:444-453: sqrt(z'*B*z) */
+    const double *z = v ? v : bv->array+(size_t)(bv->nc+j)*bv->ld; const double *bz = orc_ipmatmult(bv,z); double p=0.0; int r;
+    for (r=0;r<bv->n;r++) p+=bz[r]*z[r];
+    return orc_safe_sqrt(bv,p,nrm);
+  }
   if (v) { double scale=0.0,sumsq=1.0; orc_lassq(bv->n,v,&scale,&sumsq); *nrm=scale*sqrt(sumsq); return ORC_OK; }  /* VecNorm */
   return orc_bv_norm(bv,j,ORC_NORM_2,nrm);
 }
@@ -365,7 +388,8 @@ static int orc_mgs1(orc_bv *bv,int j,double *v,const int *which,double *h,double
     const double *vi; double dot=0.0;
     if (which && i>=0 && !which[i]) continue;
     vi=orc_bv_column(bv,i);
-    for (r=0;r<bv->n;r++) dot+=w[r]*vi[r];                 /* VecDot(z,vi) */
+    { const double *z = orc_ipmatmult(bv,w);               /* bvorthog.c:68-71: z = B*w */
+      for (r=0;r<bv->n;r++) dot+=z[r]*vi[r]; }             /* VecDot(z,vi) */
     orc_set_value(bv,i,0,c,dot);                           /* BV_SetValue(bv,i,0,c,dot) */
     for (r=0;r<bv->n;r++) w[r]+=(-dot)*vi[r];              /* VecAXPY(w,-dot,vi) */
   }

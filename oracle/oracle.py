@@ -51,6 +51,7 @@ def _load(name):
         "orc_bv_ld": (C.c_int, [vp]),
         "orc_bv_set_active": (None, [vp, C.c_int, C.c_int]),
         "orc_bv_set_orthog": (None, [vp, C.c_int, C.c_int, C.c_double]),
+        "orc_bv_set_matrix": (None, [vp, vp]),
         "orc_bv_passes_last": (C.c_int, [vp]), "orc_bv_passes_total": (C.c_long, [vp]),
         "orc_bv_mult": (C.c_int, [vp, C.c_double, C.c_double, vp, _dp, C.c_int]),
         "orc_bv_multvec": (C.c_int, [vp, C.c_double, C.c_double, _dp, _dp]),
@@ -240,6 +241,13 @@ class BV:
     def SetOrthogonalization(self, type=CGS, refine=REFINE_IFNEEDED, eta=0.7071):
         self._lib.orc_bv_set_orthog(self._h, type, refine, eta)
 
+    _B = None
+
+    def SetMatrix(self, B):
+        """BVSetMatrix(bv,B,PETSC_FALSE): B a CSR (kept alive here) or None."""
+        self._B = B
+        self._lib.orc_bv_set_matrix(self._h, B._h if B is not None else None)
+
     def SetRandomColumn(self, j, seed=0x12345678, row0=0):
         _chk(self._lib.orc_bv_setrandomcolumn(self._h, j, seed, row0))
 
@@ -374,13 +382,17 @@ class BV:
                     raise RuntimeError("Breakdown in BVOrthogonalize due to a linearly dependent column")
                 self.ScaleColumn(j, 1.0 / norm)
             return
+        Bm = getattr(self, "_B", None)
+        ip = (lambda Xm: Bm.to_scipy() @ Xm) if Bm is not None else (lambda Xm: Xm)     # BVDot with a matrix: Y^H (B X)
+        if Bm is not None and block in ("tsqr", "tsqrchol"):
+            raise RuntimeError("Orthogonalization method not available for non-standard inner product")
         Rb = np.zeros((k, k), order="F")
         if l:                                                   # BVOrthogonalize_BlockGS :492-505
-            Rb[:l, l:k] = A[:n, :l].T @ A[:n, l:k]
+            Rb[:l, l:k] = A[:n, :l].T @ ip(A[:n, l:k])
             A[:n, l:k] -= A[:n, :l] @ Rb[:l, l:k]
         V2 = A[:n, l:k]
         if block == "chol":
-            G = V2.T @ V2
+            G = V2.T @ ip(V2)
             c, info = la.dpotrf(G, lower=0)
             if info:                                            # bvlapack.c:177-185
                 c, info = la.dpotrf(G + 50.0 * np.finfo(float).eps * np.eye(k - l), lower=0)
@@ -390,7 +402,7 @@ class BV:
             A[:n, l:k] = V2 @ np.triu(S)
             Rb[l:k, l:k] = c; tri = True
         elif block == "svqb":
-            G = V2.T @ V2
+            G = V2.T @ ip(V2)
             D = 1.0 / np.sqrt(np.diag(G))
             w, U, info = la.dsyev(G * D[:, None] * D[None, :], lower=1); assert info == 0
             A[:n, l:k] = V2 @ (D[:, None] * U / np.sqrt(w)[None, :])
@@ -411,6 +423,19 @@ class BV:
             for j in range(l, k):
                 rows = j + 1 if tri else k
                 R[:rows, j] = Rb[:rows, j]
+
+    def MatLanczosOp(self, op, T, k, m):
+        """BVMatLanczos (bvkrylov.c:165-226) with the operator given as a callable."""
+        brk = False; beta = 0.0
+        for j in range(k, m):
+            self.set_column(j + 1, op(np.array(self.column(j))))
+            beta, brk = self.OrthonormalizeColumn(j + 1)
+            if brk:
+                m = j + 1
+                break
+        for j in range(k, m):
+            T[j, 0] = self.buffer[j, j + 1]; T[j, 1] = self.buffer[j + 1, j + 1]
+        return m, beta, brk
 
     def MatArnoldiOp(self, op, H, k, m):
         """BVMatArnoldi (bvkrylov.c:56-113) with the operator given as a callable y = op(x) (an ST operator)."""
@@ -644,8 +669,11 @@ class EPSResult:
 
 def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which="largest_magnitude",
                         keep=0.5, seed=0x12345678, omp=False, v0=None, orthog=(CGS, REFINE_IFNEEDED, 0.7071),
-                        max_steps=None, monitor=None, lock=True):
-    """EPSSolve for a standard symmetric problem with the default Krylov-Schur solver.
+                        max_steps=None, monitor=None, lock=True, st=None, B=None):
+    """EPSSolve for a symmetric problem with the default Krylov-Schur solver: standard (HEP), or generalized (GHEP,
+    B given: the basis carries the B-inner product, EPS_SetInnerProduct epsimpl.h:280-292; the start vector goes
+    through the operator, epssolve.c:860-868; the eigenvectors are purified and B-normalised,
+    EPSComputeVectors_Hermitian epsdefault.c:27-49). st: an ST (operator, back-transformation).
 
     EPSSetUp_KrylovSchur krylovschur.c:93-194 (EPS_KS_SYMM), EPSSetDimensions_Default epssetup.c:654-678,
     EPSSolve_KrylovSchur_Default krylovschur.c:227-337, EPSKrylovConvergence epskrylov.c:207-295,
@@ -666,9 +694,17 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
         max_it = max(100, 2 * n // ncv)
     compare = which if callable(which) else WHICH[which]
 
+    if st is not None:
+        def ds_compare(ar, ai, br, bi):
+            ar, ai = st.backtransform(ar, ai); br, bi = st.backtransform(br, bi)
+            return compare(ar, ai, br, bi)
+    else:
+        ds_compare = compare
     V = BV(n, ncv + 1, omp=omp)
     V.SetOrthogonalization(*orthog)
-    ds = DSHEP(ncv + 1, compare)
+    if B is not None:
+        V.SetMatrix(B)
+    ds = DSHEP(ncv + 1, ds_compare)
     eigr = np.zeros(ncv + 1); errest = np.zeros(ncv + 1)
 
     # EPSGetStartVector(eps,0)
@@ -677,6 +713,8 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
             V.set_column(0, v0)
         else:
             V.SetRandomColumn(i, seed)
+        if B is not None:                                   # force the vector into the range of OP (epssolve.c:860-868)
+            V.set_column(i, st.apply(np.array(V.column(i))))
         _, norm, lindep = V.OrthogonalizeColumn(i)
         if not (lindep or norm == 0.0):
             V.ScaleColumn(i, 1.0 / norm)
@@ -698,7 +736,10 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
         ds.SetDimensions(nv, nconv, nconv + l)
         k0 = nconv + l
         nv_req = nv
-        nv, beta, breakdown = V.MatLanczos(A, ds.T, nconv + l, nv)
+        if st is None:
+            nv, beta, breakdown = V.MatLanczos(A, ds.T, nconv + l, nv)
+        else:
+            nv, beta, breakdown = V.MatLanczosOp(st.apply, ds.T, nconv + l, nv)
         steps += nv - k0
         cycles.append((k0, nv, V.passes_total()))
         ds.SetDimensions(nv, nconv, nconv + l)
@@ -714,6 +755,8 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
         kk = nconv
         for kk in range(nconv, nv):
             re = eigr[kk]                                   # shift ST with sigma=0: back-transform is identity
+            if st is not None and st.kind == "shift":
+                re = st.backtransform(re, 0.0)[0]           # epskrylov.c:253
             resnorm = ds.Vectors_resnorm(kk) * beta * 1.0
             w = abs(re)
             errest[kk] = resnorm / w if w != 0.0 else np.finfo(float).max
@@ -753,6 +796,15 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
             monitor(its, nconv, eigr[:nv].copy(), errest[:nv].copy(), nv)
     ds.Truncate(nconv, True)
 
+    V.SetActiveColumns(0, nconv)
+    if st is not None:                                      # EPSComputeValues (epssolve.c:27-41)
+        for i in range(nconv):
+            eigr[i] = st.backtransform(eigr[i], 0.0)[0]
+    if B is not None:                                       # EPSComputeVectors_Hermitian: purify, then B-normalise
+        for i in range(nconv):
+            V.set_column(i, st.apply(np.array(V.column(i))))
+        for i in range(nconv):
+            V.ScaleColumn(i, 1.0 / V.NormColumn(i))
     # EPSSolve epilogue: final sort of the converged values (SlepcSortEigenvalues slepcsc.c:89-140, all real)
     perm = list(range(nconv))
     for i in range(nconv - 1, -1, -1):
@@ -772,17 +824,18 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
     return res
 
 
-def eps_compute_error(A, res, i, relative=True):
-    """EPSComputeError epssolve.c:742-815 with EPSComputeResidualNorm_Private :666-718 (real eigenvalue, B=I)."""
+def eps_compute_error(A, res, i, relative=True, B=None):
+    """EPSComputeError epssolve.c:742-815 with EPSComputeResidualNorm_Private :666-718 (real eigenvalue); for a GHEP
+    (B given) the residual is A x - k B x and the relative error is also divided by ||x||_2 (:774-780)."""
     j = int(res.perm[i])
     kr = res.eigr[j]
     x = np.array(res.V.column(j))
     u = A.mult(x)
     if abs(kr) > np.finfo(float).eps:
-        u = u + (-kr) * x
+        u = u + (-kr) * (B.mult(x) if B is not None else x)
     err = np.linalg.norm(u)
     if relative:
-        err /= abs(kr) * 1.0        # vecnorm = 1 for non-GHEP (epssolve.c:758,774)
+        err /= abs(kr) * (np.linalg.norm(x) if B is not None else 1.0)
     return err
 
 

@@ -24,7 +24,7 @@ CGS, MGS = 0, 1
 REFINE_IFNEEDED, REFINE_NEVER, REFINE_ALWAYS = 0, 1, 2
 NORM_1, NORM_2, NORM_FROBENIUS, NORM_INFINITY = 0, 1, 2, 3
 EPS_LARGEST_MAGNITUDE, EPS_SMALLEST_MAGNITUDE, EPS_LARGEST_REAL, EPS_SMALLEST_REAL = 1, 2, 3, 4
-EPS_HEP, EPS_NHEP, EPS_GNHEP = 1, 3, 4
+EPS_HEP, EPS_GHEP, EPS_NHEP, EPS_GNHEP = 1, 2, 3, 4
 EPS_ERROR_ABSOLUTE, EPS_ERROR_RELATIVE = 0, 1
 EPS_CONVERGED_TOL, EPS_CONVERGED_USER, EPS_DIVERGED_ITS, EPS_DIVERGED_BREAKDOWN = 1, 2, -1, -2
 WHICH = {"largest_magnitude": 1, "smallest_magnitude": 2, "largest_real": 3, "smallest_real": 4,
@@ -411,6 +411,11 @@ class BV:
         H = np.zeros(max(j - self.l, 0) + 1)
         _lib.check(self.ctx.L.ks_bv_orthogonalizecolumn(self.h, j, _p(H), C.byref(nrm), C.byref(lin)))
         return H[: max(j - self.l, 0)], nrm.value, bool(lin.value)
+
+    def SetMatrix(self, B):
+        """BVSetMatrix(bv,B,PETSC_FALSE); B a Mat (kept alive here) or None."""
+        self._B = B
+        _lib.check(self.ctx.L.ks_bv_set_matrix(self.h, None if B is None else B.h))
 
     def SetOrthogBlock(self, block):
         _lib.check(self.ctx.L.ks_bv_set_orthog_block(self.h, BLOCK.get(block, block)))

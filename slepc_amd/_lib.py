@@ -90,6 +90,8 @@ _SIG = {
     "ks_bv_orthogonalizesomecolumn": [vp, C.c_int, ip, dp, dp, ip],
     "ks_bv_gs_passes": [vp, llp, ip],
     "ks_bv_set_orthog_block": [vp, C.c_int],
+    "ks_bv_set_matrix": [vp, vp],
+    "ks_bv_get_matrix": [vp, C.POINTER(vp)],
     "ks_bv_orthogonalize": [vp, dp, C.c_int],
     "ks_bv_matproject": [vp, vp, vp, dp, C.c_int],
     "ks_bv_normalize": [vp, dp],

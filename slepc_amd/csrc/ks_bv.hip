@@ -251,7 +251,7 @@ extern "C" int ks_bv_destroy(ks_bv bv)
   if (!bv) return KS_SUCCESS;
   hipSetDevice(bv->ctx->device);
   hipStreamSynchronize(bv->ctx->stream);
-  hipFree(bv->array); hipFree(bv->buffer); hipFree(bv->partials); hipFree(bv->coef); hipFree(bv->hc); hipFree(bv->gs); hipFree(bv->recs); hipFree(bv->panel);
+  hipFree(bv->array); hipFree(bv->buffer); hipFree(bv->partials); hipFree(bv->coef); hipFree(bv->hc); hipFree(bv->gs); hipFree(bv->recs); hipFree(bv->panel); hipFree(bv->Bx);
   delete bv;
   return KS_SUCCESS;
 }
@@ -462,6 +462,44 @@ extern "C" int ks_bv_multinplace(ks_bv V, const double *Q, int ldq, int s, int e
 extern "C" int ks_bv_multinplace_trans(ks_bv V, const double *Q, int ldq, int s, int e) { return multinplace(V, Q, ldq, s, e, true); }
 
 // ---- ops->dot / dotvec -----------------------------------------------------------------------------
+// BVSetMatrix bvfunc.c:200-250 with indef = PETSC_FALSE: inner products become y^H B x
+extern "C" int ks_bv_set_matrix(ks_bv bv, ks_mat B)
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  if (B) {
+    KS_CHECK(B->n == bv->n && B->n_global == bv->N, KS_ERR_ARG_INCOMP, "Mismatching dimensions of the inner-product matrix (%d) and the BV (%d)", B->n, bv->n);
+    KS_HIP(hipSetDevice(bv->ctx->device));
+    if (!bv->Bx) KS_HIP(hipMalloc(&bv->Bx, sizeof(double) * std::max(bv->n, 1)));
+  }
+  bv->matrix = B;
+  return KS_SUCCESS;
+}
+extern "C" int ks_bv_get_matrix(ks_bv bv, ks_mat *B) { KS_CHECK(bv && B, KS_ERR_ARG_NULL, "NULL argument"); *B = bv->matrix; return KS_SUCCESS; }
+
+int ksb_ipmatmult(ks_bv bv, const double *x, const double **z)      // BV_IPMatMult bvimpl.h:147-158 (recomputed on every use)
+{
+  if (!bv->matrix) { *z = x; return KS_SUCCESS; }
+  KS_CALL(ks_mat_mult_internal(bv->matrix, x, bv->Bx));
+  *z = bv->Bx;
+  return KS_SUCCESS;
+}
+
+int ksb_norm_b(ks_bv bv, const double *x, double *val)              // BVNorm_Private bvglobal.c:444-453 + BV_SafeSqrt bvimpl.h:121-141
+{
+  ks_ctx ctx = bv->ctx;
+  const double *z;
+  KS_CALL(ksb_ipmatmult(bv, x, &z));
+  double p = 0.0;
+  if (bv->n > 0) { KS_CALL(ksk_dot(bv, z, bv->ld, 1, x, false)); KS_CALL(ksk_reduce_partials(bv, 1, bv->coef)); }
+  else KS_HIP(hipMemsetAsync(bv->coef, 0, sizeof(double), ctx->stream));
+  KS_CALL(ks_allreduce_sum(ctx, bv->coef, 1));
+  KS_HIP(hipMemcpyAsync(&p, bv->coef, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_CHECK(p > -bv->deftol, KS_ERR_USER_INPUT, "The inner product is not well defined: indefinite matrix %g", p);
+  *val = p < 0.0 ? 0.0 : sqrt(p);
+  return KS_SUCCESS;
+}
+
 static int dotvec_impl(ks_bv X, const double *y_dev, double *m, bool reduce)
 {
   KS_CHECK(X && y_dev, KS_ERR_ARG_NULL, "NULL argument");
@@ -469,6 +507,7 @@ static int dotvec_impl(ks_bv X, const double *y_dev, double *m, bool reduce)
   KS_HIP(hipSetDevice(ctx->device));
   const int kx = X->k - X->l;
   if (kx <= 0) return KS_SUCCESS;
+  KS_CALL(ksb_ipmatmult(X, y_dev, &y_dev));          // svec.c:117-120: z = B*y when a matrix is set
   const double *A = X->array + (size_t)(X->nc + X->l) * X->ld;
   double *out = m ? X->coef : X->buffer;      // m==NULL: result goes to the buffer scratch (svec.c:123)
   KS_CHECK((size_t)kx <= X->coef_len, KS_ERR_ARG_SIZ, "too many columns");
@@ -506,6 +545,20 @@ int ksb_dot_range(ks_bv X, int xs, int xe, ks_bv Y, int ys, int ye, double *M, i
   KS_CHECK(my <= KS_MAX_COLS, KS_ERR_SUP, "BVDot with more than %d active columns in Y", KS_MAX_COLS);
   KS_CHECK((size_t)my * nx <= X->coef_len, KS_ERR_ARG_SIZ, "result block too large");
   const double *py = Y->array + (size_t)(Y->nc + ys) * Y->ld;
+  if (X->matrix) {
+    // bvglobal.c:103-107: cached = B*X(:,xs:xe), then M = Y^H cached
+    ks_bv W = nullptr;
+    KS_CALL(ks_bv_create(ctx, X->n, X->N, nx, 0, &W));
+    int rc = KS_SUCCESS;
+    for (int j = 0; j < nx && !rc; j++) rc = ks_mat_mult_internal(X->matrix, X->array + (size_t)(X->nc + xs + j) * X->ld, ks_bv_col(W, j));
+    if (!rc) {
+      std::vector<double> T((size_t)ldm * nx, 0.0);
+      rc = ksb_dot_range(W, 0, nx, Y, ys, ye, T.data(), ldm);
+      if (!rc) for (int j = 0; j < nx; j++) for (int i = ys; i < ye; i++) M[(size_t)i + (size_t)(xs + j) * ldm] = T[(size_t)i + (size_t)j * ldm];
+    }
+    ks_bv_destroy(W);
+    return rc;
+  }
   const bool use_mfma = !getenv("KSGPU_NO_MFMA");
   const double *px0 = X->array + (size_t)(X->nc + xs) * X->ld;
   if (use_mfma && X->n > 0 && nx <= 64 && X->ld % 2 == 0 && Y->ld % 2 == 0 && aligned16(py) && aligned16(px0)) {
@@ -616,6 +669,12 @@ extern "C" int ks_bv_norm(ks_bv bv, int type, double *val)                   // 
 extern "C" int ks_bv_normcolumn(ks_bv bv, int j, int type, double *val)      // bvglobal.c:662
 {
   KS_CHECK(j >= 0, KS_ERR_ARG_OUTOFRANGE, "Argument j has wrong value %d", j);
+  if (bv && bv->matrix) {                                                   // bvglobal.c:683-687: sqrt(V[j]'*B*V[j]), type ignored
+    KS_CHECK(val, KS_ERR_ARG_NULL, "NULL argument");
+    KS_CHECK(j < bv->m, KS_ERR_ARG_OUTOFRANGE, "Argument j has wrong value %d, the number of columns is %d", j, bv->m);
+    KS_HIP(hipSetDevice(bv->ctx->device));
+    return ksb_norm_b(bv, ks_bv_col(bv, j), val);
+  }
   return norm_impl(bv, j, type, val, true);
 }
 extern "C" int ks_bv_norm_local(ks_bv bv, int j, int type, double *val) { return norm_impl(bv, j, type, val, false); }

@@ -341,7 +341,7 @@ struct ks_eps_s {
   std::vector<double> eigr, eigi, errest; std::vector<int> perm;
   int nconv = 0, its = 0, reason = 0;
   long long steps = 0, passes = 0; int restarts = 0;
-  bool solved = false;
+  bool solved = false, ghep = false;
   DsHep ds;
   DsNhep dsn;
 };
@@ -381,7 +381,7 @@ extern "C" int ks_eps_get_st(ks_eps eps, ks_st *st)                     // EPSGe
 extern "C" int ks_eps_set_problem_type(ks_eps eps, int type)
 {
   KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
-  KS_CHECK(type == KS_EPS_HEP || type == KS_EPS_NHEP || type == KS_EPS_GNHEP, KS_ERR_SUP, "EPS_HEP (Lanczos), EPS_NHEP and EPS_GNHEP (Arnoldi) are driven by this build; GHEP needs the B-inner product, which is not built");
+  KS_CHECK(type == KS_EPS_HEP || type == KS_EPS_GHEP || type == KS_EPS_NHEP || type == KS_EPS_GNHEP, KS_ERR_SUP, "EPS_HEP and EPS_GHEP (Lanczos), EPS_NHEP and EPS_GNHEP (Arnoldi) are driven by this build; PGNHEP / GHIEP are not");
   eps->problem_type = type; eps->solved = false; return KS_SUCCESS;
 }
 extern "C" int ks_eps_set_dimensions(ks_eps eps, int nev, int ncv, int mpd)
@@ -447,6 +447,10 @@ static int start_vector(ks_eps eps, int i, bool *breakdown)
 {
   if (i == 0 && eps->have_v0) KS_CALL(ks_bv_set_column_host(eps->V, 0, eps->v0.data()));
   else KS_CALL(ks_bv_set_random_column(eps->V, i, eps->seed));
+  if (eps->ghep) {                                   // force the vector to be in the range of OP (epssolve.c:860-868)
+    KS_CALL(ksk_copy(eps->ctx, ks_bv_col(eps->V, i), ks_bv_col(eps->W, 0), eps->V->n));
+    KS_CALL(ks_mat_mult_internal(eps->op, ks_bv_col(eps->W, 0), ks_bv_col(eps->V, i)));
+  }
   double norm = 0.0; int lindep = 0;
   KS_CALL(ks_bv_orthogonalizecolumn(eps->V, i, nullptr, &norm, &lindep));
   if (breakdown) *breakdown = lindep != 0;
@@ -581,7 +585,9 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   KS_CHECK(eps->which.which != KS_EPS_WHICH_USER || eps->which.fn, KS_ERR_ORDER, "Must call EPSSetEigenvalueComparison() first");   // epssetup.c:311
   int ptype = eps->problem_type;
   if (!eps->B && ptype == KS_EPS_GNHEP) ptype = KS_EPS_NHEP;          // "reverting to a standard eigenproblem" (epssetup.c:324-327)
-  KS_CHECK(!eps->B || ptype == KS_EPS_GNHEP, KS_ERR_ARG_INCOMP, "Inconsistent EPS state: the problem type does not match the number of matrices");
+  if (!eps->B && ptype == KS_EPS_GHEP) ptype = KS_EPS_HEP;
+  KS_CHECK(!eps->B || ptype == KS_EPS_GNHEP || ptype == KS_EPS_GHEP, KS_ERR_ARG_INCOMP, "Inconsistent EPS state: the problem type does not match the number of matrices");
+  const bool ghep = ptype == KS_EPS_GHEP;
   ks_st st = eps->st;
   const bool sinvert = st && st->type == KS_ST_SINVERT;
   if (st && !st->sigma_set) { if (st->sigma != eps->which.target) st->ready = false; st->sigma = eps->which.target; }   // shift defaults to the target (sinvert.c:62)
@@ -617,8 +623,10 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   long long passes0 = 0; ks_bv_gs_passes(eps->V, &passes0, nullptr);
   ks_bv V = eps->V;
   KS_CALL(ks_bv_set_active_columns(V, 0, ncv + 1));
+  KS_CALL(ks_bv_set_matrix(V, ghep ? eps->B : nullptr));             // EPS_SetInnerProduct epsimpl.h:280-292 (STGetBilinearForm = B)
+  eps->ghep = ghep;
 
-  if (ptype != KS_EPS_HEP) return solve_nhep(eps, passes0);
+  if (ptype != KS_EPS_HEP && !ghep) return solve_nhep(eps, passes0);
   const bool isshift = !st || st->type == KS_ST_SHIFT;
 
   // ---- EPSSolve_KrylovSchur_Default ----
@@ -686,6 +694,14 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   // EPSComputeValues (epssolve.c:27-41): map the eigenvalues back through the ST
   const int nc = eps->nconv;
   if (eps->cmp_ds.map) ks_st_backtransform_internal(eps->cmp_ds.map, nc, eps->eigr.data(), eps->eigi.data());
+  if (ghep) {
+    // EPSComputeVectors_Hermitian epsdefault.c:27-49: purification x <- OP x (EPS_Purify epsimpl.h:297-312), then B-normalise
+    for (int i = 0; i < nc; i++) {
+      KS_CALL(ksk_copy(eps->ctx, ks_bv_col(V, i), ks_bv_col(eps->W, 0), V->n));
+      KS_CALL(ks_mat_mult_internal(eps->op, ks_bv_col(eps->W, 0), ks_bv_col(V, i)));
+    }
+    KS_CALL(ks_bv_normalize(V, nullptr));
+  }
   // SlepcSortEigenvalues slepcsc.c:89-140 (all eigenvalues real here)
   for (int i = 0; i <= ncv; i++) eps->perm[i] = i;
   for (int i = nc - 1; i >= 0; i--) {
@@ -795,7 +811,9 @@ extern "C" int ks_eps_compute_error(ks_eps eps, int i, int type, double *error) 
     KS_CALL(ks_bv_normcolumn(W, 0, KS_NORM_2, &ni));
     nrm = hypot(nr, ni);
   }
-  if (type == KS_EPS_ERROR_RELATIVE) nrm /= hypot(kr, ki) * 1.0;  // vecnorm = 1 (not GHEP)
+  double vecnorm = 1.0;
+  if (eps->ghep) { ks_mat Bsave = V->matrix; V->matrix = nullptr; int rc = ks_bv_normcolumn(V, j, KS_NORM_2, &vecnorm); V->matrix = Bsave; if (rc) return rc; }   // epssolve.c:774: 2-norm of the eigenvector
+  if (type == KS_EPS_ERROR_RELATIVE) nrm /= hypot(kr, ki) * vecnorm;
   else KS_CHECK(type == KS_EPS_ERROR_ABSOLUTE, KS_ERR_ARG_OUTOFRANGE, "Invalid error type");
   *error = nrm;
   return KS_SUCCESS;

@@ -358,6 +358,7 @@ struct GenericGs {
 int generic_norm(ks_bv bv, int j, double *v, double *nrm)     // BV_NormVecOrColumn bvorthog.c:20-26
 {
   if (!v) return ks_bv_normcolumn(bv, j, KS_NORM_2, nrm);
+  if (bv->matrix) return ksb_norm_b(bv, v, nrm);                 // BVNormVec with a matrix (bvglobal.c:556-560)
   // VecNorm of an arbitrary device vector: dot with itself
   KS_CALL(ksk_dot(bv, v, bv->ld, 1, v, false));
   KS_CALL(ksk_reduce_partials(bv, 1, bv->coef));
@@ -376,8 +377,10 @@ int generic_mgs1(ks_bv bv, int j, double *v, const int *which, double *hh, doubl
   for (int i = -bv->nc; i < j; i++) {
     if (which && i >= 0 && !which[i]) continue;
     double dot = 0.0;
-    // VecDot(w, vi) with the global reduction
-    KS_CALL(ksk_dot(bv, ks_bv_col(bv, i), bv->ld, 1, w, false));
+    // VecDot(z, vi) with the global reduction; z = B*w when a matrix is set (bvorthog.c:68-72)
+    const double *z = w;
+    KS_CALL(ksb_ipmatmult(bv, w, &z));
+    KS_CALL(ksk_dot(bv, ks_bv_col(bv, i), bv->ld, 1, z, false));
     KS_CALL(ksk_reduce_partials(bv, 1, bv->coef));
     KS_CALL(ks_allreduce_sum(bv->ctx, bv->coef, 1));
     KS_HIP(hipMemcpyAsync(&dot, bv->coef, sizeof(double), hipMemcpyDeviceToHost, bv->ctx->stream));
@@ -478,7 +481,7 @@ int store_buffer_column(ks_bv bv, int j, const double *hh, int len)
   return KS_SUCCESS;
 }
 
-bool use_fused(ks_bv bv) { return bv->orthog_type == KS_BV_ORTHOG_CGS && bv->m <= KS_MAX_COLS && !getenv("KSGPU_NO_FUSED_GS"); }
+bool use_fused(ks_bv bv) { return bv->orthog_type == KS_BV_ORTHOG_CGS && bv->m <= KS_MAX_COLS && !bv->matrix && !getenv("KSGPU_NO_FUSED_GS"); }   // B-inner products need B*v between the sweeps: host-driven passes
 
 // Orthogonalize column j; fused or generic. Returns norm/lindep on the host (synchronises).
 int orthogonalize_column(ks_bv bv, int j, int normalize, double *H, double *norm, int *lindep)

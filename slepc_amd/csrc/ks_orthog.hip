@@ -197,6 +197,7 @@ extern "C" int ks_bv_orthogonalize(ks_bv V, double *R, int ldr)       // BVOrtho
     }
     case KS_BV_ORTHOG_BLOCK_TSQR:
     case KS_BV_ORTHOG_BLOCK_TSQRCHOL: {
+      KS_CHECK(!V->matrix, KS_ERR_SUP, "Orthogonalization method not available for non-standard inner product");   // bvorthog.c:750,754
       KS_CALL(tsqr_r(V, l, nact, R22, ldb));
       for (int j = 0; j < nact; j++) for (int i = 0; i < nact; i++) S22[(size_t)i + (size_t)j * ldb] = R22[(size_t)i + (size_t)j * ldb];
       int info = ksd::trtri_upper(nact, S22, ldb);

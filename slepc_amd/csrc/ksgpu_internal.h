@@ -145,6 +145,8 @@ struct ks_bv_s {
   ks_ctx ctx = nullptr;
   int n = 0, N = 0, m = 0, l = 0, k = 0, nc = 0, ld = 0;
   int orthog_type = KS_BV_ORTHOG_CGS, orthog_ref = KS_BV_ORTHOG_REFINE_IFNEEDED, orthog_block = KS_BV_ORTHOG_BLOCK_GS;
+  ks_mat matrix = nullptr;   // inner-product matrix B of BVSetMatrix (positive definite), borrowed; nullptr = standard
+  double *Bx = nullptr;      // B*x of the vector an inner product is being taken with (BV_IPMatMult bvimpl.h:147-158)
   double orthog_eta = 0.7071;
   double deftol = 10 * 2.220446049250313e-16;
   double *array = nullptr;      // m*ld
@@ -175,6 +177,8 @@ int ksk_scale(ks_ctx ctx, double *x, size_t n, double alpha);
 int ksk_copy(ks_ctx ctx, const double *src, double *dst, size_t n);
 
 int ks_mat_mult_internal(ks_mat A, const double *x, double *y);
+int ksb_ipmatmult(ks_bv bv, const double *x, const double **z);   // z = x, or B*x (in bv->Bx) when a matrix is set
+int ksb_norm_b(ks_bv bv, const double *x, double *val);            // sqrt(x' B x) with the BV_SafeSqrt check (BVNorm_Private)
 int ksb_dot_range(ks_bv X, int xs, int xe, ks_bv Y, int ys, int ye, double *M, int ldm);          // M(ys:ye,xs:xe) = Y(:,ys:ye)^T X(:,xs:xe)
 int ksb_mult_range(ks_bv Y, int ys, int ye, double alpha, double beta, ks_bv X, int xs, int xe, const double *Q, int ldq);
 // MFMA f64 panel contractions (ks_panel.hip)

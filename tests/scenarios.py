@@ -190,12 +190,51 @@ def _orthogonalize(bv, R, block):
         bv.Orthogonalize(R, block)
 
 
-def bv_test11(be, block, n=20, l=2, k=8, resid=True, X0=None):
+def lap1d_csr(be, n):
+    """tridiag(-1, 2, -1): the inner-product matrix B of test3.c / test11.c -withb / test18.c"""
+    rowptr, col, val = [0], [], []
+    for i in range(n):
+        for j, v in ((i - 1, -1.0), (i, 2.0), (i + 1, -1.0)):
+            if 0 <= j < n:
+                col.append(j); val.append(v)
+        rowptr.append(len(col))
+    return be.csr(np.array(rowptr, dtype=np.int32), np.array(col, dtype=np.int32), np.array(val))
+
+
+def bv_test3(be, orthog_type=0, n=10, k=5):
+    """test3.c: B-norm, BVOrthogonalizeColumn and BVDot with the inner product of tridiag(-1,2,-1)."""
+    B = lap1d_csr(be, n)
+    X = be.bv(n, k)
+    X.SetOrthogonalization(orthog_type, 0, 0.7071)
+    X.SetMatrix(B)
+    X0 = np.zeros((n, k))
+    for j in range(k):
+        for i in range(4):
+            if i + j < n:
+                X0[i + j, j] = 3 * i + j - 2
+    be.fill(X, X0)
+    out = {"norm0": X.NormColumn(0)}
+    for j in range(k):
+        _, nrm, _ = X.OrthogonalizeColumn(j)
+        X.ScaleColumn(j, 1.0 / nrm)
+    M = np.zeros((k, k), order="F")
+    X.Dot(X, M)
+    out["level"] = np.abs(M - np.eye(k)).sum(axis=0).max()
+    out["norm0_after"] = X.NormColumn(0)
+    out["X"] = X.dense()
+    return out
+
+
+def bv_test11(be, block, n=20, l=2, k=8, resid=True, X0=None, withb=False):
     """test11.c: BVOrthogonalize of the leading columns, then of the active ones; levels of orthogonality
-    ||M(l:k,l:k) - I||_F (MyMatNorm) and residuals ||X - Q R||_F as the program prints them."""
+    ||M(l:k,l:k) - I||_F (MyMatNorm) and residuals ||X - Q R||_F as the program prints them. withb: the B-inner product
+    of tridiag(-1,2,-1) (output/test11_4.out, test11_9.out)."""
     X0 = _test11_X(n, k) if X0 is None else X0
     X = be.bv(n, k); Y = be.bv(n, k)
     be.fill(X, X0); be.fill(Y, X0)
+    if withb:
+        B = lap1d_csr(be, n)
+        Y.SetMatrix(B)
     M = np.zeros((k, k), order="F")
     R = np.zeros((k, k), order="F") if resid else None
     out = {}

@@ -298,3 +298,51 @@ def test_eps_test11_sinvert_user_sort_golden():
     r = O.eps_krylovschur_nhep(A, 4, tol=1e-10, which=nc.right_of(0.5), st=O.ST(A, None, "sinvert", 0.5), v0=np.ones(A.n))
     ref = gi.eigenvalues_line(gi.read("eps/eps_test11_1.out"))
     assert r.nconv >= 4 and np.allclose(np.round(r.eigr[r.perm][:4], 5), ref, atol=1.5e-5)
+
+
+# ---- non-standard inner product (BVSetMatrix) and GHEP ------------------------------------------------------------
+@pytest.mark.parametrize("otype", [O.CGS, O.MGS])
+def test_bv_test3_bnorm_golden(be, otype):
+    """output/test3_1.out: B-Norm of X[0] = 8.94427, orthogonality < 100*eps, B-Norm of X[0] = 1."""
+    txt = gi.read("bv/test3_1.out")
+    out = sc.bv_test3(be, otype)
+    assert abs(out["norm0"] - gi.value_after(txt, "B-Norm of X[0] =")) < 5e-6
+    assert "Level of orthogonality < 100*eps" in txt and out["level"] < 100 * np.finfo(float).eps
+    assert abs(out["norm0_after"] - 1.0) < 1e-14
+
+
+@pytest.mark.parametrize("block", ["gs", "chol", "svqb"])
+def test_bv_test11_withb(be, block):
+    """output/test11_4.out / test11_9.out (-withb): block orthogonalisation in the B-inner product."""
+    txt = gi.read("bv/test11_9.out")
+    assert "Residual ||X-Q*R|| < 100*eps" in txt and "Level of orthogonality of Q < 100*eps" in txt
+    out = sc.bv_test11(be, block, withb=True)
+    for key in ("Q1", "Q2", "Q", "res1", "res"):
+        assert out[key] < 100 * np.finfo(float).eps, (block, key, out[key])
+
+
+def _test1_pencil(n=18):
+    A = O.laplacian2d(n)
+    d = 2.0 / np.log(np.arange(A.n) + 2.0)                     # test1.c:53
+    return A, O.CSR(A.n, np.arange(A.n + 1, dtype=np.int32), np.arange(A.n, dtype=np.int32), d)
+
+
+def test_eps_test1_ghep_golden():
+    """test1 -n 18 -eps_nev 4 -eps_max_it 1500 (GHEP, B diagonal, default ST: Op = B^-1 A, Lanczos in the B-inner product)
+    -> 21.89996, 21.65898, 21.28794, 20.82229 and B-orthonormal eigenvectors."""
+    A, B = _test1_pencil()
+    r = O.eps_krylovschur_hep(A, 4, max_it=1500, st=O.ST(A, B, "shift", 0.0), B=B)
+    assert np.allclose(np.round(r.eigr[r.perm][:4], 5), gi.eigenvalues_line(gi.read("eps/eps_test1_1.out")), atol=1.5e-5)
+    X = np.stack([r.V.column(j) for j in range(r.nconv)], axis=1)
+    assert np.abs(X.T @ (B.to_scipy() @ X) - np.eye(r.nconv)).max() < 1e-8       # "Level of orthogonality below the tolerance"
+    for i in range(4):
+        assert O.eps_compute_error(A, r, i, B=B) < 1e-8
+
+
+def test_eps_ex13_ghep_sinvert_golden():
+    """ex13 -eps_nev 4 -eps_ncv 22 -eps_tol 1e-5 -st_type sinvert (A 2-D Laplacian 10x10, B = 4 I)
+    -> 0.04051, 0.09963, 0.09963, 0.15875 (the double eigenvalue shows up twice)."""
+    A = O.laplacian2d(10)
+    B = O.CSR(A.n, np.arange(A.n + 1, dtype=np.int32), np.arange(A.n, dtype=np.int32), np.full(A.n, 4.0))
+    r = O.eps_krylovschur_hep(A, 4, ncv=22, tol=1e-5, which=O.which_target_magnitude(0.0), st=O.ST(A, B, "sinvert", 0.0), B=B)
+    assert np.allclose(np.round(r.eigr[r.perm][:4], 5), gi.eigenvalues_line(gi.read("eps/ex13_1.out")), atol=1.5e-5)
