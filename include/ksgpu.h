@@ -80,7 +80,8 @@ enum { KS_EPS_LARGEST_MAGNITUDE = 1, KS_EPS_SMALLEST_MAGNITUDE = 2, KS_EPS_LARGE
 typedef int (*ks_eig_compare_fn)(double ar, double ai, double br, double bi, int *res, void *ctx);
 enum { KS_EPS_HEP = 1, KS_EPS_GHEP = 2, KS_EPS_NHEP = 3, KS_EPS_GNHEP = 4 };   /* EPSProblemType, slepceps.h */
 enum { KS_ST_SHIFT = 0, KS_ST_SINVERT = 1 };                 /* STType "shift", "sinvert" */
-enum { KS_EPS_ERROR_ABSOLUTE = 0, KS_EPS_ERROR_RELATIVE = 1 };
+enum { KS_EPS_ERROR_ABSOLUTE = 0, KS_EPS_ERROR_RELATIVE = 1, KS_EPS_ERROR_BACKWARD = 2 };   /* EPSErrorType */
+enum { KS_EPS_CONV_ABS = 0, KS_EPS_CONV_REL = 1, KS_EPS_CONV_NORM = 2 };                       /* EPSConv (EPS_CONV_USER not offered) */
 enum { KS_EPS_CONVERGED_TOL = 1, KS_EPS_CONVERGED_USER = 2, KS_EPS_DIVERGED_ITS = -1, KS_EPS_DIVERGED_BREAKDOWN = -2,
        KS_EPS_DIVERGED_SYMMETRY_LOST = -3, KS_EPS_CONVERGED_ITERATING = 0 };
 
@@ -133,6 +134,7 @@ int ks_mat_load_petsc_binary(ks_ctx ctx, const char *path, ks_mat *A);
    stream (enqueue on that stream, or synchronise) and leave y complete in that order.          */
 typedef int (*ks_shell_mult_fn)(void *user, const double *x_dev, double *y_dev);
 int ks_mat_create_shell(ks_ctx ctx, int n_local, int row_start, int n_global, ks_shell_mult_fn mult, void *user, ks_mat *A);
+int ks_mat_norm_inf(ks_mat A, double *val);                             /* MatNorm(A,NORM_INFINITY) */
 int ks_mat_get_diagonal(ks_mat A, double *d_dev);                      /* MatGetDiagonal (local diagonal block) */
 int ks_mat_destroy(ks_mat A);
 int ks_mat_get_sizes(ks_mat A, int *n_local, int *n_global, long long *nnz_local);
@@ -216,6 +218,7 @@ int ks_eps_get_st(ks_eps eps, ks_st *st);                                    /* 
 int ks_eps_set_target(ks_eps eps, double target);                            /* EPSSetTarget epsopts.c:604 (sorting only: no spectral transformation) */
 int ks_eps_set_eigenvalue_comparison(ks_eps eps, ks_eig_compare_fn fn, void *ctx);   /* EPSSetEigenvalueComparison epsopts.c:563 */
 int ks_eps_set_krylovschur_restart(ks_eps eps, double keep);               /* EPSKrylovSchurSetRestart, default 0.5 */
+int ks_eps_set_convergence_test(ks_eps eps, int conv);                    /* EPSSetConvergenceTest: KS_EPS_CONV_* (epsdefault.c:224-257) */
 int ks_eps_set_krylovschur_locking(ks_eps eps, int lock);               /* EPSKrylovSchurSetLocking: 0 = non-locking variant (krylovschur.c:294) */
 int ks_eps_set_random_seed(ks_eps eps, uint64_t seed);
 int ks_eps_set_initial_vector(ks_eps eps, const double *v_host);           /* EPSSetInitialSpace with one vector */

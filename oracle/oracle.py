@@ -663,13 +663,28 @@ class DSHEP:
         return self.Q[:rows, : self.n]
 
 
+def _norm_inf(M):
+    """MatNorm(M,NORM_INFINITY)"""
+    return float(abs(M.to_scipy()).sum(axis=1).max())
+
+
+def _converged(conv, re, im, res, nrma=0.0, nrmb=1.0):
+    """EPSConvergedRelative / Absolute / Norm (epsdefault.c:224-257)"""
+    w = np.hypot(re, im)
+    if conv == "abs":
+        return res
+    if conv == "norm":
+        return res / (nrma + w * nrmb)
+    return res / w if w != 0.0 else np.finfo(float).max
+
+
 class EPSResult:
     pass
 
 
 def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which="largest_magnitude",
                         keep=0.5, seed=0x12345678, omp=False, v0=None, orthog=(CGS, REFINE_IFNEEDED, 0.7071),
-                        max_steps=None, monitor=None, lock=True, st=None, B=None):
+                        max_steps=None, monitor=None, lock=True, st=None, B=None, conv="rel"):
     """EPSSolve for a symmetric problem with the default Krylov-Schur solver: standard (HEP), or generalized (GHEP,
     B given: the basis carries the B-inner product, EPS_SetInnerProduct epsimpl.h:280-292; the start vector goes
     through the operator, epssolve.c:860-868; the eigenvectors are purified and B-normalised,
@@ -700,6 +715,8 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
             return compare(ar, ai, br, bi)
     else:
         ds_compare = compare
+    nrma = _norm_inf(A) if conv == "norm" else 0.0
+    nrmb = (_norm_inf(B) if B is not None else 1.0) if conv == "norm" else 1.0
     V = BV(n, ncv + 1, omp=omp)
     V.SetOrthogonalization(*orthog)
     if B is not None:
@@ -755,11 +772,10 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
         kk = nconv
         for kk in range(nconv, nv):
             re = eigr[kk]                                   # shift ST with sigma=0: back-transform is identity
-            if st is not None and st.kind == "shift":
+            if st is not None and (st.kind == "shift" or conv == "norm"):
                 re = st.backtransform(re, 0.0)[0]           # epskrylov.c:253
             resnorm = ds.Vectors_resnorm(kk) * beta * 1.0
-            w = abs(re)
-            errest[kk] = resnorm / w if w != 0.0 else np.finfo(float).max
+            errest[kk] = _converged(conv, re, 0.0, resnorm, nrma, nrmb)
             if marker == -1 and errest[kk] >= tol:
                 marker = kk
             if marker != -1:
@@ -1065,7 +1081,7 @@ class ST:
 
 
 def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which="largest_magnitude", keep=0.5,
-                         seed=0x12345678, v0=None, max_steps=None, st=None, lock=True):
+                         seed=0x12345678, v0=None, max_steps=None, st=None, lock=True, conv="rel", B=None):
     """EPSSolve_KrylovSchur_Default with the Arnoldi expansion (krylovschur.c:227-337, non-Hermitian branch),
     EPSKrylovConvergence for conjugate pairs (epskrylov.c:262-287), EPSComputeVectors_Schur (epsdefault.c:105-169).
     With st (an ST): the Krylov operator is st.apply, the DS sorts through the back-transformation
@@ -1080,6 +1096,8 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
     if max_it is None:
         max_it = max(100, 2 * n // ncv)
     compare = which if callable(which) else WHICH[which]
+    nrma = _norm_inf(A) if conv == "norm" else 0.0
+    nrmb = (_norm_inf(B) if B is not None else 1.0) if conv == "norm" else 1.0
     if st is not None:
         def ds_compare(ar, ai, br, bi):
             ar, ai = st.backtransform(ar, ai); br, bi = st.backtransform(br, bi)
@@ -1128,12 +1146,11 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
         k = nconv
         while k < nv:
             re, im = eigr[k], eigi[k]
-            if st is not None and st.kind == "shift":
+            if st is not None and (st.kind == "shift" or conv == "norm"):
                 re, im = st.backtransform(re, im)
             newk, resnorm = ds.Vectors(k)
             resnorm *= beta
-            w = np.hypot(re, im)
-            errest[k] = resnorm / w if w != 0.0 else np.finfo(float).max
+            errest[k] = _converged(conv, re, im, resnorm, nrma, nrmb)
             if marker == -1 and errest[k] >= tol:
                 marker = k
             if newk == k + 1:

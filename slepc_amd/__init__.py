@@ -25,7 +25,7 @@ REFINE_IFNEEDED, REFINE_NEVER, REFINE_ALWAYS = 0, 1, 2
 NORM_1, NORM_2, NORM_FROBENIUS, NORM_INFINITY = 0, 1, 2, 3
 EPS_LARGEST_MAGNITUDE, EPS_SMALLEST_MAGNITUDE, EPS_LARGEST_REAL, EPS_SMALLEST_REAL = 1, 2, 3, 4
 EPS_HEP, EPS_GHEP, EPS_NHEP, EPS_GNHEP = 1, 2, 3, 4
-EPS_ERROR_ABSOLUTE, EPS_ERROR_RELATIVE = 0, 1
+EPS_ERROR_ABSOLUTE, EPS_ERROR_RELATIVE, EPS_ERROR_BACKWARD = 0, 1, 2
 EPS_CONVERGED_TOL, EPS_CONVERGED_USER, EPS_DIVERGED_ITS, EPS_DIVERGED_BREAKDOWN = 1, 2, -1, -2
 WHICH = {"largest_magnitude": 1, "smallest_magnitude": 2, "largest_real": 3, "smallest_real": 4,
          "largest_imaginary": 5, "smallest_imaginary": 6, "target_magnitude": 7, "target_real": 8, "user": 11}
@@ -223,6 +223,9 @@ class Mat:
         m = cls(ctx, h)
         m._cb = cb                      # keep the trampoline alive as long as the matrix
         return m
+
+    def norm_inf(self):
+        v = C.c_double(); _lib.check(self.ctx.L.ks_mat_norm_inf(self.h, C.byref(v))); return v.value
 
     def get_diagonal(self):
         """MatGetDiagonal of the local diagonal block, as a host array (test convenience)."""
@@ -578,6 +581,9 @@ class EPS:
             return 0
         self._cmp_cb = EIG_COMPARE_FN(tramp)          # keep the trampoline alive as long as the solver
         _lib.check(self.ctx.L.ks_eps_set_eigenvalue_comparison(self.h, C.cast(self._cmp_cb, C.c_void_p), None))
+
+    def SetConvergenceTest(self, conv):
+        _lib.check(self.ctx.L.ks_eps_set_convergence_test(self.h, {"abs": 0, "rel": 1, "norm": 2}.get(conv, conv)))
 
     def KrylovSchurSetLocking(self, lock):
         _lib.check(self.ctx.L.ks_eps_set_krylovschur_locking(self.h, int(bool(lock))))

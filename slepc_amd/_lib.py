@@ -47,6 +47,7 @@ _SIG = {
     "ks_mat_load_petsc_binary": [vp, C.c_char_p, C.POINTER(vp)],
     "ks_mat_create_shell": [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(vp)],
     "ks_mat_get_diagonal": [vp, vp],
+    "ks_mat_norm_inf": [vp, dp],
     "ks_mat_get_sizes": [vp, ip, ip, llp],
     "ks_mat_mult": [vp, vp, vp],
     "ks_mat_mult_host": [vp, dp, dp],
@@ -107,6 +108,7 @@ _SIG = {
     "ks_eps_set_which_eigenpairs": [vp, C.c_int],
     "ks_eps_set_target": [vp, C.c_double],
     "ks_eps_set_krylovschur_locking": [vp, C.c_int],
+    "ks_eps_set_convergence_test": [vp, C.c_int],
     "ks_eps_set_eigenvalue_comparison": [vp, C.c_void_p, vp],
     "ks_eps_set_krylovschur_restart": [vp, C.c_double],
     "ks_eps_set_random_seed": [vp, C.c_uint64],

@@ -342,6 +342,7 @@ struct ks_eps_s {
   int nconv = 0, its = 0, reason = 0;
   long long steps = 0, passes = 0; int restarts = 0;
   bool solved = false, ghep = false;
+  int conv = KS_EPS_CONV_REL; double nrma = 0.0, nrmb = 0.0;   // EPSSetConvergenceTest; ||A||_inf, ||B||_inf for CONV_NORM / ERROR_BACKWARD
   DsHep ds;
   DsNhep dsn;
 };
@@ -367,7 +368,7 @@ extern "C" int ks_eps_set_operators(ks_eps eps, ks_mat A, ks_mat B)   // epssetu
   KS_CHECK(eps && A, KS_ERR_ARG_NULL, "NULL argument");
   KS_CHECK(!B || (B->n == A->n && B->n_global == A->n_global), KS_ERR_ARG_INCOMP, "Mismatching dimensions of A (%d) and B (%d)", A->n, B ? B->n : 0);
   if (eps->V && eps->A && eps->A->n != A->n) { ks_bv_destroy(eps->V); ks_bv_destroy(eps->W); eps->V = eps->W = nullptr; }
-  eps->A = A; eps->B = B; eps->solved = false;
+  eps->A = A; eps->B = B; eps->solved = false; eps->nrma = eps->nrmb = 0.0;
   if (eps->st) KS_CALL(ks_st_set_matrices(eps->st, A, B));
   return KS_SUCCESS;
 }
@@ -427,6 +428,18 @@ extern "C" int ks_eps_set_krylovschur_restart(ks_eps eps, double keep)   // kryl
   KS_CHECK(keep >= 0.1 && keep <= 0.9, KS_ERR_ARG_OUTOFRANGE, "The keep argument %g must be in the range [.1,.9]", keep);
   eps->keep = keep; return KS_SUCCESS;
 }
+extern "C" int ks_eps_set_convergence_test(ks_eps eps, int conv)            // EPSSetConvergenceTest epsopts.c
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  KS_CHECK(conv == KS_EPS_CONV_ABS || conv == KS_EPS_CONV_REL || conv == KS_EPS_CONV_NORM, KS_ERR_ARG_OUTOFRANGE, "Invalid 'conv' value");
+  eps->conv = conv; eps->solved = false; return KS_SUCCESS;
+}
+static int matrix_norms(ks_eps eps)                                         // epssetup.c:345-358
+{
+  if (!eps->nrma) KS_CALL(ks_mat_norm_inf(eps->A, &eps->nrma));
+  if (eps->B) { if (!eps->nrmb) KS_CALL(ks_mat_norm_inf(eps->B, &eps->nrmb)); } else eps->nrmb = 1.0;
+  return KS_SUCCESS;
+}
 extern "C" int ks_eps_set_krylovschur_locking(ks_eps eps, int lock)     // EPSKrylovSchurSetLocking krylovschur.c:388-423
 {
   KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
@@ -441,6 +454,17 @@ extern "C" int ks_eps_set_initial_vector(ks_eps eps, const double *v)
   return KS_SUCCESS;
 }
 extern "C" int ks_eps_set_max_steps(ks_eps eps, long long s) { KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL"); eps->max_steps = s > 0 ? s : 0; return KS_SUCCESS; }
+
+// EPSConvergedRelative / Absolute / Norm epsdefault.c:224-257
+static double converged_estimate(ks_eps eps, double re, double im, double res)
+{
+  const double w = hypot(re, im);
+  switch (eps->conv) {
+    case KS_EPS_CONV_ABS:  return res;
+    case KS_EPS_CONV_NORM: return res / (eps->nrma + w * eps->nrmb);
+    default:               return (w != 0.0) ? res / w : std::numeric_limits<double>::max();
+  }
+}
 
 // EPSGetStartVector epssolve.c:841-873
 static int start_vector(ks_eps eps, int i, bool *breakdown)
@@ -498,12 +522,11 @@ static int solve_nhep(ks_eps eps, long long passes0)
     int marker = -1, k;
     for (k = eps->nconv; k < nv; k++) {
       double re = eps->eigr[k], im = eps->eigi[k];
-      if (isshift && map) ks_st_backtransform_internal(map, 1, &re, &im);          // epskrylov.c:253
+      if ((isshift || eps->conv == KS_EPS_CONV_NORM) && map) ks_st_backtransform_internal(map, 1, &re, &im);          // epskrylov.c:253
       double resnorm = 0.0;
       const int newk = ds.vectors(k, true, &resnorm);
       resnorm *= beta;
-      const double w = hypot(re, im);
-      eps->errest[k] = (w != 0.0) ? resnorm / w : std::numeric_limits<double>::max();
+      eps->errest[k] = converged_estimate(eps, re, im, resnorm);
       if (marker == -1 && eps->errest[k] >= eps->tol) marker = k;
       if (newk == k + 1) { eps->errest[k + 1] = eps->errest[k]; k++; }
       if (marker != -1) break;
@@ -588,6 +611,7 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   if (!eps->B && ptype == KS_EPS_GHEP) ptype = KS_EPS_HEP;
   KS_CHECK(!eps->B || ptype == KS_EPS_GNHEP || ptype == KS_EPS_GHEP, KS_ERR_ARG_INCOMP, "Inconsistent EPS state: the problem type does not match the number of matrices");
   const bool ghep = ptype == KS_EPS_GHEP;
+  if (eps->conv == KS_EPS_CONV_NORM) KS_CALL(matrix_norms(eps));
   ks_st st = eps->st;
   const bool sinvert = st && st->type == KS_ST_SINVERT;
   if (st && !st->sigma_set) { if (st->sigma != eps->which.target) st->ready = false; st->sigma = eps->which.target; }   // shift defaults to the target (sinvert.c:62)
@@ -655,10 +679,9 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
     int marker = -1, k;
     for (k = eps->nconv; k < nv; k++) {
       double re = eps->eigr[k], im0 = 0.0;
-      if (isshift && eps->cmp_ds.map) ks_st_backtransform_internal(eps->cmp_ds.map, 1, &re, &im0);   // epskrylov.c:253 (identity for sigma = 0)
+      if ((isshift || eps->conv == KS_EPS_CONV_NORM) && eps->cmp_ds.map) ks_st_backtransform_internal(eps->cmp_ds.map, 1, &re, &im0);   // epskrylov.c:253 (identity for sigma = 0)
       const double resnorm = ds.vectors_resnorm(k) * beta * 1.0;
-      const double w = fabs(re);
-      eps->errest[k] = (w != 0.0) ? resnorm / w : std::numeric_limits<double>::max();     // EPSConvergedRelative
+      eps->errest[k] = converged_estimate(eps, re, 0.0, resnorm);
       if (marker == -1 && eps->errest[k] >= eps->tol) marker = k;
       if (marker != -1) break;
     }
@@ -814,6 +837,7 @@ extern "C" int ks_eps_compute_error(ks_eps eps, int i, int type, double *error) 
   double vecnorm = 1.0;
   if (eps->ghep) { ks_mat Bsave = V->matrix; V->matrix = nullptr; int rc = ks_bv_normcolumn(V, j, KS_NORM_2, &vecnorm); V->matrix = Bsave; if (rc) return rc; }   // epssolve.c:774: 2-norm of the eigenvector
   if (type == KS_EPS_ERROR_RELATIVE) nrm /= hypot(kr, ki) * vecnorm;
+  else if (type == KS_EPS_ERROR_BACKWARD) { KS_CALL(matrix_norms(eps)); nrm /= (eps->nrma + hypot(kr, ki) * eps->nrmb) * vecnorm; }   // epssolve.c:782-800
   else KS_CHECK(type == KS_EPS_ERROR_ABSOLUTE, KS_ERR_ARG_OUTOFRANGE, "Invalid error type");
   *error = nrm;
   return KS_SUCCESS;

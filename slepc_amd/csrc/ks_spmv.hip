@@ -565,6 +565,61 @@ int ks_mat_get_diagonal_internal(ks_mat A, double *d)
   KS_HIP(hipGetLastError());
   return KS_SUCCESS;
 }
+// MatNorm(A,NORM_INFINITY): max over rows of the sum of |a_ij| (diagonal and off-diagonal blocks)
+__global__ void k_rowabs_csr(int n, const int *__restrict__ rp, const double *__restrict__ val, double *__restrict__ out, int accumulate)
+{
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  double v = 0.0;
+  for (int p = rp[r]; p < rp[r + 1]; p++) v += fabs(val[p]);
+  out[r] = accumulate ? out[r] + v : v;
+}
+__global__ void k_rowabs_sell(int n, const int *__restrict__ sp, const int *__restrict__ rlen, const double *__restrict__ val, double *__restrict__ out)
+{
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const long long base = (long long)sp[r >> 6] * 64 + (r & 63);
+  double v = 0.0;
+  for (int j = 0; j < rlen[r]; j++) v += fabs(val[base + (long long)j * 64]);
+  out[r] = v;
+}
+__global__ void k_rowabs_rows(int nrows, const int *__restrict__ rows, const int *__restrict__ rp, const double *__restrict__ val, double *__restrict__ out)
+{
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrows) return;
+  double v = 0.0;
+  for (int p = rp[i]; p < rp[i + 1]; p++) v += fabs(val[p]);
+  out[rows[i]] += v;
+}
+extern "C" int ks_mat_norm_inf(ks_mat A, double *val)
+{
+  KS_CHECK(A && val, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(!A->shell_mult, KS_ERR_SUP, "a matrix-free operator has no norm operation");      // MatHasOperation(A,MATOP_NORM) epssolve.c:786
+  ks_ctx ctx = A->ctx;
+  KS_HIP(hipSetDevice(ctx->device));
+  double local = 0.0;
+  if (A->n > 0) {
+    double *w = nullptr;
+    KS_HIP(hipMalloc(&w, sizeof(double) * A->n));
+    const unsigned nb = (unsigned)((A->n + 255) / 256);
+    if (A->use_sell) hipLaunchKernelGGL(k_rowabs_sell, dim3(nb), dim3(256), 0, ctx->stream, A->n, A->s_ptr, A->s_len, A->s_val, w);
+    else hipLaunchKernelGGL(k_rowabs_csr, dim3(nb), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_val, w, 0);
+    if (A->n_orows > 0) hipLaunchKernelGGL(k_rowabs_rows, dim3((unsigned)((A->n_orows + 255) / 256)), dim3(256), 0, ctx->stream, A->n_orows, A->o_rows, A->o_rowptr, A->o_val, w);
+    std::vector<double> h(A->n);
+    int rc = hipGetLastError() == hipSuccess && hipMemcpyAsync(h.data(), w, sizeof(double) * A->n, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess ? 0 : 1;
+    hipFree(w);
+    KS_CHECK(!rc, KS_ERR_LIB, "row-sum kernel failed");
+    for (double v : h) local = std::max(local, v);
+  }
+  if (ctx->comm.size > 1) {
+    std::vector<double> all(ctx->comm.size);
+    KS_CALL(ks_comm_allgather_host(ctx, &local, (int)sizeof(double), all.data()));
+    for (double v : all) local = std::max(local, v);
+  }
+  *val = local;
+  return KS_SUCCESS;
+}
+
 extern "C" int ks_mat_get_diagonal(ks_mat A, double *d_dev)
 {
   KS_CHECK(A && d_dev, KS_ERR_ARG_NULL, "NULL argument");

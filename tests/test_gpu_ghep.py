@@ -93,11 +93,13 @@ def _test1_pencil(n=18):
     return A, O.CSR(A.n, np.arange(A.n + 1, dtype=np.int32), np.arange(A.n, dtype=np.int32), d)
 
 
-def _ghep(ctx, Ao, Bo, nev, ncv=0, tol=0.0, max_it=0, sinvert=None):
+def _ghep(ctx, Ao, Bo, nev, ncv=0, tol=0.0, max_it=0, sinvert=None, conv=None):
     import slepc_amd as ks
     A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val); B = ks.Mat.from_csr(ctx, Bo.rowptr, Bo.col, Bo.val)
     eps = ks.EPS(ctx)
     eps.SetOperators(A, B); eps.SetProblemType(ks.EPS_GHEP); eps.SetDimensions(nev, ncv); eps.SetTolerances(tol, max_it)
+    if conv:
+        eps.SetConvergenceTest(conv)
     st = eps.GetST(); st.SetKSP(rtol=1e-14)
     if sinvert is not None:
         st.SetType("sinvert"); eps.SetTarget(sinvert)
@@ -107,8 +109,8 @@ def _ghep(ctx, Ao, Bo, nev, ncv=0, tol=0.0, max_it=0, sinvert=None):
 
 def test_eps_test1_ghep_golden(ctx):
     Ao, Bo = _test1_pencil()
-    eps = _ghep(ctx, Ao, Bo, 4, max_it=1500)
-    r = O.eps_krylovschur_hep(Ao, 4, max_it=1500, st=O.ST(Ao, Bo, "shift", 0.0), B=Bo)
+    eps = _ghep(ctx, Ao, Bo, 4, max_it=1500, conv="norm")              # test1.c:75 EPS_CONV_NORM
+    r = O.eps_krylovschur_hep(Ao, 4, max_it=1500, st=O.ST(Ao, Bo, "shift", 0.0), B=Bo, conv="norm")
     lam = np.array([eps.GetEigenvalue(i)[0] for i in range(eps.GetConverged())])
     assert np.allclose(np.round(lam[:4], 5), gi.eigenvalues_line(gi.read("eps/eps_test1_1.out")), atol=1.5e-5)
     assert eps.GetConverged() == r.nconv and eps.GetIterationNumber() == r.its
@@ -117,8 +119,20 @@ def test_eps_test1_ghep_golden(ctx):
     assert np.allclose(lam, r.eigr[r.perm], rtol=1e-10)
     X = np.stack([eps.GetEigenvector(i) for i in range(r.nconv)], axis=1)
     assert np.abs(X.T @ (Bo.to_scipy() @ X) - np.eye(r.nconv)).max() < 1e-8           # B-orthonormal eigenvectors
+    import slepc_amd as ks
+    nrma = abs(Ao.to_scipy()).sum(axis=1).max(); nrmb = abs(Bo.to_scipy()).sum(axis=1).max()
     for i in range(r.nconv):
-        assert abs(eps.ComputeError(i) - O.eps_compute_error(Ao, r, i, B=Bo)) < 1e-10 and eps.ComputeError(i) < 1e-8
+        err = eps.ComputeError(i)
+        assert abs(err - O.eps_compute_error(Ao, r, i, B=Bo)) < 1e-10 and err < 1e-6
+        back = eps.ComputeError(i, ks.EPS_ERROR_BACKWARD)               # EPSErrorView(eps,EPS_ERROR_BACKWARD) test1.c:97
+        assert abs(back - err * abs(lam[i]) / (nrma + abs(lam[i]) * nrmb)) < 1e-14 and back < 1e-8
+
+
+def test_matrix_infinity_norm(ctx):
+    import slepc_amd as ks
+    for Ao in (O.laplacian3d(9, 8, 7), O.markov_matrix(15), O.load_petsc_binary(gi.matrix_path("bfw62a.petsc"))):
+        A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
+        assert abs(A.norm_inf() - abs(Ao.to_scipy()).sum(axis=1).max()) <= 1e-13 * A.norm_inf()
 
 
 def test_eps_ex13_ghep_sinvert_golden(ctx):

@@ -331,7 +331,7 @@ def test_eps_test1_ghep_golden():
     """test1 -n 18 -eps_nev 4 -eps_max_it 1500 (GHEP, B diagonal, default ST: Op = B^-1 A, Lanczos in the B-inner product)
     -> 21.89996, 21.65898, 21.28794, 20.82229 and B-orthonormal eigenvectors."""
     A, B = _test1_pencil()
-    r = O.eps_krylovschur_hep(A, 4, max_it=1500, st=O.ST(A, B, "shift", 0.0), B=B)
+    r = O.eps_krylovschur_hep(A, 4, max_it=1500, st=O.ST(A, B, "shift", 0.0), B=B, conv="norm")      # EPSSetConvergenceTest(eps,EPS_CONV_NORM) test1.c:75
     assert np.allclose(np.round(r.eigr[r.perm][:4], 5), gi.eigenvalues_line(gi.read("eps/eps_test1_1.out")), atol=1.5e-5)
     X = np.stack([r.V.column(j) for j in range(r.nconv)], axis=1)
     assert np.abs(X.T @ (B.to_scipy() @ X) - np.eye(r.nconv)).max() < 1e-8       # "Level of orthogonality below the tolerance"
