@@ -141,57 +141,10 @@ __global__ __launch_bounds__(1024) void k_gs_finish(const double *__restrict__ p
   if (BOOK && threadIdx.x == 0) gs_bookkeep(a, c_lds, buffer, st, recs);
 }
 
-// Single-rank runs fold the 1-block bookkeeping kernel into the sweep that produces its input: every block takes a
-// ticket after delivering its partial sums, and the block that draws the last one reduces the partials (in the same
-// fixed order as k_gs_finish, so the result does not depend on which block it is) and runs the bookkeeping.
-//   mode 0: no tail (the bookkeeping is a kernel of its own: multi-rank, completion programs)
-//   mode 1: reduce + bookkeeping of slot a.slot
-//   mode 2: this launch ends the column's program: only retire the pending update
-struct FinTail { int mode; GsArgs a; double *buffer; KsGsState *st; KsStepRec *recs; unsigned int *ticket; };
-
-// Cross-workgroup hand-off without fences (MI355X: the eight XCD L2s are not coherent with each other, and an
-// agent-scope release/acquire writes back / invalidates a whole L2 - measured 4x slower sweeps): the partial sums are
-// stored sc1, every storing wave waits for its stores (vmcnt(0)), one lane per workgroup then adds to the ticket
-// counter behind a workgroup barrier, and the workgroup whose add came last reads the partials back with sc1 loads.
-__device__ __forceinline__ void sweep_tail(const FinTail &f, bool produced, const double *__restrict__ partials)
-{
-  __shared__ int last_block, go;
-  __shared__ double c_tail[KS_MAX_COLS + 8];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) last_block = (__hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1);
-  __syncthreads();
-  if (!last_block) return;
-  if (threadIdx.x == 0) {
-    go = 0;
-    __hip_atomic_store(f.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (f.mode == 1 && produced) {
-      go = 1;
-      if (!f.st->active || (f.a.slot > 1 && !f.st->expl && !f.st->more_)) { go = 0; f.st->do_update = 0; }   // as k_gs_finish
-    } else f.st->do_update = 0;                      // the update that just ran was the column's last one
-  }
-  __syncthreads();
-  if (!go) return;
-  const int ncols = f.a.k + 1;
-  reduce_partials_to_lds<true>(partials, (int)gridDim.x, ncols, c_tail);
-  if ((int)threadIdx.x < ncols) f.buffer[threadIdx.x] = c_tail[threadIdx.x];
-  if (threadIdx.x == 0) gs_bookkeep(f.a, c_tail, f.buffer, f.st, f.recs);
-}
-
-// the first sweep of a column (BVDotColumnInc) with the bookkeeping of slot 1 in its tail
-template <int KT, int VEC>
-__global__ __launch_bounds__(SW_BLOCK) void k_dot_sweep_fin(const double *__restrict__ A, long long lda, int n, int ncols,
-                                                            const double *__restrict__ y, double *__restrict__ partials, int gated, FinTail tail)
-{
-  if (gated && !tail.st->active) return;
-  dot_sweep_body<KT, VEC, true>(A, lda, n, ncols, y, partials);
-  sweep_tail(tail, true, partials);
-}
-
 // v <- v - V(:,0:k) c   [* alpha if final]   and, when st->fuse_dot, partials <- [V(:,0:k) v]^T v  (k+1 values)
 template <int KT, int VEC>
 __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long long ld, int n, int k, double *v, const double *__restrict__ cg,
-                                                        double *__restrict__ partials, const KsGsState *st, int rev, FinTail tail)
+                                                        double *__restrict__ partials, const KsGsState *__restrict__ st, int rev)
 {
   if (!st->do_update) return;
   const bool fuse = st->fuse_dot != 0;
@@ -247,7 +200,7 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long lo
       }
     }
   }
-  if (!fuse) { if (tail.mode) sweep_tail(tail, false, partials); return; }
+  if (!fuse) return;
   // block combine: partial index i<k <- acc[i]; index k <- acc[KT] (the self dot)
   __shared__ double red[SW_WAVES][KT + 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -259,10 +212,8 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long lo
     double s = red[0][src];
 #pragma unroll
     for (int ww = 1; ww < SW_WAVES; ww++) s += red[ww][src];
-    if (tail.mode) st_agent(partials + (size_t)threadIdx.x * gridDim.x + blockIdx.x, s);
-    else partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s;
+    partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s;
   }
-  if (tail.mode) sweep_tail(tail, true, partials);
 }
 
 __global__ void k_scale_if(double *__restrict__ x, int n, const KsGsState *__restrict__ st)
@@ -295,7 +246,7 @@ int launch_finish(ks_bv bv, const GsArgs &a)
   return KS_SUCCESS;
 }
 
-int launch_update(ks_bv bv, int k, double *v, int slot, const FinTail &tail)
+int launch_update(ks_bv bv, int k, double *v, int slot)
 {
   ks_ctx ctx = bv->ctx;
   const double *V = ks_bv_col(bv, 0);
@@ -314,37 +265,12 @@ int launch_update(ks_bv bv, int k, double *v, int slot, const FinTail &tail)
 #define LAUNCH_UPD(KT)                                                                                                                                 \
   do {                                                                                                                                                 \
     if (v2) { grid = ks_sweep_grid_for(ctx, bv->n, 2, (const void *)k_gs_update<KT, 2>, upd_per_cu); bv->last_grid = grid;                                                        \
-      hipLaunchKernelGGL((k_gs_update<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->buffer, bv->partials, bv->gs, rev, tail); } \
+      hipLaunchKernelGGL((k_gs_update<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->buffer, bv->partials, bv->gs, rev); } \
     else { grid = ks_sweep_grid_for(ctx, bv->n, 1, (const void *)k_gs_update<KT, 1>, upd_per_cu); bv->last_grid = grid;                                                           \
-      hipLaunchKernelGGL((k_gs_update<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->buffer, bv->partials, bv->gs, rev, tail); }   \
+      hipLaunchKernelGGL((k_gs_update<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->buffer, bv->partials, bv->gs, rev); }   \
   } while (0)
   KS_KT_DISPATCH(kk, LAUNCH_UPD);
 #undef LAUNCH_UPD
-  KS_HIP(hipGetLastError());
-  return KS_SUCCESS;
-}
-
-FinTail no_tail() { FinTail t; memset(&t, 0, sizeof(t)); return t; }
-
-// the dot sweep of BVDotColumnInc with the slot-1 bookkeeping in its tail (single rank)
-int launch_dot_fin(ks_bv bv, int j, bool gate, const FinTail &tail)
-{
-  ks_ctx ctx = bv->ctx;
-  const double *A = ks_bv_col(bv, 0), *y = ks_bv_col(bv, j);
-  const int ncols = j + 1, lda = bv->ld;
-  const bool v2 = (lda % 2 == 0) && aligned16(A) && aligned16(y);
-  int grid = 1;
-  static const int dot_per_cu = getenv("KSGPU_DOT_PERCU") ? atoi(getenv("KSGPU_DOT_PERCU")) : 4;
-  KsProfScope ps(ctx, KS_K_DOT, 8.0 * bv->n * ncols, ks_kt_for(ncols));
-#define LAUNCH_DOTF(KT)                                                                                                                               \
-  do {                                                                                                                                               \
-    if (v2) { grid = ks_sweep_grid_for(ctx, bv->n, 2, (const void *)k_dot_sweep_fin<KT, 2>, dot_per_cu); bv->last_grid = grid;                        \
-      hipLaunchKernelGGL((k_dot_sweep_fin<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, y, bv->partials, gate ? 1 : 0, tail); } \
-    else { grid = ks_sweep_grid_for(ctx, bv->n, 1, (const void *)k_dot_sweep_fin<KT, 1>, dot_per_cu); bv->last_grid = grid;                          \
-      hipLaunchKernelGGL((k_dot_sweep_fin<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, y, bv->partials, gate ? 1 : 0, tail); }   \
-  } while (0)
-  KS_KT_DISPATCH(ncols, LAUNCH_DOTF);
-#undef LAUNCH_DOTF
   KS_HIP(hipGetLastError());
   return KS_SUCCESS;
 }
@@ -365,7 +291,7 @@ int enqueue_gs_slots(ks_bv bv, int j, int normalize, int krylov, int first, int 
   for (int p = first; p <= last; p++) {
     a.slot = p; a.spec_last = (halt_at_last && p == last) ? 1 : 0;
     KS_CALL(launch_finish(bv, a));
-    KS_CALL(launch_update(bv, j, v, p, no_tail()));
+    KS_CALL(launch_update(bv, j, v, p));
   }
   if (resolution_and_scale) {
     a.slot = last + 1; a.spec_last = 0;     // resolves an explicit-norm request of the last update
@@ -385,27 +311,11 @@ int enqueue_gs_slots(ks_bv bv, int j, int normalize, int krylov, int first, int 
 int enqueue_fused_gs(ks_bv bv, int j, int normalize, int krylov)
 {
   KS_CHECK(j + 1 <= KS_MAX_COLS, KS_ERR_SUP, "fused Gram-Schmidt supports at most %d columns", KS_MAX_COLS);
+  // h = V(:,0:j+1)^T v  (BVDotColumnInc bvorthog.c:32-47: k+1 dots including (v,v))
+  KS_CALL(ksk_dot(bv, ks_bv_col(bv, 0), bv->ld, j + 1, ks_bv_col(bv, j), krylov != 0));
   const int ns = spec_slots(bv), nt = total_slots(bv);
   const bool whole = (ns >= nt) && bv->orthog_ref == KS_BV_ORTHOG_REFINE_NEVER;
   static const bool optimistic = !getenv("KSGPU_NO_OPTIMISTIC");
-  static const bool tails = !getenv("KSGPU_NO_TAIL_FINISH");
-  if (tails && optimistic && !whole && !ks_is_multi(bv->ctx)) {
-    // single rank: 3 launches per column - the dot sweep and the first update carry the bookkeeping of slots 1 and 2
-    // in their tails, the second update retires itself
-    FinTail t; memset(&t, 0, sizeof(t));
-    t.a.k = j; t.a.refine = bv->orthog_ref; t.a.normalize = normalize; t.a.krylov = krylov; t.a.ldb = bv->nc + bv->m; t.a.eta = bv->orthog_eta; t.a.deftol = bv->deftol;
-    t.buffer = bv->buffer; t.st = bv->gs; t.recs = bv->recs; t.ticket = bv->ticket;
-    double *v = ks_bv_col(bv, j);
-    for (int p = 1; p <= ns; p++) {
-      t.mode = 1; t.a.slot = p; t.a.spec_last = (p == ns) ? 1 : 0;
-      if (p == 1) KS_CALL(launch_dot_fin(bv, j, krylov != 0, t));
-      else KS_CALL(launch_update(bv, j, v, p - 1, t));
-    }
-    t.mode = 2; t.a.slot = ns + 1; t.a.spec_last = 0;
-    return launch_update(bv, j, v, ns, t);
-  }
-  // h = V(:,0:j+1)^T v  (BVDotColumnInc bvorthog.c:32-47: k+1 dots including (v,v))
-  KS_CALL(ksk_dot(bv, ks_bv_col(bv, 0), bv->ld, j + 1, ks_bv_col(bv, j), krylov != 0));
   if (whole || !optimistic) return enqueue_gs_slots(bv, j, normalize, krylov, 1, nt, false, true);
   return enqueue_gs_slots(bv, j, normalize, krylov, 1, ns, true, false);
 }

@@ -42,13 +42,8 @@ __device__ __forceinline__ double wave_sum(double v)
   return v;
 }
 
-// Stores / loads that are coherent across the eight XCD L2s without a fence (sc1: write-through / read-through at
-// agent scope). Used for the block partial sums when the last block of the same launch reduces them.
-__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 // Block-combine KT per-thread accumulators and write them to partials[i*gridDim.x + blockIdx.x], i<ncols.
-template <int KT, bool SC1 = false>
+template <int KT>
 __device__ __forceinline__ void block_write_partials(double (&acc)[KT], int ncols, double *__restrict__ partials)
 {
   __shared__ double red[SW_WAVES][KT];
@@ -63,16 +58,17 @@ __device__ __forceinline__ void block_write_partials(double (&acc)[KT], int ncol
     double s = red[0][threadIdx.x];
 #pragma unroll
     for (int ww = 1; ww < SW_WAVES; ww++) s += red[ww][threadIdx.x];
-    if (SC1) st_agent(partials + (size_t)threadIdx.x * gridDim.x + blockIdx.x, s);
-    else partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s;
+    partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s;
   }
 }
 
 // partials <- A(:,0:ncols)^T y        (gemv-C of BVDotVec_BLAS_Private, bvblas.c:240-261)
-template <int KT, int VEC, bool SC1 = false>
-__device__ __forceinline__ void dot_sweep_body(const double *__restrict__ A, long long lda, int n, int ncols,
-                                               const double *__restrict__ y, double *__restrict__ partials)
+template <int KT, int VEC>
+__global__ __launch_bounds__(SW_BLOCK) void k_dot_sweep(const double *__restrict__ A, long long lda, int n, int ncols,
+                                                        const double *__restrict__ y, double *__restrict__ partials,
+                                                        const KsGsState *__restrict__ gate)
 {
+  if (gate && !gate->active) return;
   double acc[KT];
 #pragma unroll
   for (int i = 0; i < KT; i++) acc[i] = 0.0;
@@ -103,16 +99,7 @@ __device__ __forceinline__ void dot_sweep_body(const double *__restrict__ A, lon
       }
     }
   }
-  block_write_partials<KT, SC1>(acc, ncols, partials);
-}
-
-template <int KT, int VEC>
-__global__ __launch_bounds__(SW_BLOCK) void k_dot_sweep(const double *__restrict__ A, long long lda, int n, int ncols,
-                                                        const double *__restrict__ y, double *__restrict__ partials,
-                                                        const KsGsState *__restrict__ gate)
-{
-  if (gate && !gate->active) return;
-  dot_sweep_body<KT, VEC>(A, lda, n, ncols, y, partials);
+  block_write_partials<KT>(acc, ncols, partials);
 }
 
 // y = beta*y + alpha*A(:,0:ncols) q   (gemv-N of BVMultVec_BLAS_Private, bvblas.c:56-67); q on device
@@ -155,7 +142,6 @@ __global__ __launch_bounds__(SW_BLOCK) void k_multvec(const double *__restrict__
 // Each wave owns columns w, w+nw, ...; a lane first gathers its <= KS_MAX_BLOCKS/64 strided partials with
 // independent loads (all in flight together: the dependent-load chain was the whole cost of this kernel),
 // then sums them in index order, then the wave combines with a fixed shuffle tree.
-template <bool SC1 = false>
 __device__ __forceinline__ void reduce_partials_to_lds(const double *__restrict__ partials, int nblocks, int ncols, double *c_lds)
 {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -166,7 +152,7 @@ __device__ __forceinline__ void reduce_partials_to_lds(const double *__restrict_
     for (int b0 = 0; b0 < nblocks; b0 += 64 * PER_LANE) {
       double v[PER_LANE];
 #pragma unroll
-      for (int u = 0; u < PER_LANE; u++) { const int b = b0 + lane + 64 * u; v[u] = (b < nblocks) ? (SC1 ? ld_agent(p + b) : p[b]) : 0.0; }
+      for (int u = 0; u < PER_LANE; u++) { const int b = b0 + lane + 64 * u; v[u] = (b < nblocks) ? p[b] : 0.0; }
 #pragma unroll
       for (int u = 0; u < PER_LANE; u++) s += v[u];
     }

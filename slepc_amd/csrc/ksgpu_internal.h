@@ -147,7 +147,6 @@ struct ks_bv_s {
   int orthog_type = KS_BV_ORTHOG_CGS, orthog_ref = KS_BV_ORTHOG_REFINE_IFNEEDED, orthog_block = KS_BV_ORTHOG_BLOCK_GS;
   ks_mat matrix = nullptr;   // inner-product matrix B of BVSetMatrix (positive definite), borrowed; nullptr = standard
   double *Bx = nullptr;      // B*x of the vector an inner product is being taken with (BV_IPMatMult bvimpl.h:147-158)
-  unsigned int *ticket = nullptr;   // device counter on a line of its own: blocks of the current sweep that delivered their partial sums
   double orthog_eta = 0.7071;
   double deftol = 10 * 2.220446049250313e-16;
   double *array = nullptr;      // m*ld
