@@ -224,6 +224,10 @@ class Mat:
         m._cb = cb                      # keep the trampoline alive as long as the matrix
         return m
 
+    def layout(self):
+        v = C.c_int(); _lib.check(self.ctx.L.ks_mat_get_layout(self.h, C.byref(v)))
+        return ["csr", "sell", "sliced", "shell"][v.value]
+
     def norm_inf(self):
         v = C.c_double(); _lib.check(self.ctx.L.ks_mat_norm_inf(self.h, C.byref(v))); return v.value
 

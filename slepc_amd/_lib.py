@@ -44,6 +44,7 @@ _SIG = {
     "ks_mat_create_laplacian3d": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
     "ks_mat_create_laplacian2d": [vp, C.c_int, C.c_int, C.POINTER(vp)],
     "ks_mat_destroy": [vp],
+    "ks_mat_get_layout": [vp, ip],
     "ks_mat_load_petsc_binary": [vp, C.c_char_p, C.POINTER(vp)],
     "ks_mat_create_shell": [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(vp)],
     "ks_mat_get_diagonal": [vp, vp],

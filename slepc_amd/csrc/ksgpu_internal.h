@@ -86,6 +86,15 @@ struct ks_mat_s {
   // padding it needs is small; val/col stored column-major inside a slice: entry j of row 64s+lane at (sp[s]+j)*64+lane
   bool use_sell = false;
   int nslices = 0; int *s_ptr = nullptr; int *s_len = nullptr; int *s_col = nullptr; double *s_val = nullptr; long long s_entries = 0;
+  // XCD-sliced copy of the diagonal block for wide-scatter matrices (columns spread over a vector much larger than one
+  // XCD's 4 MiB L2): the columns are cut into nslice = 8*P ranges; slice s is a CSR of its own (rows 0..n-1) and is
+  // multiplied only by workgroups with blockIdx % 8 == s % 8, i.e. on one XCD, whose L2 then holds that range of x.
+  // Every XCD writes a partial y; a second kernel adds the eight partials in fixed order.
+  bool use_sliced = false;
+  int nslice = 0, slice_cols = 0;
+  int *sl_rowptr = nullptr; int *sl_col = nullptr; double *sl_val = nullptr; long long *sl_base = nullptr;   // [nslice][n+1], entries, device offsets [nslice+1]
+  double *ypart = nullptr;                    // [8][n]
+  double *diag_cache = nullptr; double norm_inf_cache = -1.0;   // kept because the CSR arrays are released after slicing
   // off-diagonal block (columns owned by other ranks), compressed to ghost indices [0,nghost)
   int *o_rowptr = nullptr; int *o_col = nullptr; double *o_val = nullptr; long long nnz_o = 0;
   int nghost = 0;
@@ -100,6 +109,7 @@ struct ks_mat_s {
   void *shell_user = nullptr;
 };
 int ks_mat_get_diagonal_internal(ks_mat A, double *d_dev);
+int ks_mat_norm_inf_local(ks_mat A, double *val);           // max row sum of |a_ij| over this rank's rows
 
 // ---- ST: spectral transformation (ks_st.hip) ----------------------------------------------------
 struct ks_st_s {

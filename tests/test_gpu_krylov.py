@@ -81,6 +81,39 @@ def test_spmv_both_layouts(ctx, monkeypatch, fmt):
     assert np.all(y[lens == 0] == 0.0)
 
 
+def test_spmv_xcd_sliced_layout(ctx, monkeypatch):
+    """The XCD-sliced layout (column ranges pinned to XCDs by blockIdx % 8, eight partial results added in fixed order):
+    forced on small and ragged matrices incl. empty rows and duplicate entries, and chosen automatically for a
+    wide-scatter matrix with a 32 MB vector; diagonal and infinity norm stay available after the CSR arrays are released."""
+    import slepc_amd as ks
+    import nhep_cases as nc
+    rng = np.random.default_rng(8)
+    monkeypatch.setenv("KSGPU_SPMV", "sliced")
+    for n, mean in [(5000, 3), (20000, 20), (70001, 7)]:
+        lens = np.clip(rng.poisson(mean, n), 0, n); lens[rng.integers(0, n, n // 20)] = 0
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        col = rng.integers(0, n, rowptr[-1]).astype(np.int32)          # unsorted, duplicates allowed
+        val = rng.uniform(-1, 1, rowptr[-1])
+        Ao = O.CSR(n, rowptr, col, val)
+        A = _mat(ctx, Ao)
+        assert A.layout() == "sliced"
+        x = rng.standard_normal(n)
+        y, y0 = A.mult(x), Ao.mult(x)
+        assert np.allclose(y, y0, rtol=0, atol=1e-13 * max(1, mean)) and np.all(y[lens == 0] == 0.0)
+        S = Ao.to_scipy()
+        assert np.allclose(A.get_diagonal(), S.diagonal(), rtol=0, atol=1e-15)
+        assert abs(A.norm_inf() - abs(S).sum(axis=1).max()) < 1e-12
+        assert np.array_equal(A.mult(x), y)                              # fixed-order partial sums: run-to-run identical
+    monkeypatch.delenv("KSGPU_SPMV")
+    Ao, _ = nc.config5_pencil_fast(1_500_000, mean_nnz=12)               # x = 12 MB > 6 MB, entries far from the diagonal
+    A = _mat(ctx, Ao)
+    assert A.layout() == "sliced"
+    assert ks.Mat.laplacian3d(ctx, 160, 160, 160).layout() == "sell"       # banded: stays with the row-ordered layouts
+    x = rng.standard_normal(Ao.n)
+    assert np.allclose(A.mult(x), Ao.mult(x), rtol=0, atol=1e-11)
+    assert abs(A.get_diagonal()[12345] - Ao.to_scipy().diagonal()[12345]) < 1e-13
+
+
 def test_spmv_rejects_bad_input(ctx):
     import slepc_amd as ks
     with pytest.raises(ks.KsError) as e:
