@@ -430,7 +430,7 @@ int build_sliced(ks_mat A)
     KS_HIP(hipMemcpyAsync(&h, cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream)); KS_HIP(hipStreamSynchronize(ctx->stream)); hipFree(cnt);
     if ((double)h < 0.5 * (double)A->nnz_d) return KS_SUCCESS;
   }
-  const int max_slice_rows = 786432;                     // 6 MiB of x per slice: the 5 MiB slices of the 40 MB probe ran at the L2 rate
+  const int max_slice_rows = getenv("KSGPU_SLICE_ROWS") ? std::max(4096, atoi(getenv("KSGPU_SLICE_ROWS"))) : 786432;   // 6 MiB of x per slice: the 5 MiB slices of the 40 MB probe ran at the L2 rate
   int P = (int)(((long long)n + 8LL * max_slice_rows - 1) / (8LL * max_slice_rows)); if (P < 1) P = 1;
   KS_CHECK(P <= 8, KS_ERR_SUP, "sliced SpMV layout supports up to %d local rows", 64 * max_slice_rows);
   const int S = 8 * P, sc = (n + S - 1) / S;

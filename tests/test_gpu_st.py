@@ -233,3 +233,20 @@ def test_config5_large_properties(ctx):
     s = st.GetKSPStats(); steps = eps.GetStats()["arnoldi_steps"]
     assert s["solves"] == steps
     print("config5 n=%d: %d steps, %d restarts, %.1f GMRES its/solve, %.2f s -> %.1f steps/s" % (n, steps, eps.GetIterationNumber(), s["iterations"] / s["solves"], dt, steps / dt))
+
+
+def test_st_apply_on_xcd_sliced_matrix(ctx):
+    """The inner GMRES running on the XCD-sliced SpMV layout (chosen automatically for this 12 MB wide-scatter matrix):
+    the solve satisfies (A - sigma B) y = B x to the KSP tolerance, checked with host arithmetic."""
+    import slepc_amd as ks
+    Ao, Bo = nc.config5_pencil_fast(1_500_000, mean_nnz=12)
+    A = _mat(ctx, Ao); B = _mat(ctx, Bo)
+    assert A.layout() == "sliced"
+    st = ks.ST(ctx)
+    st.SetType("sinvert"); st.SetShift(1.5); st.SetMatrices(A, B); st.SetKSP(rtol=1e-11)
+    x = np.random.default_rng(6).standard_normal(Ao.n)
+    y = st.Apply(x)
+    Sa, Sb = Ao.to_scipy(), Bo.to_scipy()
+    rhs = Sb @ x
+    assert np.linalg.norm(Sa @ y - 1.5 * (Sb @ y) - rhs) <= 1e-9 * np.linalg.norm(rhs)
+    assert 0 < st.GetKSPStats()["iterations"] < 60
