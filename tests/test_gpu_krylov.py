@@ -418,3 +418,27 @@ def test_full_size_properties_config3(ctx):
     th = np.linalg.eigvalsh(Tm)
     assert th.min() > 0 and th.max() < 12.0
     assert V.gs_passes()[0] >= m
+
+
+def test_eps_test2_repeated_solves_one_object(ctx):
+    """test2.c: one EPS object solved three times with changing criteria (largest real, smallest real, then closest to the
+    target 2.1 through shift-and-invert added between solves); golden output/test2_1.out."""
+    import slepc_amd as ks
+    from test_oracle_golden import _test2_sections
+    ref = _test2_sections()
+    Ao = O.laplacian1d(30)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(_mat(ctx, Ao)); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(4)
+    eps.SetWhichEigenpairs("largest_real"); eps.Solve()
+    assert np.allclose(np.round([eps.GetEigenvalue(i)[0] for i in range(4)], 5), ref[0], atol=1.5e-5)
+    eps.SetWhichEigenpairs("smallest_real"); eps.Solve()
+    assert np.allclose(np.round([eps.GetEigenvalue(i)[0] for i in range(4)], 5), ref[1], atol=1.5e-5)
+    eps.SetWhichEigenpairs("target_magnitude"); eps.SetTarget(2.1)
+    st = eps.GetST(); st.SetType("sinvert"); st.SetKSP(rtol=1e-13, restart=30)      # GMRES(30) is exact on this 30 x 30 problem
+    eps.Solve()
+    lam = [eps.GetEigenvalue(i)[0] for i in range(4)]
+    assert np.allclose(np.round(lam, 5), ref[2], atol=1.5e-5)
+    for i in range(4):
+        assert eps.ComputeError(i) < 1e-7
+    with pytest.raises(ks.KsError):                       # results belong to the last solve only
+        eps.SetWhichEigenpairs("largest_real"); eps.GetEigenvalue(0)

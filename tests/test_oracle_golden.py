@@ -346,3 +346,21 @@ def test_eps_ex13_ghep_sinvert_golden():
     B = O.CSR(A.n, np.arange(A.n + 1, dtype=np.int32), np.arange(A.n, dtype=np.int32), np.full(A.n, 4.0))
     r = O.eps_krylovschur_hep(A, 4, ncv=22, tol=1e-5, which=O.which_target_magnitude(0.0), st=O.ST(A, B, "sinvert", 0.0), B=B)
     assert np.allclose(np.round(r.eigr[r.perm][:4], 5), gi.eigenvalues_line(gi.read("eps/ex13_1.out")), atol=1.5e-5)
+
+
+def _test2_sections():
+    txt = gi.read("eps/eps_test2_1.out")
+    blocks = [b for b in txt.split("All requested eigenvalues computed up to the required tolerance:")[1:]]
+    return [np.array([float(t) for t in b.strip().splitlines()[0].replace(",", " ").split()]) for b in blocks]
+
+
+def test_eps_test2_three_solves_golden():
+    """test2 -eps_nev 4: 1-D Laplacian n=30, largest real, smallest real, then the eigenvalues closest to 2.1 (the golden
+    file's third block; computed here with shift-and-invert instead of the test's harmonic extraction - the eigenvalues
+    are the same)."""
+    A = O.laplacian1d(30)
+    ref = _test2_sections()
+    r = O.eps_krylovschur_hep(A, 4, which="largest_real");  assert np.allclose(np.round(r.eigr[r.perm][:4], 5), ref[0], atol=1.5e-5)
+    r = O.eps_krylovschur_hep(A, 4, which="smallest_real"); assert np.allclose(np.round(r.eigr[r.perm][:4], 5), ref[1], atol=1.5e-5)
+    r = O.eps_krylovschur_hep(A, 4, which=O.which_target_magnitude(2.1), st=O.ST(A, None, "sinvert", 2.1))
+    assert np.allclose(np.round(r.eigr[r.perm][:4], 5), ref[2], atol=1.5e-5)
