@@ -247,7 +247,17 @@ def main():
                                    "frac_of_hbm_peak_alg": round(tot_alg / dt / 1e9 / HBM_PEAK_GBS, 4),
                                    "compulsory_GB_per_step": round(tot_hbm / args.steps / 1e9, 3), "compulsory_GBps_vs_wall": round(tot_hbm / dt / 1e9, 1),
                                    "kernel_ms_per_step": round(tot_ms / args.steps, 4)}
-            out["kernels_untimed_instrumented_pass"] = kernels[:16]
+            # every column count has its own compiled kernel, so the per-symbol table is long: all classes, top symbols
+            classes = {}
+            for (name, var), v in prof.items():
+                c = classes.setdefault(name, {"launches": 0, "ms_total": 0.0, "alg": 0.0, "hbm": 0.0})
+                c["launches"] += v["launches"]; c["ms_total"] += v["ms"]; c["alg"] += v["alg_bytes"]; c["hbm"] += v["hbm_bytes"]
+            out["kernel_classes_untimed_instrumented_pass"] = [
+                {"class": name, "launches": c["launches"], "ms_total": round(c["ms_total"], 3), "ms_per_step": round(c["ms_total"] / args.steps, 4),
+                 "alg_GBps": round(c["alg"] / c["ms_total"] / 1e6, 1) if c["ms_total"] > 0 else 0.0,
+                 "hbm_GBps": round(c["hbm"] / c["ms_total"] / 1e6, 1) if c["ms_total"] > 0 else 0.0}
+                for name, c in sorted(classes.items(), key=lambda kv: -kv[1]["ms_total"])]
+            out["kernels_untimed_instrumented_pass"] = kernels[:12]
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(side)

@@ -6,9 +6,7 @@ for envs in "$@"; do
 import json,sys
 d=json.loads(sys.stdin.read())
 print('steps/s %.1f  ms/step %.4f  kernel_ms/step %.4f' % (d['value'], d['ms_per_step'], d['step_traffic']['kernel_ms_per_step']))
-agg={}
-for k in d['kernels_untimed_instrumented_pass']:
-    a=agg.setdefault(k['class'],[0,0.0]); a[0]+=k['launches']; a[1]+=k['ms_total']
-for c,(n,ms) in sorted(agg.items(), key=lambda kv:-kv[1][1]): print('   %-22s n=%5d ms=%8.2f  ms/step=%.4f' % (c,n,ms,ms/150))
+for k in d['kernel_classes_untimed_instrumented_pass']:
+    print('   %-22s n=%5d ms=%8.2f  ms/step=%.4f  %7.1f GB/s' % (k['class'],k['launches'],k['ms_total'],k['ms_per_step'],k['hbm_GBps']))
 "
 done

@@ -159,7 +159,7 @@ class Context:
         """{class: {launches, ms, alg_bytes, hbm_bytes}}; by_variant=True keys are (class, KT)."""
         out = {}
         for i, name in enumerate(KCLASSES):
-            variants = [4 * v for v in range(17)] if by_variant else [-1]
+            variants = list(range(65)) if by_variant else [-1]
             for var in variants:
                 n = C.c_longlong(); ms = C.c_double(); b = C.c_double(); hb = C.c_double()
                 _lib.check(self.L.ks_prof_get(self.h, i, var, C.byref(n), C.byref(ms), C.byref(b), C.byref(hb)))

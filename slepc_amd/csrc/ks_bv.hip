@@ -237,6 +237,7 @@ extern "C" int ks_bv_create(ks_ctx ctx, int n_local, int n_global, int m, int ld
   KS_HIP(hipMalloc(&bv->partials, (size_t)KS_MAX_BLOCKS * KS_PSTRIDE * sizeof(double)));
   KS_HIP(hipMalloc(&bv->coef, bv->coef_len * sizeof(double)));
   KS_HIP(hipMalloc(&bv->hc, (size_t)2 * (m + 8) * sizeof(double)));
+  KS_HIP(hipMalloc(&bv->pend, sizeof(double) * 3 * KS_PSTRIDE)); KS_HIP(hipMemsetAsync(bv->pend, 0, sizeof(double) * 3 * KS_PSTRIDE, ctx->stream));
   KS_HIP(hipMalloc(&bv->gs, sizeof(KsGsState)));
   KS_HIP(hipMemsetAsync(bv->gs, 0, sizeof(KsGsState), ctx->stream));
   KS_HIP(hipMalloc(&bv->recs, (size_t)(m + 1) * sizeof(KsStepRec)));
@@ -251,7 +252,7 @@ extern "C" int ks_bv_destroy(ks_bv bv)
   if (!bv) return KS_SUCCESS;
   hipSetDevice(bv->ctx->device);
   hipStreamSynchronize(bv->ctx->stream);
-  hipFree(bv->array); hipFree(bv->buffer); hipFree(bv->partials); hipFree(bv->coef); hipFree(bv->hc); hipFree(bv->gs); hipFree(bv->recs); hipFree(bv->panel); hipFree(bv->Bx);
+  hipFree(bv->array); hipFree(bv->buffer); hipFree(bv->partials); hipFree(bv->coef); hipFree(bv->hc); hipFree(bv->gs); hipFree(bv->recs); hipFree(bv->panel); hipFree(bv->Bx); hipFree(bv->pend);
   delete bv;
   return KS_SUCCESS;
 }

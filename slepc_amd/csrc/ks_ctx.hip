@@ -115,7 +115,7 @@ static int get_event(ks_ctx ctx, hipEvent_t *e)
 
 int ks_prof_begin(ks_ctx ctx, int kclass, int variant, double bytes, double hbm)
 {
-  KsProfPending p; p.kclass = kclass; p.variant = (variant >= 0 && variant / 4 < KS_PROF_VARIANTS) ? variant / 4 : 0; p.bytes = bytes; p.hbm = hbm;
+  KsProfPending p; p.kclass = kclass; p.variant = (variant >= 0 && variant < KS_PROF_VARIANTS) ? variant : 0; p.bytes = bytes; p.hbm = hbm;
   p.tag_col = -1; p.tag_slot = 0; p.tag_k = 0; p.tag_n = 0; p.done = false;
   if (ctx->pending.size() > 400000) { ctx->prof_on = false; return KS_ERR_MEM; }   // runaway instrumentation: stop recording, keep running
   KS_CALL(get_event(ctx, &p.e0)); KS_CALL(get_event(ctx, &p.e1));
@@ -171,11 +171,11 @@ extern "C" int ks_prof_get(ks_ctx ctx, int kclass, int variant, long long *launc
 {
   KS_CHECK(ctx, KS_ERR_ARG_NULL, "ctx is NULL");
   KS_CHECK(kclass >= 0 && kclass < KS_K_COUNT, KS_ERR_ARG_OUTOFRANGE, "kernel class %d out of range", kclass);
-  KS_CHECK(variant < 0 || variant / 4 < KS_PROF_VARIANTS, KS_ERR_ARG_OUTOFRANGE, "variant %d out of range", variant);
+  KS_CHECK(variant < KS_PROF_VARIANTS, KS_ERR_ARG_OUTOFRANGE, "variant %d out of range", variant);
   KS_CALL(ks_prof_flush(ctx));
   KsProfSlot t;
   for (int v = 0; v < KS_PROF_VARIANTS; v++) {
-    if (variant >= 0 && v != variant / 4) continue;
+    if (variant >= 0 && v != variant) continue;
     const KsProfSlot &sl = ctx->prof[kclass][v];
     t.launches += sl.launches; t.ms += sl.ms; t.bytes += sl.bytes; t.hbm += sl.hbm;
   }
@@ -201,7 +201,7 @@ void ks_prof_resolve_gs(ks_ctx ctx, const KsStepRec *recs, int col0, int col1)
     const double n = (double)p.tag_n, k = (double)p.tag_k;
     if (p.kclass == KS_K_UPD_FUSED || p.kclass == KS_K_UPD) {
       if (p.tag_slot > passes) { p.kclass = KS_K_NOOP; p.bytes = 0.0; p.hbm = 0.0; }
-      else if (p.tag_slot < passes || expl) { p.kclass = KS_K_UPD_FUSED; p.hbm = 8.0 * n * (k + 2); p.bytes = p.hbm + 8.0 * n * (k + 1); }
+      else if (p.tag_slot < passes || expl) { p.kclass = KS_K_UPD_FUSED; p.hbm = 8.0 * n * (k + (expl ? 2 : 1)); p.bytes = 8.0 * n * (k + 2) + 8.0 * n * (k + 1); }   // a fused pass that is not followed by an explicit norm keeps its result in registers: no write
       else { p.kclass = KS_K_UPD; p.hbm = 8.0 * n * (k + 2); p.bytes = p.hbm; }
     } else if (p.kclass == KS_K_GSFIN) {
       if (p.tag_slot > passes + (expl ? 1 : 0)) { p.kclass = KS_K_NOOP; p.bytes = 0.0; p.hbm = 0.0; }

@@ -40,7 +40,7 @@ struct GsArgs {
 
 // Bookkeeping for one slot.  Thread 0 only.  c[0..k] are the (globally reduced) dots of the current
 // vector against columns 0..k-1 and itself.
-__device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict__ buffer, KsGsState *st, KsStepRec *recs)
+__device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict__ buffer, double *__restrict__ pend, KsGsState *st, KsStepRec *recs)
 {
   const int k = a.k;
   int upd = 0, fuse = 0, scal = 0;
@@ -48,7 +48,7 @@ __device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict_
   bool process = true, finalize = false, after_update = false;
   double nrm = st->nrm, onrm = st->onrm;
 
-  if (a.slot == 1) { st->pass = 0; st->expl = 0; st->pending_scale = 0; st->lindep = 0; st->do_update = 0; }
+  if (a.slot == 1) { st->pass = 0; st->expl = 0; st->pending_scale = 0; st->lindep = 0; st->do_update = 0; st->store_prev = 1; st->npend = 0; }   // nothing applied yet
   else {
     if (st->expl) {
       // explicit norm of the updated vector (BV_NormVecOrColumn, bvorthog.c:126 / :191): c[k] = v'.v'
@@ -73,6 +73,11 @@ __device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict_
     for (int i = 0; i < k; i++) sum += c[i] * c[i];
     if (st->pass == 1) for (int i = 0; i < k; i++) H[i] = c[i];         // BV_CleanCoefficients + add
     else for (int i = 0; i < k; i++) H[i] += c[i];
+    // coefficients the next update applies to the vector AS IT IS IN MEMORY: the passes since it was last written back,
+    // kept apart so that the update can subtract them one pass after the other - adding c2 to c1 first would round the
+    // correction away exactly when refinement is needed (|c2| ~ eps |c1|)
+    if (st->store_prev) st->npend = 0;
+    { double *pp = pend + (size_t)st->npend * KS_PSTRIDE; for (int i = 0; i < k; i++) pp[i] = c[i]; st->npend++; }
     upd = 1;
     if (a.refine == KS_BV_ORTHOG_REFINE_NEVER) {
       // one pass, then explicit norm (bvorthog.c:189-195)
@@ -109,6 +114,12 @@ __device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict_
   }
   st->nrm = nrm; st->onrm = onrm;
   st->do_update = upd; st->fuse_dot = fuse; st->scale_now = scal;
+  if (upd) {
+    // write the vector back only when it is final, or when an explicit norm follows (its resolution slot only rescales);
+    // a fused pass that merely feeds the next pass's dots leaves memory untouched and the next update applies c1+c2
+    const int store = (!fuse || st->expl) ? 1 : 0;
+    st->store_now = store; st->store_prev = store;
+  }
   // Optimistic program: only the slots of the common case (two passes) are enqueued. If this column still needs
   // a pass or an explicit norm after them, stop every later kernel of the run and tell the host which column to
   // complete (the pending update itself still runs: it gates on do_update only).
@@ -117,7 +128,7 @@ __device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict_
 
 // REDUCE: sum block partials -> c (LDS, and global scratch = buffer column 0).  BOOK: run the bookkeeping.
 template <bool REDUCE, bool BOOK>
-__global__ __launch_bounds__(1024) void k_gs_finish(const double *__restrict__ partials, int nblocks, GsArgs a, double *buffer, KsGsState *st, KsStepRec *recs)
+__global__ __launch_bounds__(1024) void k_gs_finish(const double *__restrict__ partials, int nblocks, GsArgs a, double *buffer, double *pend, KsGsState *st, KsStepRec *recs)
 {
   __shared__ double c_lds[KS_MAX_COLS + 8];
   const int ncols = a.k + 1;
@@ -138,30 +149,27 @@ __global__ __launch_bounds__(1024) void k_gs_finish(const double *__restrict__ p
     if ((int)threadIdx.x < ncols) c_lds[threadIdx.x] = buffer[threadIdx.x];
     __syncthreads();
   }
-  if (BOOK && threadIdx.x == 0) gs_bookkeep(a, c_lds, buffer, st, recs);
+  if (BOOK && threadIdx.x == 0) gs_bookkeep(a, c_lds, buffer, pend, st, recs);
 }
 
-// v <- v - V(:,0:k) c   [* alpha if final]   and, when st->fuse_dot, partials <- [V(:,0:k) v]^T v  (k+1 values)
-template <int KT, int VEC>
-__global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long long ld, int n, int k, double *v, const double *__restrict__ cg,
-                                                        double *__restrict__ partials, const KsGsState *__restrict__ st, int rev)
+// The tile loop of the update sweep. NP > 0 / FUSE >= 0 fix the number of pending passes and the fused flag at compile
+// time (coefficients preloaded, pass loop unrolled) for the two shapes every CGS2 step runs: the first pass (one pending
+// pass, fused dots, nothing written) and the final pass (two pending passes, scaled store). NP = 0 / FUSE = -1: runtime.
+template <int KT, int VEC, int NP, int FUSE>
+__device__ __forceinline__ void upd_tiles(const double *V, long long ld, int n, int k, double *v, const double *__restrict__ cg, int npend_rt, bool fuse_rt,
+                                          bool scal, bool store, double alpha, int rev, double (&acc)[KT + 1])
 {
-  if (!st->do_update) return;
-  const bool fuse = st->fuse_dot != 0;
-  const bool scal = st->scale_now != 0;
-  const double alpha = st->alpha;
   const long long tile = (long long)SW_BLOCK * VEC;
   const long long ntiles = ((long long)n + tile - 1) / tile;
-
-  // One code path for both forms: ALL k column loads of a tile are issued back to back (k x 1 KiB in flight per
-  // wave), then the update; the fused form keeps the row panel V(r,0:k) in registers and also accumulates the
-  // next pass's dots, the final form applies the 1/nrm scaling while storing.
-  double acc[KT + 1];
+  const int npend = NP > 0 ? NP : npend_rt;
+  const bool fuse = FUSE >= 0 ? (FUSE != 0) : fuse_rt;
+  double cc[NP > 0 ? NP : 1][KT];
+  if (NP > 0) {
 #pragma unroll
-  for (int i = 0; i <= KT; i++) acc[i] = 0.0;
-  double cc[KT];
+    for (int p = 0; p < NP; p++)
 #pragma unroll
-  for (int i = 0; i < KT; i++) cc[i] = (i < k) ? -cg[i] : 0.0;
+      for (int i = 0; i < KT; i++) cc[p][i] = (i < k) ? -cg[(size_t)p * KS_PSTRIDE + i] : 0.0;
+  }
   for (long long t0 = blockIdx.x; t0 < ntiles; t0 += gridDim.x) {
     const long long t = rev ? ntiles - 1 - t0 : t0;
     const long long r = t * tile + (long long)threadIdx.x * VEC;
@@ -170,10 +178,21 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long lo
       double2 xv[KT];
 #pragma unroll
       for (int i = 0; i < KT; i++) { const int ii = i < k ? i : (k > 0 ? k - 1 : 0); xv[i] = ldcol2(V + (long long)ii * ld + r); }
+      // pass by pass, exactly as if each pass had stored its result
+      if (NP > 0) {
 #pragma unroll
-      for (int i = 0; i < KT; i++) { s.x = fma(cc[i], xv[i].x, s.x); s.y = fma(cc[i], xv[i].y, s.y); }
+        for (int p = 0; p < NP; p++)
+#pragma unroll
+          for (int i = 0; i < KT; i++) { s.x = fma(cc[p][i], xv[i].x, s.x); s.y = fma(cc[p][i], xv[i].y, s.y); }
+      } else {
+        for (int p = 0; p < npend; p++) {
+          const double *cp = cg + (size_t)p * KS_PSTRIDE;
+#pragma unroll
+          for (int i = 0; i < KT; i++) { const double c = (i < k) ? -cp[i] : 0.0; s.x = fma(c, xv[i].x, s.x); s.y = fma(c, xv[i].y, s.y); }
+        }
+      }
       if (scal) { s.x *= alpha; s.y *= alpha; }
-      *reinterpret_cast<double2 *>(v + r) = s;
+      if (store) *reinterpret_cast<double2 *>(v + r) = s;
       if (fuse) {
 #pragma unroll
         for (int i = 0; i < KT; i++) { acc[i] = fma(xv[i].x, s.x, acc[i]); acc[i] = fma(xv[i].y, s.y, acc[i]); }
@@ -187,10 +206,13 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long lo
           double xs[KT];
 #pragma unroll
           for (int i = 0; i < KT; i++) { const int ii = i < k ? i : (k > 0 ? k - 1 : 0); xs[i] = V[(long long)ii * ld + rr]; }
+          for (int p = 0; p < npend; p++) {
+            const double *cp = cg + (size_t)p * KS_PSTRIDE;
 #pragma unroll
-          for (int i = 0; i < KT; i++) s = fma(cc[i], xs[i], s);
+            for (int i = 0; i < KT; i++) s = fma((i < k) ? -cp[i] : 0.0, xs[i], s);
+          }
           if (scal) s *= alpha;
-          v[rr] = s;
+          if (store) v[rr] = s;
           if (fuse) {
 #pragma unroll
             for (int i = 0; i < KT; i++) acc[i] = fma(xs[i], s, acc[i]);
@@ -200,6 +222,29 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long lo
       }
     }
   }
+}
+
+// v <- v - V(:,0:k) c   [* alpha if final]   and, when st->fuse_dot, partials <- [V(:,0:k) v]^T v  (k+1 values)
+template <int KT, int VEC>
+__global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long long ld, int n, int k, double *v, const double *__restrict__ cg,
+                                                        double *__restrict__ partials, const KsGsState *__restrict__ st, int rev)
+{
+  if (!st->do_update) return;
+  const bool fuse = st->fuse_dot != 0;
+  const bool scal = st->scale_now != 0;
+  const bool store = st->store_now != 0;
+  const int npend = st->npend;
+  const double alpha = st->alpha;
+
+  // ALL k column loads of a tile are issued back to back (k x 1 KiB in flight per wave), then the update; the fused form
+  // keeps the row panel V(r,0:k) in registers and also accumulates the next pass's dots (and writes nothing unless an
+  // explicit norm follows), the final form applies the pending passes and the 1/nrm scaling while storing.
+  double acc[KT + 1];
+#pragma unroll
+  for (int i = 0; i <= KT; i++) acc[i] = 0.0;
+  if (VEC == 2 && fuse && npend == 1 && !scal) upd_tiles<KT, VEC, 1, 1>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
+  else if (VEC == 2 && !fuse && npend == 2) upd_tiles<KT, VEC, 2, 0>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
+  else upd_tiles<KT, VEC, 0, -1>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
   if (!fuse) return;
   // block combine: partial index i<k <- acc[i]; index k <- acc[KT] (the self dot)
   __shared__ double red[SW_WAVES][KT + 1];
@@ -236,11 +281,11 @@ int launch_finish(ks_bv bv, const GsArgs &a)
   const bool multi = ks_is_multi(ctx);
   KsProfScope ps(ctx, KS_K_GSFIN, 8.0 * bv->last_grid * (a.k + 1));
   ps.tag(a.k, a.slot, a.k, bv->n);
-  if (!multi) hipLaunchKernelGGL((k_gs_finish<true, true>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, bv->last_grid, a, bv->buffer, bv->gs, bv->recs);
+  if (!multi) hipLaunchKernelGGL((k_gs_finish<true, true>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, bv->last_grid, a, bv->buffer, bv->pend, bv->gs, bv->recs);
   else {
-    hipLaunchKernelGGL((k_gs_finish<true, false>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, bv->last_grid, a, bv->buffer, bv->gs, bv->recs);
+    hipLaunchKernelGGL((k_gs_finish<true, false>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, bv->last_grid, a, bv->buffer, bv->pend, bv->gs, bv->recs);
     KS_CALL(ks_allreduce_sum(ctx, bv->buffer, a.k + 1));
-    hipLaunchKernelGGL((k_gs_finish<false, true>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, bv->last_grid, a, bv->buffer, bv->gs, bv->recs);
+    hipLaunchKernelGGL((k_gs_finish<false, true>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, bv->last_grid, a, bv->buffer, bv->pend, bv->gs, bv->recs);
   }
   KS_HIP(hipGetLastError());
   return KS_SUCCESS;
@@ -265,9 +310,9 @@ int launch_update(ks_bv bv, int k, double *v, int slot)
 #define LAUNCH_UPD(KT)                                                                                                                                 \
   do {                                                                                                                                                 \
     if (v2) { grid = ks_sweep_grid_for(ctx, bv->n, 2, (const void *)k_gs_update<KT, 2>, upd_per_cu); bv->last_grid = grid;                                                        \
-      hipLaunchKernelGGL((k_gs_update<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->buffer, bv->partials, bv->gs, rev); } \
+      hipLaunchKernelGGL((k_gs_update<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->pend, bv->partials, bv->gs, rev); } \
     else { grid = ks_sweep_grid_for(ctx, bv->n, 1, (const void *)k_gs_update<KT, 1>, upd_per_cu); bv->last_grid = grid;                                                           \
-      hipLaunchKernelGGL((k_gs_update<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->buffer, bv->partials, bv->gs, rev); }   \
+      hipLaunchKernelGGL((k_gs_update<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->pend, bv->partials, bv->gs, rev); }   \
   } while (0)
   KS_KT_DISPATCH(kk, LAUNCH_UPD);
 #undef LAUNCH_UPD

@@ -164,15 +164,25 @@ __device__ __forceinline__ void reduce_partials_to_lds(const double *__restrict_
 
 } // namespace ksk
 
-static inline int ks_kt_for(int ncols) { const int t[12] = {4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64}; for (int i = 0; i < 12; i++) if (ncols <= t[i]) return t[i]; return 64; }
+// compiled column-tile sizes: every count up to 32 (a padded column would be a full extra HBM read: the streaming loads
+// bypass the caches), then steps of 8
+static inline int ks_kt_for(int ncols)
+{
+  static const int gran = getenv("KSGPU_KT_GRAN") ? atoi(getenv("KSGPU_KT_GRAN")) : 1;     // A/B switch: 4 = pad to multiples of 4
+  if (ncols <= 1) return gran > 1 ? gran : 1;
+  if (ncols <= 32) return gran > 1 ? (ncols + gran - 1) / gran * gran : ncols;
+  return (ncols + 7) / 8 * 8 > 64 ? 64 : (ncols + 7) / 8 * 8;
+}
 
 // dispatch helper: smallest compiled KT >= ncols
+#define KS_KT_CASE(v, MACRO) case v: { MACRO(v); } break;
 #define KS_KT_DISPATCH(ncols, MACRO)                                              \
   do {                                                                            \
-    if ((ncols) <= 4) { MACRO(4); } else if ((ncols) <= 8) { MACRO(8); }          \
-    else if ((ncols) <= 12) { MACRO(12); } else if ((ncols) <= 16) { MACRO(16); } \
-    else if ((ncols) <= 20) { MACRO(20); } else if ((ncols) <= 24) { MACRO(24); } \
-    else if ((ncols) <= 28) { MACRO(28); } else if ((ncols) <= 32) { MACRO(32); } \
-    else if ((ncols) <= 40) { MACRO(40); } else if ((ncols) <= 48) { MACRO(48); } \
-    else if ((ncols) <= 56) { MACRO(56); } else { MACRO(64); }                    \
+    switch (ks_kt_for(ncols)) {                                                   \
+      KS_KT_CASE(1, MACRO) KS_KT_CASE(2, MACRO) KS_KT_CASE(3, MACRO) KS_KT_CASE(4, MACRO) KS_KT_CASE(5, MACRO) KS_KT_CASE(6, MACRO) KS_KT_CASE(7, MACRO) KS_KT_CASE(8, MACRO) \
+      KS_KT_CASE(9, MACRO) KS_KT_CASE(10, MACRO) KS_KT_CASE(11, MACRO) KS_KT_CASE(12, MACRO) KS_KT_CASE(13, MACRO) KS_KT_CASE(14, MACRO) KS_KT_CASE(15, MACRO) KS_KT_CASE(16, MACRO) \
+      KS_KT_CASE(17, MACRO) KS_KT_CASE(18, MACRO) KS_KT_CASE(19, MACRO) KS_KT_CASE(20, MACRO) KS_KT_CASE(21, MACRO) KS_KT_CASE(22, MACRO) KS_KT_CASE(23, MACRO) KS_KT_CASE(24, MACRO) \
+      KS_KT_CASE(25, MACRO) KS_KT_CASE(26, MACRO) KS_KT_CASE(27, MACRO) KS_KT_CASE(28, MACRO) KS_KT_CASE(29, MACRO) KS_KT_CASE(30, MACRO) KS_KT_CASE(31, MACRO) KS_KT_CASE(32, MACRO) \
+      KS_KT_CASE(40, MACRO) KS_KT_CASE(48, MACRO) KS_KT_CASE(56, MACRO) default: { MACRO(64); } break;                                                                              \
+    }                                                                             \
   } while (0)

@@ -145,7 +145,10 @@ struct KsGsState {
   int lindep;         // result for the current column
   int more_;          // another pass follows the pending update (bvorthog.c:179 loop condition)
   int halt_col;       // >=0: column whose orthogonalization needs slots beyond the optimistic program (host completes it)
-  int pad2_;
+  int store_now;      // the pending update writes the vector back (final update, or an explicit norm follows); a fused pass that
+                      // only feeds the next pass's dots keeps its result in registers (writes cost ~5 read-columns of HBM time)
+  int store_prev;     // the previous update of this column stored: the coefficients applied so far are in memory
+  int npend;          // passes whose coefficients are not in memory yet: the next update applies pend[0..npend) one after the other
   double onrm, nrm, alpha;
   long long passes_total;
 };
@@ -157,6 +160,7 @@ struct ks_bv_s {
   int orthog_type = KS_BV_ORTHOG_CGS, orthog_ref = KS_BV_ORTHOG_REFINE_IFNEEDED, orthog_block = KS_BV_ORTHOG_BLOCK_GS;
   ks_mat matrix = nullptr;   // inner-product matrix B of BVSetMatrix (positive definite), borrowed; nullptr = standard
   double *Bx = nullptr;      // B*x of the vector an inner product is being taken with (BV_IPMatMult bvimpl.h:147-158)
+  double *pend = nullptr;    // [3][KS_PSTRIDE] coefficients of the passes since the vector was last written back (what the next update applies, pass by pass)
   double orthog_eta = 0.7071;
   double deftol = 10 * 2.220446049250313e-16;
   double *array = nullptr;      // m*ld
