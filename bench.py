@@ -236,11 +236,13 @@ def main():
                                "bytes_per_executed_launch": d["hbm"] / d["n_exec"],
                                "survey8d_bytes_per_executed_launch": d["alg"] / d["n_exec"],
                                "survey8d_equivalent_GBps": round(d["alg"] / d["ms_exec"] / 1e6, 1),
-                               "note": "HIP events on the library stream over the timed region. bytes per launch = 8n(k+2): read k basis "
-                                       "columns, read+write the vector (DESIGN.md section 4). A fused launch ALSO produces the k+1 dot products "
-                                       "of the next CGS pass from the same register-resident panel, work the reference pays another 8n(k+1) "
-                                       "bytes for (SURVEY 8d): survey8d_* count it that way. rocprofv3's per-symbol average covers all "
-                                       "launches incl. the ones that exit at their device-side gate: compare avg_launch_us_all_launches."}
+                               "note": "HIP events on the library stream over the timed region. One symbol is launched in two forms (DESIGN.md "
+                                       "section 4): the first CGS pass reads k basis columns and the vector, 8n(k+1) bytes, keeps its result in "
+                                       "registers and produces the k+1 dot products of the next pass (work the reference pays another 8n(k+1) "
+                                       "bytes for, SURVEY 8d: survey8d_*); the final pass reads the same and writes the vector, 8n(k+2). "
+                                       "bytes_per_executed_launch is the mean over both forms, as is the PMC figure in traffic. rocprofv3's "
+                                       "per-symbol average covers all launches incl. the ones that exit at their device-side gate: compare "
+                                       "avg_launch_us_all_launches."}
             tot_alg = sum(v["alg_bytes"] for v in prof.values()); tot_hbm = sum(v["hbm_bytes"] for v in prof.values())
             tot_ms = sum(v["ms"] for v in prof.values())
             out["step_traffic"] = {"alg_GB_per_step": round(tot_alg / args.steps / 1e9, 3), "alg_GBps_vs_wall": round(tot_alg / dt / 1e9, 1),
