@@ -84,8 +84,26 @@ def cpu_baseline(n_side, max_seconds=30.0):
     else:
         dt, steps = dt6, m1
         sample = "first %d Lanczos steps (k=1..%d) of the 216^3 workload (full run estimated %.0f s > budget)" % (m1, m1, est)
-    return {"value": steps / dt, "unit": "steps/s", "cores": threads, "kind": "port", "sample": sample,
-            "seconds": round(dt, 3), "setup_seconds": round(t1 - t0, 2), "gs_passes": V.passes_total()}
+    out = {"value": steps / dt, "unit": "steps/s", "cores": threads, "kind": "port", "sample": sample,
+           "seconds": round(dt, 3), "setup_seconds": round(t1 - t0, 2), "gs_passes": V.passes_total(),
+           "same_6_steps_all_cores": {"value": m1 / dt6, "unit": "steps/s", "cores": threads}}
+    # one core (the serial build of the oracle), on the first 6 steps only so that it stays within a few seconds
+    try:
+        del V
+        A1 = O.laplacian3d(n_side, n_side, n_side)
+        V1 = O.BV(A1.n, m1 + 2)
+        V1.SetRandomColumn(0)
+        _, nrm, _ = V1.OrthogonalizeColumn(0)
+        V1.ScaleColumn(0, 1.0 / nrm)
+        T1 = np.zeros((m1 + 2, 3), order="F")
+        t3 = time.time()
+        V1.MatLanczos(A1, T1, 0, m1)
+        d1 = time.time() - t3
+        out["single_core"] = {"value": m1 / d1, "unit": "steps/s", "cores": 1, "seconds": round(d1, 3),
+                              "sample": "first %d Lanczos steps (k=1..%d) of the 216^3 workload; compare same_6_steps_all_cores" % (m1, m1)}
+    except Exception as e:      # noqa: BLE001
+        out["single_core"] = {"value": None, "sample": "failed: %r" % (e,)}
+    return out
 
 
 def main():
