@@ -80,10 +80,10 @@ def cpu_baseline(n_side, max_seconds=30.0):
         V.MatLanczos(A, T, m1, NCV)
         dt = dt6 + (time.time() - t2)
         steps = NCV
-        sample = "first Lanczos run of the 216^3 workload: %d steps (k=1..%d), CGS2" % (NCV, NCV)
+        sample = "first Lanczos run of the %d^3 workload: %d steps (k=1..%d), CGS2" % (n_side, NCV, NCV)
     else:
         dt, steps = dt6, m1
-        sample = "first %d Lanczos steps (k=1..%d) of the 216^3 workload (full run estimated %.0f s > budget)" % (m1, m1, est)
+        sample = "first %d Lanczos steps (k=1..%d) of the %d^3 workload (full run estimated %.0f s > budget)" % (m1, m1, n_side, est)
     out = {"value": steps / dt, "unit": "steps/s", "cores": threads, "kind": "port", "sample": sample,
            "seconds": round(dt, 3), "setup_seconds": round(t1 - t0, 2), "gs_passes": V.passes_total(),
            "same_6_steps_all_cores": {"value": m1 / dt6, "unit": "steps/s", "cores": threads}}
@@ -100,7 +100,7 @@ def cpu_baseline(n_side, max_seconds=30.0):
         V1.MatLanczos(A1, T1, 0, m1)
         d1 = time.time() - t3
         out["single_core"] = {"value": m1 / d1, "unit": "steps/s", "cores": 1, "seconds": round(d1, 3),
-                              "sample": "first %d Lanczos steps (k=1..%d) of the 216^3 workload; compare same_6_steps_all_cores" % (m1, m1)}
+                              "sample": "first %d Lanczos steps (k=1..%d) of the %d^3 workload; compare same_6_steps_all_cores" % (m1, m1, n_side)}
     except Exception as e:      # noqa: BLE001
         out["single_core"] = {"value": None, "sample": "failed: %r" % (e,)}
     return out

@@ -107,8 +107,14 @@ static void orc_gemv_n(int n,int k,double alpha,const double *A,int lda,const do
   if (beta!=1.0) { if (beta==0.0) for (i=0;i<n;i++) y[i]=0.0; else for (i=0;i<n;i++) y[i]*=beta; }
   if (alpha==0.0) return;
 #ifdef _OPENMP
-  #pragma omp parallel for schedule(static) private(j)
-  for (i=0;i<n;i++) { double s=y[i]; for (j=0;j<k;j++) s += (alpha*x[j])*A[i+(size_t)j*lda]; y[i]=s; }
+  /* row-block split (one block per thread = the reference's one-MPI-rank-per-core row decomposition); inside a block the
+     netlib column order, so the block of y stays in the core's cache while the k column segments stream through */
+  #pragma omp parallel private(i,j)
+  {
+    int nt=omp_get_num_threads(), t=omp_get_thread_num();
+    long lo=(long)n*t/nt, hi=(long)n*(t+1)/nt;
+    for (j=0;j<k;j++) { double tt=alpha*x[j]; const double *a=A+(size_t)j*lda; for (i=(int)lo;i<(int)hi;i++) y[i]+=tt*a[i]; }
+  }
 #else
   for (j=0;j<k;j++) { double t=alpha*x[j]; const double *a=A+(size_t)j*lda; for (i=0;i<n;i++) y[i]+=t*a[i]; }
 #endif
@@ -119,9 +125,19 @@ static void orc_gemv_t(int n,int k,const double *A,int lda,const double *x,doubl
 {
   int j;
 #ifdef _OPENMP
-  #pragma omp parallel for schedule(static)
-#endif
+  /* row-block split with per-thread partial sums added in thread order (the MPI_Allreduce of bvblas.c:255) */
+  int nt=omp_get_max_threads();
+  double *part=(double*)calloc((size_t)nt*(k>0?k:1),sizeof(double));
+  #pragma omp parallel private(j)
+  {
+    int t=omp_get_thread_num(), ntt=omp_get_num_threads(); long lo=(long)n*t/ntt, hi=(long)n*(t+1)/ntt; long i;
+    for (j=0;j<k;j++) { const double *a=A+(size_t)j*lda; double s=0.0; for (i=lo;i<hi;i++) s+=a[i]*x[i]; part[(size_t)t*k+j]=s; }
+  }
+  for (j=0;j<k;j++) { double s=0.0; int t; for (t=0;t<nt;t++) s+=part[(size_t)t*k+j]; y[j]=s; }
+  free(part);
+#else
   for (j=0;j<k;j++) { const double *a=A+(size_t)j*lda; double t=0.0; int i; for (i=0;i<n;i++) t+=a[i]*x[i]; y[j]=t; }
+#endif
 }
 
 /* C := alpha*A*B + beta*C  (dgemm 'N','N'); A m x k, B k x n, C m x n */
@@ -258,7 +274,17 @@ int orc_bv_dotcolumn(orc_bv *X,int j,double *q)
 }
 
 /* BVScale / BVScaleColumn (bvops.c:311,341; BVScale_Svec svec.c:150-162; BVScale_BLAS_Private bvblas.c:266-278) */
-static void orc_scal(int n,double *A,double alpha) { int i; if (alpha==0.0) memset(A,0,(size_t)n*sizeof(double)); else if (alpha!=1.0) for (i=0;i<n;i++) A[i]*=alpha; }
+static void orc_scal(int n,double *A,double alpha)
+{
+  int i;
+  if (alpha==0.0) memset(A,0,(size_t)n*sizeof(double));
+  else if (alpha!=1.0) {
+#ifdef _OPENMP
+    #pragma omp parallel for schedule(static)
+#endif
+    for (i=0;i<n;i++) A[i]*=alpha;
+  }
+}
 int orc_bv_scale(orc_bv *bv,int j,double alpha)
 {
   if (alpha==1.0) return ORC_OK;                         /* bvops.c:318,351 */
@@ -593,19 +619,27 @@ long orc_laplacian3d_nnz(int nx,int ny,int nz,int z0,int nzl)
 }
 void orc_laplacian3d_fill(int nx,int ny,int nz,int z0,int nzl,int *rowptr,int *col,double *val)
 {
-  long p=0; int i,j,k; long r=0;
-  for (k=z0;k<z0+nzl;k++) for (j=0;j<ny;j++) for (i=0;i<nx;i++) {
-    long g=((long)k*ny+j)*nx+i;
-    rowptr[r++]=(int)p;
-    if (k>0)    { col[p]=(int)(g-(long)nx*ny); val[p++]=-1.0; }
-    if (j>0)    { col[p]=(int)(g-nx); val[p++]=-1.0; }
-    if (i>0)    { col[p]=(int)(g-1);  val[p++]=-1.0; }
-    col[p]=(int)g; val[p++]=6.0;
-    if (i<nx-1) { col[p]=(int)(g+1);  val[p++]=-1.0; }
-    if (j<ny-1) { col[p]=(int)(g+nx); val[p++]=-1.0; }
-    if (k<nz-1) { col[p]=(int)(g+(long)nx*ny); val[p++]=-1.0; }
+  long r,nrows=(long)nx*ny*nzl; long p=0;
+  /* row lengths, prefix sum, then the rows in parallel (each thread touches the pages of its own row block first) */
+  for (r=0;r<nrows;r++) {
+    long i=r%nx, j=(r/nx)%ny, k=z0+r/((long)nx*ny);
+    rowptr[r]=(int)p;
+    p += 1+(k>0)+(j>0)+(i>0)+(i<nx-1)+(j<ny-1)+(k<nz-1);
   }
-  rowptr[r]=(int)p;
+  rowptr[nrows]=(int)p;
+#ifdef _OPENMP
+  #pragma omp parallel for schedule(static)
+#endif
+  for (r=0;r<nrows;r++) {
+    long i=r%nx, j=(r/nx)%ny, k=z0+r/((long)nx*ny), g=((long)k*ny+j)*nx+i, q=rowptr[r];
+    if (k>0)    { col[q]=(int)(g-(long)nx*ny); val[q++]=-1.0; }
+    if (j>0)    { col[q]=(int)(g-nx); val[q++]=-1.0; }
+    if (i>0)    { col[q]=(int)(g-1);  val[q++]=-1.0; }
+    col[q]=(int)g; val[q++]=6.0;
+    if (i<nx-1) { col[q]=(int)(g+1);  val[q++]=-1.0; }
+    if (j<ny-1) { col[q]=(int)(g+nx); val[q++]=-1.0; }
+    if (k<nz-1) { col[q]=(int)(g+(long)nx*ny); val[q++]=-1.0; }
+  }
 }
 /* 2-D 5-point Laplacian (ex2.c:44-51): diag 4, off -1, row-major grid index II=i*n+j, insertion order
    (i-1), (i+1), (j-1), (j+1), diag -- PETSc sorts columns within a row, so sorted order is emitted. */
