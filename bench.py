@@ -34,6 +34,7 @@ def make_eps(ks, ctx, A):
     and reused by later ones, so the timed region holds no allocation (inputs and workspace resident in HBM)."""
     eps = ks.EPS(ctx)
     eps.SetOperators(A)
+    eps.SetProblemType(ks.EPS_HEP)
     eps.SetDimensions(NEV, NCV)
     eps.SetTolerances(1e-8, 1 << 30)
     return eps

@@ -238,6 +238,14 @@ int ks_eps_get_eigenvector_host(ks_eps eps, int i, double *xr_host);       /* n_
 int ks_eps_get_eigenpair_host(ks_eps eps, int i, double *eigr, double *eigi, double *xr_host, double *xi_host);
 int ks_eps_get_error_estimate(ks_eps eps, int i, double *errest);
 int ks_eps_compute_error(ks_eps eps, int i, int type, double *error);      /* EPSComputeError epssolve.c:742 */
+/* getters of the settings (EPSGetTolerances, EPSGetWhichEigenpairs, EPSGetTarget, EPSGetConvergenceTest, EPSGetOperators,
+   EPSGetProblemType with EPSIsGeneralized / IsHermitian / IsPositive); any output may be NULL */
+int ks_eps_get_tolerances(ks_eps eps, double *tol, int *max_it);
+int ks_eps_get_which_eigenpairs(ks_eps eps, int *which);
+int ks_eps_get_target(ks_eps eps, double *target);
+int ks_eps_get_convergence_test(ks_eps eps, int *conv);
+int ks_eps_get_operators(ks_eps eps, ks_mat *A, ks_mat *B);
+int ks_eps_get_problem_type(ks_eps eps, int *type, int *generalized, int *hermitian, int *positive);
 int ks_eps_get_bv(ks_eps eps, ks_bv *V);
 int ks_eps_get_stats(ks_eps eps, long long *arnoldi_steps, long long *gs_passes, int *restarts);
 

@@ -9,7 +9,7 @@ for name, mk, nev, ncv, steps in [("C1 2-D 100^2", lambda: ks.Mat.laplacian2d(ct
                                   ("C2 2-D 1000^2", lambda: ks.Mat.laplacian2d(ctx, 1000), 4, 20, 2000),
                                   ("C3 3-D 216^3", lambda: ks.Mat.laplacian3d(ctx, 216, 216, 216), 10, 30, 300)]:
     A = mk()
-    eps = ks.EPS(ctx); eps.SetOperators(A); eps.SetDimensions(nev, ncv); eps.SetTolerances(1e-8, 1 << 30)
+    eps = ks.EPS(ctx); eps.SetOperators(A); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(nev, ncv); eps.SetTolerances(1e-8, 1 << 30)
     def run(k):
         done = 0; s = 0
         while done < k:

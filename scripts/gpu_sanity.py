@@ -54,7 +54,7 @@ print("T diff", np.abs(To - Tg).max(), "V diff", np.abs(Vo.dense() - Vg.dense())
 Ao = O.laplacian2d(72)
 Ag = ks.Mat.laplacian2d(ctx, 72)
 t0 = time.time()
-eps = ks.EPS(ctx); eps.SetOperators(Ag); eps.SetDimensions(4, 20); eps.Solve()
+eps = ks.EPS(ctx); eps.SetOperators(Ag); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(4, 20); eps.Solve()
 print("EPS", eps.GetConverged(), eps.GetIterationNumber(), [eps.GetEigenvalue(i)[0] for i in range(4)], eps.GetStats(), time.time() - t0)
 print([eps.ComputeError(i) for i in range(4)])
 r = O.eps_krylovschur_hep(Ao, 4, ncv=20)
@@ -63,7 +63,7 @@ print("oracle", r.nconv, r.its, r.eigr[r.perm][:4], r.steps, r.passes, flush=Tru
 # timing, 3D
 for N in (100, 216):
     Ag = ks.Mat.laplacian3d(ctx, N, N, N)
-    eps = ks.EPS(ctx); eps.SetOperators(Ag); eps.SetDimensions(10, 30); eps.SetMaxSteps(60); eps.Solve()  # warm
+    eps = ks.EPS(ctx); eps.SetOperators(Ag); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(10, 30); eps.SetMaxSteps(60); eps.Solve()  # warm
     ctx.prof_enable(True); ctx.prof_reset()
     eps.SetMaxSteps(150)
     t0 = time.time(); eps.Solve(); ctx.synchronize(); dt = time.time() - t0

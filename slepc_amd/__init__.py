@@ -559,6 +559,24 @@ class EPS:
         _lib.check(self.ctx.L.ks_eps_set_operators(self.h, A.h, None if B is None else B.h))
         self._A = A; self._B = B
 
+    def GetTolerances(self):
+        t = C.c_double(); m = C.c_int(); _lib.check(self.ctx.L.ks_eps_get_tolerances(self.h, C.byref(t), C.byref(m))); return t.value, m.value
+
+    def GetWhichEigenpairs(self):
+        v = C.c_int(); _lib.check(self.ctx.L.ks_eps_get_which_eigenpairs(self.h, C.byref(v))); return v.value
+
+    def GetTarget(self):
+        v = C.c_double(); _lib.check(self.ctx.L.ks_eps_get_target(self.h, C.byref(v))); return v.value
+
+    def GetConvergenceTest(self):
+        v = C.c_int(); _lib.check(self.ctx.L.ks_eps_get_convergence_test(self.h, C.byref(v))); return v.value
+
+    def GetProblemType(self):
+        """(type, is_generalized, is_hermitian, is_positive)"""
+        v = [C.c_int() for _ in range(4)]
+        _lib.check(self.ctx.L.ks_eps_get_problem_type(self.h, *[C.byref(x) for x in v]))
+        return v[0].value, bool(v[1].value), bool(v[2].value), bool(v[3].value)
+
     def GetST(self):
         h = C.c_void_p(); _lib.check(self.ctx.L.ks_eps_get_st(self.h, C.byref(h)))
         return ST(self.ctx, _handle=h)

@@ -128,6 +128,12 @@ _SIG = {
     "ks_eps_get_bv": [vp, C.POINTER(vp)],
     "ks_eps_get_stats": [vp, llp, llp, ip],
     "ks_eps_get_st": [vp, C.POINTER(vp)],
+    "ks_eps_get_tolerances": [vp, dp, ip],
+    "ks_eps_get_which_eigenpairs": [vp, ip],
+    "ks_eps_get_target": [vp, dp],
+    "ks_eps_get_convergence_test": [vp, ip],
+    "ks_eps_get_operators": [vp, C.POINTER(vp), C.POINTER(vp)],
+    "ks_eps_get_problem_type": [vp, ip, ip, ip, ip],
     "ks_st_create": [vp, C.POINTER(vp)],
     "ks_st_destroy": [vp],
     "ks_st_set_type": [vp, C.c_int],

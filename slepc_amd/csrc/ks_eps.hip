@@ -328,7 +328,7 @@ struct ks_eps_s {
   ks_mat op = nullptr;                 // operator of the expansion: A itself, or the ST's shell matrix
   ks_st st = nullptr;                  // owned (EPSGetST)
   ks_bv V = nullptr, W = nullptr;      // basis (ncv+1 columns), work vectors (3 columns)
-  int problem_type = KS_EPS_HEP;
+  int problem_type = 0;               // not set: EPSSetUp picks NHEP (one matrix) or GNHEP (two), epssetup.c:318-322
   int nev = 1, ncv = 0, mpd = 0, ncv_user = 0, mpd_user = 0;
   double tol = 1e-8; int max_it = 0, max_it_user = 0;
   KsCompare which;                     // user settings; cmp_ds / cmp_final are what a solve uses
@@ -607,6 +607,7 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   // ---- EPSSetUp (epssetup.c:286-420) ----
   KS_CHECK(eps->which.which != KS_EPS_WHICH_USER || eps->which.fn, KS_ERR_ORDER, "Must call EPSSetEigenvalueComparison() first");   // epssetup.c:311
   int ptype = eps->problem_type;
+  if (!ptype) ptype = eps->B ? KS_EPS_GNHEP : KS_EPS_NHEP;             // default problem type (epssetup.c:318-322)
   if (!eps->B && ptype == KS_EPS_GNHEP) ptype = KS_EPS_NHEP;          // "reverting to a standard eigenproblem" (epssetup.c:324-327)
   if (!eps->B && ptype == KS_EPS_GHEP) ptype = KS_EPS_HEP;
   KS_CHECK(!eps->B || ptype == KS_EPS_GNHEP || ptype == KS_EPS_GHEP, KS_ERR_ARG_INCOMP, "Inconsistent EPS state: the problem type does not match the number of matrices");
@@ -843,6 +844,28 @@ extern "C" int ks_eps_compute_error(ks_eps eps, int i, int type, double *error) 
   return KS_SUCCESS;
 }
 
+// ---- getters of the settings (EPSGetTolerances, EPSGetWhichEigenpairs, EPSGetTarget, EPSGetProblemType, EPSIs*, ...) ----
+extern "C" int ks_eps_get_tolerances(ks_eps eps, double *tol, int *max_it)
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  if (tol) *tol = eps->tol;
+  if (max_it) *max_it = eps->solved ? eps->max_it : eps->max_it_user;      // 0 before set-up when left to the default
+  return KS_SUCCESS;
+}
+extern "C" int ks_eps_get_which_eigenpairs(ks_eps eps, int *which) { KS_CHECK(eps && which, KS_ERR_ARG_NULL, "NULL argument"); *which = eps->which.which; return KS_SUCCESS; }
+extern "C" int ks_eps_get_target(ks_eps eps, double *target) { KS_CHECK(eps && target, KS_ERR_ARG_NULL, "NULL argument"); *target = eps->which.target; return KS_SUCCESS; }
+extern "C" int ks_eps_get_convergence_test(ks_eps eps, int *conv) { KS_CHECK(eps && conv, KS_ERR_ARG_NULL, "NULL argument"); *conv = eps->conv; return KS_SUCCESS; }
+extern "C" int ks_eps_get_operators(ks_eps eps, ks_mat *A, ks_mat *B) { KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL"); if (A) *A = eps->A; if (B) *B = eps->B; return KS_SUCCESS; }
+extern "C" int ks_eps_get_problem_type(ks_eps eps, int *type, int *generalized, int *hermitian, int *positive)   // EPSGetProblemType + EPSIsGeneralized/IsHermitian/IsPositive
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  const int t = eps->problem_type;
+  if (type) *type = t;
+  if (generalized) *generalized = (t == KS_EPS_GHEP || t == KS_EPS_GNHEP);
+  if (hermitian) *hermitian = (t == KS_EPS_HEP || t == KS_EPS_GHEP);
+  if (positive) *positive = (t == KS_EPS_GHEP);
+  return KS_SUCCESS;
+}
 extern "C" int ks_eps_get_bv(ks_eps eps, ks_bv *V) { KS_CHECK(eps && V, KS_ERR_ARG_NULL, "NULL argument"); *V = eps->V; return KS_SUCCESS; }
 extern "C" int ks_eps_get_stats(ks_eps eps, long long *steps, long long *passes, int *restarts)
 {

@@ -300,7 +300,7 @@ def test_lanczos_argument_checks(ctx):
 def _solve_gpu(ctx, A, nev, ncv=0, which="largest_magnitude", tol=0.0):
     import slepc_amd as ks
     eps = ks.EPS(ctx)
-    eps.SetOperators(A); eps.SetDimensions(nev, ncv); eps.SetWhichEigenpairs(which); eps.SetTolerances(tol)
+    eps.SetOperators(A); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(nev, ncv); eps.SetWhichEigenpairs(which); eps.SetTolerances(tol)
     eps.Solve()
     return eps
 
@@ -379,7 +379,7 @@ def test_eps_config2_1M(ctx):
     """BASELINE config 2: 2-D Laplacian n=1e6 on one MI355X, Ritz values vs analytic spectrum + residuals."""
     import slepc_amd as ks
     eps = ks.EPS(ctx)
-    eps.SetOperators(ks.Mat.laplacian2d(ctx, 1000)); eps.SetDimensions(4, 20); eps.SetTolerances(1e-8, 400)
+    eps.SetOperators(ks.Mat.laplacian2d(ctx, 1000)); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(4, 20); eps.SetTolerances(1e-8, 400)
     eps.Solve()
     exact = O.laplacian_eigenvalues([1000, 1000])
     nconv = eps.GetConverged()

@@ -96,7 +96,7 @@ def _worker(rank, world, port, q):
         res["orth"] = float(np.abs(M - np.eye(m + 1)).max())
         res["normF"] = V.Norm(ks.NORM_FROBENIUS)
         # (3) full Krylov-Schur solve, replicated control flow
-        eps = ks.EPS(ctx); eps.SetOperators(A); eps.SetDimensions(3, 12); eps.Solve()
+        eps = ks.EPS(ctx); eps.SetOperators(A); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(3, 12); eps.Solve()
         res["eig"] = [eps.GetEigenvalue(i)[0] for i in range(3)]
         res["its"] = eps.GetIterationNumber(); res["nconv"] = eps.GetConverged()
         res["err"] = [eps.ComputeError(i) for i in range(3)]
@@ -156,7 +156,7 @@ def _rccl_worker(q):
         ctx.init_rccl(0, 1, ks.Context.get_unique_id())
         Ao = O.laplacian2d(40)
         A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
-        eps = ks.EPS(ctx); eps.SetOperators(A); eps.SetDimensions(4, 20); eps.Solve()
+        eps = ks.EPS(ctx); eps.SetOperators(A); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(4, 20); eps.Solve()
         r = O.eps_krylovschur_hep(Ao, 4, ncv=20)
         ok = (eps.GetConverged() == r.nconv and eps.GetIterationNumber() == r.its and
               np.allclose([eps.GetEigenvalue(i)[0] for i in range(4)], r.eigr[r.perm][:4], rtol=1e-10))

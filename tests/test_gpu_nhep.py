@@ -263,3 +263,35 @@ def test_mpd_limits_the_projected_problem(ctx, ptype):
     with pytest.raises(ks.KsError) as e:
         bad = ks.EPS(ctx); bad.SetOperators(A); bad.SetDimensions(8, 30, 12); bad.Solve()      # ncv > nev + mpd
     assert e.value.rc == 71
+
+
+def test_eps_interface_getters_and_defaults(ctx):
+    """test14.c-style walk through the setters/getters (the options this build has), then the solve of that test:
+    diagonal matrix 1..20, target magnitude 4.8, absolute convergence test, tol 2.2e-4 -> 5, 4, 6, 3
+    (output/test14_1.out). The problem type left unset resolves to NHEP (epssetup.c:318-322)."""
+    import slepc_amd as ks
+    n = 20
+    Ao = O.CSR(n, np.arange(n + 1), np.arange(n), np.arange(1, n + 1, dtype=float))
+    A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A)
+    assert eps.GetProblemType() == (0, False, False, False)                  # "Problem type before changing = 0"
+    eps.SetProblemType(ks.EPS_HEP)
+    assert eps.GetProblemType() == (1, False, True, False)                   # "... changed to 1. hermitian"
+    eps.SetTarget(4.8); eps.SetWhichEigenpairs("target_magnitude")
+    assert (eps.GetWhichEigenpairs(), eps.GetTarget()) == (7, 4.8)           # "Which = 7, target = 4.8"
+    eps.SetDimensions(4)
+    assert eps.GetDimensions()[0] == 4
+    eps.SetTolerances(2.2e-4, 200)
+    assert eps.GetTolerances() == (2.2e-4, 200)                              # "Tolerance = 0.00022, max_its = 200"
+    eps.SetConvergenceTest("abs")
+    assert eps.GetConvergenceTest() == 0                                     # "Convergence test = 0"
+    eps.Solve()
+    assert eps.GetConvergedReason() == 1
+    lam = [eps.GetEigenvalue(i)[0] for i in range(4)]
+    assert np.allclose(np.round(lam, 5), gi.eigenvalues_line(gi.read("eps/eps_test14_1.out")), atol=1.5e-5)
+    assert eps.GetDimensions() == (4, 19, 19)
+    # default problem type: a solver left alone treats one matrix as NHEP and two as GNHEP
+    e2 = ks.EPS(ctx); e2.SetOperators(A); e2.SetDimensions(2); e2.Solve()
+    assert np.allclose([e2.GetEigenvalue(i)[0] for i in range(2)], [20.0, 19.0], rtol=1e-9)
+    assert e2.GetEigenvalue(0)[1] == 0.0
