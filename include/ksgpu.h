@@ -161,6 +161,10 @@ int ks_bv_get_buffer(ks_bv bv, double **dev);                                   
 int ks_bv_set_column_host(ks_bv bv, int j, const double *host);                     /* H2D of n_local doubles */
 int ks_bv_get_column_host(ks_bv bv, int j, double *host);                           /* D2H, synchronises */
 int ks_bv_get_buffer_host(ks_bv bv, double *host);                                  /* D2H of the (nc+m)*m coefficient buffer */
+int ks_bv_resize(ks_bv bv, int m, int copy);                                    /* BVResize bvbasic.c:190 (ops->resize) */
+int ks_bv_set_random(ks_bv bv, uint64_t seed);                                   /* BVSetRandom bvops.c:380: all active columns */
+int ks_bv_insert_vec(ks_bv bv, int j, const double *w_dev);                      /* BVInsertVec bvops.c:568 */
+int ks_bv_copy_vec(ks_bv bv, int j, double *w_dev);                              /* BVCopyVec bvops.c:484 */
 int ks_bv_set_random_column(ks_bv bv, int j, uint64_t seed);                        /* BVSetRandomColumn with -bv_reproducible_random semantics */
 
 int ks_bv_mult(ks_bv Y, double alpha, double beta, ks_bv X, const double *Q, int ldq);          /* ops->mult; Q NULL -> Y=beta*Y+alpha*X */

@@ -344,6 +344,19 @@ class BV:
     def SetRandomColumn(self, j, seed=0x12345678):
         _lib.check(self.ctx.L.ks_bv_set_random_column(self.h, j, seed))
 
+    def SetRandom(self, seed=0x12345678):
+        _lib.check(self.ctx.L.ks_bv_set_random(self.h, seed))
+
+    def Resize(self, m, copy=True):
+        _lib.check(self.ctx.L.ks_bv_resize(self.h, m, int(bool(copy))))
+        self.m = m
+
+    def InsertVec(self, j, w_ptr):
+        _lib.check(self.ctx.L.ks_bv_insert_vec(self.h, j, C.c_void_p(w_ptr)))
+
+    def CopyVec(self, j, w_ptr):
+        _lib.check(self.ctx.L.ks_bv_copy_vec(self.h, j, C.c_void_p(w_ptr)))
+
     # -- ops
     def Mult(self, alpha, beta, X, Q=None):
         if Q is None:

@@ -91,6 +91,10 @@ _SIG = {
     "ks_bv_orthogonalizevec": [vp, vp, dp, dp, ip],
     "ks_bv_orthogonalizesomecolumn": [vp, C.c_int, ip, dp, dp, ip],
     "ks_bv_gs_passes": [vp, llp, ip],
+    "ks_bv_resize": [vp, C.c_int, C.c_int],
+    "ks_bv_set_random": [vp, C.c_uint64],
+    "ks_bv_insert_vec": [vp, C.c_int, vp],
+    "ks_bv_copy_vec": [vp, C.c_int, vp],
     "ks_bv_set_orthog_block": [vp, C.c_int],
     "ks_bv_set_matrix": [vp, vp],
     "ks_bv_get_matrix": [vp, C.POINTER(vp)],

@@ -257,6 +257,53 @@ extern "C" int ks_bv_destroy(ks_bv bv)
   return KS_SUCCESS;
 }
 
+// BVResize bvbasic.c:190-260: change the number of columns, optionally keeping the first min(m_old, m_new) of them.
+// The column storage and everything sized by m are re-created; settings (orthogonalisation, inner-product matrix,
+// ownership start) and the leading dimension stay. Active columns are reset to [0, m) as in the reference.
+extern "C" int ks_bv_resize(ks_bv bv, int m, int copy)
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  KS_CHECK(m > 0, KS_ERR_ARG_OUTOFRANGE, "Number of columns %d must be positive", m);
+  if (m == bv->m) return KS_SUCCESS;
+  ks_bv nb = nullptr;
+  KS_CALL(ks_bv_create(bv->ctx, bv->n, bv->N, m, bv->ld, &nb));
+  if (copy) {
+    const int mc = std::min(m, bv->m);
+    for (int j = 0; j < mc; j++) { int rc = ksk_copy(bv->ctx, ks_bv_col(bv, j), ks_bv_col(nb, j), bv->n); if (rc) { ks_bv_destroy(nb); return rc; } }
+    KS_HIP(hipStreamSynchronize(bv->ctx->stream));
+  }
+  // swap the storage of the two objects, keep the caller's handle and settings
+  std::swap(bv->array, nb->array); std::swap(bv->buffer, nb->buffer); std::swap(bv->coef, nb->coef); std::swap(bv->coef_len, nb->coef_len);
+  std::swap(bv->hc, nb->hc); std::swap(bv->recs, nb->recs); std::swap(bv->panel, nb->panel); std::swap(bv->panel_len, nb->panel_len);
+  std::swap(bv->m, nb->m);
+  bv->l = 0; bv->k = m;
+  return ks_bv_destroy(nb);
+}
+
+// BVSetRandom bvops.c:380-407: every active column, reproducible (value depends on seed, column and global row only)
+extern "C" int ks_bv_set_random(ks_bv bv, uint64_t seed)
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  for (int j = bv->l; j < bv->k; j++) KS_CALL(ks_bv_set_random_column(bv, j, seed));
+  return KS_SUCCESS;
+}
+
+// BVInsertVec bvops.c:568 / BVCopyVec bvops.c:484 on device vectors of n_local doubles
+extern "C" int ks_bv_insert_vec(ks_bv bv, int j, const double *w_dev)
+{
+  KS_CHECK(bv && w_dev, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(j >= 0 && j < bv->m, KS_ERR_ARG_OUTOFRANGE, "Argument j has wrong value %d, the number of columns is %d", j, bv->m);
+  KS_HIP(hipSetDevice(bv->ctx->device));
+  return ksk_copy(bv->ctx, w_dev, ks_bv_col(bv, j), bv->n);
+}
+extern "C" int ks_bv_copy_vec(ks_bv bv, int j, double *w_dev)
+{
+  KS_CHECK(bv && w_dev, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(j >= 0 && j < bv->m, KS_ERR_ARG_OUTOFRANGE, "Argument j has wrong value %d, the number of columns is %d", j, bv->m);
+  KS_HIP(hipSetDevice(bv->ctx->device));
+  return ksk_copy(bv->ctx, ks_bv_col(bv, j), w_dev, bv->n);
+}
+
 extern "C" int ks_bv_duplicate(ks_bv bv, ks_bv *out)
 {
   KS_CHECK(bv && out, KS_ERR_ARG_NULL, "NULL argument");

@@ -206,3 +206,38 @@ def test_panel_dot_exact_on_integers(ctx, gpu):
     gpu.fill(X, Xh); gpu.fill(Y, Yh)
     M = np.zeros((k, k), order="F"); X.Dot(Y, M)
     assert np.array_equal(M, Xh[:k, :k])
+
+
+def test_resize_setrandom_insert_copy_vec(ctx):
+    """BVResize (test4.c grows X by four columns with copy=TRUE), BVSetRandom on the active window, BVInsertVec / BVCopyVec."""
+    import slepc_amd as ks
+    n = 3001
+    X0 = np.random.default_rng(3).standard_normal((n, 5))
+    X = ks.BV(ctx, n, 5); X.set_dense(X0)
+    X.SetOrthogonalization(ks.MGS, ks.REFINE_ALWAYS, 0.5)
+    X.Resize(9, copy=True)
+    D = X.dense()
+    assert D.shape == (n, 9) and np.array_equal(D[:, :5], X0) and np.all(D[:, 5:] == 0.0)
+    X.Resize(3, copy=True)
+    assert np.array_equal(X.dense(), X0[:, :3])
+    X.Resize(6, copy=False)
+    assert X.dense().shape == (n, 6)
+    # the resized basis still works with every kernel sized by m (buffer, records, coefficient staging)
+    X.set_dense(np.random.default_rng(4).standard_normal((n, 6)))
+    for j in range(6):
+        nrm, _ = X.OrthonormalizeColumn(j)
+    Q = X.dense()
+    assert np.abs(Q.T @ Q - np.eye(6)).max() < 1e-13
+    # BVSetRandom touches the active columns only and is reproducible
+    X.SetActiveColumns(2, 5); X.SetRandom(77)
+    D2 = X.dense()
+    assert np.array_equal(D2[:, :2], Q[:, :2]) and np.array_equal(D2[:, 5], Q[:, 5])
+    Y = ks.BV(ctx, n, 6); Y.SetActiveColumns(2, 5); Y.SetRandom(77)
+    assert np.array_equal(Y.dense()[:, 2:5], D2[:, 2:5]) and np.all((D2[:, 2:5] >= 0) & (D2[:, 2:5] < 1))
+    # BVInsertVec / BVCopyVec
+    W = ks.BV(ctx, n, 2); w = np.arange(n, dtype=float); W.set_column(0, w)
+    X.InsertVec(4, W.column_ptr(0)); assert np.array_equal(X.column(4), w)
+    X.CopyVec(0, W.column_ptr(1)); assert np.array_equal(W.column(1), Q[:, 0])
+    with pytest.raises(ks.KsError) as e:
+        X.Resize(0)
+    assert e.value.rc == 63
