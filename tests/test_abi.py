@@ -64,3 +64,27 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cuh", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ex2_abi")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
+           os.path.join(root, "tests", "c_abi", "ex2_abi.c"), "-o", exe, "-L" + os.path.join(root, "slepc_amd"), "-l:libksgpu.so",
+           "-Wl,-rpath," + os.path.join(root, "slepc_amd")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_header_is_plain_c_and_library_links_from_c(tmp_path):
+    """include/ksgpu.h compiles as strict C99 (-pedantic -Werror) and a C program links against libksgpu.so; without a
+    GPU the program stops at ks_ctx_create with the PETSc-numbered error and says there is no CPU fallback."""
+    import subprocess
+    import torch
+    exe = _build_c_example(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("the run itself is checked by tests/test_gpu_krylov.py::test_c_program_against_the_abi")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "97" in r.stderr and "no CPU fallback" in r.stderr

@@ -442,3 +442,16 @@ def test_eps_test2_repeated_solves_one_object(ctx):
         assert eps.ComputeError(i) < 1e-7
     with pytest.raises(ks.KsError):                       # results belong to the last solve only
         eps.SetWhichEigenpairs("largest_real"); eps.GetEigenvalue(0)
+
+
+def test_c_program_against_the_abi(tmp_path):
+    """tests/c_abi/ex2_abi.c: the reference's ex2 written in C99 against include/ksgpu.h only; its output line matches
+    output/ex2_1.out (or the _alt file)."""
+    import subprocess
+    from test_abi import _build_c_example
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe, "72"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lam = gi.eigenvalues_line(r.stdout)
+    ref = gi.eigenvalues_line(gi.read("eps/ex2_1.out")); alt = gi.eigenvalues_line(gi.read("eps/ex2_1_alt.out"))
+    assert len(lam) == 4 and all(min(abs(l - a), abs(l - b)) < 1.5e-5 for l, a, b in zip(lam, ref, alt))
