@@ -110,13 +110,14 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_one_gpu_against_oracle():
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_sharing_one_gpu_against_oracle(world):
+    """world = 2: every rank has one slab neighbour; world = 4: the inner ranks exchange with two (9 planes split 3,2,2,2)."""
     import torch.multiprocessing as mp
     from oracle import oracle as O
-    world = 2
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    port = 29700 + (os.getpid() % 1500)
+    port = 29700 + (os.getpid() % 1500) + 7 * world
     procs = [mpc.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs: p.start()
     out = dict(q.get(timeout=400) for _ in range(world))
@@ -143,7 +144,8 @@ def test_two_ranks_one_gpu_against_oracle():
         assert o["nconv"] == r.nconv and o["its"] == r.its
         assert np.allclose(o["eig"], r.eigr[r.perm][:3], rtol=1e-10)
         assert max(o["err"]) < 1e-8
-    assert out[0]["eig"] == out[1]["eig"]                    # replicated scalars are bitwise identical on all ranks
+    for rk in range(1, world):
+        assert out[0]["eig"] == out[rk]["eig"]               # replicated scalars are bitwise identical on all ranks
 
 
 def _rccl_worker(q):
