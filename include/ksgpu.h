@@ -156,7 +156,7 @@ int ks_bv_set_active_columns(ks_bv bv, int l, int k);                           
 int ks_bv_get_active_columns(ks_bv bv, int *l, int *k);
 int ks_bv_set_orthogonalization(ks_bv bv, int type, int refine, double eta);        /* BVSetOrthogonalization; eta<=0 keeps 0.7071 */
 int ks_bv_get_array(ks_bv bv, double **dev);                                        /* ops->getarray: device pointer of the m*ld block */
-int ks_bv_get_column(ks_bv bv, int j, double **dev);                                /* ops->getcolumn: device pointer view of column j */
+int ks_bv_get_column(ks_bv bv, int j, double **dev);                                /* ops->getcolumn: device pointer view of column j (j<0: constraint) */
 int ks_bv_get_buffer(ks_bv bv, double **dev);                                       /* BVGetBufferVec bvbasic.c:775: (nc+m)*m device doubles */
 int ks_bv_set_column_host(ks_bv bv, int j, const double *host);                     /* H2D of n_local doubles */
 int ks_bv_get_column_host(ks_bv bv, int j, double *host);                           /* D2H, synchronises */
@@ -165,6 +165,10 @@ int ks_bv_resize(ks_bv bv, int m, int copy);                                    
 int ks_bv_set_random(ks_bv bv, uint64_t seed);                                   /* BVSetRandom bvops.c:380: all active columns */
 int ks_bv_insert_vec(ks_bv bv, int j, const double *w_dev);                      /* BVInsertVec bvops.c:568 */
 int ks_bv_copy_vec(ks_bv bv, int j, double *w_dev);                              /* BVCopyVec bvops.c:484 */
+int ks_bv_insert_vecs(ks_bv bv, int s, int *m, const double *const *W_dev, int orth); /* BVInsertVecs bvfunc.c:331: *m device vectors into columns s..; orth drops dependent ones, *m = kept */
+int ks_bv_insert_constraints(ks_bv bv, int *nc, const double *const *C_dev);     /* BVInsertConstraints bvfunc.c:411: destructive; *nc = kept; constraints are columns -nc..-1 */
+int ks_bv_set_num_constraints(ks_bv bv, int nc);                                 /* BVSetNumConstraints bvbasic.c:260 */
+int ks_bv_get_num_constraints(ks_bv bv, int *nc);                                /* BVGetNumConstraints bvbasic.c:310 */
 int ks_bv_set_random_column(ks_bv bv, int j, uint64_t seed);                        /* BVSetRandomColumn with -bv_reproducible_random semantics */
 
 int ks_bv_mult(ks_bv Y, double alpha, double beta, ks_bv X, const double *Q, int ldq);          /* ops->mult; Q NULL -> Y=beta*Y+alpha*X */
@@ -229,6 +233,7 @@ int ks_eps_set_convergence_test(ks_eps eps, int conv);                    /* EPS
 int ks_eps_set_krylovschur_locking(ks_eps eps, int lock);               /* EPSKrylovSchurSetLocking: 0 = non-locking variant (krylovschur.c:294) */
 int ks_eps_set_random_seed(ks_eps eps, uint64_t seed);
 int ks_eps_set_initial_vector(ks_eps eps, const double *v_host);           /* EPSSetInitialSpace with one vector */
+int ks_eps_set_deflation_space(ks_eps eps, int n, const double *const *v_dev); /* EPSSetDeflationSpace epssetup.c:555: n device vectors, copied; used by the next solve only */
 int ks_eps_set_max_steps(ks_eps eps, long long max_steps);                 /* bench harness: stop after this many Arnoldi steps (0 = off) */
 int ks_eps_solve(ks_eps eps);
 int ks_eps_get_converged(ks_eps eps, int *nconv);

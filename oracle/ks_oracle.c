@@ -46,7 +46,7 @@ typedef struct {
   int     n, N;          /* local/global rows (single rank in the oracle: n == N) */
   int     m;             /* number of columns */
   int     l, k;          /* leading / active columns */
-  int     nc;            /* constraints (always 0 here; kept so the buffer indexing reads like the reference) */
+  int     nc;            /* constraints: columns -nc..-1 of the storage (BVInsertConstraints bvfunc.c:411) */
   int     ld;            /* leading dimension */
   int     orthog_type, orthog_ref;
   double  orthog_eta;
@@ -542,6 +542,59 @@ int orc_bv_orthonormalizecolumn(orc_bv *bv,int j,double *norm,int *lindep)
   if (lindep) *lindep=lndep;
   return ORC_OK;
 }
+
+/* BVInsertVecs bvfunc.c:331-375: copy W(:,i) into columns s.., orthonormalising and dropping dependent ones */
+int orc_bv_insert_vecs(orc_bv *V,int s,int *m,const double *W,int ldw,int orth)
+{
+  int i,ndep=0,ierr;
+  if (!*m) return ORC_OK;
+  if (*m<0 || s<0 || s>=V->m || s+*m>V->m) return ORC_ERR_ARG;
+  for (i=0;i<*m;i++) {
+    double norm=0.0; int lindep=0;
+    memcpy(orc_bv_column(V,s+i-ndep),W+(size_t)i*ldw,(size_t)V->n*sizeof(double));
+    if (orth) {
+      if ((ierr=orc_bv_orthogonalizecolumn(V,s+i-ndep,NULL,&norm,&lindep))) return ierr;
+      if (norm==0.0 || lindep) ndep++;
+      else orc_scal(V->n,orc_bv_column(V,s+i-ndep),1.0/norm);
+    }
+  }
+  *m-=ndep;
+  return ORC_OK;
+}
+
+/* BVInsertConstraints bvfunc.c:411-439: destructive; the storage grows to nc+m columns (BVResize without copy),
+   the vectors are orthonormalised into the leading columns, which then become columns -nc..-1 */
+int orc_bv_insert_constraints(orc_bv *V,int *nc,const double *C,int ldc)
+{
+  int msave=V->m,tot,ierr;
+  if (!*nc) return ORC_OK;
+  if (*nc<0 || V->nc) return ORC_ERR_ARG;
+  tot=*nc+msave;
+  free(V->array); free(V->buffer); free(V->h); free(V->c);
+  V->array=(double*)calloc((size_t)tot*V->ld,sizeof(double));
+  V->h=(double*)calloc(tot,sizeof(double)); V->c=(double*)calloc(tot,sizeof(double));
+  V->buffer=(double*)calloc((size_t)tot*tot,sizeof(double));
+  V->m=tot; V->l=0; V->k=tot;
+  ierr=orc_bv_insert_vecs(V,0,nc,C,ldc,1);
+  V->nc=*nc; V->m=msave; V->l=0; V->k=msave;
+  free(V->buffer); V->buffer=(double*)calloc((size_t)(V->nc+V->m)*V->m,sizeof(double));   /* BVGetBufferVec bvbasic.c:775-791: (nc+m)*m */
+  return ierr;
+}
+
+/* BVSetNumConstraints bvbasic.c:260-294 (only lessening is used: EPSSolve drops the deflation space, epssolve.c:201-205) */
+int orc_bv_set_num_constraints(orc_bv *V,int nc)
+{
+  int total=V->nc+V->m,diff=nc-V->nc,i;
+  if (nc<0 || total-nc<=0) return ORC_ERR_ARG;
+  if (!diff) return ORC_OK;
+  if (diff<0) for (i=0;i<V->m;i++) memcpy(orc_bv_column(V,i+diff),orc_bv_column(V,i),(size_t)V->n*sizeof(double));
+  V->nc=nc; V->m=total-nc;
+  if (V->l>V->m) V->l=V->m;
+  if (V->k>V->m) V->k=V->m;
+  free(V->buffer); V->buffer=(double*)calloc((size_t)total*V->m,sizeof(double));
+  return ORC_OK;
+}
+int orc_bv_get_num_constraints(const orc_bv *V) { return V->nc; }
 
 /* BV_OrthogonalizeColumn_Safe bvimpl.h:452-465 */
 static int orc_orthogonalizecolumn_safe(orc_bv *bv,int j,double *norm,int *lindep)

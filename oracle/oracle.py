@@ -75,6 +75,10 @@ def _load(name):
         "orc_bv_orthonormalizecolumn": (C.c_int, [vp, C.c_int, _dp, _ip]),
         "orc_bv_matarnoldi": (C.c_int, [vp, vp, _dp, C.c_int, C.c_int, _ip, _dp, _ip]),
         "orc_bv_matlanczos": (C.c_int, [vp, vp, _dp, C.c_int, C.c_int, _ip, _dp, _ip]),
+        "orc_bv_insert_vecs": (C.c_int, [vp, C.c_int, _ip, _dp, C.c_int, C.c_int]),
+        "orc_bv_insert_constraints": (C.c_int, [vp, _ip, _dp, C.c_int]),
+        "orc_bv_set_num_constraints": (C.c_int, [vp, C.c_int]),
+        "orc_bv_get_num_constraints": (C.c_int, [vp]),
         "orc_num_threads": (C.c_int, []),
         "orc_laplacian3d_nnz": (C.c_long, [C.c_int] * 5),
         "orc_laplacian3d_fill": (None, [C.c_int] * 5 + [_ip, _ip, _dp]),
@@ -213,10 +217,46 @@ class BV:
         self.n, self.m = n, m
         self.ld = self._lib.orc_bv_ld(self._h)
         self.l, self.k = 0, m
+        self.nc = 0
+        self._remap()
+
+    def _remap(self):
+        """numpy views of the storage: `array` = the regular columns (ld, m), `constraints` = columns -nc..-1,
+        `buffer` = the (nc+m, m) coefficient buffer, all column-major."""
+        m, nc, ld = self.m, self.nc, self.ld
         arr = self._lib.orc_bv_array(self._h)
-        self.array = np.ctypeslib.as_array(arr, shape=(m * self.ld,)).reshape(m, self.ld).T  # (ld, m) view, col-major
+        full = np.ctypeslib.as_array(arr, shape=((nc + m) * ld,)).reshape(nc + m, ld).T
+        self.constraints = full[:, :nc]
+        self.array = full[:, nc:]
         buf = self._lib.orc_bv_buffer(self._h)
-        self.buffer = np.ctypeslib.as_array(buf, shape=(m * m,)).reshape(m, m).T              # (m, m) view, col-major
+        self.buffer = np.ctypeslib.as_array(buf, shape=((nc + m) * m,)).reshape(m, nc + m).T
+
+    def constraints_dense(self):
+        return np.array(self.constraints[: self.n, :])
+
+    def InsertVecs(self, s, W, orth=True):
+        """BVInsertVecs(V,s,&m,W,orth): returns the number of vectors kept."""
+        Wf = np.asfortranarray(W, dtype=np.float64)
+        m = np.array([Wf.shape[1]], np.int32)
+        _chk(self._lib.orc_bv_insert_vecs(self._h, s, _pi(m), _p(Wf), Wf.shape[0], int(bool(orth))))
+        return int(m[0])
+
+    def InsertConstraints(self, Cmat):
+        """BVInsertConstraints(V,&nc,C) with the vectors as the columns of Cmat: returns the number kept."""
+        Cf = np.asfortranarray(Cmat, dtype=np.float64)
+        nc = np.array([Cf.shape[1]], np.int32)
+        _chk(self._lib.orc_bv_insert_constraints(self._h, _pi(nc), _p(Cf), Cf.shape[0]))
+        self.nc = int(nc[0])
+        self.l, self.k = 0, self.m
+        self._remap()
+        return self.nc
+
+    def SetNumConstraints(self, nc):
+        _chk(self._lib.orc_bv_set_num_constraints(self._h, nc))
+        self.m = self.nc + self.m - nc
+        self.nc = nc
+        self.l, self.k = min(self.l, self.m), min(self.k, self.m)
+        self._remap()
 
     def __del__(self):
         try:
@@ -434,7 +474,7 @@ class BV:
                 m = j + 1
                 break
         for j in range(k, m):
-            T[j, 0] = self.buffer[j, j + 1]; T[j, 1] = self.buffer[j + 1, j + 1]
+            T[j, 0] = self.buffer[self.nc + j, j + 1]; T[j, 1] = self.buffer[self.nc + j + 1, j + 1]
         return m, beta, brk
 
     def MatArnoldiOp(self, op, H, k, m):
@@ -447,10 +487,10 @@ class BV:
                 m = j + 1
                 break
         for j in range(k, m - 1):
-            H[: j + 2, j] = self.buffer[: j + 2, j + 1]
-        H[:m, m - 1] = self.buffer[:m, m]
+            H[: j + 2, j] = self.buffer[self.nc: self.nc + j + 2, j + 1]
+        H[:m, m - 1] = self.buffer[self.nc: self.nc + m, m]
         if H.shape[0] > m:
-            H[m, m - 1] = self.buffer[m, m]
+            H[m, m - 1] = self.buffer[self.nc + m, m]
         return m, beta, brk
 
 
@@ -684,7 +724,7 @@ class EPSResult:
 
 def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which="largest_magnitude",
                         keep=0.5, seed=0x12345678, omp=False, v0=None, orthog=(CGS, REFINE_IFNEEDED, 0.7071),
-                        max_steps=None, monitor=None, lock=True, st=None, B=None, conv="rel"):
+                        max_steps=None, monitor=None, lock=True, st=None, B=None, conv="rel", deflation=None):
     """EPSSolve for a symmetric problem with the default Krylov-Schur solver: standard (HEP), or generalized (GHEP,
     B given: the basis carries the B-inner product, EPS_SetInnerProduct epsimpl.h:280-292; the start vector goes
     through the operator, epssolve.c:860-868; the eigenvectors are purified and B-normalised,
@@ -721,6 +761,8 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
     V.SetOrthogonalization(*orthog)
     if B is not None:
         V.SetMatrix(B)
+    if deflation is not None:                                # EPSSetDeflationSpace -> BVInsertConstraints (epssetup.c:397-404)
+        V.InsertConstraints(deflation)
     ds = DSHEP(ncv + 1, ds_compare)
     eigr = np.zeros(ncv + 1); errest = np.zeros(ncv + 1)
 

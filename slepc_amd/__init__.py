@@ -336,10 +336,49 @@ class BV:
             self.set_column(j, X[:, j])
 
     def buffer(self):
-        """(m x m) coefficient buffer, column 0 = scratch, column j = H(:,j)  (BVGetBufferVec)."""
-        b = np.empty(self.m * self.m)
+        """(nc+m x m) coefficient buffer, column 0 = scratch, column j = H(:,j)  (BVGetBufferVec)."""
+        rows = self.nc + self.m
+        b = np.empty(rows * self.m)
         _lib.check(self.ctx.L.ks_bv_get_buffer_host(self.h, _p(b)))
-        return b.reshape(self.m, self.m).T.copy()
+        return b.reshape(self.m, rows).T.copy()
+
+    @property
+    def nc(self):
+        v = C.c_int()
+        _lib.check(self.ctx.L.ks_bv_get_num_constraints(self.h, C.byref(v)))
+        return v.value
+
+    def _upload(self, W):
+        """Columns of a host matrix as device vectors (a scratch BV keeps them alive): (holder, pointer array)."""
+        W = np.asarray(W, dtype=np.float64)
+        tmp = BV(self.ctx, self.n, max(W.shape[1], 1), N=self.N)
+        tmp.set_dense(W)
+        ptrs = (C.c_void_p * W.shape[1])(*[tmp.column_ptr(j) for j in range(W.shape[1])])
+        return tmp, ptrs
+
+    def InsertVecs(self, s, W, orth=True):
+        """BVInsertVecs(V,s,&m,W,orth) with the vectors given as the columns of a host matrix: returns the number kept."""
+        tmp, ptrs = self._upload(W)
+        m = C.c_int(len(ptrs))
+        _lib.check(self.ctx.L.ks_bv_insert_vecs(self.h, s, C.byref(m), ptrs, int(bool(orth))))
+        return m.value
+
+    def InsertConstraints(self, Cmat):
+        """BVInsertConstraints(V,&nc,C): destructive; returns the number of independent constraints kept."""
+        tmp, ptrs = self._upload(Cmat)
+        nc = C.c_int(len(ptrs))
+        _lib.check(self.ctx.L.ks_bv_insert_constraints(self.h, C.byref(nc), ptrs))
+        return nc.value
+
+    def SetNumConstraints(self, nc):
+        _lib.check(self.ctx.L.ks_bv_set_num_constraints(self.h, nc))
+        mm = C.c_int()
+        _lib.check(self.ctx.L.ks_bv_get_sizes(self.h, None, None, C.byref(mm), None))
+        self.m = mm.value
+
+    def constraints_dense(self):
+        nc = self.nc
+        return np.stack([self.column(j) for j in range(-nc, 0)], axis=1) if nc else np.zeros((self.n, 0))
 
     def SetRandomColumn(self, j, seed=0x12345678):
         _lib.check(self.ctx.L.ks_bv_set_random_column(self.h, j, seed))
@@ -631,6 +670,16 @@ class EPS:
 
     def SetInitialVector(self, v):
         _lib.check(self.ctx.L.ks_eps_set_initial_vector(self.h, _p(_f64(v)) if v is not None else None))
+
+    def SetDeflationSpace(self, Cmat):
+        """EPSSetDeflationSpace with the vectors given as the columns of a host matrix (local rows of this rank)."""
+        Cmat = np.asarray(Cmat, dtype=np.float64)
+        if Cmat.size == 0:
+            _lib.check(self.ctx.L.ks_eps_set_deflation_space(self.h, 0, None)); return
+        tmp = BV(self.ctx, Cmat.shape[0], Cmat.shape[1])
+        tmp.set_dense(Cmat)
+        ptrs = (C.c_void_p * Cmat.shape[1])(*[tmp.column_ptr(j) for j in range(Cmat.shape[1])])
+        _lib.check(self.ctx.L.ks_eps_set_deflation_space(self.h, Cmat.shape[1], ptrs))
 
     def SetMaxSteps(self, steps):
         _lib.check(self.ctx.L.ks_eps_set_max_steps(self.h, steps))

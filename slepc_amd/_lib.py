@@ -94,6 +94,10 @@ _SIG = {
     "ks_bv_resize": [vp, C.c_int, C.c_int],
     "ks_bv_set_random": [vp, C.c_uint64],
     "ks_bv_insert_vec": [vp, C.c_int, vp],
+    "ks_bv_insert_vecs": [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_int],
+    "ks_bv_insert_constraints": [vp, C.POINTER(C.c_int), C.POINTER(C.c_void_p)],
+    "ks_bv_set_num_constraints": [vp, C.c_int],
+    "ks_bv_get_num_constraints": [vp, C.POINTER(C.c_int)],
     "ks_bv_copy_vec": [vp, C.c_int, vp],
     "ks_bv_set_orthog_block": [vp, C.c_int],
     "ks_bv_set_matrix": [vp, vp],
@@ -118,6 +122,7 @@ _SIG = {
     "ks_eps_set_krylovschur_restart": [vp, C.c_double],
     "ks_eps_set_random_seed": [vp, C.c_uint64],
     "ks_eps_set_initial_vector": [vp, dp],
+    "ks_eps_set_deflation_space": [vp, C.c_int, C.POINTER(C.c_void_p)],
     "ks_eps_set_max_steps": [vp, C.c_longlong],
     "ks_eps_solve": [vp],
     "ks_eps_get_converged": [vp, ip],

@@ -265,6 +265,7 @@ extern "C" int ks_bv_resize(ks_bv bv, int m, int copy)
   KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
   KS_CHECK(m > 0, KS_ERR_ARG_OUTOFRANGE, "Number of columns %d must be positive", m);
   if (m == bv->m) return KS_SUCCESS;
+  KS_CHECK(!bv->nc, KS_ERR_ARG_WRONGSTATE, "Cannot resize a BV with constraints");                    // bvbasic.c:350
   ks_bv nb = nullptr;
   KS_CALL(ks_bv_create(bv->ctx, bv->n, bv->N, m, bv->ld, &nb));
   if (copy) {
@@ -303,6 +304,67 @@ extern "C" int ks_bv_copy_vec(ks_bv bv, int j, double *w_dev)
   KS_HIP(hipSetDevice(bv->ctx->device));
   return ksk_copy(bv->ctx, ks_bv_col(bv, j), w_dev, bv->n);
 }
+
+// BVInsertVecs bvfunc.c:331-375: copy the device vectors W[0..*m) into columns s.., one at a time; with orth each is
+// orthogonalised against everything before it (constraints included), normalised, or dropped when dependent.
+extern "C" int ks_bv_insert_vecs(ks_bv bv, int s, int *m, const double *const *W_dev, int orth)
+{
+  KS_CHECK(bv && m, KS_ERR_ARG_NULL, "NULL argument");
+  if (!*m) return KS_SUCCESS;
+  KS_CHECK(*m > 0, KS_ERR_ARG_OUTOFRANGE, "Number of vectors (given %d) cannot be negative", *m);
+  KS_CHECK(W_dev, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(s >= 0 && s < bv->m, KS_ERR_ARG_OUTOFRANGE, "Argument s has wrong value %d, should be between 0 and %d", s, bv->m - 1);
+  KS_CHECK(s + *m <= bv->m, KS_ERR_ARG_OUTOFRANGE, "Too many vectors provided, there is only room for %d", bv->m);
+  KS_HIP(hipSetDevice(bv->ctx->device));
+  int ndep = 0;
+  for (int i = 0; i < *m; i++) {
+    KS_CHECK(W_dev[i], KS_ERR_ARG_NULL, "vector %d is NULL", i);
+    KS_CALL(ksk_copy(bv->ctx, W_dev[i], ks_bv_col(bv, s + i - ndep), bv->n));
+    if (orth) {
+      double norm = 0.0; int lindep = 0;
+      KS_CALL(ks_bv_orthogonalizecolumn(bv, s + i - ndep, nullptr, &norm, &lindep));
+      if (norm == 0.0 || lindep) ndep++;                                             // "Removing linearly dependent vector"
+      else KS_CALL(ks_bv_scalecolumn(bv, s + i - ndep, 1.0 / norm));
+    }
+  }
+  *m -= ndep;
+  return KS_SUCCESS;
+}
+
+// BVInsertConstraints bvfunc.c:411-439. DESTRUCTIVE: the storage is re-created with *nc + m columns (BVResize without
+// copy), the vectors are orthonormalised into its leading columns, which from then on are columns -nc..-1: every
+// Gram-Schmidt sweep starts there, everything else keeps addressing the m regular columns.
+extern "C" int ks_bv_insert_constraints(ks_bv bv, int *nc, const double *const *C_dev)
+{
+  KS_CHECK(bv && nc, KS_ERR_ARG_NULL, "NULL argument");
+  if (!*nc) return KS_SUCCESS;
+  KS_CHECK(*nc > 0, KS_ERR_ARG_OUTOFRANGE, "Number of constraints (given %d) cannot be negative", *nc);
+  KS_CHECK(C_dev, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(!bv->nc, KS_ERR_ARG_WRONGSTATE, "Constraints already present in this BV object");
+  const int msave = bv->m;
+  KS_CALL(ks_bv_resize(bv, *nc + msave, 0));
+  int rc = ks_bv_insert_vecs(bv, 0, nc, C_dev, 1);
+  if (rc) { ks_bv_resize(bv, msave, 0); return rc; }
+  bv->nc = *nc; bv->m = msave; bv->l = 0; bv->k = msave;
+  return KS_SUCCESS;
+}
+
+// BVSetNumConstraints bvbasic.c:260-294: fewer constraints shift the regular columns down and turn the freed ones
+// into regular columns at the end (EPSSolve drops its deflation space this way, epssolve.c:201-205)
+extern "C" int ks_bv_set_num_constraints(ks_bv bv, int nc)
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  KS_CHECK(nc >= 0, KS_ERR_ARG_OUTOFRANGE, "Number of constraints (given %d) cannot be negative", nc);
+  const int diff = nc - bv->nc, total = bv->nc + bv->m;
+  if (!diff) return KS_SUCCESS;
+  KS_CHECK(total - nc > 0, KS_ERR_ARG_OUTOFRANGE, "Not enough columns for the given nc value");
+  KS_HIP(hipSetDevice(bv->ctx->device));
+  if (diff < 0) for (int i = 0; i < bv->m; i++) KS_CALL(ksk_copy(bv->ctx, ks_bv_col(bv, i), ks_bv_col(bv, i + diff), bv->n));
+  bv->nc = nc; bv->m = total - nc;
+  bv->l = std::min(bv->l, bv->m); bv->k = std::min(bv->k, bv->m);
+  return KS_SUCCESS;
+}
+extern "C" int ks_bv_get_num_constraints(ks_bv bv, int *nc) { KS_CHECK(bv && nc, KS_ERR_ARG_NULL, "NULL argument"); *nc = bv->nc; return KS_SUCCESS; }
 
 extern "C" int ks_bv_duplicate(ks_bv bv, ks_bv *out)
 {
@@ -361,7 +423,8 @@ extern "C" int ks_bv_get_buffer(ks_bv bv, double **dev) { KS_CHECK(bv && dev, KS
 extern "C" int ks_bv_get_column(ks_bv bv, int j, double **dev)
 {
   KS_CHECK(bv && dev, KS_ERR_ARG_NULL, "NULL argument");
-  KS_CHECK(j >= 0 && j < bv->m, KS_ERR_ARG_OUTOFRANGE, "You requested column %d but only columns 0 to %d are available", j, bv->m - 1);
+  KS_CHECK(j < bv->m, KS_ERR_ARG_OUTOFRANGE, "You requested column %d but only columns 0 to %d are available", j, bv->m - 1);
+  KS_CHECK(j >= -bv->nc, KS_ERR_ARG_OUTOFRANGE, "You requested constraint %d but only %d are available", -j, bv->nc);       // bvbasic.c BVGetColumn: negative = constraint
   *dev = ks_bv_col(bv, j);
   return KS_SUCCESS;
 }
@@ -379,7 +442,7 @@ extern "C" int ks_bv_set_column_host(ks_bv bv, int j, const double *host)
 extern "C" int ks_bv_get_column_host(ks_bv bv, int j, double *host)
 {
   KS_CHECK(bv && host, KS_ERR_ARG_NULL, "NULL argument");
-  KS_CHECK(j >= 0 && j < bv->m, KS_ERR_ARG_OUTOFRANGE, "column %d out of range", j);
+  KS_CHECK(j >= -bv->nc && j < bv->m, KS_ERR_ARG_OUTOFRANGE, "column %d out of range", j);
   KS_HIP(hipSetDevice(bv->ctx->device));
   KS_HIP(hipMemcpyAsync(host, ks_bv_col(bv, j), sizeof(double) * bv->n, hipMemcpyDeviceToHost, bv->ctx->stream));
   KS_HIP(hipStreamSynchronize(bv->ctx->stream));
@@ -390,7 +453,7 @@ extern "C" int ks_bv_get_buffer_host(ks_bv bv, double *host)
 {
   KS_CHECK(bv && host, KS_ERR_ARG_NULL, "NULL argument");
   KS_HIP(hipSetDevice(bv->ctx->device));
-  KS_HIP(hipMemcpyAsync(host, bv->buffer, sizeof(double) * bv->m * bv->m, hipMemcpyDeviceToHost, bv->ctx->stream));
+  KS_HIP(hipMemcpyAsync(host, bv->buffer, sizeof(double) * (bv->nc + bv->m) * bv->m, hipMemcpyDeviceToHost, bv->ctx->stream));
   KS_HIP(hipStreamSynchronize(bv->ctx->stream));
   return KS_SUCCESS;
 }

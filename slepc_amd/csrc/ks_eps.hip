@@ -336,6 +336,7 @@ struct ks_eps_s {
   double keep = 0.5; bool lock = true;   // EPSKrylovSchurSetRestart / SetLocking
   uint64_t seed = 0x12345678ULL;
   std::vector<double> v0; bool have_v0 = false;
+  ks_bv defl = nullptr; int nds = 0;       // deflation space handed over by EPSSetDeflationSpace, consumed by the next solve
   long long max_steps = 0;
   // results
   std::vector<double> eigr, eigi, errest; std::vector<int> perm;
@@ -357,7 +358,7 @@ extern "C" int ks_eps_create(ks_ctx ctx, ks_eps *out)
 extern "C" int ks_eps_destroy(ks_eps eps)
 {
   if (!eps) return KS_SUCCESS;
-  ks_bv_destroy(eps->V); ks_bv_destroy(eps->W);
+  ks_bv_destroy(eps->V); ks_bv_destroy(eps->W); ks_bv_destroy(eps->defl);
   ks_st_destroy(eps->st);
   delete eps;
   return KS_SUCCESS;
@@ -451,6 +452,21 @@ extern "C" int ks_eps_set_initial_vector(ks_eps eps, const double *v)
   KS_CHECK(eps && eps->A, KS_ERR_ORDER, "set the operators first");
   if (!v) { eps->have_v0 = false; return KS_SUCCESS; }
   eps->v0.assign(v, v + eps->A->n); eps->have_v0 = true;
+  return KS_SUCCESS;
+}
+// EPSSetDeflationSpace epssetup.c:555-570: the vectors are copied now and become constraints of the basis at the next
+// solve (BVInsertConstraints, epssetup.c:397-404), which also forgets them (epssolve.c:201-205): "the deflation space
+// should be set every time". They need not be orthonormal; dependent ones are dropped.
+extern "C" int ks_eps_set_deflation_space(ks_eps eps, int n, const double *const *v_dev)
+{
+  KS_CHECK(eps && eps->A, KS_ERR_ORDER, "set the operators first");
+  KS_CHECK(n >= 0, KS_ERR_ARG_OUTOFRANGE, "Argument n cannot be negative");
+  ks_bv_destroy(eps->defl); eps->defl = nullptr; eps->nds = 0;
+  if (!n) return KS_SUCCESS;
+  KS_CHECK(v_dev, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CALL(ks_bv_create(eps->ctx, eps->A->n, eps->A->n_global, n, 0, &eps->defl));
+  for (int i = 0; i < n; i++) { KS_CHECK(v_dev[i], KS_ERR_ARG_NULL, "vector %d is NULL", i); KS_CALL(ks_bv_insert_vec(eps->defl, i, v_dev[i])); }
+  eps->nds = n; eps->solved = false;
   return KS_SUCCESS;
 }
 extern "C" int ks_eps_set_max_steps(ks_eps eps, long long s) { KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL"); eps->max_steps = s > 0 ? s : 0; return KS_SUCCESS; }
@@ -595,6 +611,7 @@ static int solve_nhep(ks_eps eps, long long passes0)
   }
   long long passes1 = 0; ks_bv_gs_passes(V, &passes1, nullptr);
   eps->passes = passes1 - passes0;
+  KS_CALL(ks_bv_set_num_constraints(V, 0));                            // remove the deflation space (epssolve.c:201-205)
   eps->solved = true;
   return KS_SUCCESS;
 }
@@ -637,7 +654,7 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   KS_CHECK(ncv + 1 <= KS_MAX_COLS || getenv("KSGPU_NO_FUSED_GS"), KS_ERR_SUP, "ncv+1 = %d exceeds the %d columns supported by the fused kernels", ncv + 1, KS_MAX_COLS);
   eps->ncv = ncv; eps->mpd = mpd;
   eps->max_it = eps->max_it_user ? eps->max_it_user : std::max(100, 2 * n / ncv);
-  if (eps->V) { int vm = 0; ks_bv_get_sizes(eps->V, nullptr, nullptr, &vm, nullptr); if (vm != ncv + 1) { ks_bv_destroy(eps->V); eps->V = nullptr; } }
+  if (eps->V) { int vm = 0; ks_bv_get_sizes(eps->V, nullptr, nullptr, &vm, nullptr); if (vm != ncv + 1 || eps->V->nc) { ks_bv_destroy(eps->V); eps->V = nullptr; } }
   if (!eps->V) { KS_CALL(ks_bv_create(eps->ctx, A->n, A->n_global, ncv + 1, 0, &eps->V)); eps->V->row_start = A->row_start; }   // EPSAllocateSolution(eps,1)
   if (!eps->W) { KS_CALL(ks_bv_create(eps->ctx, A->n, A->n_global, 3, 0, &eps->W)); }
   eps->eigr.assign(ncv + 1, 0.0); eps->eigi.assign(ncv + 1, 0.0); eps->errest.assign(ncv + 1, 0.0);
@@ -650,6 +667,15 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   KS_CALL(ks_bv_set_active_columns(V, 0, ncv + 1));
   KS_CALL(ks_bv_set_matrix(V, ghep ? eps->B : nullptr));             // EPS_SetInnerProduct epsimpl.h:280-292 (STGetBilinearForm = B)
   eps->ghep = ghep;
+  if (eps->nds) {                                                      // process the deflation space (epssetup.c:397-404)
+    std::vector<const double *> cp(eps->nds);
+    for (int i = 0; i < eps->nds; i++) cp[i] = ks_bv_col(eps->defl, i);
+    int kd = eps->nds;
+    int rc = ks_bv_insert_constraints(V, &kd, cp.data());
+    ks_bv_destroy(eps->defl); eps->defl = nullptr; eps->nds = 0;
+    if (rc) return rc;
+    KS_CHECK(kd + ncv + 1 <= KS_MAX_COLS || getenv("KSGPU_NO_FUSED_GS"), KS_ERR_SUP, "constraints + ncv + 1 = %d exceeds the %d columns supported by the fused kernels", kd + ncv + 1, KS_MAX_COLS);
+  }
 
   if (ptype != KS_EPS_HEP && !ghep) return solve_nhep(eps, passes0);
   const bool isshift = !st || st->type == KS_ST_SHIFT;
@@ -738,6 +764,7 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   }
   long long passes1 = 0; ks_bv_gs_passes(V, &passes1, nullptr);
   eps->passes = passes1 - passes0;
+  KS_CALL(ks_bv_set_num_constraints(V, 0));                            // remove the deflation space (epssolve.c:201-205)
   eps->solved = true;
   return KS_SUCCESS;
 }

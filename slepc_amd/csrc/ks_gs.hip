@@ -28,7 +28,8 @@ using namespace ksk;
 namespace {
 
 struct GsArgs {
-  int k;           // column being orthogonalized (number of previous columns)
+  int k;           // number of previous columns: the nc constraints and the regular columns 0..col-1
+  int col;         // column being orthogonalized (index of its record and of its buffer column)
   int slot;        // 1..4 position in the launch sequence of this column
   int refine;      // KS_BV_ORTHOG_REFINE_*
   int normalize;   // BVOrthonormalizeColumn: scale by 1/nrm
@@ -44,7 +45,7 @@ __device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict_
 {
   const int k = a.k;
   int upd = 0, fuse = 0, scal = 0;
-  double *H = buffer + (size_t)k * a.ldb;        // H(:,k): buffer column k (bvbasic.c:784-786)
+  double *H = buffer + (size_t)a.col * a.ldb;    // H(:,col): buffer column col, entries nc+i (bvbasic.c:784-786)
   bool process = true, finalize = false, after_update = false;
   double nrm = st->nrm, onrm = st->onrm;
 
@@ -107,8 +108,8 @@ __device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict_
     const double alpha = (nrm != 1.0 && nrm != 0.0) ? 1.0 / nrm : 1.0;                                       // bvorthog.c:417-419
     st->alpha = alpha; st->lindep = lindep;
     if (a.normalize && alpha != 1.0) { if (after_update) st->pending_scale = 1; else scal = 1; }
-    KsStepRec r; r.nrm = nrm; r.onrm = onrm; r.passes = st->pass; r.lindep = lindep; r.expl = after_update ? 1 : 0; r.col = k;
-    recs[k] = r;
+    KsStepRec r; r.nrm = nrm; r.onrm = onrm; r.passes = st->pass; r.lindep = lindep; r.expl = after_update ? 1 : 0; r.col = a.col;
+    recs[a.col] = r;
     if (a.krylov && lindep) st->active = 0;          // bvkrylov.c:92-95: stop the expansion
     st->more_ = 0;
   }
@@ -123,7 +124,7 @@ __device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict_
   // Optimistic program: only the slots of the common case (two passes) are enqueued. If this column still needs
   // a pass or an explicit norm after them, stop every later kernel of the run and tell the host which column to
   // complete (the pending update itself still runs: it gates on do_update only).
-  if (a.spec_last && (st->more_ || st->expl)) { st->active = 0; st->halt_col = k; }
+  if (a.spec_last && (st->more_ || st->expl)) { st->active = 0; st->halt_col = a.col; }
 }
 
 // REDUCE: sum block partials -> c (LDS, and global scratch = buffer column 0).  BOOK: run the bookkeeping.
@@ -280,7 +281,7 @@ int launch_finish(ks_bv bv, const GsArgs &a)
   ks_ctx ctx = bv->ctx;
   const bool multi = ks_is_multi(ctx);
   KsProfScope ps(ctx, KS_K_GSFIN, 8.0 * bv->last_grid * (a.k + 1));
-  ps.tag(a.k, a.slot, a.k, bv->n);
+  ps.tag(a.col, a.slot, a.k, bv->n);
   if (!multi) hipLaunchKernelGGL((k_gs_finish<true, true>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, bv->last_grid, a, bv->buffer, bv->pend, bv->gs, bv->recs);
   else {
     hipLaunchKernelGGL((k_gs_finish<true, false>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, bv->last_grid, a, bv->buffer, bv->pend, bv->gs, bv->recs);
@@ -291,10 +292,11 @@ int launch_finish(ks_bv bv, const GsArgs &a)
   return KS_SUCCESS;
 }
 
-int launch_update(ks_bv bv, int k, double *v, int slot)
+int launch_update(ks_bv bv, int col, double *v, int slot)
 {
   ks_ctx ctx = bv->ctx;
-  const double *V = ks_bv_col(bv, 0);
+  const int k = bv->nc + col;
+  const double *V = ks_bv_col(bv, -bv->nc);      // constraints first, then the regular columns
   const bool v2 = (bv->ld % 2 == 0) && aligned16(V) && aligned16(v);
   int grid = 1;
   const int kk = std::max(k, 1);
@@ -306,7 +308,7 @@ int launch_update(ks_bv bv, int k, double *v, int slot)
   const int upd_per_cu = upd_env ? upd_env : (ntl >= 16LL * ctx->num_cu ? 1 : (ntl >= 8LL * ctx->num_cu ? 2 : 0));
   const int rev = (snake && (slot & 1)) ? 1 : 0;     // dot: forward, update 1: backward, update 2: forward, update 3: backward
   KsProfScope ps(ctx, KS_K_UPD_FUSED, 8.0 * bv->n * (k + 2), ks_kt_for(kk));
-  ps.tag(k, slot, k, bv->n);
+  ps.tag(col, slot, k, bv->n);
 #define LAUNCH_UPD(KT)                                                                                                                                 \
   do {                                                                                                                                                 \
     if (v2) { grid = ks_sweep_grid_for(ctx, bv->n, 2, (const void *)k_gs_update<KT, 2>, upd_per_cu); bv->last_grid = grid;                                                        \
@@ -331,7 +333,7 @@ int total_slots(ks_bv bv) { return bv->orthog_ref == KS_BV_ORTHOG_REFINE_IFNEEDE
 int enqueue_gs_slots(ks_bv bv, int j, int normalize, int krylov, int first, int last, bool halt_at_last, bool resolution_and_scale)
 {
   ks_ctx ctx = bv->ctx;
-  GsArgs a; a.k = j; a.refine = bv->orthog_ref; a.normalize = normalize; a.krylov = krylov; a.ldb = bv->nc + bv->m; a.eta = bv->orthog_eta; a.deftol = bv->deftol;
+  GsArgs a; a.k = bv->nc + j; a.col = j; a.refine = bv->orthog_ref; a.normalize = normalize; a.krylov = krylov; a.ldb = bv->nc + bv->m; a.eta = bv->orthog_eta; a.deftol = bv->deftol;
   double *v = ks_bv_col(bv, j);
   for (int p = first; p <= last; p++) {
     a.slot = p; a.spec_last = (halt_at_last && p == last) ? 1 : 0;
@@ -355,9 +357,9 @@ int enqueue_gs_slots(ks_bv bv, int j, int normalize, int krylov, int first, int 
 // Optimistic program of column j (against columns 0..j-1).
 int enqueue_fused_gs(ks_bv bv, int j, int normalize, int krylov)
 {
-  KS_CHECK(j + 1 <= KS_MAX_COLS, KS_ERR_SUP, "fused Gram-Schmidt supports at most %d columns", KS_MAX_COLS);
-  // h = V(:,0:j+1)^T v  (BVDotColumnInc bvorthog.c:32-47: k+1 dots including (v,v))
-  KS_CALL(ksk_dot(bv, ks_bv_col(bv, 0), bv->ld, j + 1, ks_bv_col(bv, j), krylov != 0));
+  KS_CHECK(bv->nc + j + 1 <= KS_MAX_COLS, KS_ERR_SUP, "fused Gram-Schmidt supports at most %d columns", KS_MAX_COLS);
+  // h = V(:,-nc:j+1)^T v  (BVDotColumnInc bvorthog.c:32-47 with l = -nc: nc+j+1 dots including (v,v))
+  KS_CALL(ksk_dot(bv, ks_bv_col(bv, -bv->nc), bv->ld, bv->nc + j + 1, ks_bv_col(bv, j), krylov != 0));
   const int ns = spec_slots(bv), nt = total_slots(bv);
   const bool whole = (ns >= nt) && bv->orthog_ref == KS_BV_ORTHOG_REFINE_NEVER;
   static const bool optimistic = !getenv("KSGPU_NO_OPTIMISTIC");
@@ -526,7 +528,7 @@ int store_buffer_column(ks_bv bv, int j, const double *hh, int len)
   return KS_SUCCESS;
 }
 
-bool use_fused(ks_bv bv) { return bv->orthog_type == KS_BV_ORTHOG_CGS && bv->m <= KS_MAX_COLS && !bv->matrix && !getenv("KSGPU_NO_FUSED_GS"); }   // B-inner products need B*v between the sweeps: host-driven passes
+bool use_fused(ks_bv bv) { return bv->orthog_type == KS_BV_ORTHOG_CGS && bv->nc + bv->m <= KS_MAX_COLS && !bv->matrix && !getenv("KSGPU_NO_FUSED_GS"); }   // B-inner products need B*v between the sweeps: host-driven passes
 
 // Orthogonalize column j; fused or generic. Returns norm/lindep on the host (synchronises).
 int orthogonalize_column(ks_bv bv, int j, int normalize, double *H, double *norm, int *lindep)

@@ -283,3 +283,46 @@ def bv_test12(be, block="gs", n=20, k=8):
     level = np.abs(M - np.eye(k)).sum(axis=0).max()                   # MatShift(-1); MatNorm(NORM_1)
     res = np.linalg.norm(X0 - X.dense() @ R)
     return {"level": level, "res": res, "R": R.copy()}
+
+
+def graph_laplacian_2d(n, m):
+    """eps/tests/test10.c:42-52: Laplacian of the n x m mesh graph (degree on the diagonal, -1 per edge), II = i*n + j."""
+    import scipy.sparse as sp
+    rows, cols, vals = [], [], []
+    for II in range(n * m):
+        i, j = divmod(II, n)
+        w = 0.0
+        for ok, JJ in ((i > 0, II - n), (i < m - 1, II + n), (j > 0, II - 1), (j < n - 1, II + 1)):
+            if ok:
+                rows.append(II); cols.append(JJ); vals.append(-1.0); w += 1.0
+        rows.append(II); cols.append(II); vals.append(w)
+    S = sp.csr_matrix((vals, (rows, cols)), shape=(n * m, n * m)); S.sort_indices()
+    return S
+
+
+def bv_test6(be, orthog_type=0, n=20, k=8, nc=2, refine=0):
+    """test6.c: BVInsertConstraints with nc staircase vectors, then the BVOrthogonalizeColumn loop on k columns;
+    level of orthogonality ||X'X - I||_1, plus what the program does not print: the columns against the constraints."""
+    X = be.bv(n, k)
+    X.SetOrthogonalization(orthog_type, refine, 0.7071)
+    Cm = np.zeros((n, nc))
+    for j in range(nc):
+        Cm[: j + 1, j] = 1.0
+    kept = X.InsertConstraints(Cm)
+    X0 = np.zeros((n, k))
+    for j in range(k):
+        for i in range(n // 2 + 1):
+            if i + j < n:
+                X0[i + j, j] = (3.0 * i + j - 2) / (2 * (i + j + 1))
+    be.fill(X, X0)
+    norms = []
+    for j in range(k):
+        _, norm, _ = X.OrthogonalizeColumn(j)
+        norms.append(norm)
+        X.ScaleColumn(j, 1.0 / norm)
+    M = np.zeros((k, k), order="F")
+    X.Dot(X, M)
+    Cq = np.array(X.constraints_dense())[:n]
+    Q = X.dense()[:n]
+    return {"kept": kept, "level": np.abs(M - np.eye(k)).sum(axis=0).max(), "norms": np.array(norms), "X": Q, "C": Cq,
+            "cross": np.abs(Cq.T @ Q).max(), "clevel": np.abs(Cq.T @ Cq - np.eye(kept)).max(), "buffer": np.array(X.buffer() if callable(X.buffer) else X.buffer)}

@@ -364,3 +364,41 @@ def test_eps_test2_three_solves_golden():
     r = O.eps_krylovschur_hep(A, 4, which="smallest_real"); assert np.allclose(np.round(r.eigr[r.perm][:4], 5), ref[1], atol=1.5e-5)
     r = O.eps_krylovschur_hep(A, 4, which=O.which_target_magnitude(2.1), st=O.ST(A, None, "sinvert", 2.1))
     assert np.allclose(np.round(r.eigr[r.perm][:4], 5), ref[2], atol=1.5e-5)
+
+
+@pytest.mark.parametrize("otype", [0, 1])
+def test_bv_test6_constraints_golden(be, otype):
+    """output/test6_1.out (suffix 1: CGS, suffix 3: -bv_orthog_type mgs): 8 columns + 2 constraints of length 20."""
+    txt = gi.read("bv/test6_1.out")
+    assert "8 columns + 2 constraints, of length 20" in txt and "Level of orthogonality < 100*eps" in txt
+    out = sc.bv_test6(be, otype)
+    eps = np.finfo(float).eps
+    assert out["kept"] == 2 and out["level"] < 100 * eps
+    assert out["cross"] < 100 * eps and out["clevel"] < 100 * eps      # deflated: X is orthogonal to the constraints too
+    # the constraints span e_0, e_1: every orthogonalised column has zeros there
+    assert np.abs(out["X"][:2, :]).max() < 100 * eps
+
+
+def test_bv_insert_constraints_drops_dependent_vectors(be):
+    X = be.bv(12, 4)
+    Cm = np.zeros((12, 3)); Cm[0, 0] = 2.0; Cm[0, 1] = -1.0; Cm[3, 2] = 1.0      # the second is a multiple of the first
+    assert X.InsertConstraints(Cm) == 2
+    Cq = X.constraints_dense()
+    assert np.allclose(np.abs(Cq[[0, 3], [0, 1]]), 1.0) and np.count_nonzero(Cq) == 2
+    X.set_column(0, np.ones(12))
+    _, nrm, lin = X.OrthogonalizeColumn(0)
+    assert not lin and abs(nrm - np.sqrt(10.0)) < 1e-14
+    X.SetNumConstraints(0)                                               # constraints discarded, regular columns keep their index
+    assert X.m == 6 and X.nc == 0 and np.allclose(X.dense()[:, 0], np.r_[0.0, 1, 1, 0, np.ones(8)])
+
+
+def test_eps_test10_deflation_golden():
+    """test10 -eps_nev 4 -m 11: graph Laplacian of the 10x11 mesh with the constant null vector deflated
+    (EPSSetDeflationSpace) -> 0.08101, 0.09789, 0.17890, 0.31749."""
+    S = sc.graph_laplacian_2d(10, 11)
+    A = O.CSR(S.shape[0], S.indptr, S.indices, S.data)
+    r = O.eps_krylovschur_hep(A, 4, which="smallest_real", max_it=500, deflation=np.ones((A.n, 1)))
+    assert r.nconv >= 4
+    assert np.allclose(np.round(r.eigr[r.perm][:4], 5), gi.eigenvalues_line(gi.read("eps/eps_test10_1.out")), atol=1.5e-5)
+    lam = np.linalg.eigvalsh(S.toarray())
+    assert abs(lam[0]) < 1e-12 and np.allclose(np.sort(r.eigr[r.perm][:4]), lam[1:5], rtol=1e-7)
