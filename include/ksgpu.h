@@ -81,6 +81,7 @@ typedef int (*ks_eig_compare_fn)(double ar, double ai, double br, double bi, int
 enum { KS_EPS_HEP = 1, KS_EPS_GHEP = 2, KS_EPS_NHEP = 3, KS_EPS_GNHEP = 4 };   /* EPSProblemType, slepceps.h */
 enum { KS_ST_SHIFT = 0, KS_ST_SINVERT = 1 };                 /* STType "shift", "sinvert" */
 enum { KS_EPS_ERROR_ABSOLUTE = 0, KS_EPS_ERROR_RELATIVE = 1, KS_EPS_ERROR_BACKWARD = 2 };   /* EPSErrorType */
+enum { KS_EPS_RITZ = 0, KS_EPS_HARMONIC = 1, KS_EPS_HARMONIC_RELATIVE, KS_EPS_HARMONIC_RIGHT, KS_EPS_HARMONIC_LARGEST, KS_EPS_REFINED, KS_EPS_REFINED_HARMONIC };  /* EPSExtraction slepceps.h:94-100; Krylov-Schur offers the first two */
 enum { KS_EPS_CONV_ABS = 0, KS_EPS_CONV_REL = 1, KS_EPS_CONV_NORM = 2 };                       /* EPSConv (EPS_CONV_USER not offered) */
 enum { KS_EPS_CONVERGED_TOL = 1, KS_EPS_CONVERGED_USER = 2, KS_EPS_DIVERGED_ITS = -1, KS_EPS_DIVERGED_BREAKDOWN = -2,
        KS_EPS_DIVERGED_SYMMETRY_LOST = -3, KS_EPS_CONVERGED_ITERATING = 0 };
@@ -253,6 +254,8 @@ int ks_eps_get_tolerances(ks_eps eps, double *tol, int *max_it);
 int ks_eps_get_which_eigenpairs(ks_eps eps, int *which);
 int ks_eps_get_target(ks_eps eps, double *target);
 int ks_eps_get_convergence_test(ks_eps eps, int *conv);
+int ks_eps_set_extraction(ks_eps eps, int extr);                          /* EPSSetExtraction epsopts.c:968: KS_EPS_RITZ | KS_EPS_HARMONIC (target = EPSSetTarget) */
+int ks_eps_get_extraction(ks_eps eps, int *extr);
 int ks_eps_get_operators(ks_eps eps, ks_mat *A, ks_mat *B);
 int ks_eps_get_problem_type(ks_eps eps, int *type, int *generalized, int *hermitian, int *positive);
 int ks_eps_get_bv(ks_eps eps, ks_bv *V);

@@ -957,6 +957,32 @@ class DSNHEP:
     def SetState(self, st):
         self.state = st
 
+    def TranslateHarmonic(self, tau, beta, recover, g):
+        """DSTranslateHarmonic_NHEP dsnhep.c:466-537. g: array of ld entries, kept by the caller between the two calls.
+        Forward: g = (A - tau I)^{-T} (beta e_n), A(:,n-1) += beta g. Recover (after solve/sort, with ds.l = nconv and
+        ds.k = number of kept vectors): the rank-one update is undone on the kept block. Returns gamma = sqrt(1+|g|^2)."""
+        import scipy.linalg as sl
+        n, A = self.n, self.A
+        if not recover:
+            g[:] = 0.0; g[n - 1] = beta
+            Bm = np.array(A[:n, :n], order="F"); Bm[np.arange(n), np.arange(n)] -= tau
+            lu = sl.lu_factor(Bm, check_finite=False)                       # LAPACKgetrf
+            g[:n] = sl.lu_solve(lu, g[:n], trans=1, check_finite=False)     # LAPACKgetrs 'C'
+            A[:n, n - 1] += g[:n] * beta
+        else:
+            Q = self.Q
+            ncol = self.l + self.k
+            ghat = -(Q[:n, :ncol].T @ g[:n])                                # BLASgemv 'C'
+            for i in range(ncol):
+                for j in range(self.l, ncol):
+                    A[i, j] += ghat[i] * Q[n - 1, j] * beta
+            g[:n] = g[:n] + Q[:n, :ncol] @ ghat
+        gamma = float(np.hypot(1.0, np.linalg.norm(g[:n])))
+        if recover:                                                         # ds->extrarow
+            for j in range(self.l, self.l + self.k):
+                A[n, j] *= gamma
+        return gamma
+
     def _eig_from_T(self, wr, wi, j0, j1):
         """recover eigenvalues of the diagonal blocks j0..j1-1 of the quasi-triangular A (dsutil.c:65-79,160-170)"""
         A, n = self.A, self.n
@@ -1123,13 +1149,16 @@ class ST:
 
 
 def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which="largest_magnitude", keep=0.5,
-                         seed=0x12345678, v0=None, max_steps=None, st=None, lock=True, conv="rel", B=None):
+                         seed=0x12345678, v0=None, max_steps=None, st=None, lock=True, conv="rel", B=None, harmonic=None):
     """EPSSolve_KrylovSchur_Default with the Arnoldi expansion (krylovschur.c:227-337, non-Hermitian branch),
     EPSKrylovConvergence for conjugate pairs (epskrylov.c:262-287), EPSComputeVectors_Schur (epsdefault.c:105-169).
     With st (an ST): the Krylov operator is st.apply, the DS sorts through the back-transformation
     (EPSSetUpSort_Default epssetup.c:222-240, SlepcSCCompare slepcsc.c:41-62), convergence is tested on the
     transformed eigenvalue except for STSHIFT (epskrylov.c:253), and EPSComputeValues maps the eigenvalues back
-    (epssolve.c:27-41) before the conjugate-pair fix-up and the final sort (epssolve.c:160-178)."""
+    (epssolve.c:27-41) before the conjugate-pair fix-up and the final sort (epssolve.c:160-178).
+    harmonic: the target tau of EPSSetExtraction(EPS_HARMONIC) - the Krylov decomposition is translated before the
+    projected solve and translated back before the restart (krylovschur.c:270-271,310-320); a symmetric problem takes
+    this same path (variant EPS_KS_DEFAULT, krylovschur.c:139)."""
     n = A.n
     if ncv is None:
         ncv = min(n, nev + mpd) if mpd is not None else (min(n, max(2 * nev, nev + 15)) if nev < 500 else min(n, nev + 500))
@@ -1149,6 +1178,7 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
     V = BV(n, ncv + 1)
     ds = DSNHEP(ncv + 1, ds_compare)
     eigr = np.zeros(ncv + 1); eigi = np.zeros(ncv + 1); errest = np.zeros(ncv + 1)
+    gh = np.zeros(ncv + 1)
 
     def start_vector(i):
         if v0 is not None and i == 0:
@@ -1180,6 +1210,9 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
         ds.SetDimensions(nv, nconv, nconv + l)
         ds.SetState(DS_STATE_RAW if l else DS_STATE_INTERMEDIATE)
         V.SetActiveColumns(nconv, nv)
+        gamma = 1.0
+        if harmonic is not None:
+            gamma = ds.TranslateHarmonic(harmonic, beta, False, gh)
         ds.Solve(eigr, eigi)
         ds.Sort(eigr, eigi)
         ds.UpdateExtraRow()
@@ -1191,7 +1224,7 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
             if st is not None and (st.kind == "shift" or conv == "norm"):
                 re, im = st.backtransform(re, im)
             newk, resnorm = ds.Vectors(k)
-            resnorm *= beta
+            resnorm *= beta * gamma
             errest[k] = _converged(conv, re, im, resnorm, nrma, nrmb)
             if marker == -1 and errest[k] >= tol:
                 marker = k
@@ -1219,6 +1252,14 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
                 if k < nev and start_vector(k):
                     reason = -2
             else:
+                if harmonic is not None:                   # undo the translation (krylovschur.c:310-320)
+                    ds.SetDimensions(nv, k, l)
+                    gamma = ds.TranslateHarmonic(0.0, beta, True, gh)
+                    V.SetActiveColumns(0, nv)               # gamma u^ = u - U g~
+                    V.MultColumn(-1.0, 1.0, nv, gh[:nv].copy())
+                    V.ScaleColumn(nv, 1.0 / gamma)
+                    V.SetActiveColumns(nconv, nv)
+                    ds.SetDimensions(nv, k, nv)
                 ds.Truncate(k + l, False)
         V.MultInPlace(ds.Qmat(), nconv, k + l)
         if reason == 0 and not breakdown:

@@ -671,6 +671,13 @@ class EPS:
     def SetInitialVector(self, v):
         _lib.check(self.ctx.L.ks_eps_set_initial_vector(self.h, _p(_f64(v)) if v is not None else None))
 
+    def SetExtraction(self, extr):
+        """EPSSetExtraction: "ritz" or "harmonic" (target from SetTarget)."""
+        _lib.check(self.ctx.L.ks_eps_set_extraction(self.h, {"ritz": 0, "harmonic": 1}.get(extr, extr)))
+
+    def GetExtraction(self):
+        v = C.c_int(); _lib.check(self.ctx.L.ks_eps_get_extraction(self.h, C.byref(v))); return v.value
+
     def SetDeflationSpace(self, Cmat):
         """EPSSetDeflationSpace with the vectors given as the columns of a host matrix (local rows of this rank)."""
         Cmat = np.asarray(Cmat, dtype=np.float64)

@@ -7,6 +7,7 @@
 #include <complex>
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 namespace ksd {
 
@@ -506,6 +507,39 @@ void tsqr_combine(int n, double *R1, int ld1, double *R2, int ld2)
     }
 }
 
+// P A = L U with row interchanges (unblocked right-looking dgetf2), then A^T x = b as U^T y = b, L^T z = y, x = P^T z
+int lu_solve_trans(int n, double *A, int ld, double *b)
+{
+  std::vector<int> piv(n);
+  int info = 0;
+  for (int j = 0; j < n; j++) {
+    int p = j; double mx = fabs(A[j + (size_t)j * ld]);
+    for (int i = j + 1; i < n; i++) { const double v = fabs(A[i + (size_t)j * ld]); if (v > mx) { mx = v; p = i; } }
+    piv[j] = p;
+    if (mx == 0.0) { if (!info) info = j + 1; continue; }
+    if (p != j) for (int c = 0; c < n; c++) std::swap(A[j + (size_t)c * ld], A[p + (size_t)c * ld]);
+    const double d = 1.0 / A[j + (size_t)j * ld];
+    for (int i = j + 1; i < n; i++) A[i + (size_t)j * ld] *= d;
+    for (int c = j + 1; c < n; c++) {
+      const double u = A[j + (size_t)c * ld];
+      if (u != 0.0) for (int i = j + 1; i < n; i++) A[i + (size_t)c * ld] -= A[i + (size_t)j * ld] * u;
+    }
+  }
+  if (info) return info;
+  for (int i = 0; i < n; i++) {                       // U^T y = b: forward substitution over the columns of U
+    double s = b[i];
+    for (int r = 0; r < i; r++) s -= A[r + (size_t)i * ld] * b[r];
+    b[i] = s / A[i + (size_t)i * ld];
+  }
+  for (int i = n - 1; i >= 0; i--) {                  // L^T z = y: unit lower triangle, backward
+    double s = b[i];
+    for (int r = i + 1; r < n; r++) s -= A[r + (size_t)i * ld] * b[r];
+    b[i] = s;
+  }
+  for (int j = n - 1; j >= 0; j--) if (piv[j] != j) std::swap(b[j], b[piv[j]]);   // x = P^T z
+  return 0;
+}
+
 } // namespace ksd
 
 // ---- C hooks for the CPU unit tests (tests/test_dense_host.py builds this file alone with g++) ----------------
@@ -519,5 +553,6 @@ int ksd_potrf_upper(int n, double *A, int ld) { return ksd::potrf_upper(n, A, ld
 int ksd_trtri_upper(int n, double *A, int ld) { return ksd::trtri_upper(n, A, ld); }
 int ksd_sym_eig(int n, double *A, int ld, double *w) { return ksd::sym_eig(n, A, ld, w); }
 void ksd_tsqr_combine(int n, double *R1, int ld1, double *R2, int ld2) { ksd::tsqr_combine(n, R1, ld1, R2, ld2); }
+int ksd_lu_solve_trans(int n, double *A, int ld, double *b) { return ksd::lu_solve_trans(n, A, ld, b); }
 }
 #endif

@@ -38,5 +38,8 @@ int sym_eig(int n, double *A, int ld, double *w);
 // R factor of the QR factorisation of the stacked upper triangles [R1; R2] (both n x n, column-major, ld), by Givens
 // rotations, into R1 (the reduction operator of the parallel TSQR, SlepcGivensPacked bvlapack.c:456-478).
 void tsqr_combine(int n, double *R1, int ld1, double *R2, int ld2);
+// Solve A^T x = b for a general n x n matrix by LU with partial pivoting (dgetrf + dgetrs 'T'): A is overwritten by its
+// factors, b by x. Returns 0, or the 1-based index of an exactly zero pivot.
+int lu_solve_trans(int n, double *A, int ld, double *b);
 
 } // namespace ksd

@@ -232,6 +232,32 @@ struct DsNhep {
   double &q(int i, int j) { return Q[(size_t)i + (size_t)j * ld]; }
   void set_dimensions(int n_, int l_, int k_) { n = n_; t = n_; l = l_; k = k_; }
 
+  // DSTranslateHarmonic_NHEP dsnhep.c:466-537. g (ld entries) lives in the caller between the two calls. Forward:
+  // g = (A - tau I)^{-T} (beta e_n) and A(:,n-1) += beta g. Recover (after solve and sort, with l = converged and
+  // k = kept): the rank-one term is removed from the kept block and g is projected out of the kept Schur vectors.
+  int translate_harmonic(double tau, double beta, bool recover, double *g, double *gamma_out)
+  {
+    if (!recover) {
+      std::vector<double> W((size_t)n * n);
+      for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) W[i + (size_t)j * n] = a(i, j) - (i == j ? tau : 0.0);
+      std::fill(g, g + ld, 0.0); g[n - 1] = beta;
+      if (ksd::lu_solve_trans(n, W.data(), n, g)) return 1;                                  // getrf + getrs 'C'
+      for (int i = 0; i < n; i++) a(i, n - 1) += g[i] * beta;
+    } else {
+      const int ncol = l + k;
+      std::vector<double> ghat(ncol);
+      for (int j = 0; j < ncol; j++) { double s2 = 0.0; for (int i = 0; i < n; i++) s2 += q(i, j) * g[i]; ghat[j] = -s2; }   // gemv 'C', alpha = -1
+      for (int i = 0; i < ncol; i++) for (int j = l; j < ncol; j++) a(i, j) += ghat[i] * q(n - 1, j) * beta;
+      for (int j = 0; j < ncol; j++) { const double t2 = ghat[j]; if (t2 != 0.0) for (int i = 0; i < n; i++) g[i] += t2 * q(i, j); }   // gemv 'N'
+    }
+    double scale = 0.0, ssq = 1.0;                                                           // dnrm2
+    for (int i = 0; i < n; i++) if (g[i] != 0.0) { const double ax = fabs(g[i]); if (scale < ax) { ssq = 1.0 + ssq * (scale / ax) * (scale / ax); scale = ax; } else ssq += (ax / scale) * (ax / scale); }
+    const double gamma = hypot(1.0, scale * sqrt(ssq));                                      // SlepcAbs(1.0, nrm2)
+    if (gamma_out) *gamma_out = gamma;
+    if (recover) for (int j = l; j < l + k; j++) a(n, j) *= gamma;                           // extra row
+    return 0;
+  }
+
   void eig_from_T(double *wr, double *wi, int j0, int j1)                                    // dsutil.c:65-79,160-170
   {
     for (int j = j0; j < j1; j++) {
@@ -343,6 +369,7 @@ struct ks_eps_s {
   int nconv = 0, its = 0, reason = 0;
   long long steps = 0, passes = 0; int restarts = 0;
   bool solved = false, ghep = false;
+  int extraction = KS_EPS_RITZ;                                  // EPSSetExtraction: Ritz or harmonic (krylovschur.c:120)
   int conv = KS_EPS_CONV_REL; double nrma = 0.0, nrmb = 0.0;   // EPSSetConvergenceTest; ||A||_inf, ||B||_inf for CONV_NORM / ERROR_BACKWARD
   DsHep ds;
   DsNhep dsn;
@@ -435,6 +462,14 @@ extern "C" int ks_eps_set_convergence_test(ks_eps eps, int conv)            // E
   KS_CHECK(conv == KS_EPS_CONV_ABS || conv == KS_EPS_CONV_REL || conv == KS_EPS_CONV_NORM, KS_ERR_ARG_OUTOFRANGE, "Invalid 'conv' value");
   eps->conv = conv; eps->solved = false; return KS_SUCCESS;
 }
+extern "C" int ks_eps_set_extraction(ks_eps eps, int extr)                  // EPSSetExtraction epsopts.c:968-994; krylovschur.c:120 accepts these two
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  KS_CHECK(extr >= KS_EPS_RITZ && extr <= KS_EPS_REFINED_HARMONIC, KS_ERR_ARG_OUTOFRANGE, "Invalid extraction type");
+  KS_CHECK(extr == KS_EPS_RITZ || extr == KS_EPS_HARMONIC, KS_ERR_SUP, "Unsupported extraction type");
+  eps->extraction = extr; eps->solved = false; return KS_SUCCESS;
+}
+extern "C" int ks_eps_get_extraction(ks_eps eps, int *extr) { KS_CHECK(eps && extr, KS_ERR_ARG_NULL, "NULL argument"); *extr = eps->extraction; return KS_SUCCESS; }
 static int matrix_norms(ks_eps eps)                                         // epssetup.c:345-358
 {
   if (!eps->nrma) KS_CALL(ks_mat_norm_inf(eps->A, &eps->nrma));
@@ -513,6 +548,8 @@ static int solve_nhep(ks_eps eps, long long passes0)
   const bool isshift = !map || map->type == KS_ST_SHIFT;
   DsNhep &ds = eps->dsn;
   ds.allocate(ncv + 1); ds.which = eps->cmp_ds; ds.state = DS_RAW;
+  const bool harmonic = eps->extraction == KS_EPS_HARMONIC;
+  std::vector<double> g(harmonic ? ncv + 1 : 0);
   KS_CALL(start_vector(eps, 0, nullptr));
   int l = 0;
   while (eps->reason == KS_EPS_CONVERGED_ITERATING) {
@@ -528,6 +565,10 @@ static int solve_nhep(ks_eps eps, long long passes0)
     ds.state = l ? DS_RAW : DS_INTERMEDIATE;
     KS_CALL(ks_bv_set_active_columns(V, eps->nconv, nv));
 
+    // translation of the Krylov decomposition for harmonic extraction (krylovschur.c:270-271)
+    double gamma = 1.0;
+    if (harmonic) KS_CHECK(!ds.translate_harmonic(eps->which.target, beta, false, g.data(), &gamma), KS_ERR_LIB, "harmonic extraction: H - target*I is singular");
+
     int info = ds.solve(eps->eigr.data(), eps->eigi.data());
     KS_CHECK(info == 0, KS_ERR_LIB, "Hessenberg QR iteration failed to converge (info=%d)", info);
     info = ds.sort(eps->eigr.data(), eps->eigi.data());
@@ -541,7 +582,7 @@ static int solve_nhep(ks_eps eps, long long passes0)
       if ((isshift || eps->conv == KS_EPS_CONV_NORM) && map) ks_st_backtransform_internal(map, 1, &re, &im);          // epskrylov.c:253
       double resnorm = 0.0;
       const int newk = ds.vectors(k, true, &resnorm);
-      resnorm *= beta;
+      resnorm *= beta * gamma;                                 // corrf: only in harmonic KS (epskrylov.c:265)
       eps->errest[k] = converged_estimate(eps, re, im, resnorm);
       if (marker == -1 && eps->errest[k] >= eps->tol) marker = k;
       if (newk == k + 1) { eps->errest[k + 1] = eps->errest[k]; k++; }
@@ -565,7 +606,18 @@ static int solve_nhep(ks_eps eps, long long passes0)
           KS_CALL(start_vector(eps, k, &brk));
           if (brk) eps->reason = KS_EPS_DIVERGED_BREAKDOWN;
         }
-      } else ds.truncate(k + l, false);
+      } else {
+        if (harmonic) {                                        // undo the translation (krylovschur.c:310-320): gamma u^ = u - U g~
+          ds.set_dimensions(nv, k, l);
+          ds.translate_harmonic(0.0, beta, true, g.data(), &gamma);
+          KS_CALL(ks_bv_set_active_columns(V, 0, nv));
+          KS_CALL(ks_bv_multcolumn(V, -1.0, 1.0, nv, g.data()));
+          KS_CALL(ks_bv_scalecolumn(V, nv, 1.0 / gamma));
+          KS_CALL(ks_bv_set_active_columns(V, eps->nconv, nv));
+          ds.set_dimensions(nv, k, nv);
+        }
+        ds.truncate(k + l, false);
+      }
     }
     KS_CALL(ks_bv_multinplace(V, ds.Q.data(), ds.ld, eps->nconv, k + l));
     if (eps->reason == KS_EPS_CONVERGED_ITERATING && !breakdown) KS_CALL(ks_bv_copycolumn(V, nv, k + l));
@@ -632,7 +684,7 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   if (eps->conv == KS_EPS_CONV_NORM) KS_CALL(matrix_norms(eps));
   ks_st st = eps->st;
   const bool sinvert = st && st->type == KS_ST_SINVERT;
-  if (st && !st->sigma_set) { if (st->sigma != eps->which.target) st->ready = false; st->sigma = eps->which.target; }   // shift defaults to the target (sinvert.c:62)
+  if (sinvert && !st->sigma_set) { if (st->sigma != eps->which.target) st->ready = false; st->sigma = eps->which.target; }   // the shift of sinvert defaults to the target (STSetDefaultShift epsbasic.c:386, sinvert.c:64); STSHIFT keeps 0
   KsCompare cmp = eps->which;
   if (!cmp.which) cmp.which = sinvert ? KS_EPS_TARGET_MAGNITUDE : KS_EPS_LARGEST_MAGNITUDE;   // epsdefault.c:209-219
   KS_CHECK(!sinvert || cmp.which == KS_EPS_TARGET_MAGNITUDE || cmp.which == KS_EPS_TARGET_REAL || cmp.which == KS_EPS_WHICH_USER, KS_ERR_USER_INPUT,
@@ -677,7 +729,8 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
     KS_CHECK(kd + ncv + 1 <= KS_MAX_COLS || getenv("KSGPU_NO_FUSED_GS"), KS_ERR_SUP, "constraints + ncv + 1 = %d exceeds the %d columns supported by the fused kernels", kd + ncv + 1, KS_MAX_COLS);
   }
 
-  if (ptype != KS_EPS_HEP && !ghep) return solve_nhep(eps, passes0);
+  KS_CHECK(eps->extraction == KS_EPS_RITZ || !ghep, KS_ERR_SUP, "harmonic extraction with a B-inner product is not built");
+  if ((ptype != KS_EPS_HEP && !ghep) || eps->extraction == KS_EPS_HARMONIC) return solve_nhep(eps, passes0);   // variant EPS_KS_DEFAULT (krylovschur.c:133-151)
   const bool isshift = !st || st->type == KS_ST_SHIFT;
 
   // ---- EPSSolve_KrylovSchur_Default ----

@@ -29,6 +29,7 @@ def lib():
     lib.ksd_sym_eig.argtypes = [C.c_int, P, C.c_int, P]
     lib.ksd_tsqr_combine.argtypes = [C.c_int, P, C.c_int, P, C.c_int]
     lib.ksd_tsqr_combine.restype = None
+    lib.ksd_lu_solve_trans.argtypes = [C.c_int, P, C.c_int, P]
     return lib
 
 
@@ -188,3 +189,23 @@ def test_cholesky_reports_indefinite(lib):
     assert lib.ksd_potrf_upper(2, p(B), 2) == 2
     Z = np.asfortranarray(np.array([[1.0, 2.0], [0.0, 0.0]]))
     assert lib.ksd_trtri_upper(2, p(Z), 2) == 2
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 33, 64])
+def test_lu_solve_transposed_matches_lapack(lib, n):
+    """(A - tau I)^T g = beta e_n of the harmonic translation (dsnhep.c:496-502): dgetrf + dgetrs 'T'."""
+    import scipy.linalg as sl
+    rng = np.random.default_rng(100 + n)
+    A0 = np.triu(rng.standard_normal((n, n)), -1) - 0.3 * np.eye(n)       # upper Hessenberg, as the projected matrix
+    b0 = np.zeros(n); b0[-1] = 0.7
+    A = np.asfortranarray(A0.copy()); b = b0.copy()
+    assert lib.ksd_lu_solve_trans(n, p(A), n, p(b)) == 0
+    ref = sl.lu_solve(sl.lu_factor(A0), b0, trans=1)
+    assert np.abs(b - ref).max() <= 1e3 * n * np.finfo(float).eps * max(np.abs(ref).max(), 1.0) * np.linalg.cond(A0)
+    assert np.abs(A0.T @ b - b0).max() <= 1e3 * n * np.finfo(float).eps * np.abs(A0).max() * max(np.abs(b).max(), 1.0)
+    # pivoting: a zero leading entry must not break it; an exactly singular matrix is reported
+    Z = np.asfortranarray(np.array([[0.0, 2.0], [3.0, 1.0]])); c = np.array([1.0, 1.0])
+    assert lib.ksd_lu_solve_trans(2, p(Z), 2, p(c)) == 0
+    assert np.allclose(np.array([[0.0, 2.0], [3.0, 1.0]]).T @ c, [1.0, 1.0])
+    S = np.asfortranarray(np.array([[1.0, 2.0], [2.0, 4.0]])); d = np.array([1.0, 0.0])
+    assert lib.ksd_lu_solve_trans(2, p(S), 2, p(d)) == 2

@@ -295,3 +295,74 @@ def test_eps_interface_getters_and_defaults(ctx):
     e2 = ks.EPS(ctx); e2.SetOperators(A); e2.SetDimensions(2); e2.Solve()
     assert np.allclose([e2.GetEigenvalue(i)[0] for i in range(2)], [20.0, 19.0], rtol=1e-9)
     assert e2.GetEigenvalue(0)[1] == 0.0
+
+
+def _test2_interior_block():
+    txt = gi.read("eps/eps_test2_1.out")
+    b = txt.split("All requested eigenvalues computed up to the required tolerance:")[3]
+    return np.array([float(t) for t in b.strip().splitlines()[0].replace(",", " ").split()])
+
+
+@pytest.mark.parametrize("lock", [True, False])
+def test_eps_test2_harmonic_extraction_golden(ctx, lock):
+    """test2_1_krylovschur, third solve: EPSSetExtraction(EPS_HARMONIC) on the HEP problem with target 2.1 ->
+    2.10130, 1.89870, 2.30286, 2.50131; the symmetric problem runs the Arnoldi variant (krylovschur.c:139)."""
+    import slepc_amd as ks
+    Ao = O.laplacian1d(30)
+    A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(4)
+    eps.SetWhichEigenpairs("largest_real"); eps.Solve()                     # the program's first solve, Ritz extraction
+    assert abs(eps.GetEigenvalue(0)[0] - 3.98974) < 1e-5
+    eps.SetWhichEigenpairs("target_magnitude"); eps.SetTarget(2.1); eps.SetExtraction("harmonic")
+    eps.KrylovSchurSetLocking(lock)
+    assert eps.GetExtraction() == 1
+    eps.Solve()
+    r = O.eps_krylovschur_nhep(Ao, 4, which=O.which_target_magnitude(2.1), harmonic=2.1, lock=lock)
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(4)])
+    assert np.allclose(np.round(lam, 5), _test2_interior_block(), atol=1.5e-5)
+    _check_against_oracle(eps, r, Ao)
+    eps.SetExtraction("ritz")                                               # and back: the Lanczos variant again
+    eps.SetWhichEigenpairs("smallest_real"); eps.Solve()
+    assert abs(eps.GetEigenvalue(0)[0] - 0.01026) < 1e-5
+
+
+def test_harmonic_extraction_nonsymmetric_interior(ctx):
+    """Harmonic Ritz values converge to interior eigenvalues from a plain Arnoldi run: the planted pair 0.3 +- 0.8i of a
+    matrix whose other eigenvalues surround it, against the oracle run of the same algorithm and numpy's spectrum."""
+    import slepc_amd as ks
+    n = 400
+    rng = np.random.default_rng(4)
+    D = np.zeros((n, n))
+    ev = np.r_[np.linspace(-3.0, -1.5, n // 2 - 1), np.linspace(1.6, 3.0, n - n // 2 - 1)]
+    D[:2, :2] = [[0.3, 0.8], [-0.8, 0.3]]
+    D[np.arange(2, n), np.arange(2, n)] = ev
+    Qm = np.linalg.qr(rng.standard_normal((n, n)))[0]
+    import scipy.sparse as sp
+    M = sp.csr_matrix(Qm @ D @ Qm.T); M.sort_indices()
+    Ao = O.CSR(n, M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data)
+    A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A); eps.SetProblemType(ks.EPS_NHEP); eps.SetDimensions(2, 30); eps.SetTolerances(1e-9, 300)
+    eps.SetWhichEigenpairs("target_magnitude"); eps.SetTarget(0.25); eps.SetExtraction("harmonic")
+    eps.Solve()
+    assert eps.GetConverged() >= 2
+    got = sorted([complex(*eps.GetEigenvalue(i)) for i in range(2)], key=lambda z: z.imag)
+    assert abs(got[0] - (0.3 - 0.8j)) < 1e-8 and abs(got[1] - (0.3 + 0.8j)) < 1e-8
+    r = O.eps_krylovschur_nhep(Ao, 2, ncv=30, tol=1e-9, max_it=300, which=O.which_target_magnitude(0.25), harmonic=0.25)
+    assert eps.GetIterationNumber() == r.its and eps.GetConverged() == r.nconv
+    for i in range(2):
+        assert eps.ComputeError(i) < 1e-8
+
+
+def test_harmonic_extraction_rejected_for_ghep(ctx):
+    import slepc_amd as ks
+    A = ks.Mat.laplacian2d(ctx, 10)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A, A); eps.SetProblemType(ks.EPS_GHEP); eps.SetExtraction("harmonic")
+    with pytest.raises(ks.KsError) as e:
+        eps.Solve()
+    assert e.value.rc == 56
+    with pytest.raises(ks.KsError) as e:
+        eps.SetExtraction(5)                                               # EPS_REFINED: "Unsupported extraction type"
+    assert e.value.rc == 56

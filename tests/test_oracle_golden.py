@@ -402,3 +402,17 @@ def test_eps_test10_deflation_golden():
     assert np.allclose(np.round(r.eigr[r.perm][:4], 5), gi.eigenvalues_line(gi.read("eps/eps_test10_1.out")), atol=1.5e-5)
     lam = np.linalg.eigvalsh(S.toarray())
     assert abs(lam[0]) < 1e-12 and np.allclose(np.sort(r.eigr[r.perm][:4]), lam[1:5], rtol=1e-7)
+
+
+@pytest.mark.parametrize("lock", [True, False])
+def test_eps_test2_interior_harmonic_golden(lock):
+    """test2_1_krylovschur (-eps_krylovschur_locking {{0 1}}), third block: EPSSetExtraction(EPS_HARMONIC), target 2.1,
+    target magnitude -> 2.10130, 1.89870, 2.30286, 2.50131. The symmetric problem runs the Arnoldi/NHEP variant."""
+    A = O.laplacian1d(30)
+    r = O.eps_krylovschur_nhep(A, 4, which=O.which_target_magnitude(2.1), harmonic=2.1, lock=lock)
+    assert r.nconv >= 4 and np.all(r.eigi[: r.nconv] == 0.0)
+    assert np.allclose(np.round(r.eigr[r.perm][:4], 5), _test2_sections()[2], atol=1.5e-5)
+    S = A.to_scipy()
+    for i in range(4):
+        k = r.perm[i]; x = np.array(r.V.column(k))
+        assert np.linalg.norm(S @ x - r.eigr[k] * x) / abs(r.eigr[k]) < 1e-7
