@@ -256,6 +256,8 @@ int ks_eps_get_target(ks_eps eps, double *target);
 int ks_eps_get_convergence_test(ks_eps eps, int *conv);
 int ks_eps_set_extraction(ks_eps eps, int extr);                          /* EPSSetExtraction epsopts.c:968: KS_EPS_RITZ | KS_EPS_HARMONIC (target = EPSSetTarget) */
 int ks_eps_get_extraction(ks_eps eps, int *extr);
+int ks_eps_set_true_residual(ks_eps eps, int trueres);                    /* EPSSetTrueResidual: convergence on ||A x - k B x|| of the Ritz vector (epskrylov.c:256-264) */
+int ks_eps_get_true_residual(ks_eps eps, int *trueres);
 int ks_eps_get_operators(ks_eps eps, ks_mat *A, ks_mat *B);
 int ks_eps_get_problem_type(ks_eps eps, int *type, int *generalized, int *hermitian, int *positive);
 int ks_eps_get_bv(ks_eps eps, ks_bv *V);

@@ -724,7 +724,7 @@ class EPSResult:
 
 def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which="largest_magnitude",
                         keep=0.5, seed=0x12345678, omp=False, v0=None, orthog=(CGS, REFINE_IFNEEDED, 0.7071),
-                        max_steps=None, monitor=None, lock=True, st=None, B=None, conv="rel", deflation=None):
+                        max_steps=None, monitor=None, lock=True, st=None, B=None, conv="rel", deflation=None, trueres=False):
     """EPSSolve for a symmetric problem with the default Krylov-Schur solver: standard (HEP), or generalized (GHEP,
     B given: the basis carries the B-inner product, EPS_SetInnerProduct epsimpl.h:280-292; the start vector goes
     through the operator, epssolve.c:860-868; the eigenvectors are purified and B-normalised,
@@ -817,6 +817,10 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
             if st is not None and (st.kind == "shift" or conv == "norm"):
                 re = st.backtransform(re, 0.0)[0]           # epskrylov.c:253
             resnorm = ds.Vectors_resnorm(kk) * beta * 1.0
+            if trueres:                                     # epskrylov.c:245,256-264
+                if st is not None and not (st.kind == "shift" or conv == "norm"):
+                    re = st.backtransform(re, 0.0)[0]
+                resnorm = _true_residual(A, B, V, nv, re, 0.0, ds.Q[:, kk], purify=st.apply if B is not None else None)
             errest[kk] = _converged(conv, re, 0.0, resnorm, nrma, nrmb)
             if marker == -1 and errest[kk] >= tol:
                 marker = kk
@@ -880,6 +884,30 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
     res.V = V; res.cycles = cycles; res.ncv = ncv
     res.passes = V.passes_total()
     return res
+
+
+def _residual_norm(A, B, kr, ki, xr, xi=None):
+    """EPSComputeResidualNorm_Private epssolve.c:666-718 in real arithmetic."""
+    Bm = (lambda v: B.mult(v)) if B is not None else (lambda v: v)
+    if ki == 0 or abs(ki) < abs(kr * np.finfo(float).eps):
+        u = A.mult(xr)
+        if abs(kr) > np.finfo(float).eps:
+            u = u + (-kr) * Bm(xr)
+        return float(np.linalg.norm(u))
+    u = A.mult(xr) - kr * Bm(xr) + ki * Bm(xi)
+    w = A.mult(xi) - kr * Bm(xi) - ki * Bm(xr)
+    return float(np.hypot(np.linalg.norm(u), np.linalg.norm(w)))
+
+
+def _true_residual(A, B, V, nv, re, im, Zr, Zi=None, purify=None):
+    """EPSComputeRitzVector epsdefault.c:313-364 + the residual of epskrylov.c:256-264 (-eps_true_residual)."""
+    X = np.array(V.dense())[: V.n, :nv]
+    x = X @ Zr[:nv]
+    if purify is not None:                                   # STApply, B-norm, scale (GHEP)
+        y = purify(x)
+        x = y / np.sqrt(y @ B.mult(y))
+    y = X @ Zi[:nv] if Zi is not None else None
+    return _residual_norm(A, B, re, im, x, y)
 
 
 def eps_compute_error(A, res, i, relative=True, B=None):
@@ -1149,7 +1177,8 @@ class ST:
 
 
 def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which="largest_magnitude", keep=0.5,
-                         seed=0x12345678, v0=None, max_steps=None, st=None, lock=True, conv="rel", B=None, harmonic=None):
+                         seed=0x12345678, v0=None, max_steps=None, st=None, lock=True, conv="rel", B=None, harmonic=None,
+                         trueres=False):
     """EPSSolve_KrylovSchur_Default with the Arnoldi expansion (krylovschur.c:227-337, non-Hermitian branch),
     EPSKrylovConvergence for conjugate pairs (epskrylov.c:262-287), EPSComputeVectors_Schur (epsdefault.c:105-169).
     With st (an ST): the Krylov operator is st.apply, the DS sorts through the back-transformation
@@ -1225,6 +1254,10 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
                 re, im = st.backtransform(re, im)
             newk, resnorm = ds.Vectors(k)
             resnorm *= beta * gamma
+            if trueres:                                     # epskrylov.c:245,256-264
+                if st is not None and not (st.kind == "shift" or conv == "norm"):
+                    re, im = st.backtransform(re, im)
+                resnorm = _true_residual(A, B, V, nv, re, im, ds.X[:, k], ds.X[:, newk] if newk == k + 1 else None)
             errest[k] = _converged(conv, re, im, resnorm, nrma, nrmb)
             if marker == -1 and errest[k] >= tol:
                 marker = k

@@ -678,6 +678,12 @@ class EPS:
     def GetExtraction(self):
         v = C.c_int(); _lib.check(self.ctx.L.ks_eps_get_extraction(self.h, C.byref(v))); return v.value
 
+    def SetTrueResidual(self, flag=True):
+        _lib.check(self.ctx.L.ks_eps_set_true_residual(self.h, int(bool(flag))))
+
+    def GetTrueResidual(self):
+        v = C.c_int(); _lib.check(self.ctx.L.ks_eps_get_true_residual(self.h, C.byref(v))); return bool(v.value)
+
     def SetDeflationSpace(self, Cmat):
         """EPSSetDeflationSpace with the vectors given as the columns of a host matrix (local rows of this rank)."""
         Cmat = np.asarray(Cmat, dtype=np.float64)

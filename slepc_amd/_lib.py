@@ -143,6 +143,8 @@ _SIG = {
     "ks_eps_get_convergence_test": [vp, ip],
     "ks_eps_set_extraction": [vp, C.c_int],
     "ks_eps_get_extraction": [vp, C.POINTER(C.c_int)],
+    "ks_eps_set_true_residual": [vp, C.c_int],
+    "ks_eps_get_true_residual": [vp, C.POINTER(C.c_int)],
     "ks_eps_get_operators": [vp, C.POINTER(vp), C.POINTER(vp)],
     "ks_eps_get_problem_type": [vp, ip, ip, ip, ip],
     "ks_st_create": [vp, C.POINTER(vp)],

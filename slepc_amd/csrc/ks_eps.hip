@@ -369,6 +369,7 @@ struct ks_eps_s {
   int nconv = 0, its = 0, reason = 0;
   long long steps = 0, passes = 0; int restarts = 0;
   bool solved = false, ghep = false;
+  bool trueres = false;                                          // EPSSetTrueResidual
   int extraction = KS_EPS_RITZ;                                  // EPSSetExtraction: Ritz or harmonic (krylovschur.c:120)
   int conv = KS_EPS_CONV_REL; double nrma = 0.0, nrmb = 0.0;   // EPSSetConvergenceTest; ||A||_inf, ||B||_inf for CONV_NORM / ERROR_BACKWARD
   DsHep ds;
@@ -462,6 +463,12 @@ extern "C" int ks_eps_set_convergence_test(ks_eps eps, int conv)            // E
   KS_CHECK(conv == KS_EPS_CONV_ABS || conv == KS_EPS_CONV_REL || conv == KS_EPS_CONV_NORM, KS_ERR_ARG_OUTOFRANGE, "Invalid 'conv' value");
   eps->conv = conv; eps->solved = false; return KS_SUCCESS;
 }
+extern "C" int ks_eps_set_true_residual(ks_eps eps, int trueres)            // EPSSetTrueResidual epsopts.c
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  eps->trueres = trueres != 0; eps->solved = false; return KS_SUCCESS;
+}
+extern "C" int ks_eps_get_true_residual(ks_eps eps, int *trueres) { KS_CHECK(eps && trueres, KS_ERR_ARG_NULL, "NULL argument"); *trueres = eps->trueres ? 1 : 0; return KS_SUCCESS; }
 extern "C" int ks_eps_set_extraction(ks_eps eps, int extr)                  // EPSSetExtraction epsopts.c:968-994; krylovschur.c:120 accepts these two
 {
   KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
@@ -515,6 +522,64 @@ static double converged_estimate(ks_eps eps, double re, double im, double res)
     case KS_EPS_CONV_NORM: return res / (eps->nrma + w * eps->nrmb);
     default:               return (w != 0.0) ? res / w : std::numeric_limits<double>::max();
   }
+}
+
+// EPSComputeResidualNorm_Private epssolve.c:666-718 (STGetMatrix 0/1 = the user's A and B): || A x - k B x ||_2 for a
+// real eigenvalue, hypot of the two real-arithmetic residuals for a pair (xi_sign * xi is the imaginary part).
+// Work vectors: W columns 0..2.
+static int residual_norm(ks_eps eps, double kr, double ki, const double *xr, const double *xi, double xi_sign, double *out)
+{
+  ks_bv W = eps->W; ks_ctx ctx = eps->ctx; ks_mat A = eps->A, B = eps->B;
+  const long long n = W->n;
+  double *u = ks_bv_col(W, 0);
+  double nrm = 0.0;
+  if (ki == 0.0 || fabs(ki) < fabs(kr * std::numeric_limits<double>::epsilon())) {
+    KS_CALL(ks_mat_mult_internal(A, xr, u));                                        // u = A*x
+    if (fabs(kr) > std::numeric_limits<double>::epsilon()) {
+      const double *w = xr;
+      if (B) { KS_CALL(ks_mat_mult_internal(B, xr, ks_bv_col(W, 2))); w = ks_bv_col(W, 2); }   // w = B*x
+      KS_CALL(ksk_lincomb(ctx, n, nullptr, 1.0, u, -kr, w, u));                      // u = A*x - k*B*x
+    }
+    KS_CALL(ks_bv_normcolumn(W, 0, KS_NORM_2, &nrm));
+  } else {
+    const double sg = xi_sign;
+    const double *v = xr, *w = xi;                                                   // v = B*xr, w = B*xi (before the sign)
+    if (B) { KS_CALL(ks_mat_mult_internal(B, xr, ks_bv_col(W, 1))); KS_CALL(ks_mat_mult_internal(B, xi, ks_bv_col(W, 2))); v = ks_bv_col(W, 1); w = ks_bv_col(W, 2); }
+    double nr = 0.0, ni = 0.0;
+    KS_CALL(ks_mat_mult_internal(A, xr, u));                                        // u = A*xr - kr*B*xr + ki*B*xi
+    KS_CALL(ksk_lincomb(ctx, n, nullptr, 1.0, u, -kr, v, u));
+    KS_CALL(ksk_lincomb(ctx, n, nullptr, 1.0, u, ki * sg, w, u));
+    KS_CALL(ks_bv_normcolumn(W, 0, KS_NORM_2, &nr));
+    KS_CALL(ks_mat_mult_internal(A, xi, u));                                        // u = A*xi - kr*B*xi - ki*B*xr
+    KS_CALL(ksk_lincomb(ctx, n, nullptr, sg, u, -kr * sg, w, u));
+    KS_CALL(ksk_lincomb(ctx, n, nullptr, 1.0, u, -ki, v, u));
+    KS_CALL(ks_bv_normcolumn(W, 0, KS_NORM_2, &ni));
+    nrm = hypot(nr, ni);
+  }
+  *out = nrm;
+  return KS_SUCCESS;
+}
+
+// EPSComputeRitzVector epsdefault.c:313-364 followed by the residual of epskrylov.c:256-264 (-eps_true_residual):
+// x = V(:,0:nv) Zr [, y = V(:,0:nv) Zi], purified through the operator for a GHEP, into W columns 3 and 4.
+static int true_residual(ks_eps eps, int nv, double re, double im, const double *Zr, const double *Zi, double *resnorm)
+{
+  ks_bv V = eps->V, W = eps->W;
+  int ls = 0, ksv = 0;
+  KS_CALL(ks_bv_get_active_columns(V, &ls, &ksv));
+  KS_CALL(ks_bv_set_active_columns(V, 0, nv));
+  double *x = ks_bv_col(W, 3), *y = ks_bv_col(W, 4);
+  KS_CALL(ks_bv_multvec(V, 1.0, 0.0, x, Zr));
+  if (eps->ghep) {                                                                   // eps->purify (epssetup.c:365-373)
+    double norm = 0.0;
+    KS_CALL(ks_mat_mult_internal(eps->op, x, y));
+    KS_CALL(ksb_norm_b(V, y, &norm));
+    KS_CALL(ksk_scale(eps->ctx, y, V->n, 1.0 / norm));
+    KS_CALL(ksk_copy(eps->ctx, y, x, V->n));
+  }
+  if (Zi) KS_CALL(ks_bv_multvec(V, 1.0, 0.0, y, Zi));
+  KS_CALL(ks_bv_set_active_columns(V, ls, ksv));
+  return residual_norm(eps, re, im, x, Zi ? y : nullptr, 1.0, resnorm);
 }
 
 // EPSGetStartVector epssolve.c:841-873
@@ -582,6 +647,10 @@ static int solve_nhep(ks_eps eps, long long passes0)
       if ((isshift || eps->conv == KS_EPS_CONV_NORM) && map) ks_st_backtransform_internal(map, 1, &re, &im);          // epskrylov.c:253
       double resnorm = 0.0;
       const int newk = ds.vectors(k, true, &resnorm);
+      if (eps->trueres) {                                      // epskrylov.c:256-264
+        if (!((isshift || eps->conv == KS_EPS_CONV_NORM) && map) && map) ks_st_backtransform_internal(map, 1, &re, &im);
+        KS_CALL(true_residual(eps, nv, re, im, ds.X.data() + (size_t)k * ds.ld, newk == k + 1 ? ds.X.data() + (size_t)newk * ds.ld : nullptr, &resnorm));
+      } else
       resnorm *= beta * gamma;                                 // corrf: only in harmonic KS (epskrylov.c:265)
       eps->errest[k] = converged_estimate(eps, re, im, resnorm);
       if (marker == -1 && eps->errest[k] >= eps->tol) marker = k;
@@ -708,7 +777,7 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   eps->max_it = eps->max_it_user ? eps->max_it_user : std::max(100, 2 * n / ncv);
   if (eps->V) { int vm = 0; ks_bv_get_sizes(eps->V, nullptr, nullptr, &vm, nullptr); if (vm != ncv + 1 || eps->V->nc) { ks_bv_destroy(eps->V); eps->V = nullptr; } }
   if (!eps->V) { KS_CALL(ks_bv_create(eps->ctx, A->n, A->n_global, ncv + 1, 0, &eps->V)); eps->V->row_start = A->row_start; }   // EPSAllocateSolution(eps,1)
-  if (!eps->W) { KS_CALL(ks_bv_create(eps->ctx, A->n, A->n_global, 3, 0, &eps->W)); }
+  if (!eps->W) { KS_CALL(ks_bv_create(eps->ctx, A->n, A->n_global, 5, 0, &eps->W)); }     // work vectors: u, B*xr, B*xi, Ritz vector x, y
   eps->eigr.assign(ncv + 1, 0.0); eps->eigi.assign(ncv + 1, 0.0); eps->errest.assign(ncv + 1, 0.0);
   eps->perm.resize(ncv + 1); for (int i = 0; i <= ncv; i++) eps->perm[i] = i;
   DsHep &ds = eps->ds;
@@ -760,7 +829,11 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
     for (k = eps->nconv; k < nv; k++) {
       double re = eps->eigr[k], im0 = 0.0;
       if ((isshift || eps->conv == KS_EPS_CONV_NORM) && eps->cmp_ds.map) ks_st_backtransform_internal(eps->cmp_ds.map, 1, &re, &im0);   // epskrylov.c:253 (identity for sigma = 0)
-      const double resnorm = ds.vectors_resnorm(k) * beta * 1.0;
+      double resnorm = ds.vectors_resnorm(k) * beta * 1.0;
+      if (eps->trueres) {                                      // epskrylov.c:256-264: X(:,k) = Q(:,k) for DSHEP (dshep.c:140-155)
+        if (!((isshift || eps->conv == KS_EPS_CONV_NORM) && eps->cmp_ds.map) && eps->cmp_ds.map) ks_st_backtransform_internal(eps->cmp_ds.map, 1, &re, &im0);
+        KS_CALL(true_residual(eps, nv, re, 0.0, ds.Q.data() + (size_t)k * ds.ld, nullptr, &resnorm));
+      }
       eps->errest[k] = converged_estimate(eps, re, 0.0, resnorm);
       if (marker == -1 && eps->errest[k] >= eps->tol) marker = k;
       if (marker != -1) break;
@@ -883,37 +956,13 @@ extern "C" int ks_eps_compute_error(ks_eps eps, int i, int type, double *error) 
   KS_CHECK(i >= 0 && i < eps->nconv, KS_ERR_ARG_OUTOFRANGE, "The index can be nconv-1 at most, see EPSGetConverged()");
   const int j = eps->perm[i];
   const double kr = eps->eigr[j], ki = eps->eigi[j];
-  ks_bv W = eps->W, V = eps->V; ks_ctx ctx = eps->ctx; ks_mat A = eps->A, B = eps->B;
-  const long long n = V->n;
-  double *u = ks_bv_col(W, 0);
+  ks_bv V = eps->V;
   double nrm = 0.0;
-  // EPSComputeResidualNorm_Private epssolve.c:666-718 (STGetMatrix 0/1 = the user's A and B)
-  if (ki == 0.0 || fabs(ki) < fabs(kr * std::numeric_limits<double>::epsilon())) {
-    const double *x = ks_bv_col(V, j);
-    KS_CALL(ks_mat_mult_internal(A, x, u));                                         // u = A*x
-    if (fabs(kr) > std::numeric_limits<double>::epsilon()) {
-      const double *w = x;
-      if (B) { KS_CALL(ks_mat_mult_internal(B, x, ks_bv_col(W, 2))); w = ks_bv_col(W, 2); }   // w = B*x
-      KS_CALL(ksk_lincomb(ctx, n, nullptr, 1.0, u, -kr, w, u));                      // u = A*x - k*B*x
-    }
-    KS_CALL(ks_bv_normcolumn(W, 0, KS_NORM_2, &nrm));
-  } else {
+  if (ki == 0.0) KS_CALL(residual_norm(eps, kr, ki, ks_bv_col(V, j), nullptr, 1.0, &nrm));
+  else {
     // complex pair in real arithmetic: xr = V(:,jr), xi = sg*V(:,jr+1) (BV_GetEigenvector bvimpl.h:423-446)
     const int jr = ki > 0.0 ? j : j - 1;
-    const double sg = ki > 0.0 ? 1.0 : -1.0;
-    const double *xr = ks_bv_col(V, jr), *xi = ks_bv_col(V, jr + 1);
-    const double *v = xr, *w = xi;                                                   // v = B*xr, w = B*(V(:,jr+1))
-    if (B) { KS_CALL(ks_mat_mult_internal(B, xr, ks_bv_col(W, 1))); KS_CALL(ks_mat_mult_internal(B, xi, ks_bv_col(W, 2))); v = ks_bv_col(W, 1); w = ks_bv_col(W, 2); }
-    double nr = 0.0, ni = 0.0;
-    KS_CALL(ks_mat_mult_internal(A, xr, u));                                        // u = A*xr - kr*B*xr + ki*B*xi
-    KS_CALL(ksk_lincomb(ctx, n, nullptr, 1.0, u, -kr, v, u));
-    KS_CALL(ksk_lincomb(ctx, n, nullptr, 1.0, u, ki * sg, w, u));
-    KS_CALL(ks_bv_normcolumn(W, 0, KS_NORM_2, &nr));
-    KS_CALL(ks_mat_mult_internal(A, xi, u));                                        // u = A*xi - kr*B*xi - ki*B*xr
-    KS_CALL(ksk_lincomb(ctx, n, nullptr, sg, u, -kr * sg, w, u));
-    KS_CALL(ksk_lincomb(ctx, n, nullptr, 1.0, u, -ki, v, u));
-    KS_CALL(ks_bv_normcolumn(W, 0, KS_NORM_2, &ni));
-    nrm = hypot(nr, ni);
+    KS_CALL(residual_norm(eps, kr, ki, ks_bv_col(V, jr), ks_bv_col(V, jr + 1), ki > 0.0 ? 1.0 : -1.0, &nrm));
   }
   double vecnorm = 1.0;
   if (eps->ghep) { ks_mat Bsave = V->matrix; V->matrix = nullptr; int rc = ks_bv_normcolumn(V, j, KS_NORM_2, &vecnorm); V->matrix = Bsave; if (rc) return rc; }   // epssolve.c:774: 2-norm of the eigenvector

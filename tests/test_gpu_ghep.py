@@ -163,3 +163,21 @@ def test_ghep_larger_sinvert(ctx):
     assert np.allclose(lam, ref, rtol=1e-8)
     for i in range(5):
         assert eps.ComputeError(i) < 1e-5        # convergence is tested on theta = 1/(lambda - sigma); |lambda| ~ 1e-3 here
+
+
+def test_eps_test1_true_residual_golden(ctx):
+    """test1_1_ks_trueres: -eps_true_residual on the GHEP of test1 reprints test1_1.out; the Ritz vector is purified
+    through the operator and B-normalised before its residual is taken (epsdefault.c:327-333)."""
+    import slepc_amd as ks
+    Ao, Bo = _test1_pencil()
+    A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val); B = ks.Mat.from_csr(ctx, Bo.rowptr, Bo.col, Bo.val)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A, B); eps.SetProblemType(ks.EPS_GHEP); eps.SetDimensions(4); eps.SetTolerances(0.0, 1500)
+    eps.SetConvergenceTest("norm"); eps.SetTrueResidual(True)
+    eps.GetST().SetKSP(rtol=1e-14)
+    eps.Solve()
+    r = O.eps_krylovschur_hep(Ao, 4, max_it=1500, st=O.ST(Ao, Bo, "shift", 0.0), B=Bo, conv="norm", trueres=True)
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(eps.GetConverged())])
+    assert np.allclose(np.round(lam[:4], 5), gi.eigenvalues_line(gi.read("eps/eps_test1_1.out")), atol=1.5e-5)
+    assert eps.GetConverged() == r.nconv and eps.GetIterationNumber() == r.its
+    assert np.allclose(lam, r.eigr[r.perm], rtol=1e-10)

@@ -366,3 +366,49 @@ def test_harmonic_extraction_rejected_for_ghep(ctx):
     with pytest.raises(ks.KsError) as e:
         eps.SetExtraction(5)                                               # EPS_REFINED: "Unsupported extraction type"
     assert e.value.rc == 56
+
+
+def test_true_residual_test9_golden(ctx):
+    """test9 suffix 4: -eps_nev 4 -eps_true_residual reprints test9_1.out; the solver's estimate is then the true
+    relative residual of the Ritz pair."""
+    import slepc_amd as ks
+    Ao = O.markov_matrix(15)
+    v0 = nc.test9_v0(Ao.n)
+    A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A); eps.SetProblemType(ks.EPS_NHEP); eps.SetDimensions(4, 8); eps.SetTolerances(0.5e-10, 300)
+    eps.SetEigenvalueComparison(nc.my_eigen_sort); eps.SetInitialVector(v0); eps.SetTrueResidual(True)
+    assert eps.GetTrueResidual()
+    eps.Solve()
+    r = O.eps_krylovschur_nhep(Ao, 4, ncv=8, max_it=300, tol=0.5e-10, which=nc.my_eigen_sort, v0=v0, trueres=True)
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(4)])
+    assert np.allclose(np.round(lam, 5), gi.eigenvalues_line(gi.read("eps/eps_test9_1.out")), atol=1.5e-5)
+    _check_against_oracle(eps, r, Ao, tol=1e-9)
+    for i in range(4):
+        assert abs(eps.GetErrorEstimate(i) - eps.ComputeError(i)) < 1e-10
+
+
+def test_true_residual_complex_pairs_and_sinvert(ctx):
+    """Conjugate pairs (two Ritz vectors per test) and the back-transformed eigenvalue under shift-and-invert."""
+    import slepc_amd as ks
+    Ao = nc.planted_pairs(1500)
+    A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A); eps.SetProblemType(ks.EPS_NHEP); eps.SetDimensions(4, 24); eps.SetTrueResidual(True)
+    eps.SetWhichEigenpairs("largest_imaginary")
+    eps.Solve()
+    r = O.eps_krylovschur_nhep(Ao, 4, ncv=24, which="largest_imaginary", trueres=True)
+    _check_against_oracle(eps, r, Ao)
+    assert any(eps.GetEigenvalue(i)[1] != 0.0 for i in range(4))
+    Lo = O.laplacian2d(30)
+    L = ks.Mat.from_csr(ctx, Lo.rowptr, Lo.col, Lo.val)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(L); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(3, 16); eps.SetTarget(-0.5); eps.SetTrueResidual(True)
+    eps.SetWhichEigenpairs("target_magnitude")
+    st = eps.GetST(); st.SetType("sinvert"); st.SetKSP(rtol=1e-13)
+    eps.Solve()
+    r = O.eps_krylovschur_hep(Lo, 3, ncv=16, which=O.which_target_magnitude(-0.5), st=O.ST(Lo, None, "sinvert", -0.5), trueres=True)
+    assert eps.GetConverged() == r.nconv and eps.GetIterationNumber() == r.its
+    assert np.allclose([eps.GetEigenvalue(i)[0] for i in range(3)], r.eigr[r.perm][:3], rtol=1e-10)
+    for i in range(3):
+        assert eps.ComputeError(i) < 1e-8 and abs(eps.GetErrorEstimate(i) - eps.ComputeError(i)) < 1e-9

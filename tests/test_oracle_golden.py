@@ -416,3 +416,22 @@ def test_eps_test2_interior_harmonic_golden(lock):
     for i in range(4):
         k = r.perm[i]; x = np.array(r.V.column(k))
         assert np.linalg.norm(S @ x - r.eigr[k] * x) / abs(r.eigr[k]) < 1e-7
+
+
+def test_eps_true_residual_golden():
+    """-eps_true_residual (EPSSetTrueResidual): test1_1_ks_trueres reprints test1_1.out (GHEP, purified Ritz vectors) and
+    test9 suffix 4 reprints test9_1.out (NHEP, user ordering); the convergence test then runs on ||A x - k B x||."""
+    import nhep_cases as nc
+    A, B = _test1_pencil()
+    r = O.eps_krylovschur_hep(A, 4, max_it=1500, st=O.ST(A, B, "shift", 0.0), B=B, conv="norm", trueres=True)
+    assert np.allclose(np.round(r.eigr[r.perm][:4], 5), gi.eigenvalues_line(gi.read("eps/eps_test1_1.out")), atol=1.5e-5)
+    for i in range(4):
+        assert O.eps_compute_error(A, r, i, B=B) < 1e-8
+    M = O.markov_matrix(15)
+    r = O.eps_krylovschur_nhep(M, 4, ncv=8, max_it=300, tol=0.5e-10, which=nc.my_eigen_sort, v0=nc.test9_v0(M.n), trueres=True)
+    assert r.nconv >= 4 and r.reason > 0
+    assert np.allclose(np.round(r.eigr[r.perm][:4], 5), gi.eigenvalues_line(gi.read("eps/eps_test9_1.out")), atol=1.5e-5)
+    # the estimate the solver stopped on IS the true relative residual of the Ritz pair
+    for i in range(4):
+        j = r.perm[i]
+        assert abs(r.errest[j] - O.eps_compute_error_nhep(M, r, i)) < 1e-10
