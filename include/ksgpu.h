@@ -82,7 +82,11 @@ enum { KS_EPS_HEP = 1, KS_EPS_GHEP = 2, KS_EPS_NHEP = 3, KS_EPS_GNHEP = 4 };   /
 enum { KS_ST_SHIFT = 0, KS_ST_SINVERT = 1 };                 /* STType "shift", "sinvert" */
 enum { KS_EPS_ERROR_ABSOLUTE = 0, KS_EPS_ERROR_RELATIVE = 1, KS_EPS_ERROR_BACKWARD = 2 };   /* EPSErrorType */
 enum { KS_EPS_RITZ = 0, KS_EPS_HARMONIC = 1, KS_EPS_HARMONIC_RELATIVE, KS_EPS_HARMONIC_RIGHT, KS_EPS_HARMONIC_LARGEST, KS_EPS_REFINED, KS_EPS_REFINED_HARMONIC };  /* EPSExtraction slepceps.h:94-100; Krylov-Schur offers the first two */
-enum { KS_EPS_CONV_ABS = 0, KS_EPS_CONV_REL = 1, KS_EPS_CONV_NORM = 2 };                       /* EPSConv (EPS_CONV_USER not offered) */
+enum { KS_EPS_CONV_ABS = 0, KS_EPS_CONV_REL = 1, KS_EPS_CONV_NORM = 2, KS_EPS_CONV_USER = 3 };   /* EPSConv slepceps.h:153-156 */
+/* user callbacks of the solver (slepceps.h EPSConvergenceTestFn, EPSStoppingTestFn, EPSMonitorFn); non-zero return = error */
+typedef int (*ks_eps_converged_fn)(ks_eps eps, double eigr, double eigi, double res, double *errest, void *ctx);
+typedef int (*ks_eps_stopping_fn)(ks_eps eps, int its, int max_it, int nconv, int nev, int *reason, void *ctx);
+typedef int (*ks_eps_monitor_fn)(ks_eps eps, int its, int nconv, const double *eigr, const double *eigi, const double *errest, int nest, void *ctx);
 enum { KS_EPS_CONVERGED_TOL = 1, KS_EPS_CONVERGED_USER = 2, KS_EPS_DIVERGED_ITS = -1, KS_EPS_DIVERGED_BREAKDOWN = -2,
        KS_EPS_DIVERGED_SYMMETRY_LOST = -3, KS_EPS_CONVERGED_ITERATING = 0 };
 
@@ -256,6 +260,10 @@ int ks_eps_get_target(ks_eps eps, double *target);
 int ks_eps_get_convergence_test(ks_eps eps, int *conv);
 int ks_eps_set_extraction(ks_eps eps, int extr);                          /* EPSSetExtraction epsopts.c:968: KS_EPS_RITZ | KS_EPS_HARMONIC (target = EPSSetTarget) */
 int ks_eps_get_extraction(ks_eps eps, int *extr);
+int ks_eps_set_convergence_test_function(ks_eps eps, ks_eps_converged_fn fn, void *ctx); /* EPSSetConvergenceTestFunction: selects KS_EPS_CONV_USER; NULL restores the relative test */
+int ks_eps_set_stopping_test_function(ks_eps eps, ks_eps_stopping_fn fn, void *ctx);    /* EPSSetStoppingTestFunction (ex29.c); NULL = EPSStoppingBasic */
+int ks_eps_stopping_basic(ks_eps eps, int its, int max_it, int nconv, int nev, int *reason, void *ctx); /* EPSStoppingBasic epsdefault.c:290 */
+int ks_eps_monitor_set(ks_eps eps, ks_eps_monitor_fn fn, void *ctx);                    /* EPSMonitorSet (one slot; NULL cancels): called once per restart with the DS-ordered values, untransformed */
 int ks_eps_set_true_residual(ks_eps eps, int trueres);                    /* EPSSetTrueResidual: convergence on ||A x - k B x|| of the Ritz vector (epskrylov.c:256-264) */
 int ks_eps_get_true_residual(ks_eps eps, int *trueres);
 int ks_eps_get_operators(ks_eps eps, ks_mat *A, ks_mat *B);

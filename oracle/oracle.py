@@ -710,6 +710,8 @@ def _norm_inf(M):
 
 def _converged(conv, re, im, res, nrma=0.0, nrmb=1.0):
     """EPSConvergedRelative / Absolute / Norm (epsdefault.c:224-257)"""
+    if callable(conv):                                       # EPS_CONV_USER: EPSSetConvergenceTestFunction
+        return conv(re, im, res)
     w = np.hypot(re, im)
     if conv == "abs":
         return res
@@ -724,7 +726,7 @@ class EPSResult:
 
 def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which="largest_magnitude",
                         keep=0.5, seed=0x12345678, omp=False, v0=None, orthog=(CGS, REFINE_IFNEEDED, 0.7071),
-                        max_steps=None, monitor=None, lock=True, st=None, B=None, conv="rel", deflation=None, trueres=False):
+                        max_steps=None, monitor=None, lock=True, st=None, B=None, conv="rel", deflation=None, trueres=False, stopping=None):
     """EPSSolve for a symmetric problem with the default Krylov-Schur solver: standard (HEP), or generalized (GHEP,
     B given: the basis carries the B-inner product, EPS_SetInnerProduct epsimpl.h:280-292; the start vector goes
     through the operator, epssolve.c:860-868; the eigenvectors are purified and B-normalised,
@@ -830,10 +832,13 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
             kk = nv
         k = marker if marker != -1 else nv
         # EPSStoppingBasic
-        if k >= nev:
+        if stopping is not None:                            # EPSSetStoppingTestFunction
+            reason = stopping(its, max_it, k, nev)
+        elif k >= nev:
             reason = 1      # EPS_CONVERGED_TOL (slepceps.h)
         elif its >= max_it:
             reason = -1     # EPS_DIVERGED_ITS
+        nconv_mon = k                                       # krylovschur.c:289: the monitor sees the count before the non-locking reset
         if max_steps is not None and steps >= max_steps and reason == 0:
             reason = 2      # EPS_CONVERGED_USER (step cap of the bench harness)
         # update l
@@ -855,7 +860,7 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
             V.CopyColumn(nv, k + l)
         nconv = k
         if monitor:
-            monitor(its, nconv, eigr[:nv].copy(), errest[:nv].copy(), nv)
+            monitor(its, nconv_mon, eigr[:nv].copy(), errest[:nv].copy(), nv)
     ds.Truncate(nconv, True)
 
     V.SetActiveColumns(0, nconv)
@@ -1178,7 +1183,7 @@ class ST:
 
 def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which="largest_magnitude", keep=0.5,
                          seed=0x12345678, v0=None, max_steps=None, st=None, lock=True, conv="rel", B=None, harmonic=None,
-                         trueres=False):
+                         trueres=False, stopping=None, monitor=None):
     """EPSSolve_KrylovSchur_Default with the Arnoldi expansion (krylovschur.c:227-337, non-Hermitian branch),
     EPSKrylovConvergence for conjugate pairs (epskrylov.c:262-287), EPSComputeVectors_Schur (epsdefault.c:105-169).
     With st (an ST): the Krylov operator is st.apply, the DS sorts through the back-transformation
@@ -1267,10 +1272,13 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
                 break
             k += 1
         k = marker if marker != -1 else nv
-        if k >= nev:
+        if stopping is not None:
+            reason = stopping(its, max_it, k, nev)
+        elif k >= nev:
             reason = 1      # EPS_CONVERGED_TOL
         elif its >= max_it:
             reason = -1
+        nconv_mon = k
         if max_steps is not None and steps >= max_steps and reason == 0:
             reason = 2      # EPS_CONVERGED_USER (step cap of the bench harness)
         if reason != 0 or breakdown or k == nv:
@@ -1298,6 +1306,8 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
         if reason == 0 and not breakdown:
             V.CopyColumn(nv, k + l)
         nconv = k
+        if monitor:
+            monitor(its, nconv_mon, eigr[:nv].copy(), eigi[:nv].copy(), errest[:nv].copy(), nv)
     ds.Truncate(nconv, True)
     # EPSComputeVectors_Schur: X = V * Z, Z = eigenvectors of the truncated T
     V.SetActiveColumns(0, nconv)

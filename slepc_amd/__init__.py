@@ -33,6 +33,9 @@ BLOCK = {"gs": 0, "chol": 1, "tsqr": 2, "tsqrchol": 3, "svqb": 4}
 SHELL_MULT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 ST_SHIFT, ST_SINVERT = 0, 1
 EIG_COMPARE_FN = C.CFUNCTYPE(C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_void_p)
+EPS_CONVERGED_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_void_p)
+EPS_STOPPING_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p)
+EPS_MONITOR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_void_p)
 
 KCLASSES = ["spmv_csr", "bv_dot_sweep", "gs_bookkeeping", "gs_update_fused_dot", "gs_update", "bv_scale", "bv_multinplace",
             "bv_copy", "bv_mult", "bv_dot_panel", "bv_norm", "halo_exchange", "allreduce", "gated_noop", "other"]
@@ -677,6 +680,53 @@ class EPS:
 
     def GetExtraction(self):
         v = C.c_int(); _lib.check(self.ctx.L.ks_eps_get_extraction(self.h, C.byref(v))); return v.value
+
+    def SetConvergenceTestFunction(self, func):
+        """func(eigr, eigi, res) -> error estimate (EPSSetConvergenceTestFunction); None restores the relative test."""
+        if func is None:
+            self._conv_cb = None
+            _lib.check(self.ctx.L.ks_eps_set_convergence_test_function(self.h, None, None)); return
+
+        def tramp(_eps, re, im, res, out, _ctx):
+            try:
+                out[0] = float(func(re, im, res)); return 0
+            except Exception:       # noqa: BLE001 - must not unwind through C
+                import traceback; traceback.print_exc(); return 76
+        self._conv_cb = EPS_CONVERGED_FN(tramp)
+        _lib.check(self.ctx.L.ks_eps_set_convergence_test_function(self.h, C.cast(self._conv_cb, C.c_void_p), None))
+
+    def SetStoppingTestFunction(self, func):
+        """func(its, max_it, nconv, nev) -> reason (0 = keep iterating); EPS.StoppingBasic is the default rule."""
+        if func is None:
+            self._stop_cb = None
+            _lib.check(self.ctx.L.ks_eps_set_stopping_test_function(self.h, None, None)); return
+
+        def tramp(_eps, its, max_it, nconv, nev, reason, _ctx):
+            try:
+                reason[0] = int(func(its, max_it, nconv, nev)); return 0
+            except Exception:       # noqa: BLE001
+                import traceback; traceback.print_exc(); return 76
+        self._stop_cb = EPS_STOPPING_FN(tramp)
+        _lib.check(self.ctx.L.ks_eps_set_stopping_test_function(self.h, C.cast(self._stop_cb, C.c_void_p), None))
+
+    def StoppingBasic(self, its, max_it, nconv, nev):
+        r = C.c_int()
+        _lib.check(self.ctx.L.ks_eps_stopping_basic(self.h, its, max_it, nconv, nev, C.byref(r), None))
+        return r.value
+
+    def MonitorSet(self, func):
+        """func(its, nconv, eigr, eigi, errest) with numpy copies of the first nest entries; None cancels."""
+        if func is None:
+            self._mon_cb = None
+            _lib.check(self.ctx.L.ks_eps_monitor_set(self.h, None, None)); return
+
+        def tramp(_eps, its, nconv, er, ei, ee, nest, _ctx):
+            try:
+                func(its, nconv, np.array(er[:nest]), np.array(ei[:nest]), np.array(ee[:nest])); return 0
+            except Exception:       # noqa: BLE001
+                import traceback; traceback.print_exc(); return 76
+        self._mon_cb = EPS_MONITOR_FN(tramp)
+        _lib.check(self.ctx.L.ks_eps_monitor_set(self.h, C.cast(self._mon_cb, C.c_void_p), None))
 
     def SetTrueResidual(self, flag=True):
         _lib.check(self.ctx.L.ks_eps_set_true_residual(self.h, int(bool(flag))))

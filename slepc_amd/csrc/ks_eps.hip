@@ -369,6 +369,10 @@ struct ks_eps_s {
   int nconv = 0, its = 0, reason = 0;
   long long steps = 0, passes = 0; int restarts = 0;
   bool solved = false, ghep = false;
+  ks_eps_converged_fn conv_fn = nullptr; void *conv_ctx = nullptr;     // EPSSetConvergenceTestFunction (conv = KS_EPS_CONV_USER)
+  ks_eps_stopping_fn stop_fn = nullptr; void *stop_ctx = nullptr;      // EPSSetStoppingTestFunction; NULL = EPSStoppingBasic
+  ks_eps_monitor_fn mon_fn = nullptr; void *mon_ctx = nullptr;         // EPSMonitorSet (one monitor)
+  int cb_err = 0;                                                      // first non-zero return of a user callback
   bool trueres = false;                                          // EPSSetTrueResidual
   int extraction = KS_EPS_RITZ;                                  // EPSSetExtraction: Ritz or harmonic (krylovschur.c:120)
   int conv = KS_EPS_CONV_REL; double nrma = 0.0, nrmb = 0.0;   // EPSSetConvergenceTest; ||A||_inf, ||B||_inf for CONV_NORM / ERROR_BACKWARD
@@ -460,7 +464,8 @@ extern "C" int ks_eps_set_krylovschur_restart(ks_eps eps, double keep)   // kryl
 extern "C" int ks_eps_set_convergence_test(ks_eps eps, int conv)            // EPSSetConvergenceTest epsopts.c
 {
   KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
-  KS_CHECK(conv == KS_EPS_CONV_ABS || conv == KS_EPS_CONV_REL || conv == KS_EPS_CONV_NORM, KS_ERR_ARG_OUTOFRANGE, "Invalid 'conv' value");
+  KS_CHECK(conv == KS_EPS_CONV_ABS || conv == KS_EPS_CONV_REL || conv == KS_EPS_CONV_NORM || conv == KS_EPS_CONV_USER, KS_ERR_ARG_OUTOFRANGE, "Invalid 'conv' value");
+  KS_CHECK(conv != KS_EPS_CONV_USER || eps->conv_fn, KS_ERR_ORDER, "Must call EPSSetConvergenceTestFunction() first");
   eps->conv = conv; eps->solved = false; return KS_SUCCESS;
 }
 extern "C" int ks_eps_set_true_residual(ks_eps eps, int trueres)            // EPSSetTrueResidual epsopts.c
@@ -513,11 +518,57 @@ extern "C" int ks_eps_set_deflation_space(ks_eps eps, int n, const double *const
 }
 extern "C" int ks_eps_set_max_steps(ks_eps eps, long long s) { KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL"); eps->max_steps = s > 0 ? s : 0; return KS_SUCCESS; }
 
+// EPSStoppingBasic epsdefault.c:290-307; user functions may call it first, as ex29.c does
+extern "C" int ks_eps_stopping_basic(ks_eps eps, int its, int max_it, int nconv, int nev, int *reason, void *ctx)
+{
+  (void)eps; (void)ctx;
+  KS_CHECK(reason, KS_ERR_ARG_NULL, "NULL argument");
+  *reason = KS_EPS_CONVERGED_ITERATING;
+  if (nconv >= nev) *reason = KS_EPS_CONVERGED_TOL;
+  else if (its >= max_it) *reason = KS_EPS_DIVERGED_ITS;
+  return KS_SUCCESS;
+}
+extern "C" int ks_eps_set_stopping_test_function(ks_eps eps, ks_eps_stopping_fn fn, void *ctx)   // EPSSetStoppingTestFunction epsopts.c
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  eps->stop_fn = fn; eps->stop_ctx = ctx; return KS_SUCCESS;
+}
+extern "C" int ks_eps_set_convergence_test_function(ks_eps eps, ks_eps_converged_fn fn, void *ctx)   // EPSSetConvergenceTestFunction epsopts.c
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  if (fn) { eps->conv_fn = fn; eps->conv_ctx = ctx; eps->conv = KS_EPS_CONV_USER; }
+  else { eps->conv_fn = nullptr; eps->conv_ctx = nullptr; if (eps->conv == KS_EPS_CONV_USER) eps->conv = KS_EPS_CONV_REL; }
+  eps->solved = false; return KS_SUCCESS;
+}
+extern "C" int ks_eps_monitor_set(ks_eps eps, ks_eps_monitor_fn fn, void *ctx)                   // EPSMonitorSet epsmon.c (one slot); NULL = EPSMonitorCancel
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  eps->mon_fn = fn; eps->mon_ctx = ctx; return KS_SUCCESS;
+}
+// the stopping test of one restart: user function or the basic one, then the step cap of the bench harness
+static int stopping_test(ks_eps eps, int k)
+{
+  int reason = KS_EPS_CONVERGED_ITERATING;
+  if (eps->stop_fn) { const int rc = eps->stop_fn(eps, eps->its, eps->max_it, k, eps->nev, &reason, eps->stop_ctx); KS_CHECK(!rc, rc, "the user's stopping test returned %d", rc); }
+  else ks_eps_stopping_basic(eps, eps->its, eps->max_it, k, eps->nev, &reason, nullptr);
+  eps->reason = reason;
+  if (eps->reason == KS_EPS_CONVERGED_ITERATING && eps->max_steps && eps->steps >= eps->max_steps) eps->reason = KS_EPS_CONVERGED_USER;
+  return KS_SUCCESS;
+}
+static int monitor(ks_eps eps, int nconv, int nest)                                            // EPSMonitor epsmon.c:21-33
+{
+  if (!eps->mon_fn) return KS_SUCCESS;
+  const int rc = eps->mon_fn(eps, eps->its, nconv, eps->eigr.data(), eps->eigi.data(), eps->errest.data(), nest, eps->mon_ctx);
+  KS_CHECK(!rc, rc, "the user's monitor returned %d", rc);
+  return KS_SUCCESS;
+}
+
 // EPSConvergedRelative / Absolute / Norm epsdefault.c:224-257
 static double converged_estimate(ks_eps eps, double re, double im, double res)
 {
   const double w = hypot(re, im);
   switch (eps->conv) {
+    case KS_EPS_CONV_USER: { double e = 0.0; const int rc = eps->conv_fn(eps, re, im, res, &e, eps->conv_ctx); if (rc && !eps->cb_err) eps->cb_err = rc; return e; }
     case KS_EPS_CONV_ABS:  return res;
     case KS_EPS_CONV_NORM: return res / (eps->nrma + w * eps->nrmb);
     default:               return (w != 0.0) ? res / w : std::numeric_limits<double>::max();
@@ -658,9 +709,9 @@ static int solve_nhep(ks_eps eps, long long passes0)
       if (marker != -1) break;
     }
     k = (marker != -1) ? marker : nv;
-    if (k >= nev) eps->reason = KS_EPS_CONVERGED_TOL;
-    else if (eps->its >= eps->max_it) eps->reason = KS_EPS_DIVERGED_ITS;
-    if (eps->reason == KS_EPS_CONVERGED_ITERATING && eps->max_steps && eps->steps >= eps->max_steps) eps->reason = KS_EPS_CONVERGED_USER;
+    KS_CHECK(!eps->cb_err, eps->cb_err, "the user's convergence test returned %d", eps->cb_err);
+    KS_CALL(stopping_test(eps, k));
+    const int nconv_mon = k;
 
     if (eps->reason != KS_EPS_CONVERGED_ITERATING || breakdown || k == nv) l = 0;
     else {
@@ -691,6 +742,7 @@ static int solve_nhep(ks_eps eps, long long passes0)
     KS_CALL(ks_bv_multinplace(V, ds.Q.data(), ds.ld, eps->nconv, k + l));
     if (eps->reason == KS_EPS_CONVERGED_ITERATING && !breakdown) KS_CALL(ks_bv_copycolumn(V, nv, k + l));
     eps->nconv = k;
+    KS_CALL(monitor(eps, nconv_mon, nv));
     eps->restarts++;
   }
   ds.truncate(eps->nconv, true);
@@ -782,6 +834,7 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   eps->perm.resize(ncv + 1); for (int i = 0; i <= ncv; i++) eps->perm[i] = i;
   DsHep &ds = eps->ds;
   ds.allocate(ncv + 1); ds.which = eps->cmp_ds; ds.state = DS_RAW;
+  eps->cb_err = 0;
   eps->nconv = 0; eps->its = 0; eps->reason = KS_EPS_CONVERGED_ITERATING; eps->steps = 0; eps->restarts = 0; eps->solved = false;
   long long passes0 = 0; ks_bv_gs_passes(eps->V, &passes0, nullptr);
   ks_bv V = eps->V;
@@ -840,9 +893,9 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
     }
     if (marker != -1) k = marker;
     // EPSStoppingBasic
-    if (k >= nev) eps->reason = KS_EPS_CONVERGED_TOL;
-    else if (eps->its >= eps->max_it) eps->reason = KS_EPS_DIVERGED_ITS;
-    if (eps->reason == KS_EPS_CONVERGED_ITERATING && eps->max_steps && eps->steps >= eps->max_steps) eps->reason = KS_EPS_CONVERGED_USER;
+    KS_CHECK(!eps->cb_err, eps->cb_err, "the user's convergence test returned %d", eps->cb_err);
+    KS_CALL(stopping_test(eps, k));
+    const int nconv_mon = k;
 
     // update l
     if (eps->reason != KS_EPS_CONVERGED_ITERATING || breakdown || k == nv) l = 0;
@@ -861,6 +914,7 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
     KS_CALL(ks_bv_multinplace(V, ds.Q.data(), ds.ld, eps->nconv, k + l));
     if (eps->reason == KS_EPS_CONVERGED_ITERATING && !breakdown) KS_CALL(ks_bv_copycolumn(V, nv, k + l));
     eps->nconv = k;
+    KS_CALL(monitor(eps, nconv_mon, nv));
     eps->restarts++;
   }
   ds.truncate(eps->nconv, true);

@@ -412,3 +412,46 @@ def test_true_residual_complex_pairs_and_sinvert(ctx):
     assert np.allclose([eps.GetEigenvalue(i)[0] for i in range(3)], r.eigr[r.perm][:3], rtol=1e-10)
     for i in range(3):
         assert eps.ComputeError(i) < 1e-8 and abs(eps.GetErrorEstimate(i) - eps.ComputeError(i)) < 1e-9
+
+
+def test_user_stopping_convergence_and_monitor_callbacks(ctx):
+    """ex29.c pattern: a user stopping test that first applies EPSStoppingBasic and then its own rule
+    (EPSSetStoppingTestFunction); EPSSetConvergenceTestFunction; EPSMonitorSet. Same rules in the oracle."""
+    import slepc_amd as ks
+    Ao = O.markov_matrix(30)
+    A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A); eps.SetProblemType(ks.EPS_NHEP); eps.SetDimensions(6, 16); eps.SetWhichEigenpairs("largest_real")
+
+    def stop_rule(basic):
+        def f(its, max_it, nconv, nev):
+            r = basic(its, max_it, nconv, nev)
+            return 2 if (r == 0 and its >= 3) else r                    # EPS_CONVERGED_USER after three restarts
+        return f
+    seen = []
+    eps.SetStoppingTestFunction(stop_rule(eps.StoppingBasic))
+    eps.MonitorSet(lambda its, nconv, er, ei, ee: seen.append((its, nconv, er.copy(), ee.copy())))
+    eps.Solve()
+    seen_o = []
+    basic_o = lambda its, max_it, nconv, nev: 1 if nconv >= nev else (-1 if its >= max_it else 0)   # noqa: E731
+    r = O.eps_krylovschur_nhep(Ao, 6, ncv=16, which="largest_real", stopping=stop_rule(basic_o),
+                               monitor=lambda its, nconv, er, ei, ee, nest: seen_o.append((its, nconv, er, ee)))
+    assert eps.GetConvergedReason() == ks.EPS_CONVERGED_USER == r.reason and eps.GetIterationNumber() == 3 == r.its
+    assert eps.GetConverged() == r.nconv and r.nconv < 6                  # ex29_1.out: "finished with 0 converged eigenpairs; reason=CONVERGED_USER"
+    assert [(a[0], a[1]) for a in seen] == [(b[0], b[1]) for b in seen_o] and len(seen) == 3
+    for a, b in zip(seen, seen_o):
+        assert a[2].shape == b[2].shape and np.allclose(a[2], b[2], rtol=1e-9) and np.allclose(a[3], b[3], rtol=1e-4, atol=1e-14)
+    # user convergence test: absolute residual with a loose threshold, as a function
+    eps.SetStoppingTestFunction(None); eps.MonitorSet(None)
+    eps.SetConvergenceTestFunction(lambda re, im, res: res * 10.0)
+    eps.SetTolerances(1e-6, 0)
+    eps.Solve()
+    assert eps.GetConvergenceTest() == 3
+    r = O.eps_krylovschur_nhep(Ao, 6, ncv=16, which="largest_real", tol=1e-6, conv=lambda re, im, res: res * 10.0)
+    assert eps.GetConverged() == r.nconv and eps.GetIterationNumber() == r.its and eps.GetConvergedReason() == 1
+    eps.SetConvergenceTestFunction(None)
+    assert eps.GetConvergenceTest() == 1
+    # an exception in a callback surfaces as an error of the solve, not a crash
+    eps.MonitorSet(lambda *a: 1 / 0)
+    with pytest.raises(ks.KsError):
+        eps.Solve()
