@@ -215,6 +215,7 @@ def main():
             "config": {"workload": workload, "rows_per_gpu": n_local, "nnz_per_gpu": A.nnz, "n_global": A.N, "nev": NEV, "ncv": NCV,
                        "orthog": "CGS, refine ifneeded eta=0.7071", "gs_passes_per_step": st["gs_passes"] / st["steps"],
                        "restarts": st["restarts"], "parallelism": "row-slab x%d" % world,
+                       "spmv_layout": A.layout() + (" (2-byte entries: offset code + value code, lossless; y bit-identical to SELL-64; KSGPU_SPMV=sell disables)" if A.layout() == "dict" else ""),
                        "unit_of_value": "Arnoldi steps on a 10 077 696-row shard, summed over the %d shard(s): value = n_gpus * global_steps_per_s" % world,
                        "global_steps_per_s": args.steps / dt},
         }

@@ -113,6 +113,94 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_sell(int nrows, int nslices
   }
 }
 
+// ---- dictionary ELL ----------------------------------------------------------------------------------
+// Stencil and graph matrices repeat a handful of values at a handful of column offsets (the 7-point Laplacian: 2 values,
+// 7 offsets). When a matrix has at most 255 distinct values (compared bit for bit), at most 256 distinct offsets
+// col - row and rows of at most 16 entries, every entry is stored as two bytes (offset code, value code; value code 255
+// marks padding): 16 or 32 bytes per row instead of 12 per entry, one 16-byte load per lane. The dictionaries sit in
+// LDS. Entries keep their CSR order and the products are accumulated in that order with fma, exactly as k_spmv_sell
+// does, so y is bit-identical to the SELL / CSR result.
+template <int W>
+__global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_dict(int nrows, const uint4 *__restrict__ codes, const double *__restrict__ dval, int nval, const int *__restrict__ doff, int noff,
+                                                          const double *__restrict__ x, double *__restrict__ y, int xcd_remap)
+{
+  __shared__ double sv[256];
+  __shared__ int so[256];
+  for (int i = threadIdx.x; i < nval; i += SPMV_BLOCK) sv[i] = dval[i];
+  for (int i = threadIdx.x; i < noff; i += SPMV_BLOCK) so[i] = doff[i];
+  __syncthreads();
+  constexpr int Q = W / 8;                                  // uint4 (8 entries) per row
+  // Workgroups b, b+8, b+16, ... run on the same XCD (round-robin dispatch). With xcd_remap (grid a multiple of 8) each
+  // XCD walks ONE contiguous eighth of the row groups, so that the x entries its rows share (the +-nx, +-nx*ny
+  // neighbours of a stencil) are fetched into that XCD's L2 once instead of into all eight.
+  const long long groups = ((long long)nrows + SPMV_BLOCK - 1) / SPMV_BLOCK;
+  long long g0 = 0, g1 = groups, lb = blockIdx.x, nb = gridDim.x;
+  if (xcd_remap) {
+    const long long gper = (groups + 7) / 8;
+    g0 = (blockIdx.x % 8) * gper; g1 = g0 + gper < groups ? g0 + gper : groups;
+    lb = blockIdx.x / 8; nb = gridDim.x / 8;
+  }
+  for (long long g = g0 + lb; g < g1; g += nb) {
+    const long long r = g * SPMV_BLOCK + threadIdx.x;
+    if (r >= nrows) break;
+    uint4 c[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) c[q] = ksk::ldstream4(codes + r * Q + q);
+    double a[W], xv[W];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      const unsigned wds[4] = {c[q].x, c[q].y, c[q].z, c[q].w};
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const unsigned code = (wds[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+        const unsigned oc = code & 0xffu, vc = code >> 8;
+        const bool ok = vc != 255u;
+        a[q * 8 + e] = ok ? sv[vc] : 0.0;
+        xv[q * 8 + e] = ok ? x[r + so[oc]] : 0.0;
+      }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < W; e++) acc = fma(a[e], xv[e], acc);
+    y[r] = acc;
+  }
+}
+
+// one thread per row: encode the row's entries against the sorted candidate dictionaries (binary search); entries that
+// are not covered are counted and the first `cap` of them recorded so that the host can extend the dictionaries
+__global__ void k_dict_encode(int n, int W, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+                              const long long *__restrict__ dbits, int nv, const int *__restrict__ doffs, int no,
+                              unsigned short *__restrict__ codes, int *miss, long long *miss_bits, int *miss_off, int cap)
+{
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int p0 = rowptr[r], len = rowptr[r + 1] - p0;
+  for (int j = 0; j < W; j++) {
+    unsigned short code = 0xff00u;                                       // padding
+    if (j < len) {
+      const long long bits = __double_as_longlong(val[p0 + j]);
+      const int off = col[p0 + j] - (int)r;
+      int lo = 0, hi = nv; while (lo < hi) { const int m = (lo + hi) >> 1; if (dbits[m] < bits) lo = m + 1; else hi = m; }
+      const int vi = (lo < nv && dbits[lo] == bits) ? lo : -1;
+      lo = 0; hi = no; while (lo < hi) { const int m = (lo + hi) >> 1; if (doffs[m] < off) lo = m + 1; else hi = m; }
+      const int oi = (lo < no && doffs[lo] == off) ? lo : -1;
+      if (vi < 0 || oi < 0) {
+        if (*(volatile int *)miss < cap) { const int idx = atomicAdd(miss, 1); if (idx < cap) { miss_bits[idx] = bits; miss_off[idx] = off; } }
+        else atomicAdd(miss + 1, 1);
+        code = 0;
+      } else code = (unsigned short)((vi << 8) | oi);
+    }
+    codes[r * W + j] = code;
+  }
+}
+__global__ void k_max_rowlen(int n, const int *__restrict__ rowptr, int *out)
+{
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int len = (r < n) ? rowptr[r + 1] - rowptr[r] : 0;
+  for (int off = 32; off > 0; off >>= 1) len = max(len, __shfl_xor(len, off, 64));
+  if ((threadIdx.x & 63) == 0 && len > 0) atomicMax(out, len);
+}
+
 __global__ void k_sell_widths(int n, int nslices, const int *__restrict__ rowptr, int *__restrict__ width, int *__restrict__ rlen)
 {
   const long long s = (long long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
@@ -467,6 +555,62 @@ int build_sliced(ks_mat A)
   return KS_SUCCESS;
 }
 
+// Try the dictionary layout (see k_spmv_dict). Needs the CSR arrays of the diagonal block on the device.
+int build_dict(ks_mat A)
+{
+  ks_ctx ctx = A->ctx;
+  const char *force = getenv("KSGPU_SPMV");
+  if (force && strcmp(force, "dict")) return KS_SUCCESS;                 // any other forced layout
+  const int n = A->n;
+  int *d_int = nullptr;
+  KS_HIP(hipMalloc(&d_int, sizeof(int) * 4));
+  KS_HIP(hipMemsetAsync(d_int, 0, sizeof(int) * 4, ctx->stream));
+  hipLaunchKernelGGL(k_max_rowlen, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, A->d_rowptr, d_int + 2);
+  int maxlen = 0;
+  KS_HIP(hipMemcpyAsync(&maxlen, d_int + 2, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  KS_HIP(hipStreamSynchronize(ctx->stream));
+  if (maxlen > 16 || maxlen == 0) { hipFree(d_int); return KS_SUCCESS; }
+  const int W = maxlen <= 8 ? 8 : 16;
+  if ((double)W * n > 4.0 * (double)A->nnz_d + 4096.0) { hipFree(d_int); return KS_SUCCESS; }   // mostly padding: nothing to gain
+  const int cap = 4096;
+  unsigned short *codes = nullptr; long long *d_bits = nullptr, *m_bits = nullptr; int *d_offs = nullptr, *m_off = nullptr;
+  KS_HIP(hipMalloc(&codes, sizeof(unsigned short) * (size_t)n * W));
+  KS_HIP(hipMalloc(&d_bits, sizeof(long long) * 256)); KS_HIP(hipMalloc(&d_offs, sizeof(int) * 256));
+  KS_HIP(hipMalloc(&m_bits, sizeof(long long) * cap)); KS_HIP(hipMalloc(&m_off, sizeof(int) * cap));
+  auto cleanup = [&]() { hipFree(d_int); hipFree(codes); hipFree(d_bits); hipFree(d_offs); hipFree(m_bits); hipFree(m_off); };
+  std::vector<long long> vals; std::vector<int> offs;                   // sorted candidate dictionaries
+  bool done = false;
+  for (int round = 0; round < 8 && !done; round++) {
+    KS_HIP(hipMemsetAsync(d_int, 0, sizeof(int) * 2, ctx->stream));
+    if (!vals.empty()) KS_HIP(hipMemcpyAsync(d_bits, vals.data(), sizeof(long long) * vals.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (!offs.empty()) KS_HIP(hipMemcpyAsync(d_offs, offs.data(), sizeof(int) * offs.size(), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_dict_encode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, W, A->d_rowptr, A->d_col, A->d_val,
+                       d_bits, (int)vals.size(), d_offs, (int)offs.size(), codes, d_int, m_bits, m_off, cap);
+    int miss[2] = {0, 0};
+    KS_HIP(hipMemcpyAsync(miss, d_int, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
+    KS_HIP(hipStreamSynchronize(ctx->stream));
+    if (miss[0] == 0) { done = true; break; }
+    const int got = std::min(miss[0], cap);
+    std::vector<long long> mb(got); std::vector<int> mo(got);
+    KS_HIP(hipMemcpy(mb.data(), m_bits, sizeof(long long) * got, hipMemcpyDeviceToHost));
+    KS_HIP(hipMemcpy(mo.data(), m_off, sizeof(int) * got, hipMemcpyDeviceToHost));
+    vals.insert(vals.end(), mb.begin(), mb.end()); std::sort(vals.begin(), vals.end()); vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+    offs.insert(offs.end(), mo.begin(), mo.end()); std::sort(offs.begin(), offs.end()); offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+    if (vals.size() > 255 || offs.size() > 256) break;                   // not a dictionary matrix
+  }
+  if (!done) { cleanup(); return KS_SUCCESS; }
+  std::vector<double> dv(256, 0.0); std::vector<int> dof(256, 0);
+  for (size_t i = 0; i < vals.size(); i++) memcpy(&dv[i], &vals[i], sizeof(double));
+  for (size_t i = 0; i < offs.size(); i++) dof[i] = offs[i];
+  KS_HIP(hipMalloc(&A->dc_val, sizeof(double) * 256)); KS_HIP(hipMalloc(&A->dc_off, sizeof(int) * 256));
+  KS_HIP(hipMemcpy(A->dc_val, dv.data(), sizeof(double) * 256, hipMemcpyHostToDevice));
+  KS_HIP(hipMemcpy(A->dc_off, dof.data(), sizeof(int) * 256, hipMemcpyHostToDevice));
+  A->dc_codes = codes; codes = nullptr;
+  A->use_dict = true; A->dict_w = W; A->dict_nval = (int)vals.size(); A->dict_noff = (int)offs.size();
+  cleanup();
+  return KS_SUCCESS;
+}
+
 int build_sell(ks_mat A)
 {
   if (A->use_sliced) return KS_SUCCESS;
@@ -474,6 +618,7 @@ int build_sell(ks_mat A)
   const char *force = getenv("KSGPU_SPMV");
   if (force && !strcmp(force, "csr")) return KS_SUCCESS;
   if (A->n == 0 || A->nnz_d == 0) return KS_SUCCESS;
+  KS_CALL(build_dict(A));                                   // independent of the SELL decision below; needs the CSR arrays
   const int ns = (A->n + 63) / 64;
   int *width = nullptr;
   KS_HIP(hipMalloc(&width, sizeof(int) * (ns + 1)));
@@ -626,6 +771,7 @@ extern "C" int ks_mat_destroy(ks_mat A)
   hipFree(A->o_rowptr); hipFree(A->o_col); hipFree(A->o_val); hipFree(A->o_rows);
   hipFree(A->ghost); hipFree(A->send_idx); hipFree(A->send_buf);
   hipFree(A->s_ptr); hipFree(A->s_len); hipFree(A->s_col); hipFree(A->s_val);
+  hipFree(A->dc_codes); hipFree(A->dc_val); hipFree(A->dc_off);
   hipFree(A->sl_rowptr); hipFree(A->sl_col); hipFree(A->sl_val); hipFree(A->sl_base); hipFree(A->ypart); hipFree(A->diag_cache);
   delete A;
   return KS_SUCCESS;
@@ -634,7 +780,7 @@ extern "C" int ks_mat_destroy(ks_mat A)
 extern "C" int ks_mat_get_layout(ks_mat A, int *layout)     // storage of the diagonal block: KS_MAT_LAYOUT_*
 {
   KS_CHECK(A && layout, KS_ERR_ARG_NULL, "NULL argument");
-  *layout = A->shell_mult ? KS_MAT_LAYOUT_SHELL : (A->use_sliced ? KS_MAT_LAYOUT_SLICED : (A->use_sell ? KS_MAT_LAYOUT_SELL : KS_MAT_LAYOUT_CSR));
+  *layout = A->shell_mult ? KS_MAT_LAYOUT_SHELL : (A->use_sliced ? KS_MAT_LAYOUT_SLICED : (A->use_dict ? KS_MAT_LAYOUT_DICT : (A->use_sell ? KS_MAT_LAYOUT_SELL : KS_MAT_LAYOUT_CSR)));
   return KS_SUCCESS;
 }
 extern "C" int ks_mat_get_sizes(ks_mat A, int *n_local, int *n_global, long long *nnz_local)
@@ -660,11 +806,23 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
                              A->ghost, A->recv_off.data(), A->recv_cnt.data(), (int)sizeof(double)));
   }
   {
-    KsProfScope ps(ctx, KS_K_SPMV, 12.0 * A->nnz + 4.0 * (A->n + 1) + 16.0 * A->n, A->use_sell ? 8 : 0);   // variant 8: k_spmv_sell<8>, 0: k_spmv_csr
+    const double csr_bytes = 12.0 * A->nnz + 4.0 * (A->n + 1) + 16.0 * A->n;                    // what the CSR algorithm moves
+    KsProfScope ps(ctx, KS_K_SPMV, csr_bytes, A->use_dict ? 16 : (A->use_sell ? 8 : 0),         // variant 16: k_spmv_dict, 8: k_spmv_sell<8>, 0: k_spmv_csr
+                   A->use_dict ? (2.0 * A->dict_w + 16.0) * A->n + 12.0 * A->nnz_o : -1.0);       // the dictionary layout's own compulsory bytes
     if (A->use_sliced) {
       const int per_xcd = std::max(1, std::min((A->n + 255) / 256, (ctx->num_cu / 8) * 8));       // 8 resident workgroups per CU of the XCD
       hipLaunchKernelGGL(k_spmv_sliced, dim3((unsigned)(8 * per_xcd)), dim3(256), 0, ctx->stream, A->n, A->nslice, A->sl_rowptr, A->sl_base, A->sl_col, A->sl_val, x, A->ypart);
       hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)std::min((A->n + 255) / 256, ctx->num_cu * 8)), dim3(256), 0, ctx->stream, A->n, A->ypart, y);
+    } else if (A->use_dict) {
+      static const int dremap_env = getenv("KSGPU_DICT_REMAP") ? atoi(getenv("KSGPU_DICT_REMAP")) : 1;
+      static const int dmul = getenv("KSGPU_DICT_BMUL") ? atoi(getenv("KSGPU_DICT_BMUL")) : 64;
+      const long long groups = ((long long)A->n + SPMV_BLOCK - 1) / SPMV_BLOCK;
+      long long nblk = std::max<long long>(1, std::min<long long>(groups, (long long)ctx->num_cu * dmul));
+      const int dremap = (dremap_env && nblk >= 64) ? 1 : 0;               // small matrices: nothing to pin
+      if (dremap) nblk = std::min<long long>((nblk + 7) / 8, (groups + 7) / 8) * 8;
+      const dim3 gr((unsigned)nblk);
+      if (A->dict_w == 8) hipLaunchKernelGGL((k_spmv_dict<8>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, (const uint4 *)A->dc_codes, A->dc_val, A->dict_nval, A->dc_off, A->dict_noff, x, y, dremap);
+      else hipLaunchKernelGGL((k_spmv_dict<16>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, (const uint4 *)A->dc_codes, A->dc_val, A->dict_nval, A->dc_off, A->dict_noff, x, y, dremap);
     } else if (A->use_sell) {
       static const int remap = getenv("KSGPU_SELL_REMAP") ? 1 : 0;
       const long long groups = ((long long)A->nslices + 3) / 4;

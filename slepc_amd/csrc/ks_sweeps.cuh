@@ -26,7 +26,10 @@ typedef double ks_d2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double2 ldcol2(const double *p) { const ks_d2v t = __builtin_nontemporal_load(reinterpret_cast<const ks_d2v *>(p)); double2 v; v.x = t.x; v.y = t.y; return v; }
 __device__ __forceinline__ double ldstream(const double *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ int ldstream(const int *p) { return __builtin_nontemporal_load(p); }
+typedef unsigned ks_u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ldstream4(const uint4 *p) { const ks_u4v t = __builtin_nontemporal_load(reinterpret_cast<const ks_u4v *>(p)); uint4 v; v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w; return v; }
 #else
+__device__ __forceinline__ uint4 ldstream4(const uint4 *p) { return *p; }
 __device__ __forceinline__ double2 ldcol2(const double *p) { return *reinterpret_cast<const double2 *>(p); }
 __device__ __forceinline__ double ldstream(const double *p) { return *p; }
 __device__ __forceinline__ int ldstream(const int *p) { return *p; }

@@ -86,6 +86,9 @@ struct ks_mat_s {
   // padding it needs is small; val/col stored column-major inside a slice: entry j of row 64s+lane at (sp[s]+j)*64+lane
   bool use_sell = false;
   int nslices = 0; int *s_ptr = nullptr; int *s_len = nullptr; int *s_col = nullptr; double *s_val = nullptr; long long s_entries = 0;
+  // dictionary ELL (few distinct values and few distinct column offsets, rows of at most 16 entries): 2 bytes per entry
+  bool use_dict = false; int dict_w = 0; int dict_nval = 0, dict_noff = 0;
+  unsigned short *dc_codes = nullptr; double *dc_val = nullptr; int *dc_off = nullptr;
   // XCD-sliced copy of the diagonal block for wide-scatter matrices (columns spread over a vector much larger than one
   // XCD's 4 MiB L2): the columns are cut into nslice = 8*P ranges; slice s is a CSR of its own (rows 0..n-1) and is
   // multiplied only by workgroups with blockIdx % 8 == s % 8, i.e. on one XCD, whose L2 then holds that range of x.

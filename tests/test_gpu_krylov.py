@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import golden_inputs as gi
+import scenarios as sc
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -81,6 +82,54 @@ def test_spmv_both_layouts(ctx, monkeypatch, fmt):
     assert np.all(y[lens == 0] == 0.0)
 
 
+def test_spmv_dictionary_layout(ctx, monkeypatch):
+    """Dictionary ELL (two bytes per entry: offset code, value code) is picked for matrices with few distinct values
+    and offsets and rows of at most 16 entries; its result is BIT-IDENTICAL to the SELL layout's (same order, same
+    fma chain). Ragged rows, empty rows, padding that must not touch NaN, 13-entry rows (32-byte form), and matrices
+    that do not qualify."""
+    import scipy.sparse as sp
+    import slepc_amd as ks
+
+    def both(make):
+        monkeypatch.setenv("KSGPU_SPMV", "sell"); S = make(); assert S.layout() == "sell"
+        monkeypatch.delenv("KSGPU_SPMV"); D = make()
+        return S, D
+    rng = np.random.default_rng(8)
+    # the generators
+    for make, n in ((lambda: ks.Mat.laplacian3d(ctx, 37, 23, 19), 37 * 23 * 19), (lambda: ks.Mat.laplacian2d(ctx, 300), 90000)):
+        S, D = both(make)
+        assert D.layout() == "dict"
+        x = rng.standard_normal(n)
+        assert np.array_equal(S.mult(x), D.mult(x))
+        assert np.array_equal(S.get_diagonal(), D.get_diagonal()) and S.norm_inf() == D.norm_inf()
+    # user CSR: mesh-graph Laplacian (values -1, 2, 3, 4), ragged with empty rows, NaN guarded by the padding mask
+    G = sc.graph_laplacian_2d(50, 41)
+    S, D = both(lambda: ks.Mat.from_csr(ctx, G.indptr, G.indices, G.data))
+    assert D.layout() == "dict"
+    x = rng.standard_normal(G.shape[0])
+    y = D.mult(x)
+    assert np.array_equal(S.mult(x), y) and np.abs(y - G @ x).max() < 1e-13
+    n = 3000
+    lens = rng.integers(0, 14, n); lens[::5] = 0
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate([np.sort(np.clip(r + rng.choice(np.arange(-40, 41), l, replace=False), 0, n - 1)) for r, l in enumerate(lens)] + [np.empty(0, int)]).astype(np.int32)
+    # clipping can repeat a column inside a row: legal CSR for a product, and it keeps the offset set small
+    val = rng.choice([0.5, -1.25, 3.0, -0.0, 1e-300], rowptr[-1])
+    S, D = both(lambda: ks.Mat.from_csr(ctx, rowptr, col, val))
+    assert D.layout() == "dict"                                            # 13-entry rows: the 32-byte form
+    xb = rng.standard_normal(n); xb[n - 1] = np.nan
+    y, y0 = D.mult(xb), S.mult(xb)
+    assert np.array_equal(np.isnan(y), np.isnan(y0)) and np.array_equal(y[~np.isnan(y)], y0[~np.isnan(y0)])
+    assert np.all(y[lens == 0] == 0.0) and np.signbit(y[lens == 0]).sum() == 0
+    ref = O.CSR(n, rowptr, col, val).mult(xb); ok = ~np.isnan(ref)
+    assert np.allclose(y[ok], ref[ok], rtol=0, atol=1e-13)
+    # not dictionary matrices: too many distinct values / rows too long / too many offsets
+    val2 = rng.standard_normal(rowptr[-1])
+    assert ks.Mat.from_csr(ctx, rowptr, col, val2).layout() in ("sell", "csr")
+    R = sp.random(2000, 2000, density=20 / 2000, random_state=3, format="csr", data_rvs=lambda k: np.ones(k)); R.sort_indices()
+    assert ks.Mat.from_csr(ctx, R.indptr, R.indices, R.data).layout() in ("sell", "csr")
+
+
 def test_spmv_xcd_sliced_layout(ctx, monkeypatch):
     """The XCD-sliced layout (column ranges pinned to XCDs by blockIdx % 8, eight partial results added in fixed order):
     forced on small and ragged matrices incl. empty rows and duplicate entries, and chosen automatically for a
@@ -108,7 +157,7 @@ def test_spmv_xcd_sliced_layout(ctx, monkeypatch):
     Ao, _ = nc.config5_pencil_fast(1_500_000, mean_nnz=12)               # x = 12 MB > 6 MB, entries far from the diagonal
     A = _mat(ctx, Ao)
     assert A.layout() == "sliced"
-    assert ks.Mat.laplacian3d(ctx, 160, 160, 160).layout() == "sell"       # banded: stays with the row-ordered layouts
+    assert ks.Mat.laplacian3d(ctx, 160, 160, 160).layout() == "dict"       # banded: stays with the row-ordered layouts
     x = rng.standard_normal(Ao.n)
     assert np.allclose(A.mult(x), Ao.mult(x), rtol=0, atol=1e-11)
     assert abs(A.get_diagonal()[12345] - Ao.to_scipy().diagonal()[12345]) < 1e-13
