@@ -53,8 +53,10 @@ int linop_apply(ks_st st, double a, ks_mat A, double b, ks_mat B, bool identity_
   const long long n = st->n;
   if (A) {
     KS_CALL(ks_mat_mult_internal(A, x, out));
-    if (B) { KS_CALL(ks_mat_mult_internal(B, x, tmp)); return lincomb(ctx, n, s, a, out, b, tmp, out); }
-    if (identity_term) return lincomb(ctx, n, s, a, out, b, x, out);
+    if (b != 0.0) {                                         // a zero shift leaves A alone (MatMult_Shell, stshellmat.c:52: "if (ctx->alpha!=0.0)")
+      if (B) { KS_CALL(ks_mat_mult_internal(B, x, tmp)); return lincomb(ctx, n, s, a, out, b, tmp, out); }
+      if (identity_term) return lincomb(ctx, n, s, a, out, b, x, out);
+    }
     if (s || a != 1.0) return lincomb(ctx, n, s, a, out, 0.0, nullptr, out);
     return KS_SUCCESS;
   }
