@@ -787,6 +787,13 @@ class EPS:
     def ComputeError(self, i, type=EPS_ERROR_RELATIVE):
         v = C.c_double(); _lib.check(self.ctx.L.ks_eps_compute_error(self.h, i, type, C.byref(v))); return v.value
 
+    def GetEigenpairDev(self, i, xr_ptr, xi_ptr=None):
+        """EPSGetEigenpair into device vectors (raw pointers of n_local doubles); returns (eigr, eigi)."""
+        kr = C.c_double(); ki = C.c_double()
+        _lib.check(self.ctx.L.ks_eps_get_eigenpair(self.h, i, C.byref(kr), C.byref(ki), C.c_void_p(xr_ptr) if xr_ptr else None,
+                                                   C.c_void_p(xi_ptr) if xi_ptr else None))
+        return kr.value, ki.value
+
     def GetBV(self):
         h = C.c_void_p(); _lib.check(self.ctx.L.ks_eps_get_bv(self.h, C.byref(h)))
         return BV(self.ctx, 0, 0, _handle=h)

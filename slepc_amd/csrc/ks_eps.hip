@@ -994,6 +994,27 @@ extern "C" int ks_eps_get_eigenpair_host(ks_eps eps, int i, double *eigr, double
   } else { if (xr) KS_CALL(ks_bv_get_column_host(eps->V, k, xr)); if (xi) for (int r = 0; r < nloc; r++) xi[r] = 0.0; }
   return KS_SUCCESS;
 }
+// the same with device vectors of n_local doubles (what EPSGetEigenpair fills when the Vecs live on the GPU)
+extern "C" int ks_eps_get_eigenpair(ks_eps eps, int i, double *eigr, double *eigi, double *xr_dev, double *xi_dev)
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  KS_CHECK(eps->solved, KS_ERR_ARG_WRONGSTATE, "Must call EPSSolve() first");
+  KS_CHECK(i >= 0 && i < eps->nconv, KS_ERR_ARG_OUTOFRANGE, "The index can be nconv-1 at most, see EPSGetConverged()");
+  const int k = eps->perm[i]; const size_t nloc = eps->V->n;
+  const double im = eps->eigi[k];
+  ks_ctx ctx = eps->ctx; ks_bv V = eps->V;
+  KS_HIP(hipSetDevice(ctx->device));
+  if (eigr) *eigr = eps->eigr[k];
+  if (eigi) *eigi = im;
+  const int kr = im < 0.0 ? k - 1 : k;
+  if (xr_dev) KS_CALL(ksk_copy(ctx, ks_bv_col(V, kr), xr_dev, nloc));
+  if (xi_dev) {
+    if (im == 0.0) KS_HIP(hipMemsetAsync(xi_dev, 0, nloc * sizeof(double), ctx->stream));
+    else { KS_CALL(ksk_copy(ctx, ks_bv_col(V, kr + 1), xi_dev, nloc)); if (im < 0.0) KS_CALL(ksk_scale(ctx, xi_dev, nloc, -1.0)); }
+  }
+  KS_HIP(hipStreamSynchronize(ctx->stream));
+  return KS_SUCCESS;
+}
 extern "C" int ks_eps_get_error_estimate(ks_eps eps, int i, double *errest)
 {
   KS_CHECK(eps && errest, KS_ERR_ARG_NULL, "NULL argument");

@@ -83,6 +83,23 @@ def test_eps_complex_pairs(ctx, which):
         k += 1
 
 
+def test_get_eigenpair_into_device_vectors(ctx):
+    """ks_eps_get_eigenpair (device destinations) returns what the host variant returns, for both members of a pair."""
+    import slepc_amd as ks
+    Ao = nc.planted_pairs(1500)
+    eps = _solve(ctx, Ao, 4, ncv=24, which="largest_imaginary")
+    W = ks.BV(ctx, Ao.n, 2)
+    seen_pair = False
+    for i in range(eps.GetConverged()):
+        kr, ki, xr, xi = eps.GetEigenpair(i)
+        kr2, ki2 = eps.GetEigenpairDev(i, W.column_ptr(0), W.column_ptr(1))
+        assert (kr, ki) == (kr2, ki2) and np.array_equal(W.column(0), xr) and np.array_equal(W.column(1), xi)
+        seen_pair |= ki < 0.0
+    assert seen_pair
+    kr3, _ = eps.GetEigenpairDev(0, W.column_ptr(0))                     # xi optional
+    assert kr3 == eps.GetEigenvalue(0)[0]
+
+
 def test_eps_planted_pairs_larger(ctx):
     """n = 200000 rows: the sweeps run multi-block; well-separated pairs, so the restart path is rounding-insensitive."""
     Ao = nc.planted_pairs(200000)
