@@ -110,3 +110,13 @@ def test2_X(n=20, k=8):
             if i + j < n:
                 X[i + j, j] = (3.0 * i + j - 2) / (2 * (i + j + 1))
     return X
+
+
+def eigenvalue_lines(text):
+    """Every line that follows 'All requested eigenvalues computed ...' (one per solve of the program), as arrays."""
+    out = []
+    lines = text.splitlines()
+    for i, line in enumerate(lines):
+        if "All requested eigenvalues computed" in line:
+            out.append(np.array([float(t) for t in lines[i + 1].replace(",", " ").split()]))
+    return out

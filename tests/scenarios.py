@@ -326,3 +326,23 @@ def bv_test6(be, orthog_type=0, n=20, k=8, nc=2, refine=0):
     Q = X.dense()[:n]
     return {"kept": kept, "level": np.abs(M - np.eye(k)).sum(axis=0).max(), "norms": np.array(norms), "X": Q, "C": Cq,
             "cross": np.abs(Cq.T @ Q).max(), "clevel": np.abs(Cq.T @ Cq - np.eye(kept)).max(), "buffer": np.array(X.buffer() if callable(X.buffer) else X.buffer)}
+
+
+def tridiag_csr(n, sub, diag, sup):
+    """Tridiagonal Toeplitz matrix as scipy CSR (sorted)."""
+    import scipy.sparse as sp
+    S = sp.diags([np.full(n - 1, sub), np.full(n, diag), np.full(n - 1, sup)], [-1, 0, 1], format="csr"); S.sort_indices()
+    return S
+
+
+def laplacian2d_csr(n, m):
+    """eps/tests/test28.c:40-48: 5-point Laplacian on an n x m grid, II = i*n + j."""
+    import scipy.sparse as sp
+    S = (sp.kron(sp.identity(m), tridiag_csr(n, -1.0, 4.0, -1.0)) + sp.kron(tridiag_csr(m, -1.0, 0.0, -1.0), sp.identity(n))).tocsr()
+    S.sort_indices()
+    return S
+
+
+def test16_converged(re, im, res):
+    """eps/tests/test16.c:20-25 MyConvergedAbsolute"""
+    return res if re < 0.0 else 100.0 * res

@@ -1,0 +1,97 @@
+"""More of the reference's EPS test programs run through the C ABI on the GPU, each against its golden output and the
+CPU oracle: test16 (user convergence function), test20 (second solve with a larger subspace on the same solver),
+test24 (exact eigenvectors as deflation space), test28 (second solve with a matrix of another size on the same solver)."""
+import numpy as np
+import pytest
+
+import golden_inputs as gi
+import scenarios as sc
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _csr(S):
+    return O.CSR(S.shape[0], S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64))
+
+
+def _mat(ctx, S):
+    import slepc_amd as ks
+    return ks.Mat.from_csr(ctx, S.indptr, S.indices, S.data)
+
+
+def _same_run(eps, r):
+    assert eps.GetConverged() == r.nconv and eps.GetIterationNumber() == r.its and eps.GetConvergedReason() == r.reason
+    st = eps.GetStats()
+    assert st["arnoldi_steps"] == r.steps and st["gs_passes"] == r.passes
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(r.nconv)])
+    assert np.allclose(lam, r.eigr[r.perm][: r.nconv], rtol=1e-10, atol=1e-13)
+    return lam
+
+
+def test_eps_test16_user_convergence_golden(ctx):
+    import slepc_amd as ks
+    S = sc.tridiag_csr(200, -1.0, -1e-3, -1.0)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(_mat(ctx, S)); eps.SetProblemType(ks.EPS_HEP)
+    eps.SetConvergenceTestFunction(sc.test16_converged)
+    eps.SetDimensions(6, 24); eps.SetWhichEigenpairs("smallest_magnitude")
+    eps.Solve()
+    r = O.eps_krylovschur_hep(_csr(S), 6, ncv=24, which="smallest_magnitude", conv=sc.test16_converged)
+    lam = _same_run(eps, r)
+    assert np.allclose(np.round(lam[:6], 5), gi.eigenvalue_lines(gi.read("eps/eps_test16_1.out"))[0], atol=1.5e-5)
+
+
+def test_eps_test20_changing_ncv_golden(ctx):
+    import slepc_amd as ks
+    S = sc.tridiag_csr(18, -1.0, 2.0, -1.0)
+    tol = max(1000 * np.finfo(float).eps, 1e-9)
+    ref = gi.eigenvalue_lines(gi.read("eps/eps_test20_1.out"))
+    eps = ks.EPS(ctx)
+    eps.SetOperators(_mat(ctx, S)); eps.SetProblemType(ks.EPS_HEP); eps.SetTolerances(tol, 1500); eps.SetWhichEigenpairs("smallest_real")
+    eps.Solve()
+    r = O.eps_krylovschur_hep(_csr(S), 1, tol=tol, max_it=1500, which="smallest_real")
+    lam = _same_run(eps, r)
+    assert abs(round(lam[0], 5) - ref[0][0]) < 1.5e-5
+    nev, ncv, mpd = eps.GetDimensions()
+    assert (nev, ncv) == (1, r.ncv)
+    eps.SetDimensions(nev, ncv + 2)                                       # EPSSetDimensions(eps,nev,ncv+2,PETSC_DETERMINE)
+    eps.Solve()
+    r2 = O.eps_krylovschur_hep(_csr(S), 1, ncv=ncv + 2, tol=tol, max_it=1500, which="smallest_real")
+    lam2 = _same_run(eps, r2)
+    assert eps.GetDimensions()[1] == ncv + 2 and abs(round(lam2[0], 5) - ref[1][0]) < 1.5e-5
+
+
+def test_eps_test24_exact_eigenvectors_deflated_golden(ctx):
+    import slepc_amd as ks
+    n = 30
+    S = sc.tridiag_csr(n, -1.0, 2.0, -1.0)
+    alpha, beta = np.pi / (n + 1), np.sqrt(2.0 / (n + 1))
+    Cm = np.stack([np.sin(alpha * (np.arange(n) + 1) * (i + 1)) * beta for i in range(2)], axis=1)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(_mat(ctx, S)); eps.SetProblemType(ks.EPS_HEP); eps.SetWhichEigenpairs("smallest_real")
+    eps.SetConvergenceTest("abs"); eps.SetDimensions(4); eps.SetTolerances(1e-8, 1200)
+    eps.SetDeflationSpace(Cm)
+    eps.Solve()
+    r = O.eps_krylovschur_hep(_csr(S), 4, tol=1e-8, max_it=1200, which="smallest_real", conv="abs", deflation=Cm)
+    lam = _same_run(eps, r)
+    assert np.allclose(np.round(lam[:4], 5), gi.eigenvalue_lines(gi.read("eps/eps_test24_1.out"))[0], atol=1.5e-5)
+    X = np.stack([eps.GetEigenvector(i) for i in range(4)], axis=1)
+    assert np.abs(Cm.T @ X).max() < 1e-12
+
+
+def test_eps_test28_second_matrix_of_another_size_golden(ctx):
+    """EPSSetOperators with a matrix of a different size resets the solver (epssetup.c:477: EPSReset)."""
+    import slepc_amd as ks
+    ref = gi.eigenvalue_lines(gi.read("eps/eps_test28_1.out"))
+    eps = ks.EPS(ctx)
+    for k, (n, m) in enumerate(((10, 11), (20, 22))):
+        S = sc.laplacian2d_csr(n, m)
+        eps.SetOperators(_mat(ctx, S))
+        if k == 0:
+            eps.SetProblemType(ks.EPS_HEP); eps.SetWhichEigenpairs("smallest_real"); eps.SetDimensions(3)
+        eps.Solve()
+        r = O.eps_krylovschur_hep(_csr(S), 3, which="smallest_real")
+        lam = _same_run(eps, r)
+        assert np.allclose(np.round(lam[:3], 5), ref[k], atol=1.5e-5)
+        assert eps.GetEigenvector(0).shape == (n * m,) and eps.ComputeError(0) < 1e-7

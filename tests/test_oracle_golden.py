@@ -435,3 +435,46 @@ def test_eps_true_residual_golden():
     for i in range(4):
         j = r.perm[i]
         assert abs(r.errest[j] - O.eps_compute_error_nhep(M, r, i)) < 1e-10
+
+
+def _csr(S):
+    return O.CSR(S.shape[0], S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64))
+
+
+def test_eps_test16_user_convergence_golden():
+    """test16 -n 200 -eps_nev 6 -eps_ncv 24 -eps_smallest_magnitude with MyConvergedAbsolute
+    -> 0.01463, -0.01663, 0.04589, -0.04789, 0.07713, -0.07913."""
+    A = _csr(sc.tridiag_csr(200, -1.0, -1e-3, -1.0))
+    r = O.eps_krylovschur_hep(A, 6, ncv=24, which="smallest_magnitude", conv=sc.test16_converged)
+    assert r.nconv >= 6
+    assert np.allclose(np.round(r.eigr[r.perm][:6], 5), gi.eigenvalues_line(gi.read("eps/eps_test16_1.out")), atol=1.5e-5)
+
+
+def test_eps_test20_changing_ncv_golden():
+    """test20 -n 18 -eps_max_it 1500: smallest real eigenvalue of the 1-D Laplacian, then again with ncv + 2."""
+    A = _csr(sc.tridiag_csr(18, -1.0, 2.0, -1.0))
+    tol = max(1000 * np.finfo(float).eps, 1e-9)
+    ref = gi.eigenvalue_lines(gi.read("eps/eps_test20_1.out"))
+    r = O.eps_krylovschur_hep(A, 1, tol=tol, max_it=1500, which="smallest_real")
+    assert abs(round(r.eigr[r.perm][0], 5) - ref[0][0]) < 1.5e-5
+    r2 = O.eps_krylovschur_hep(A, 1, ncv=r.ncv + 2, tol=tol, max_it=1500, which="smallest_real")
+    assert r2.ncv == r.ncv + 2 and abs(round(r2.eigr[r2.perm][0], 5) - ref[1][0]) < 1.5e-5
+
+
+def test_eps_test24_constraints_are_exact_eigenvectors_golden():
+    """test24 -ncon 2: the two lowest eigenvectors of the 1-D Laplacian (n = 30) deflated -> 0.09172, 0.16208, 0.25131,
+    0.35847 (the golden file comes from the program's LOBPCG run; the eigenvalues do not depend on the solver)."""
+    n = 30
+    A = _csr(sc.tridiag_csr(n, -1.0, 2.0, -1.0))
+    alpha, beta = np.pi / (n + 1), np.sqrt(2.0 / (n + 1))
+    Cm = np.stack([np.sin(alpha * (np.arange(n) + 1) * (i + 1)) * beta for i in range(2)], axis=1)
+    r = O.eps_krylovschur_hep(A, 4, tol=1e-8, max_it=1200, which="smallest_real", conv="abs", deflation=Cm)
+    assert np.allclose(np.round(r.eigr[r.perm][:4], 5), gi.eigenvalue_lines(gi.read("eps/eps_test24_1.out"))[0], atol=1.5e-5)
+
+
+def test_eps_test28_two_sizes_golden():
+    """test28: 2-D Laplacians on 10x11 and 20x22 grids solved one after the other, nev = 3, smallest real."""
+    ref = gi.eigenvalue_lines(gi.read("eps/eps_test28_1.out"))
+    for (n, m), want in zip(((10, 11), (20, 22)), ref):
+        r = O.eps_krylovschur_hep(_csr(sc.laplacian2d_csr(n, m)), 3, which="smallest_real")
+        assert np.allclose(np.round(r.eigr[r.perm][:3], 5), want, atol=1.5e-5)
