@@ -1,0 +1,28 @@
+"""Time of the MFMA panel kernels at n = 216^3: BVDot(X,Y) with 31+31 columns, the Gram matrix BVDot(X,X), and the
+restart product BVMultInPlace (30 columns in, 20 out)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import slepc_amd as ks
+
+ctx = ks.Context(0)
+n, m = 216 ** 3, 32
+X = ks.BV(ctx, n, m); Y = ks.BV(ctx, n, m)
+for j in range(m):
+    X.SetRandomColumn(j); Y.SetRandomColumn(j, 7)
+X.SetActiveColumns(0, 31); Y.SetActiveColumns(0, 31)
+M = np.zeros((31, 31), order="F")
+
+def timed(f, reps=20):
+    f(); ctx.synchronize(); t = time.time()
+    for _ in range(reps):
+        f()
+    ctx.synchronize(); return (time.time() - t) / reps
+
+t = timed(lambda: X.Dot(Y, M)); print("BVDot(X,Y) 31x31: %.0f us  %.2f TB/s (62 columns)" % (t * 1e6, 62 * 8.0 * n / t / 1e12))
+t = timed(lambda: X.Dot(X, M)); print("BVDot(X,X) 31x31: %.0f us  %.2f TB/s of the 31 columns it has to read, %.2f TB/s in BVDot's 62" % (t * 1e6, 31 * 8.0 * n / t / 1e12, 62 * 8.0 * n / t / 1e12))
+G = M.copy(); X.Dot(Y, M); X.Dot(X, M)
+Xh = None
+Q = np.asfortranarray(np.random.default_rng(0).standard_normal((31, 31)))
+X.SetActiveColumns(0, 30)
+t = timed(lambda: X.MultInPlace(Q, 0, 20), reps=5); print("BVMultInPlace 30 -> 20: %.0f us  %.2f TB/s" % (t * 1e6, 50 * 8.0 * n / t / 1e12))

@@ -41,13 +41,16 @@ __device__ __forceinline__ void stage_column(const double *__restrict__ src, lon
 }
 
 // partialsM[b][i*NT16 + j] = sum over the block's rows of Y(r,i) X(r,j)
-template <int MT, int NT>
+// SAME: Y and X are the same columns (a Gram matrix, BVDot(X,X,M) and the CHOL / SVQB orthogonalisations): the panel is
+// read and staged once and serves as both operands - half the HBM bytes, the same MFMA sequence, the same bits.
+template <int MT, int NT, bool SAME>
 __global__ __launch_bounds__(PB) void k_panel_dot_mfma(const double *__restrict__ Y, long long ldy, int my, const double *__restrict__ X, long long ldx, int nx,
                                                         int n, double *__restrict__ partialsM)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int MC = MT * 16, NC = NT * 16;
-  double *ldsY = lds, *ldsX = lds + MC * RP;
+  constexpr int SC = SAME ? MC : MC + NC;               // staged columns
+  double *ldsY = lds, *ldsX = SAME ? lds : lds + MC * RP;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   d4 acc[MT][NT];
 #pragma unroll
@@ -56,8 +59,8 @@ __global__ __launch_bounds__(PB) void k_panel_dot_mfma(const double *__restrict_
     for (int b = 0; b < NT; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
   const long long ntiles = ((long long)n + TR - 1) / TR;
   // software pipeline: the NEXT tile's columns are already in flight (registers) while this tile is multiplied
-  constexpr int CW = (MC + NC) / (PB / 64);          // columns staged by one wave
-  constexpr bool PREF = (MT + NT) <= 4;              // register budget: prefetch for panels up to 32+32 columns
+  constexpr int CW = SC / (PB / 64);                 // columns staged by one wave
+  constexpr bool PREF = SC <= 64;                    // register budget: prefetch for up to 64 staged columns
   double2 pre[PREF ? CW : 1];
   auto colsrc = [&](int c) -> const double * {
     return (c < MC) ? (c < my ? Y + (long long)c * ldy : nullptr) : (c - MC < nx ? X + (long long)(c - MC) * ldx : nullptr);
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(PB) void k_panel_dot_mfma(const double *__restrict_
 #pragma unroll
       for (int q = 0; q < CW; q++) *reinterpret_cast<double2 *>(lds + (w + q * (PB / 64)) * RP + 2 * lane) = pre[q];
     } else {
-      for (int c = w; c < MC + NC; c += PB / 64) stage_column(colsrc(c), r0, n, lds + c * RP, lane);
+      for (int c = w; c < SC; c += PB / 64) stage_column(colsrc(c), r0, n, lds + c * RP, lane);
     }
     __syncthreads();
     if (PREF && t + gridDim.x < ntiles) {
@@ -204,7 +207,8 @@ int ksp_dot_mfma(ks_bv bv, const double *Y, int ldy, int my, const double *X, in
   KS_CHECK(ldy % 2 == 0 && ldx % 2 == 0 && (((uintptr_t)Y | (uintptr_t)X) & 15) == 0, KS_ERR_SUP, "MFMA panel kernels need 16-byte aligned columns");
   const int MT = (my + 15) / 16, NT = (nx + 15) / 16, MC = MT * 16, NC = NT * 16;
   const long long ntiles = ((long long)n + TR - 1) / TR;
-  const size_t lds_bytes = std::max<size_t>((size_t)(MC + NC) * RP, (size_t)4 * MC * NC) * sizeof(double);
+  const bool same = (Y == X && ldy == ldx && my == nx);
+  const size_t lds_bytes = std::max<size_t>((size_t)(same ? MC : MC + NC) * RP, (size_t)4 * MC * NC) * sizeof(double);
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (150 * 1024) / lds_bytes));
   const int grid = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)ctx->num_cu * per_cu));
   const size_t need = (size_t)grid * MC * NC;
@@ -214,10 +218,14 @@ int ksp_dot_mfma(ks_bv bv, const double *Y, int ldy, int my, const double *X, in
     KS_HIP(hipMalloc(&bv->panel, need * sizeof(double)));
     bv->panel_len = need;
   }
-  KsProfScope ps(ctx, KS_K_BVDOT, 8.0 * n * (my + nx));
-#define DOT_CASE(M_, N_) case (M_) * 8 + (N_): \
-    KS_HIP(hipFuncSetAttribute((const void *)k_panel_dot_mfma<M_, N_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-    hipLaunchKernelGGL((k_panel_dot_mfma<M_, N_>), dim3(grid), dim3(PB), lds_bytes, ctx->stream, Y, (long long)ldy, my, X, (long long)ldx, nx, n, bv->panel); break;
+  KsProfScope ps(ctx, KS_K_BVDOT, 8.0 * n * (my + nx), 0, same ? 8.0 * n * my : -1.0);
+#define DOT_LAUNCH(M_, N_, S_) do { \
+    KS_HIP(hipFuncSetAttribute((const void *)k_panel_dot_mfma<M_, N_, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+    hipLaunchKernelGGL((k_panel_dot_mfma<M_, N_, S_>), dim3(grid), dim3(PB), lds_bytes, ctx->stream, Y, (long long)ldy, my, X, (long long)ldx, nx, n, bv->panel); } while (0)
+#define DOT_CASE(M_, N_) case (M_) * 8 + (N_): DOT_LAUNCH(M_, N_, false); break;
+  if (same) {
+    switch (MT) { case 1: DOT_LAUNCH(1, 1, true); break; case 2: DOT_LAUNCH(2, 2, true); break; case 3: DOT_LAUNCH(3, 3, true); break; default: DOT_LAUNCH(4, 4, true); break; }
+  } else
   switch (MT * 8 + NT) {
     DOT_CASE(1, 1) DOT_CASE(1, 2) DOT_CASE(1, 3) DOT_CASE(1, 4)
     DOT_CASE(2, 1) DOT_CASE(2, 2) DOT_CASE(2, 3) DOT_CASE(2, 4)
@@ -226,6 +234,7 @@ int ksp_dot_mfma(ks_bv bv, const double *Y, int ldy, int my, const double *X, in
     default: KS_FAIL(KS_ERR_PLIB, "bad tile counts");
   }
 #undef DOT_CASE
+#undef DOT_LAUNCH
   KS_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_reduce_blocks, dim3((MC * NC + 255) / 256), dim3(256), 0, ctx->stream, bv->panel, grid, MC, NC, my, nx, M_dev);
   KS_HIP(hipGetLastError());
