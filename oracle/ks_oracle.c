@@ -655,6 +655,14 @@ int orc_bv_matlanczos(orc_bv *V,const orc_csr *A,double *T,int ldt,int k,int *m,
 orc_csr *orc_csr_wrap(int n,int ncols,const int *rowptr,const int *col,const double *val)
 { orc_csr *A=(orc_csr*)calloc(1,sizeof(orc_csr)); A->n=n; A->ncols=ncols; A->nnz=rowptr[n]; A->rowptr=rowptr; A->col=col; A->val=val; return A; }
 void orc_csr_free(orc_csr *A) { free(A); }
+void orc_set_num_threads(int t)
+{
+#ifdef _OPENMP
+  if (t > 0) omp_set_num_threads(t);
+#else
+  (void)t;
+#endif
+}
 int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -80,6 +80,7 @@ def _load(name):
         "orc_bv_set_num_constraints": (C.c_int, [vp, C.c_int]),
         "orc_bv_get_num_constraints": (C.c_int, [vp]),
         "orc_num_threads": (C.c_int, []),
+        "orc_set_num_threads": (None, [C.c_int]),
         "orc_laplacian3d_nnz": (C.c_long, [C.c_int] * 5),
         "orc_laplacian3d_fill": (None, [C.c_int] * 5 + [_ip, _ip, _dp]),
         "orc_laplacian2d_nnz": (C.c_long, [C.c_int, C.c_int]),
@@ -108,6 +109,24 @@ def _p(a):
 
 def _pi(a):
     return None if a is None else a.ctypes.data_as(_ip)
+
+
+def usable_cores():
+    """Host cores this process may really use: the smallest of the CPU count, the affinity mask and the cgroup CPU quota
+    (cpu.max); an OpenMP team larger than the quota is throttled at its barriers."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, p = open(path).read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 class OracleError(RuntimeError):
