@@ -25,6 +25,23 @@ __global__ __launch_bounds__(256) void k_cols(const d2 *__restrict__ a, long lon
   if (s == 12345.678) out[0] = s;
 }
 
+// the access shape of the MFMA panel kernels: a 128-row tile, wave w streams columns w, w+4, ... (1 KB per column per tile)
+template <int KT>
+__global__ __launch_bounds__(256) void k_cols_wave(const d2 *__restrict__ a, long long ld2, long long n2, double *__restrict__ out)
+{
+  double s = 0.0;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long ntiles = (n2 + 63) / 64;
+  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    d2 v[KT / 4];
+#pragma unroll
+    for (int q = 0; q < KT / 4; q++) { const long long j = t * 64 + lane; v[q] = j < n2 ? __builtin_nontemporal_load(a + (long long)(w + 4 * q) * ld2 + j) : d2{0.0, 0.0}; }
+#pragma unroll
+    for (int q = 0; q < KT / 4; q++) s += v[q].x + v[q].y;
+  }
+  if (s == 12345.678) out[0] = s;
+}
+
 int main()
 {
   const long long ncol = 10077696, ld2 = ncol / 2, KTMAX = 28;
@@ -40,5 +57,7 @@ int main()
   char nm[96];
 #define RUN(KT, VL, g) snprintf(nm, 96, "KT=%2d VL=%d grid %5d", KT, VL, g); time([&] { hipLaunchKernelGGL((k_cols<KT, VL>), dim3(g), dim3(256), 0, 0, a, ld2, ld2, out); }, nm, ncol * 8.0 * KT)
   for (int g : {256, 512, 768, 1024, 2048}) { RUN(28, 1, g); RUN(28, 2, g); RUN(14, 2, g); RUN(14, 4, g); RUN(7, 4, g); RUN(7, 8, g); RUN(4, 8, g); RUN(1, 8, g); }
+#define RUNW(KT, g) snprintf(nm, 96, "wave-columns KT=%2d grid %5d", KT, g); time([&] { hipLaunchKernelGGL((k_cols_wave<KT>), dim3(g), dim3(256), 0, 0, a, ld2, ld2, out); }, nm, ncol * 8.0 * KT)
+  for (int g : {512, 1024, 2048, 4096}) { RUNW(28, g); RUNW(16, g); RUNW(8, g); }
   return 0;
 }
