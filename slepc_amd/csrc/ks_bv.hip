@@ -147,7 +147,11 @@ int ksk_dot(ks_bv bv, const double *A, int lda, int ncols, const double *y, bool
   KS_CHECK(ncols >= 1 && ncols <= KS_MAX_COLS, KS_ERR_PLIB, "dot sweep with %d columns", ncols);
   const bool v2 = (lda % 2 == 0) && aligned16(A) && aligned16(y);
   int grid = 1;
-  static const int dot_per_cu = getenv("KSGPU_DOT_PERCU") ? atoi(getenv("KSGPU_DOT_PERCU")) : 4;   // measured best (2: -25 %, 3: -6 %, 6: +-0, 8: -10 %)
+  // Every wave keeps all ncols column loads of its tile in flight (ncols KiB); about 120 KiB per CU saturate the HBM path,
+  // more resident blocks only add concurrent DRAM streams: 1 block per CU at 30 columns (6.34 TB/s, 4 blocks: 6.20), more for
+  // narrow sweeps.
+  static const int dot_env = getenv("KSGPU_DOT_PERCU") ? atoi(getenv("KSGPU_DOT_PERCU")) : 0;
+  const int dot_per_cu = dot_env ? dot_env : std::max(1, std::min(4, (30 + ncols - 1) / ncols));
   const KsGsState *g = gate ? bv->gs : nullptr;
   KsProfScope ps(ctx, KS_K_DOT, 8.0 * bv->n * (ncols + (y >= A && y < A + (size_t)ncols * lda ? 0 : 1)), ks_kt_for(ncols));
 #define LAUNCH_DOT(KT)                                                                                                                        \

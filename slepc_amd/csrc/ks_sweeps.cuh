@@ -81,14 +81,14 @@ __global__ __launch_bounds__(SW_BLOCK) void k_dot_sweep(const double *__restrict
     const long long r = t * tile + (long long)threadIdx.x * VEC;
     if (VEC == 2) {
       if (r + 1 < n) {
-        const double2 yv = *reinterpret_cast<const double2 *>(y + r);
+        // all KT column loads of the tile are issued back to back (KT KiB in flight per wave), then the products
+        double2 xv[KT];
 #pragma unroll
-        for (int i = 0; i < KT; i++) {
-          const int ii = i < ncols ? i : ncols - 1;
-          const double2 xv = ldcol2(A + (long long)ii * lda + r);
-          acc[i] = fma(xv.x, yv.x, acc[i]);
-          acc[i] = fma(xv.y, yv.y, acc[i]);
-        }
+        for (int i = 0; i < KT; i++) { const int ii = i < ncols ? i : ncols - 1; xv[i] = ldcol2(A + (long long)ii * lda + r); }
+        const double2 yv = *reinterpret_cast<const double2 *>(y + r);
+        __builtin_amdgcn_sched_barrier(0);              // keep the scheduler from folding the loads back into a 2-deep load/fma chain
+#pragma unroll
+        for (int i = 0; i < KT; i++) { acc[i] = fma(xv[i].x, yv.x, acc[i]); acc[i] = fma(xv[i].y, yv.y, acc[i]); }
       } else if (r < n) {
         const double yv = y[r];
 #pragma unroll
