@@ -86,6 +86,8 @@ enum { KS_EPS_CONV_ABS = 0, KS_EPS_CONV_REL = 1, KS_EPS_CONV_NORM = 2, KS_EPS_CO
 /* user callbacks of the solver (slepceps.h EPSConvergenceTestFn, EPSStoppingTestFn, EPSMonitorFn); non-zero return = error */
 typedef int (*ks_eps_converged_fn)(ks_eps eps, double eigr, double eigi, double res, double *errest, void *ctx);
 typedef int (*ks_eps_stopping_fn)(ks_eps eps, int its, int max_it, int nconv, int nev, int *reason, void *ctx);
+/* SlepcArbitrarySelectionFn (slepcsc.h): (eigr, eigi, xr, xi, &rr, &ri, ctx); xr/xi are device vectors of n_local doubles */
+typedef int (*ks_eps_arbitrary_fn)(double eigr, double eigi, const double *xr_dev, const double *xi_dev, double *rr, double *ri, void *ctx);
 typedef int (*ks_eps_monitor_fn)(ks_eps eps, int its, int nconv, const double *eigr, const double *eigi, const double *errest, int nest, void *ctx);
 enum { KS_EPS_CONVERGED_TOL = 1, KS_EPS_CONVERGED_USER = 2, KS_EPS_DIVERGED_ITS = -1, KS_EPS_DIVERGED_BREAKDOWN = -2,
        KS_EPS_DIVERGED_SYMMETRY_LOST = -3, KS_EPS_CONVERGED_ITERATING = 0 };
@@ -264,6 +266,7 @@ int ks_eps_get_extraction(ks_eps eps, int *extr);
 int ks_eps_set_convergence_test_function(ks_eps eps, ks_eps_converged_fn fn, void *ctx); /* EPSSetConvergenceTestFunction: selects KS_EPS_CONV_USER; NULL restores the relative test */
 int ks_eps_set_stopping_test_function(ks_eps eps, ks_eps_stopping_fn fn, void *ctx);    /* EPSSetStoppingTestFunction (ex29.c); NULL = EPSStoppingBasic */
 int ks_eps_stopping_basic(ks_eps eps, int its, int max_it, int nconv, int nev, int *reason, void *ctx); /* EPSStoppingBasic epsdefault.c:290 */
+int ks_eps_set_arbitrary_selection(ks_eps eps, ks_eps_arbitrary_fn fn, void *ctx);      /* EPSSetArbitrarySelection epsopts.c:600 (symmetric variant; the DS sorts on rr/ri, krylovschur.c:275-279); NULL disables */
 int ks_eps_monitor_set(ks_eps eps, ks_eps_monitor_fn fn, void *ctx);                    /* EPSMonitorSet (one slot; NULL cancels): called once per restart with the DS-ordered values, untransformed */
 int ks_eps_set_true_residual(ks_eps eps, int trueres);                    /* EPSSetTrueResidual: convergence on ||A x - k B x|| of the Ritz vector (epskrylov.c:256-264) */
 int ks_eps_get_true_residual(ks_eps eps, int *trueres);

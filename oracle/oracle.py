@@ -669,22 +669,25 @@ class DSHEP:
         e[: n - 1] = 0.0                    # compact: zero e[0..n-2], keep e[n-1] (extra row)
         self.state = DS_STATE_CONDENSED
 
-    def Sort(self, wr):                    # DSSort dsops.c:329-345 -> DSSort_HEP dshep.c:323-347
+    def Sort(self, wr, rr=None, ri=None):  # DSSort dsops.c:329-345 -> DSSort_HEP dshep.c:323-347
+        """rr/ri: auxiliary values of an arbitrary selection; the order then comes from them (dshep.c:335-336)."""
         n, l = self.n, self.l
         d = self.d
         perm = self.perm
         perm[:n] = np.arange(n)
-        # DSSortEigenvaluesReal_Private dspriv.c:224-243 (insertion sort, n = ds->t)
+        key = d if rr is None else rr
+        kim = (lambda i: 0.0) if ri is None else (lambda i: ri[i])
+        # DSSortEigenvaluesReal_Private dspriv.c:224-243 / DSSortEigenvalues_Private :172-222 (insertion sort, n = ds->t)
         nn = self.t
         for i in range(l + 1, nn):
-            re = d[perm[i]]
+            re = key[perm[i]]; rim = kim(perm[i])
             j = i - 1
-            result = self.compare(re, 0.0, d[perm[j]], 0.0)
+            result = self.compare(re, rim, key[perm[j]], kim(perm[j]))
             while result < 0 and j >= l:
                 perm[j], perm[j + 1] = perm[j + 1], perm[j]
                 j -= 1
                 if j >= l:
-                    result = self.compare(re, 0.0, d[perm[j]], 0.0)
+                    result = self.compare(re, rim, key[perm[j]], kim(perm[j]))
         self.last_perm = perm[:n].copy()
         for i in range(l, n):
             wr[i] = d[perm[i]]
@@ -745,7 +748,7 @@ class EPSResult:
 
 def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which="largest_magnitude",
                         keep=0.5, seed=0x12345678, omp=False, v0=None, orthog=(CGS, REFINE_IFNEEDED, 0.7071),
-                        max_steps=None, monitor=None, lock=True, st=None, B=None, conv="rel", deflation=None, trueres=False, stopping=None):
+                        max_steps=None, monitor=None, lock=True, st=None, B=None, conv="rel", deflation=None, trueres=False, stopping=None, arbitrary=None):
     """EPSSolve for a symmetric problem with the default Krylov-Schur solver: standard (HEP), or generalized (GHEP,
     B given: the basis carries the B-inner product, EPS_SetInnerProduct epsimpl.h:280-292; the start vector goes
     through the operator, epssolve.c:860-868; the eigenvectors are purified and B-normalised,
@@ -827,7 +830,18 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
         V.SetActiveColumns(nconv, nv)
 
         ds.Solve(eigr)
-        ds.Sort(eigr)
+        if arbitrary is not None:                           # EPSGetArbitraryValues krylovschur.c:30-58
+            rr = np.zeros(ncv + 1); ri = np.zeros(ncv + 1)
+            Xall = np.array(V.dense())[:n, :nv]
+            for i in range(ds.l, ds.n):
+                re = eigr[i] if st is None else st.backtransform(eigr[i], 0.0)[0]
+                x = Xall @ ds.Q[:nv, i]
+                if B is not None:                           # purification of EPSComputeRitzVector
+                    y = st.apply(x); x = y / np.sqrt(y @ B.mult(y))
+                rr[i], ri[i] = arbitrary(re, 0.0, x, np.zeros(n))
+            ds.Sort(eigr, rr, ri)
+        else:
+            ds.Sort(eigr)
         ds.UpdateExtraRow()
 
         # EPSKrylovConvergence(eps,FALSE,nconv,nv-nconv,beta,0.0,1.0,&k)

@@ -35,6 +35,7 @@ ST_SHIFT, ST_SINVERT = 0, 1
 EIG_COMPARE_FN = C.CFUNCTYPE(C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_void_p)
 EPS_CONVERGED_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_void_p)
 EPS_STOPPING_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p)
+EPS_ARBITRARY_FN = C.CFUNCTYPE(C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
 EPS_MONITOR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_void_p)
 
 KCLASSES = ["spmv_csr", "bv_dot_sweep", "gs_bookkeeping", "gs_update_fused_dot", "gs_update", "bv_scale", "bv_multinplace",
@@ -727,6 +728,25 @@ class EPS:
                 import traceback; traceback.print_exc(); return 76
         self._mon_cb = EPS_MONITOR_FN(tramp)
         _lib.check(self.ctx.L.ks_eps_monitor_set(self.h, C.cast(self._mon_cb, C.c_void_p), None))
+
+    def SetArbitrarySelection(self, func):
+        """func(eigr, eigi, xr, xi) -> (rr, ri) with the Ritz vector as host arrays (copied from the device for the call);
+        EPSSetArbitrarySelection. None disables."""
+        if func is None:
+            self._arb_cb = None
+            _lib.check(self.ctx.L.ks_eps_set_arbitrary_selection(self.h, None, None)); return
+        n = self._A.n
+
+        def tramp(re, im, xr, xi, rr, ri, _ctx):
+            try:
+                hx = np.empty(n); hy = np.empty(n)
+                self.ctx.memcpy_d2h(hx, xr); self.ctx.memcpy_d2h(hy, xi)
+                a, b = func(re, im, hx, hy)
+                rr[0] = float(a); ri[0] = float(b); return 0
+            except Exception:       # noqa: BLE001
+                import traceback; traceback.print_exc(); return 76
+        self._arb_cb = EPS_ARBITRARY_FN(tramp)
+        _lib.check(self.ctx.L.ks_eps_set_arbitrary_selection(self.h, C.cast(self._arb_cb, C.c_void_p), None))
 
     def SetTrueResidual(self, flag=True):
         _lib.check(self.ctx.L.ks_eps_set_true_residual(self.h, int(bool(flag))))

@@ -149,6 +149,7 @@ _SIG = {
     "ks_eps_set_stopping_test_function": [vp, vp, vp],
     "ks_eps_stopping_basic": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), vp],
     "ks_eps_monitor_set": [vp, vp, vp],
+    "ks_eps_set_arbitrary_selection": [vp, vp, vp],
     "ks_eps_get_true_residual": [vp, C.POINTER(C.c_int)],
     "ks_eps_get_operators": [vp, C.POINTER(vp), C.POINTER(vp)],
     "ks_eps_get_problem_type": [vp, ip, ip, ip, ip],

@@ -177,18 +177,21 @@ struct DsHep {
     return 0;
   }
 
-  void sort(double *wr)                                                                     // dsops.c:329-345, dshep.c:323-347
+  // rr/ri: auxiliary values of an arbitrary selection (DSSort with rr: the order comes from them, dshep.c:335-336)
+  void sort(double *wr, const double *rr = nullptr, const double *ri = nullptr)             // dsops.c:329-345, dshep.c:323-347
   {
     for (int i = 0; i < n; i++) perm[i] = i;
     double *dd = d();
-    // DSSortEigenvaluesReal_Private dspriv.c:224-243: insertion sort of the first t values from l
+    const double *key = rr ? rr : dd;
+    auto im = [&](int i) { return ri ? ri[i] : 0.0; };
+    // DSSortEigenvaluesReal_Private dspriv.c:224-243 / DSSortEigenvalues_Private :172-222: insertion sort of the first t values from l
     for (int i = l + 1; i < t; i++) {
-      const double re = dd[perm[i]];
+      const double re = key[perm[i]], rim = im(perm[i]);
       int j = i - 1;
-      int result = compare_eig(which, re, 0.0, dd[perm[j]], 0.0);
+      int result = compare_eig(which, re, rim, key[perm[j]], im(perm[j]));
       while (result < 0 && j >= l) {
         std::swap(perm[j], perm[j + 1]); j--;
-        if (j >= l) result = compare_eig(which, re, 0.0, dd[perm[j]], 0.0);
+        if (j >= l) result = compare_eig(which, re, rim, key[perm[j]], im(perm[j]));
       }
     }
     for (int i = l; i < n; i++) wr[i] = dd[perm[i]];
@@ -372,6 +375,7 @@ struct ks_eps_s {
   ks_eps_converged_fn conv_fn = nullptr; void *conv_ctx = nullptr;     // EPSSetConvergenceTestFunction (conv = KS_EPS_CONV_USER)
   ks_eps_stopping_fn stop_fn = nullptr; void *stop_ctx = nullptr;      // EPSSetStoppingTestFunction; NULL = EPSStoppingBasic
   ks_eps_monitor_fn mon_fn = nullptr; void *mon_ctx = nullptr;         // EPSMonitorSet (one monitor)
+  ks_eps_arbitrary_fn arb_fn = nullptr; void *arb_ctx = nullptr;       // EPSSetArbitrarySelection
   int cb_err = 0;                                                      // first non-zero return of a user callback
   bool trueres = false;                                          // EPSSetTrueResidual
   int extraction = KS_EPS_RITZ;                                  // EPSSetExtraction: Ritz or harmonic (krylovschur.c:120)
@@ -540,6 +544,11 @@ extern "C" int ks_eps_set_convergence_test_function(ks_eps eps, ks_eps_converged
   else { eps->conv_fn = nullptr; eps->conv_ctx = nullptr; if (eps->conv == KS_EPS_CONV_USER) eps->conv = KS_EPS_CONV_REL; }
   eps->solved = false; return KS_SUCCESS;
 }
+extern "C" int ks_eps_set_arbitrary_selection(ks_eps eps, ks_eps_arbitrary_fn fn, void *ctx)      // EPSSetArbitrarySelection epsopts.c:600-615
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  eps->arb_fn = fn; eps->arb_ctx = ctx; eps->solved = false; return KS_SUCCESS;
+}
 extern "C" int ks_eps_monitor_set(ks_eps eps, ks_eps_monitor_fn fn, void *ctx)                   // EPSMonitorSet epsmon.c (one slot); NULL = EPSMonitorCancel
 {
   KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
@@ -613,7 +622,14 @@ static int residual_norm(ks_eps eps, double kr, double ki, const double *xr, con
 
 // EPSComputeRitzVector epsdefault.c:313-364 followed by the residual of epskrylov.c:256-264 (-eps_true_residual):
 // x = V(:,0:nv) Zr [, y = V(:,0:nv) Zi], purified through the operator for a GHEP, into W columns 3 and 4.
+static int ritz_vector(ks_eps eps, int nv, const double *Zr, const double *Zi);
 static int true_residual(ks_eps eps, int nv, double re, double im, const double *Zr, const double *Zi, double *resnorm)
+{
+  KS_CALL(ritz_vector(eps, nv, Zr, Zi));
+  return residual_norm(eps, re, im, ks_bv_col(eps->W, 3), Zi ? ks_bv_col(eps->W, 4) : nullptr, 1.0, resnorm);
+}
+// EPSComputeRitzVector epsdefault.c:313-364: x (W column 3) and, for a pair, y (W column 4)
+static int ritz_vector(ks_eps eps, int nv, const double *Zr, const double *Zi)
 {
   ks_bv V = eps->V, W = eps->W;
   int ls = 0, ksv = 0;
@@ -629,8 +645,9 @@ static int true_residual(ks_eps eps, int nv, double re, double im, const double 
     KS_CALL(ksk_copy(eps->ctx, y, x, V->n));
   }
   if (Zi) KS_CALL(ks_bv_multvec(V, 1.0, 0.0, y, Zi));
+  else KS_HIP(hipMemsetAsync(y, 0, sizeof(double) * V->n, eps->ctx->stream));   // VecSet(y,0.0) epsdefault.c:352
   KS_CALL(ks_bv_set_active_columns(V, ls, ksv));
-  return residual_norm(eps, re, im, x, Zi ? y : nullptr, 1.0, resnorm);
+  return KS_SUCCESS;
 }
 
 // EPSGetStartVector epssolve.c:841-873
@@ -852,6 +869,7 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   }
 
   KS_CHECK(eps->extraction == KS_EPS_RITZ || !ghep, KS_ERR_SUP, "harmonic extraction with a B-inner product is not built");
+  KS_CHECK(!eps->arb_fn || ((ptype == KS_EPS_HEP || ghep) && eps->extraction == KS_EPS_RITZ), KS_ERR_SUP, "arbitrary selection is built for the symmetric (Lanczos) variant only");
   if ((ptype != KS_EPS_HEP && !ghep) || eps->extraction == KS_EPS_HARMONIC) return solve_nhep(eps, passes0);   // variant EPS_KS_DEFAULT (krylovschur.c:133-151)
   const bool isshift = !st || st->type == KS_ST_SHIFT;
 
@@ -874,7 +892,18 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
     // solve projected problem
     int info = ds.solve(eps->eigr.data());
     KS_CHECK(info == 0, KS_ERR_LIB, "tridiagonal QL iteration failed to converge (info=%d)", info);
-    ds.sort(eps->eigr.data());
+    if (eps->arb_fn) {                                         // EPSGetArbitraryValues krylovschur.c:30-58, then DSSort on rr/ri
+      std::vector<double> rr(ncv + 1, 0.0), ri(ncv + 1, 0.0);
+      for (int i = ds.l; i < ds.n; i++) {
+        double re = eps->eigr[i], im0 = 0.0;
+        if (eps->cmp_ds.map) ks_st_backtransform_internal(eps->cmp_ds.map, 1, &re, &im0);
+        KS_CALL(ritz_vector(eps, nv, ds.Q.data() + (size_t)i * ds.ld, nullptr));       // DSVectors(X,i) = Q(:,i) for DSHEP
+        KS_HIP(hipStreamSynchronize(eps->ctx->stream));
+        const int rc = eps->arb_fn(re, im0, ks_bv_col(eps->W, 3), ks_bv_col(eps->W, 4), &rr[i], &ri[i], eps->arb_ctx);
+        KS_CHECK(!rc, rc, "the user's arbitrary selection function returned %d", rc);
+      }
+      ds.sort(eps->eigr.data(), rr.data(), ri.data());
+    } else ds.sort(eps->eigr.data());
     ds.update_extra_row();
 
     // EPSKrylovConvergence(eps,FALSE,nconv,nv-nconv,beta,0.0,1.0,&k)

@@ -95,3 +95,40 @@ def test_eps_test28_second_matrix_of_another_size_golden(ctx):
         lam = _same_run(eps, r)
         assert np.allclose(np.round(lam[:3], 5), ref[k], atol=1.5e-5)
         assert eps.GetEigenvector(0).shape == (n * m,) and eps.ComputeError(0) < 1e-7
+
+
+def test_eps_test13_arbitrary_selection_golden(ctx):
+    """test13: EPSSetArbitrarySelection on the second solve of the same solver object (the callback sees the Ritz vectors
+    on the device; the Python mirror copies them to the host for the user's function)."""
+    import slepc_amd as ks
+    S = sc.tridiag_csr(30, -1.0, 0.0, -1.0)
+    tol = 1000 * np.finfo(float).eps
+    ref = gi.eigenvalue_lines(gi.read("eps/eps_test13_1.out"))
+    eps = ks.EPS(ctx)
+    eps.SetProblemType(ks.EPS_HEP); eps.SetTolerances(tol, 5000); eps.SetOperators(_mat(ctx, S)); eps.SetWhichEigenpairs("smallest_real")
+    eps.Solve()
+    r = O.eps_krylovschur_hep(_csr(S), 1, tol=tol, max_it=5000, which="smallest_real")
+    lam = _same_run(eps, r)
+    assert abs(round(lam[0], 5) - ref[0][0]) < 1.5e-5
+    sx = eps.GetEigenvector(0)
+    calls = []
+
+    def pick(re, im, xr, xi):
+        calls.append(re)
+        assert not np.any(xi)
+        return abs(xr @ sx), 0.0
+    eps.SetArbitrarySelection(pick); eps.SetWhichEigenpairs("largest_magnitude")
+    eps.Solve()
+    so = np.array(r.V.column(r.perm[0]))
+    r2 = O.eps_krylovschur_hep(_csr(S), 1, tol=tol, max_it=5000, which="largest_magnitude", arbitrary=lambda re, im, xr, xi: (abs(xr @ so), 0.0))
+    lam2 = _same_run(eps, r2)
+    assert abs(round(lam2[0], 5) - ref[1][0]) < 1.5e-5 and len(calls) > 0
+    assert abs(abs(eps.GetEigenvector(0) @ sx) - 1.0) < 1e-6
+    # the non-symmetric variant does not offer it
+    eps.SetProblemType(ks.EPS_NHEP)
+    with pytest.raises(ks.KsError) as e:
+        eps.Solve()
+    assert e.value.rc == 56
+    eps.SetArbitrarySelection(None)
+    eps.Solve()
+    assert eps.GetConverged() >= 1

@@ -478,3 +478,19 @@ def test_eps_test28_two_sizes_golden():
     for (n, m), want in zip(((10, 11), (20, 22)), ref):
         r = O.eps_krylovschur_hep(_csr(sc.laplacian2d_csr(n, m)), 3, which="smallest_real")
         assert np.allclose(np.round(r.eigr[r.perm][:3], 5), want, atol=1.5e-5)
+
+
+def test_eps_test13_arbitrary_selection_golden():
+    """test13 -eps_max_it 5000: tridiag(-1,0,-1), n = 30. First solve: smallest real -> -1.98974; second solve with
+    EPSSetArbitrarySelection(|x . x_first|) and EPS_LARGEST_MAGNITUDE picks the Ritz vector closest to the stored
+    eigenvector and converges to the same eigenvalue."""
+    A = _csr(sc.tridiag_csr(30, -1.0, 0.0, -1.0))
+    tol = 1000 * np.finfo(float).eps
+    ref = gi.eigenvalue_lines(gi.read("eps/eps_test13_1.out"))
+    r = O.eps_krylovschur_hep(A, 1, tol=tol, max_it=5000, which="smallest_real")
+    assert abs(round(r.eigr[r.perm][0], 5) - ref[0][0]) < 1.5e-5
+    sx = np.array(r.V.column(r.perm[0]))
+    r2 = O.eps_krylovschur_hep(A, 1, tol=tol, max_it=5000, which="largest_magnitude", arbitrary=lambda re, im, xr, xi: (abs(xr @ sx), 0.0))
+    assert abs(round(r2.eigr[r2.perm][0], 5) - ref[1][0]) < 1.5e-5
+    # without the selection the largest-magnitude solve is free to return +1.98974 or -1.98974 (equal magnitude)
+    assert abs(abs(np.array(r2.V.column(r2.perm[0])) @ sx) - 1.0) < 1e-6
