@@ -469,6 +469,31 @@ def test_full_size_properties_config3(ctx):
     assert V.gs_passes()[0] >= m
 
 
+def test_config3_first_lanczos_run_matches_the_cpu_oracle_at_full_size(ctx):
+    """The first Lanczos run (30 steps, CGS with refinement) of BASELINE config 3 at its full size on the GPU and on the CPU
+    oracle (OpenMP build, team sized to the cores the box grants): the tridiagonal coefficients agree to 1e-10 relative,
+    the Gram-Schmidt pass counts are identical, sampled basis rows agree."""
+    import slepc_amd as ks
+    N, m = 216, 30
+    O.lib(omp=True).orc_set_num_threads(O.usable_cores())
+    Ao = O.laplacian3d(N, N, N, omp=True)
+    Vo = O.BV(Ao.n, m + 1, omp=True)
+    _start(Vo)
+    To = np.zeros((m + 1, 3), order="F")
+    mo, bo, brko = Vo.MatLanczos(Ao, To, 0, m)
+    A = ks.Mat.laplacian3d(ctx, N, N, N)
+    V = ks.BV(ctx, A.n, m + 1)
+    _start(V)
+    T = np.zeros((m + 1, 3), order="F")
+    mm, beta, brk = V.MatLanczos(A, T, 0, m)
+    assert (mm, brk) == (mo, brko) == (m, False)
+    assert np.allclose(T[:m, :2], To[:m, :2], rtol=1e-10, atol=0) and abs(beta - bo) <= 1e-10 * abs(bo)
+    assert V.gs_passes()[0] == Vo.passes_total()
+    rows = np.random.default_rng(0).integers(0, A.n, 2000)
+    for j in (0, 1, 15, 30):
+        assert np.allclose(V.column(j)[rows], np.array(Vo.column(j))[rows], rtol=0, atol=1e-12)
+
+
 def test_config3_solved_to_convergence(ctx):
     """BASELINE config 3 itself, solved to convergence (about 7 300 Arnoldi steps, 8 s): every converged Ritz value lies
     within 1e-10 (relative) of the analytic spectrum of the 216^3 Laplacian (ex19.c:19-45) - measured: 1e-13 - the triple
