@@ -211,7 +211,12 @@ int ksk_copy(ks_ctx ctx, const double *src, double *dst, size_t n)
 static int stage_coefs(ks_bv bv, const double *host, size_t len, double **dev)
 {
   ks_ctx ctx = bv->ctx;
-  KS_CHECK(len <= bv->coef_len, KS_ERR_ARG_SIZ, "coefficient block of %zu doubles exceeds scratch (%zu)", len, bv->coef_len);
+  if (len > bv->coef_len) {                                 // a wider coefficient block than this BV's own m x m: grow the scratch
+    KS_HIP(hipStreamSynchronize(ctx->stream));
+    hipFree(bv->coef); bv->coef = nullptr; bv->coef_len = 0;
+    KS_HIP(hipMalloc(&bv->coef, (len + 64) * sizeof(double)));
+    bv->coef_len = len + 64;
+  }
   // the pinned area may still be in use by an earlier async copy: make the copy synchronous w.r.t. the host
   KS_HIP(hipMemcpyAsync(bv->coef, host, len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   KS_HIP(hipStreamSynchronize(ctx->stream));
@@ -473,8 +478,43 @@ extern "C" int ks_bv_set_random_column(ks_bv bv, int j, uint64_t seed)   // BVSe
 }
 
 // ---- ops->mult / multvec / multinplace -----------------------------------------------------------
+static int panel_mult64(ks_ctx ctx, int kclass, const double *A, int lda, int n, int kin, const double *Qdev, int ldq, bool transq,
+                        int nout, double alpha, double beta, double *C, int ldc);
+// C(:,0:nout) = beta*C + alpha*A(:,0:kin)*Q for any kin, nout: 64 x 64 blocks of Q on the panel kernels, accumulated over the
+// inner blocks. When C aliases columns of A (BVMultInPlace) and the product is wider than one block, the result goes to a
+// temporary panel first (the reference's BVMultInPlace_BLAS_Private works through a workspace too, bvblas.c:74-106).
 static int panel_mult(ks_ctx ctx, int kclass, const double *A, int lda, int n, int kin, const double *Qdev, int ldq, bool transq,
                       int nout, double alpha, double beta, double *C, int ldc)
+{
+  if (n == 0 || nout == 0) return KS_SUCCESS;
+  KS_CHECK(kin >= 1, KS_ERR_PLIB, "panel product with %d inner columns", kin);
+  if (kin <= KS_MAX_COLS && nout <= 64) return panel_mult64(ctx, kclass, A, lda, n, kin, Qdev, ldq, transq, nout, alpha, beta, C, ldc);
+  const bool alias = (C < A + (size_t)kin * lda) && (A < C + (size_t)nout * ldc);
+  double *T = C; int ldt = ldc;
+  if (alias) {
+    KS_CHECK(beta == 0.0, KS_ERR_PLIB, "in-place wide panel product with beta != 0");
+    ldt = ((n + 31) / 32) * 32;
+    KS_HIP(hipMalloc(&T, sizeof(double) * (size_t)ldt * nout));
+  }
+  int rc = KS_SUCCESS;
+  for (int jo = 0; jo < nout && !rc; jo += 64) {
+    const int nb = std::min(64, nout - jo);
+    for (int ki = 0; ki < kin && !rc; ki += KS_MAX_COLS) {
+      const int kb = std::min(KS_MAX_COLS, kin - ki);
+      const double *qb = transq ? Qdev + jo + (size_t)ki * ldq : Qdev + ki + (size_t)jo * ldq;
+      rc = panel_mult64(ctx, kclass, A + (size_t)ki * lda, lda, n, kb, qb, ldq, transq, nb, alpha, ki == 0 ? beta : 1.0, T + (size_t)jo * ldt, ldt);
+    }
+  }
+  if (alias) {
+    for (int j = 0; j < nout && !rc; j++) rc = ksk_copy(ctx, T + (size_t)j * ldt, C + (size_t)j * ldc, n);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(T);
+  }
+  return rc;
+}
+
+static int panel_mult64(ks_ctx ctx, int kclass, const double *A, int lda, int n, int kin, const double *Qdev, int ldq, bool transq,
+                        int nout, double alpha, double beta, double *C, int ldc)
 {
   if (n == 0 || nout == 0) return KS_SUCCESS;
   KS_CHECK(kin >= 1 && kin <= KS_MAX_COLS, KS_ERR_SUP, "panel product with %d inner columns (max %d)", kin, KS_MAX_COLS);
@@ -657,7 +697,12 @@ int ksb_dot_range(ks_bv X, int xs, int xe, ks_bv Y, int ys, int ye, double *M, i
   ks_ctx ctx = X->ctx;
   KS_HIP(hipSetDevice(ctx->device));
   const int my = ye - ys, nx = xe - xs;
-  KS_CHECK(my <= KS_MAX_COLS, KS_ERR_SUP, "BVDot with more than %d active columns in Y", KS_MAX_COLS);
+  if (my > KS_MAX_COLS || nx > 64) {                        // wide panels: 64 x 64 blocks of M, each one sweep on the matrix cores
+    for (int yb = ys; yb < ye; yb += KS_MAX_COLS)
+      for (int xb = xs; xb < xe; xb += 64)
+        KS_CALL(ksb_dot_range(X, xb, std::min(xe, xb + 64), Y, yb, std::min(ye, yb + KS_MAX_COLS), M, ldm));
+    return KS_SUCCESS;
+  }
   KS_CHECK((size_t)my * nx <= X->coef_len, KS_ERR_ARG_SIZ, "result block too large");
   const double *py = Y->array + (size_t)(Y->nc + ys) * Y->ld;
   if (X->matrix) {

@@ -221,7 +221,8 @@ void lanv2(double &a, double &b, double &c, double &d, double &rt1r, double &rt1
 
 void hess_reduce(int n, int ilo, double *A, int ld, double *Q)
 {
-  double v[128], w[128];
+  std::vector<double> v_(n + 1), w_(n + 1);
+  double *v = v_.data(), *w = w_.data();
   for (int i = ilo; i < n - 2; i++) {
     const int nr = n - i - 1;                      // length of the reflector (rows i+1..n-1)
     double alpha = AT(A, i + 1, i), tau;
@@ -384,7 +385,8 @@ int trevc_one(int n, const double *T, int ld, int k, double *xr, double *xi)
   double tnorm = 0.0;
   for (int j = 0; j < n; j++) for (int i = 0; i <= std::min(j + 1, n - 1); i++) tnorm = std::max(tnorm, std::fabs(AT(T, i, j)));
   const double smin = std::max(DBL_EPSILON * (std::fabs(wr) + std::fabs(wi)), std::max(DBL_EPSILON * tnorm * 1e-3, DBL_MIN / DBL_EPSILON));
-  std::complex<double> x[128];
+  std::vector<std::complex<double>> x_(n + 1);
+  std::complex<double> *x = x_.data();
   for (int j = 0; j < n; j++) x[j] = 0.0;
   int top;                                          // first row of the eigenvalue's block
   if (!pair) {
@@ -462,8 +464,8 @@ int trtri_upper(int n, double *A, int ld)
 int sym_eig(int n, double *A, int ld, double *w)
 {
   if (n <= 0) return 0;
-  double S[64 * 64], V[64 * 64];
-  if (n > 64) return -1;
+  std::vector<double> S_((size_t)n * n), V_((size_t)n * n);
+  double *S = S_.data(), *V = V_.data();
   for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) { S[i + j * n] = (i >= j) ? AT(A, i, j) : AT(A, j, i); V[i + j * n] = (i == j) ? 1.0 : 0.0; }
   for (int sweep = 0; sweep < 60; sweep++) {
     double off = 0.0, dg = 0.0;
@@ -483,7 +485,8 @@ int sym_eig(int n, double *A, int ld, double *w)
         for (int k = 0; k < n; k++) { const double vkp = V[k + p * n], vkq = V[k + q * n]; V[k + p * n] = c * vkp - s2 * vkq; V[k + q * n] = s2 * vkp + c * vkq; }
       }
   }
-  int idx[64];
+  std::vector<int> idx_(n);
+  int *idx = idx_.data();
   for (int i = 0; i < n; i++) idx[i] = i;
   std::sort(idx, idx + n, [&](int a, int b) { return S[a + a * n] < S[b + b * n]; });
   for (int j = 0; j < n; j++) { w[j] = S[idx[j] + idx[j] * n]; for (int i = 0; i < n; i++) AT(A, i, j) = V[i + idx[j] * n]; }

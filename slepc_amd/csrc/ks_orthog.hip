@@ -155,7 +155,8 @@ extern "C" int ks_bv_orthogonalize(ks_bv V, double *R, int ldr)       // BVOrtho
   if (nact <= 0) return KS_SUCCESS;
   KS_HIP(hipSetDevice(V->ctx->device));
   if (V->orthog_block == KS_BV_ORTHOG_BLOCK_GS) return orthogonalize_gs(V, R, ldr);
-  KS_CHECK(nact <= 64, KS_ERR_SUP, "block orthogonalization of %d columns (max 64)", nact);
+  KS_CHECK(nact <= 64 || V->orthog_block == KS_BV_ORTHOG_BLOCK_CHOL || V->orthog_block == KS_BV_ORTHOG_BLOCK_SVQB, KS_ERR_SUP,
+           "TSQR block orthogonalization of %d columns (max 64: the running R factor lives in LDS); use GS, CHOL or SVQB", nact);
   const int ldb = k;
   std::vector<double> Rb((size_t)ldb * k, 0.0), S((size_t)ldb * k, 0.0);     // Rb plays V->Abuffer, S the inverse
   double *R22 = Rb.data() + (size_t)l * ldb + l, *S22 = S.data() + (size_t)l * ldb + l;

@@ -43,7 +43,7 @@ def schur(lib, A0, ilo=0):
     return H, A, Q, wr, wi
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 17, 30, 64])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 17, 30, 64, 150])
 @pytest.mark.parametrize("ilo", [0, 3])
 def test_schur_form(lib, n, ilo):
     ilo = min(ilo, n - 1)
@@ -80,7 +80,7 @@ def test_schur_matches_lapack_eigenvalue_order(lib):
         assert np.allclose(wr, er[:n], rtol=0, atol=1e-11) and np.allclose(wi, ei[:n], rtol=0, atol=1e-11)
 
 
-@pytest.mark.parametrize("n", [4, 9, 20, 40])
+@pytest.mark.parametrize("n", [4, 9, 20, 40, 140])
 def test_reorder_and_eigenvectors(lib, n):
     rng = np.random.default_rng(n)
     A0 = rng.standard_normal((n, n))
@@ -156,7 +156,7 @@ def test_reorder_matches_lapack(lib):
     assert np.all(np.diff(wr) <= 1e-12)
 
 
-@pytest.mark.parametrize("n", [1, 2, 5, 17, 40, 64])
+@pytest.mark.parametrize("n", [1, 2, 5, 17, 40, 64, 100])
 def test_cholesky_inverse_symmetric_eig_tsqr_combine(lib, n):
     """The k x k kernels of the block orthogonalisations (bvlapack.c:136-341,456-478) against LAPACK."""
     import scipy.linalg.lapack as la

@@ -1,0 +1,95 @@
+"""Bases wider than the 64 columns of the register-tiled / MFMA panel kernels: the BV operations block over 64-column
+panels, Gram-Schmidt runs the host-driven pass loop over 64-column chunks, and the solver accepts ncv + 1 > 64."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(float).eps
+
+
+@pytest.mark.parametrize("n,mx,my", [(5000, 100, 70), (40000, 150, 130)])
+def test_wide_bv_panel_operations(ctx, n, mx, my):
+    import slepc_amd as ks
+    rng = np.random.default_rng(n)
+    X0 = rng.standard_normal((n, mx)); Y0 = rng.standard_normal((n, my))
+    X = ks.BV(ctx, n, mx); Y = ks.BV(ctx, n, my)
+    X.set_dense(X0); Y.set_dense(Y0)
+    # BVDot: M = Y' X on 64 x 64 blocks
+    X.SetActiveColumns(3, mx - 2); Y.SetActiveColumns(1, my)
+    M = np.full((my, mx), 7.0, order="F")
+    X.Dot(Y, M)
+    want = Y0[:, 1:my].T @ X0[:, 3: mx - 2]
+    assert np.allclose(M[1:my, 3: mx - 2], want, rtol=1e-12, atol=1e-10 * np.sqrt(n))
+    G = np.zeros((mx, mx), order="F")
+    X.SetActiveColumns(0, mx); X.Dot(X, G)
+    assert np.allclose(G, X0.T @ X0, rtol=1e-12, atol=1e-10 * np.sqrt(n)) and np.allclose(G, G.T, rtol=0, atol=1e-9)
+    # BVMult: Y = beta Y + alpha X Q with more than 64 inner and outer columns
+    Q = np.asfortranarray(rng.standard_normal((mx, my)))
+    Y.SetActiveColumns(0, my)
+    Y.Mult(0.5, -2.0, X, Q)
+    Y1 = -2.0 * Y0 + 0.5 * X0 @ Q
+    assert np.allclose(Y.dense(), Y1, rtol=1e-12, atol=1e-11 * mx)
+    # BVMultInPlace over a wide window, both forms
+    Q2 = np.asfortranarray(rng.standard_normal((mx, mx)))
+    X.SetActiveColumns(2, mx - 1)
+    X.MultInPlace(Q2, 5, mx - 4)
+    X1 = X0.copy(); X1[:, 5: mx - 4] = X0[:, 2: mx - 1] @ Q2[2: mx - 1, 5: mx - 4]
+    assert np.allclose(X.dense(), X1, rtol=1e-12, atol=1e-11 * mx)
+    X.set_dense(X0)
+    X.MultInPlace(Q2, 5, mx - 4, trans=True)
+    X2 = X0.copy(); X2[:, 5: mx - 4] = X0[:, 2: mx - 1] @ Q2[5: mx - 4, 2: mx - 1].T
+    assert np.allclose(X.dense(), X2, rtol=1e-12, atol=1e-11 * mx)
+    # DotVec / MultVec across chunks
+    X.set_dense(X0); X.SetActiveColumns(0, mx)
+    v = ks.BV(ctx, n, 1); v0 = rng.standard_normal(n); v.set_column(0, v0)
+    d = X.DotVec(v.column_ptr(0))
+    assert np.allclose(d, X0.T @ v0, rtol=1e-12, atol=1e-10 * np.sqrt(n))
+    q = rng.standard_normal(mx)
+    X.MultVec(1.5, 0.25, v.column_ptr(0), q)
+    assert np.allclose(v.column(0), 0.25 * v0 + 1.5 * X0 @ q, rtol=1e-12, atol=1e-11 * mx)
+
+
+@pytest.mark.parametrize("block", ["gs", "chol", "svqb"])
+def test_wide_block_orthogonalization(ctx, block):
+    import slepc_amd as ks
+    n, k = 20000, 100
+    X0 = np.random.default_rng(7).standard_normal((n, k))
+    V = ks.BV(ctx, n, k); V.set_dense(X0); V.SetOrthogBlock(block)
+    R = np.zeros((k, k), order="F")
+    V.Orthogonalize(R)
+    Q = V.dense()
+    assert np.abs(Q.T @ Q - np.eye(k)).max() < 500 * EPS * np.sqrt(k)
+    assert np.abs(X0 - Q @ R).max() < 1e4 * EPS * np.abs(X0).max() * np.sqrt(k)
+    V.SetOrthogBlock("tsqr")
+    with pytest.raises(ks.KsError) as e:
+        V.Orthogonalize(None)
+    assert e.value.rc == 56
+
+
+@pytest.mark.parametrize("ptype,nev,ncv", [("hep", 40, 100), ("nhep", 40, 100), ("hep", 70, 200), ("nhep", 70, 200)])
+def test_solver_with_a_wide_basis(ctx, ptype, nev, ncv):
+    """nev = 40, ncv = 100 (101 columns) and nev = 70, ncv = 200: restart products are blocked, Gram-Schmidt is host-driven;
+    counts and values as the oracle."""
+    import slepc_amd as ks
+    import nhep_cases as nc
+    if ptype == "hep":
+        Ao = O.laplacian2d(41, 23)
+        r = O.eps_krylovschur_hep(Ao, nev, ncv=ncv)
+    else:
+        Ao = nc.planted_pairs(1200)
+        r = O.eps_krylovschur_nhep(Ao, nev, ncv=ncv)
+    A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A); eps.SetProblemType(ks.EPS_HEP if ptype == "hep" else ks.EPS_NHEP); eps.SetDimensions(nev, ncv)
+    eps.Solve()
+    assert eps.GetConverged() == r.nconv >= nev and eps.GetIterationNumber() == r.its
+    st = eps.GetStats()
+    assert st["arnoldi_steps"] == r.steps
+    for i in range(nev):
+        kr, ki = eps.GetEigenvalue(i)
+        j = r.perm[i]
+        w = np.hypot(r.eigr[j], r.eigi[j] if ptype == "nhep" else 0.0)
+        assert abs(kr - r.eigr[j]) <= 1e-9 * w and (ptype == "hep" or abs(ki - r.eigi[j]) <= 1e-9 * w)
+        assert eps.ComputeError(i) < 1e-7
