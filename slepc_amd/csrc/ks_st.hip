@@ -234,7 +234,7 @@ extern "C" int ks_st_set_ksp(ks_st st, double rtol, int max_it, int restart)   /
   KS_CHECK(st, KS_ERR_ARG_NULL, "ST is NULL");
   if (rtol > 0.0) st->rtol = rtol;
   if (max_it > 0) st->max_it = max_it;
-  if (restart > 0) { KS_CHECK(restart + 1 <= KS_MAX_COLS, KS_ERR_ARG_OUTOFRANGE, "GMRES restart %d exceeds %d", restart, KS_MAX_COLS - 1); if (restart != st->restart) { st->restart = restart; st->ready = false; } }
+  if (restart > 0 && restart != st->restart) { st->restart = restart; st->ready = false; }   // a basis wider than 64 columns orthogonalises through the host-driven loop
   return KS_SUCCESS;
 }
 extern "C" int ks_st_setup(ks_st st) { KS_CHECK(st, KS_ERR_ARG_NULL, "ST is NULL"); return ks_st_setup_internal(st); }

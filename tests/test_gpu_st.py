@@ -7,6 +7,7 @@ With the reference's default inner tolerance (1e-8) the results are checked thro
 import numpy as np
 import pytest
 
+import golden_inputs as gi
 import nhep_cases as nc
 from oracle import oracle as O
 
@@ -250,3 +251,41 @@ def test_st_apply_on_xcd_sliced_matrix(ctx):
     rhs = Sb @ x
     assert np.linalg.norm(Sa @ y - 1.5 * (Sb @ y) - rhs) <= 1e-9 * np.linalg.norm(rhs)
     assert 0 < st.GetKSPStats()["iterations"] < 60
+
+
+def test_eps_test11_sinvert_indefinite_shift_golden(ctx):
+    """test11 -eps_nev 4 -st_type sinvert: the shift 0.5 lies inside the spectrum of the Markov matrix, where GMRES(30)
+    stagnates; with the restart length at n (full GMRES, a Krylov basis wider than the fused kernels) the inner solves
+    converge and the golden values come out: 0.51928, 0.55740, 0.57028, 0.57143."""
+    import slepc_amd as ks
+    Ao = O.markov_matrix(15)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(_mat(ctx, Ao)); eps.SetProblemType(ks.EPS_NHEP); eps.SetDimensions(4); eps.SetTolerances(1e-10, 0)
+    eps.SetEigenvalueComparison(nc.right_of(0.5)); eps.SetInitialVector(np.ones(Ao.n))
+    st = eps.GetST(); st.SetType("sinvert"); st.SetShift(0.5); st.SetKSP(rtol=1e-13, restart=Ao.n, max_it=10 * Ao.n)
+    eps.Solve()
+    r = O.eps_krylovschur_nhep(Ao, 4, tol=1e-10, which=nc.right_of(0.5), st=O.ST(Ao, None, "sinvert", 0.5), v0=np.ones(Ao.n))
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(4)])
+    assert np.allclose(np.round(lam, 5), gi.eigenvalues_line(gi.read("eps/eps_test11_1.out")), atol=1.5e-5)
+    assert eps.GetConverged() == r.nconv and eps.GetIterationNumber() == r.its
+    assert np.allclose(lam, r.eigr[r.perm][:4], rtol=1e-9)
+    assert st.GetKSPStats()["iterations"] / st.GetKSPStats()["solves"] <= Ao.n
+
+
+def test_eps_test1_sinvert_target_22_golden(ctx):
+    """test1_1_ks_sinvert: -st_type sinvert -eps_target 22 on the GHEP of test1 reprints test1_1.out; A - 22 B is
+    indefinite, full GMRES (restart = n = 324) solves it."""
+    import slepc_amd as ks
+    from test_gpu_ghep import _test1_pencil
+    Ao, Bo = _test1_pencil()
+    eps = ks.EPS(ctx)
+    eps.SetOperators(_mat(ctx, Ao), _mat(ctx, Bo)); eps.SetProblemType(ks.EPS_GHEP); eps.SetDimensions(4); eps.SetTolerances(0.0, 1500)
+    eps.SetConvergenceTest("norm"); eps.SetTarget(22.0)
+    st = eps.GetST(); st.SetType("sinvert"); st.SetKSP(rtol=1e-13, restart=Ao.n, max_it=10 * Ao.n)
+    eps.Solve()
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(4)])
+    r = O.eps_krylovschur_hep(Ao, 4, max_it=1500, which=O.which_target_magnitude(22.0), st=O.ST(Ao, Bo, "sinvert", 22.0), B=Bo, conv="norm")
+    assert np.allclose(np.sort(np.round(lam, 5)), np.sort(gi.eigenvalues_line(gi.read("eps/eps_test1_1.out"))), atol=1.5e-5)
+    assert np.allclose(lam, r.eigr[r.perm][:4], rtol=1e-8)
+    for i in range(4):
+        assert eps.ComputeError(i) < 1e-6
