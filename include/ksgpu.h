@@ -79,7 +79,7 @@ enum { KS_EPS_LARGEST_MAGNITUDE = 1, KS_EPS_SMALLEST_MAGNITUDE = 2, KS_EPS_LARGE
 /* SlepcEigenvalueComparisonFn (include/slepcsc.h): *res < 0 if a is preferred to b, > 0 if b is preferred, 0 if equal */
 typedef int (*ks_eig_compare_fn)(double ar, double ai, double br, double bi, int *res, void *ctx);
 enum { KS_EPS_HEP = 1, KS_EPS_GHEP = 2, KS_EPS_NHEP = 3, KS_EPS_GNHEP = 4 };   /* EPSProblemType, slepceps.h */
-enum { KS_ST_SHIFT = 0, KS_ST_SINVERT = 1 };                 /* STType "shift", "sinvert" */
+enum { KS_ST_SHIFT = 0, KS_ST_SINVERT = 1, KS_ST_CAYLEY = 2 };   /* STType "shift", "sinvert", "cayley" */
 enum { KS_EPS_ERROR_ABSOLUTE = 0, KS_EPS_ERROR_RELATIVE = 1, KS_EPS_ERROR_BACKWARD = 2 };   /* EPSErrorType */
 enum { KS_EPS_RITZ = 0, KS_EPS_HARMONIC = 1, KS_EPS_HARMONIC_RELATIVE, KS_EPS_HARMONIC_RIGHT, KS_EPS_HARMONIC_LARGEST, KS_EPS_REFINED, KS_EPS_REFINED_HARMONIC };  /* EPSExtraction slepceps.h:94-100; Krylov-Schur offers the first two */
 enum { KS_EPS_CONV_ABS = 0, KS_EPS_CONV_REL = 1, KS_EPS_CONV_NORM = 2, KS_EPS_CONV_USER = 3 };   /* EPSConv slepceps.h:153-156 */
@@ -284,6 +284,8 @@ int ks_st_destroy(ks_st st);
 int ks_st_set_type(ks_st st, int type);                                   /* STSetType */
 int ks_st_set_shift(ks_st st, double sigma);                              /* STSetShift */
 int ks_st_get_shift(ks_st st, double *sigma);
+int ks_st_cayley_set_antishift(ks_st st, double nu);                      /* STCayleySetAntishift cayley.c:236 (default: the shift) */
+int ks_st_cayley_get_antishift(ks_st st, double *nu);
 int ks_st_set_matrices(ks_st st, ks_mat A, ks_mat B /* may be NULL */);   /* STSetMatrices */
 int ks_st_set_ksp(ks_st st, double rtol, int max_it, int restart);        /* KSPSetTolerances / KSPGMRESSetRestart on STGetKSP; 0 keeps */
 int ks_st_setup(ks_st st);                                                /* STSetUp */

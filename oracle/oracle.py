@@ -783,8 +783,9 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
     nrmb = (_norm_inf(B) if B is not None else 1.0) if conv == "norm" else 1.0
     V = BV(n, ncv + 1, omp=omp)
     V.SetOrthogonalization(*orthog)
+    Bip = st.bilinear if (B is not None and st is not None and st.kind == "cayley") else B     # STGetBilinearForm
     if B is not None:
-        V.SetMatrix(B)
+        V.SetMatrix(Bip)
     if deflation is not None:                                # EPSSetDeflationSpace -> BVInsertConstraints (epssetup.c:397-404)
         V.InsertConstraints(deflation)
     ds = DSHEP(ncv + 1, ds_compare)
@@ -837,7 +838,7 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
                 re = eigr[i] if st is None else st.backtransform(eigr[i], 0.0)[0]
                 x = Xall @ ds.Q[:nv, i]
                 if B is not None:                           # purification of EPSComputeRitzVector
-                    y = st.apply(x); x = y / np.sqrt(y @ B.mult(y))
+                    y = st.apply(x); x = y / np.sqrt(y @ Bip.mult(y))
                 rr[i], ri[i] = arbitrary(re, 0.0, x, np.zeros(n))
             ds.Sort(eigr, rr, ri)
         else:
@@ -855,7 +856,7 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
             if trueres:                                     # epskrylov.c:245,256-264
                 if st is not None and not (st.kind == "shift" or conv == "norm"):
                     re = st.backtransform(re, 0.0)[0]
-                resnorm = _true_residual(A, B, V, nv, re, 0.0, ds.Q[:, kk], purify=st.apply if B is not None else None)
+                resnorm = _true_residual(A, B, V, nv, re, 0.0, ds.Q[:, kk], purify=st.apply if B is not None else None, Bnorm=Bip)
             errest[kk] = _converged(conv, re, 0.0, resnorm, nrma, nrmb)
             if marker == -1 and errest[kk] >= tol:
                 marker = kk
@@ -937,13 +938,13 @@ def _residual_norm(A, B, kr, ki, xr, xi=None):
     return float(np.hypot(np.linalg.norm(u), np.linalg.norm(w)))
 
 
-def _true_residual(A, B, V, nv, re, im, Zr, Zi=None, purify=None):
+def _true_residual(A, B, V, nv, re, im, Zr, Zi=None, purify=None, Bnorm=None):
     """EPSComputeRitzVector epsdefault.c:313-364 + the residual of epskrylov.c:256-264 (-eps_true_residual)."""
     X = np.array(V.dense())[: V.n, :nv]
     x = X @ Zr[:nv]
     if purify is not None:                                   # STApply, B-norm, scale (GHEP)
         y = purify(x)
-        x = y / np.sqrt(y @ B.mult(y))
+        x = y / np.sqrt(y @ (Bnorm if Bnorm is not None else B).mult(y))
     y = X @ Zi[:nv] if Zi is not None else None
     return _residual_norm(A, B, re, im, x, y)
 
@@ -1183,7 +1184,9 @@ class ST:
         sinvert: nmat=1  M = none,        P = A - sigma I   nmat=2  M = B,       P = A - sigma B
     The linear solves use the reference's default KSP, preonly + LU (stsles.c:54-56), here SuperLU through scipy."""
 
-    def __init__(self, A, B=None, kind="shift", sigma=0.0):
+    def __init__(self, A, B=None, kind="shift", sigma=0.0, nu=None):
+        """kind "cayley" (cayley.c:138-165): Op = (A - sigma B)^-1 (A + nu B), antishift nu = sigma unless given; its
+        bilinear form for symmetric problems is A + nu B (STGetBilinearForm_Cayley, cayley.c:70-77)."""
         import scipy.sparse as sp
         import scipy.sparse.linalg as spl
         self.kind = kind; self.sigma = float(sigma); self.n = A.n
@@ -1195,6 +1198,12 @@ class ST:
             self.M = T.tocsr(); self.lu = spl.splu(Sb) if Sb is not None else None
         elif kind == "sinvert":
             self.M = Sb.tocsr() if Sb is not None else None; self.lu = spl.splu(T)
+        elif kind == "cayley":
+            self.nu = self.sigma if nu is None else float(nu)
+            assert (self.nu != 0.0 or self.sigma != 0.0) and self.nu != -self.sigma
+            self.M = (Sa + self.nu * Ib).tocsr(); self.lu = spl.splu(T)
+            Mb = self.M.tocsr(); Mb.sort_indices()
+            self.bilinear = CSR(A.n, Mb.indptr.astype(np.int32), Mb.indices.astype(np.int32), Mb.data.astype(np.float64))
         else:
             raise ValueError(kind)
         self.solves = 0
@@ -1208,6 +1217,12 @@ class ST:
     def backtransform(self, re, im):
         if self.kind == "shift":                       # shift.c:49-56
             return re + self.sigma, im
+        if self.kind == "cayley":                      # cayley.c:79-107 (real scalars)
+            if im == 0.0:
+                return (self.nu + re * self.sigma) / (re - 1.0), 0.0
+            # (nu + theta sigma)/(theta - 1); cayley.c:93-99 takes |theta - 1|^2 after overwriting theta's parts: not followed
+            t = im * im + re * (re - 2.0) + 1.0
+            return (self.sigma * (re * re + im * im - re) + self.nu * (re - 1.0)) / t, (-self.sigma * im - self.nu * im) / t
         if im == 0.0:                                  # sinvert.c:16-40 (real scalars)
             return 1.0 / re + self.sigma, 0.0
         t = re * re + im * im

@@ -31,7 +31,7 @@ WHICH = {"largest_magnitude": 1, "smallest_magnitude": 2, "largest_real": 3, "sm
          "largest_imaginary": 5, "smallest_imaginary": 6, "target_magnitude": 7, "target_real": 8, "user": 11}
 BLOCK = {"gs": 0, "chol": 1, "tsqr": 2, "tsqrchol": 3, "svqb": 4}
 SHELL_MULT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
-ST_SHIFT, ST_SINVERT = 0, 1
+ST_SHIFT, ST_SINVERT, ST_CAYLEY = 0, 1, 2
 EIG_COMPARE_FN = C.CFUNCTYPE(C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_void_p)
 EPS_CONVERGED_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_void_p)
 EPS_STOPPING_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p)
@@ -553,7 +553,7 @@ class ST:
             pass
 
     def SetType(self, t):
-        _lib.check(self.ctx.L.ks_st_set_type(self.h, {"shift": ST_SHIFT, "sinvert": ST_SINVERT}.get(t, t)))
+        _lib.check(self.ctx.L.ks_st_set_type(self.h, {"shift": ST_SHIFT, "sinvert": ST_SINVERT, "cayley": ST_CAYLEY}.get(t, t)))
 
     def SetShift(self, sigma):
         _lib.check(self.ctx.L.ks_st_set_shift(self.h, sigma))
@@ -564,6 +564,12 @@ class ST:
     def SetMatrices(self, A, B=None):
         _lib.check(self.ctx.L.ks_st_set_matrices(self.h, A.h, None if B is None else B.h))
         self._A, self._B = A, B
+
+    def CayleySetAntishift(self, nu):
+        _lib.check(self.ctx.L.ks_st_cayley_set_antishift(self.h, nu))
+
+    def CayleyGetAntishift(self):
+        v = C.c_double(); _lib.check(self.ctx.L.ks_st_cayley_get_antishift(self.h, C.byref(v))); return v.value
 
     def SetKSP(self, rtol=0.0, max_it=0, restart=0):
         _lib.check(self.ctx.L.ks_st_set_ksp(self.h, rtol, max_it, restart))

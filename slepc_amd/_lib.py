@@ -158,6 +158,8 @@ _SIG = {
     "ks_st_set_type": [vp, C.c_int],
     "ks_st_set_shift": [vp, C.c_double],
     "ks_st_get_shift": [vp, dp],
+    "ks_st_cayley_set_antishift": [vp, C.c_double],
+    "ks_st_cayley_get_antishift": [vp, C.POINTER(C.c_double)],
     "ks_st_set_matrices": [vp, vp, vp],
     "ks_st_set_ksp": [vp, C.c_double, C.c_int, C.c_int],
     "ks_st_setup": [vp],

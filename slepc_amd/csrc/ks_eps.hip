@@ -822,7 +822,8 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   const bool ghep = ptype == KS_EPS_GHEP;
   if (eps->conv == KS_EPS_CONV_NORM) KS_CALL(matrix_norms(eps));
   ks_st st = eps->st;
-  const bool sinvert = st && st->type == KS_ST_SINVERT;
+  const bool cayley = st && st->type == KS_ST_CAYLEY;
+  const bool sinvert = (st && st->type == KS_ST_SINVERT) || cayley;   // the set-up rules below are those of EPSCheckSinvertCayley
   if (sinvert && !st->sigma_set) { if (st->sigma != eps->which.target) st->ready = false; st->sigma = eps->which.target; }   // the shift of sinvert defaults to the target (STSetDefaultShift epsbasic.c:386, sinvert.c:64); STSHIFT keeps 0
   KsCompare cmp = eps->which;
   if (!cmp.which) cmp.which = sinvert ? KS_EPS_TARGET_MAGNITUDE : KS_EPS_LARGEST_MAGNITUDE;   // epsdefault.c:209-219
@@ -858,7 +859,7 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   long long passes0 = 0; ks_bv_gs_passes(eps->V, &passes0, nullptr);
   ks_bv V = eps->V;
   KS_CALL(ks_bv_set_active_columns(V, 0, ncv + 1));
-  KS_CALL(ks_bv_set_matrix(V, ghep ? eps->B : nullptr));             // EPS_SetInnerProduct epsimpl.h:280-292 (STGetBilinearForm = B)
+  KS_CALL(ks_bv_set_matrix(V, ghep ? (cayley ? st->bil : eps->B) : nullptr));   // EPS_SetInnerProduct epsimpl.h:280-292: STGetBilinearForm = B, or A + nu B for STCAYLEY (cayley.c:70-77)
   eps->ghep = ghep;
   if (eps->nds) {                                                      // process the deflation space (epssetup.c:397-404)
     std::vector<const double *> cp(eps->nds);

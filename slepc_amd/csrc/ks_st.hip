@@ -4,6 +4,7 @@
 // STApply_Generic (src/sys/classes/st/interface/stsolve.c:16-25):  y = P^-1 M x,
 //     shift:    nmat=1  M = A - sigma I, P none          nmat=2  M = A - sigma B, P = B
 //     sinvert:  nmat=1  M none,          P = A - sigma I nmat=2  M = B,           P = A - sigma B
+//     cayley:   nmat=1  M = A + nu I,    P = A - sigma I nmat=2  M = A + nu B,    P = A - sigma B   (cayley/cayley.c:138-165)
 // in the reference's ST_MATMODE_SHELL form: A - sigma B is never assembled, it is applied as two SpMVs and an
 // axpy (stshellmat.c), and its diagonal is diag(A) - sigma diag(B). The linear solves are the KSP that mode
 // defaults to (stsles.c:51-53): GMRES(30) with a Jacobi preconditioner on the left, relative tolerance
@@ -67,7 +68,7 @@ int linop_apply(ks_st st, double a, ks_mat A, double b, ks_mat B, bool identity_
 // the matrix P of the table above, y = s .* P x
 int apply_P(ks_st st, const double *s, const double *x, double *out, double *tmp)
 {
-  if (st->type == KS_ST_SINVERT) return linop_apply(st, 1.0, st->A, -st->sigma, st->B, !st->B, s, x, out, tmp);
+  if (st->type == KS_ST_SINVERT || st->type == KS_ST_CAYLEY) return linop_apply(st, 1.0, st->A, -st->sigma, st->B, !st->B, s, x, out, tmp);
   return linop_apply(st, 0.0, nullptr, 1.0, st->B, false, s, x, out, tmp);           // shift, nmat=2: P = B
 }
 
@@ -130,6 +131,12 @@ int gmres_solve(ks_st st, const double *rhs, double *y)
 }
 
 int st_shell_mult(void *user, const double *x, double *y) { return ks_st_apply_internal((ks_st)user, x, y); }
+// y = (A + nu B) x, MatMult_Cayley cayley.c:21-44
+int st_bilinear_mult(void *user, const double *x, double *y)
+{
+  ks_st st = (ks_st)user;
+  return linop_apply(st, 1.0, st->A, st->nu, st->B, !st->B, nullptr, x, y, ks_bv_col(st->W, 2));
+}
 
 } // namespace
 
@@ -143,7 +150,12 @@ int ks_st_setup_internal(ks_st st)
   KS_CHECK(!B || (B->n == A->n && B->n_global == A->n_global), KS_ERR_ARG_INCOMP, "Mismatching dimensions of A (%d) and B (%d)", A->n, B ? B->n : 0);
   KS_HIP(hipSetDevice(ctx->device));
   st->n = A->n;
-  const bool need_solve = (st->type == KS_ST_SINVERT) || (st->type == KS_ST_SHIFT && B);
+  if (st->type == KS_ST_CAYLEY) {                                      // STComputeOperator_Cayley cayley.c:138-147
+    if (!st->nu_set) st->nu = st->sigma;
+    KS_CHECK(st->nu != 0.0 || st->sigma != 0.0, KS_ERR_USER_INPUT, "Values of shift and antishift cannot be zero simultaneously");
+    KS_CHECK(st->nu != -st->sigma, KS_ERR_USER_INPUT, "It is not allowed to set the antishift equal to minus the shift (the target)");
+  }
+  const bool need_solve = (st->type == KS_ST_SINVERT) || (st->type == KS_ST_CAYLEY) || (st->type == KS_ST_SHIFT && B);
   if (st->W) { int wn = 0; ks_bv_get_sizes(st->W, &wn, nullptr, nullptr, nullptr); if (wn != A->n) { ks_bv_destroy(st->W); ks_bv_destroy(st->K); st->W = st->K = nullptr; if (st->dinv) hipFree(st->dinv); st->dinv = nullptr; } }
   if (!st->W) KS_CALL(ks_bv_create(ctx, A->n, A->n_global, 3, 0, &st->W));
   if (need_solve) {
@@ -153,7 +165,7 @@ int ks_st_setup_internal(ks_st st)
     // Jacobi: diag(P)
     double *da = ks_bv_col(st->W, 1), *db = ks_bv_col(st->W, 2);
     const unsigned nb = (unsigned)std::max<long long>(1, std::min<long long>(((long long)A->n + 255) / 256, (long long)ctx->num_cu * 16));
-    if (st->type == KS_ST_SINVERT) {
+    if (st->type == KS_ST_SINVERT || st->type == KS_ST_CAYLEY) {
       KS_CALL(ks_mat_get_diagonal_internal(A, da));
       if (B) KS_CALL(ks_mat_get_diagonal_internal(B, db));
       hipLaunchKernelGGL(k_jacobi_setup, dim3(nb), dim3(256), 0, ctx->stream, (long long)A->n, 1.0, da, -st->sigma, B ? db : nullptr, st->dinv);
@@ -165,6 +177,10 @@ int ks_st_setup_internal(ks_st st)
   }
   if (!st->op) KS_CALL(ks_mat_create_shell(ctx, A->n, A->row_start, A->n_global, st_shell_mult, st, &st->op));
   st->op->n = A->n; st->op->row_start = A->row_start; st->op->n_global = A->n_global;
+  if (st->type == KS_ST_CAYLEY) {
+    if (!st->bil) KS_CALL(ks_mat_create_shell(ctx, A->n, A->row_start, A->n_global, st_bilinear_mult, st, &st->bil));
+    st->bil->n = A->n; st->bil->row_start = A->row_start; st->bil->n_global = A->n_global;
+  }
   st->ready = true;
   return KS_SUCCESS;
 }
@@ -177,6 +193,10 @@ int ks_st_apply_internal(ks_st st, const double *x, double *y)     // STApply_Ge
     if (st->B) { KS_CALL(ks_mat_mult_internal(st->B, x, w)); return gmres_solve(st, w, y); }
     return gmres_solve(st, x, y);
   }
+  if (st->type == KS_ST_CAYLEY) {                                      // y = (A - sigma B)^-1 (A + nu B) x
+    KS_CALL(linop_apply(st, 1.0, st->A, st->nu, st->B, !st->B, nullptr, x, w, t1));
+    return gmres_solve(st, w, y);
+  }
   // shift
   if (st->B) { KS_CALL(linop_apply(st, 1.0, st->A, -st->sigma, st->B, false, nullptr, x, w, t1)); return gmres_solve(st, w, y); }
   return linop_apply(st, 1.0, st->A, -st->sigma, nullptr, st->sigma != 0.0, nullptr, x, y, t1);
@@ -187,6 +207,17 @@ void ks_st_backtransform_internal(ks_st st, int n, double *eigr, double *eigi)
   if (!st) return;
   for (int j = 0; j < n; j++) {
     if (st->type == KS_ST_SHIFT) eigr[j] += st->sigma;                                  // shift.c:49-56
+    else if (st->type == KS_ST_CAYLEY) {                                                 // cayley.c:79-107
+      if (eigi[j] == 0.0) eigr[j] = (st->nu + eigr[j] * st->sigma) / (eigr[j] - 1.0);
+      else {
+        // lambda = (nu + theta sigma) / (theta - 1) for theta = a + b i. Stated deviation: cayley.c:93-99 forms the denominator
+        // |theta - 1|^2 = b^2 + a (a - 2) + 1 AFTER it has overwritten a and b with the numerator; here it is taken from theta.
+        const double a = eigr[j], b = eigi[j];
+        const double t = b * b + a * (a - 2.0) + 1.0;
+        eigr[j] = (st->sigma * (a * a + b * b - a) + st->nu * (a - 1.0)) / t;
+        eigi[j] = (-st->sigma * b - st->nu * b) / t;
+      }
+    }
     else if (eigi[j] == 0.0) eigr[j] = 1.0 / eigr[j] + st->sigma;                        // sinvert.c:16-40
     else { const double t = eigr[j] * eigr[j] + eigi[j] * eigi[j]; eigr[j] = eigr[j] / t + st->sigma; eigi[j] = -eigi[j] / t; }
   }
@@ -204,13 +235,14 @@ extern "C" int ks_st_destroy(ks_st st)
   ks_bv_destroy(st->K); ks_bv_destroy(st->W);
   if (st->dinv) hipFree(st->dinv);
   if (st->op) ks_mat_destroy(st->op);
+  if (st->bil) ks_mat_destroy(st->bil);
   delete st;
   return KS_SUCCESS;
 }
 extern "C" int ks_st_set_type(ks_st st, int type)                    // STSetType
 {
   KS_CHECK(st, KS_ERR_ARG_NULL, "ST is NULL");
-  KS_CHECK(type == KS_ST_SHIFT || type == KS_ST_SINVERT, KS_ERR_SUP, "only STSHIFT and STSINVERT are built");
+  KS_CHECK(type == KS_ST_SHIFT || type == KS_ST_SINVERT || type == KS_ST_CAYLEY, KS_ERR_SUP, "only STSHIFT, STSINVERT and STCAYLEY are built");
   if (st->type != type) { st->type = type; st->ready = false; }
   return KS_SUCCESS;
 }
@@ -221,6 +253,14 @@ extern "C" int ks_st_set_shift(ks_st st, double sigma)               // STSetShi
   st->sigma_set = true;
   return KS_SUCCESS;
 }
+extern "C" int ks_st_cayley_set_antishift(ks_st st, double nu)       // STCayleySetAntishift cayley.c:236
+{
+  KS_CHECK(st, KS_ERR_ARG_NULL, "ST is NULL");
+  if (st->nu != nu || !st->nu_set) { st->nu = nu; st->ready = false; }
+  st->nu_set = true;
+  return KS_SUCCESS;
+}
+extern "C" int ks_st_cayley_get_antishift(ks_st st, double *nu) { KS_CHECK(st && nu, KS_ERR_ARG_NULL, "NULL argument"); *nu = st->nu; return KS_SUCCESS; }
 extern "C" int ks_st_get_shift(ks_st st, double *sigma) { KS_CHECK(st && sigma, KS_ERR_ARG_NULL, "NULL argument"); *sigma = st->sigma; return KS_SUCCESS; }
 extern "C" int ks_st_set_matrices(ks_st st, ks_mat A, ks_mat B)      // STSetMatrices (n = 1 or 2)
 {

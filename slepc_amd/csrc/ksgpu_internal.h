@@ -119,6 +119,8 @@ struct ks_st_s {
   ks_ctx ctx = nullptr;
   int type = KS_ST_SHIFT;
   double sigma = 0.0; bool sigma_set = false;
+  double nu = 0.0; bool nu_set = false;      // STCAYLEY antishift (defaults to sigma, cayley.c:140)
+  ks_mat bil = nullptr;                       // STCAYLEY: shell matrix A + nu B, the bilinear form of symmetric problems (cayley.c:70-77)
   ks_mat A = nullptr, B = nullptr;            // borrowed
   double rtol = 1e-8; int max_it = 10000, restart = 30;   // KSP: SLEPC_DEFAULT_TOL (stsles.c:407), PETSc defaults
   ks_bv K = nullptr, W = nullptr;             // GMRES basis (restart+1 columns), work vectors (3 columns)

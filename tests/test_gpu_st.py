@@ -289,3 +289,48 @@ def test_eps_test1_sinvert_target_22_golden(ctx):
     assert np.allclose(lam, r.eigr[r.perm][:4], rtol=1e-8)
     for i in range(4):
         assert eps.ComputeError(i) < 1e-6
+
+
+def test_eps_test1_cayley_golden(ctx):
+    """test1_1_ks_cayley: -st_type cayley -eps_target 22 (GHEP): inner solves with A - 22 B (indefinite: full GMRES), the
+    basis orthonormal in the A + 22 B inner product (a matrix-free operator), same values as test1_1.out and the oracle."""
+    import slepc_amd as ks
+    from test_gpu_ghep import _test1_pencil
+    Ao, Bo = _test1_pencil()
+    eps = ks.EPS(ctx)
+    eps.SetOperators(_mat(ctx, Ao), _mat(ctx, Bo)); eps.SetProblemType(ks.EPS_GHEP); eps.SetDimensions(4); eps.SetTolerances(0.0, 1500)
+    eps.SetConvergenceTest("norm"); eps.SetTarget(22.0)
+    st = eps.GetST(); st.SetType("cayley"); st.SetKSP(rtol=1e-13, restart=Ao.n, max_it=10 * Ao.n)
+    eps.Solve()
+    assert st.GetShift() == 22.0 and st.CayleyGetAntishift() == 22.0       # both default to the target
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(eps.GetConverged())])
+    r = O.eps_krylovschur_hep(Ao, 4, max_it=1500, which=O.which_target_magnitude(22.0), st=O.ST(Ao, Bo, "cayley", 22.0), B=Bo, conv="norm")
+    assert np.allclose(np.round(lam[:4], 5), gi.eigenvalues_line(gi.read("eps/eps_test1_1.out")), atol=1.5e-5)
+    assert eps.GetConverged() == r.nconv and eps.GetIterationNumber() == r.its
+    assert np.allclose(lam, r.eigr[r.perm][: r.nconv], rtol=1e-8)
+    for i in range(4):
+        assert eps.ComputeError(i) < 1e-6
+
+
+def test_cayley_standard_nonsymmetric_and_backtransform(ctx):
+    """STCAYLEY on a standard non-symmetric problem with its own antishift, complex pairs through the Moebius map."""
+    import slepc_amd as ks
+    st = ks.ST(ctx); st.SetType("cayley"); st.SetShift(1.0); st.CayleySetAntishift(1.0)
+    re, im = st.BackTransform(np.array([2.0, 3.0]), np.array([1.0, 0.0]))
+    assert np.allclose(re, [2.0, 2.0]) and np.allclose(im, [-1.0, 0.0])  # (1 + theta)/(theta - 1)
+    Ao = nc.planted_pairs(800)
+    A = _mat(ctx, Ao)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A); eps.SetProblemType(ks.EPS_NHEP); eps.SetDimensions(4, 24); eps.SetTarget(-2.0)
+    s2 = eps.GetST(); s2.SetType("cayley"); s2.CayleySetAntishift(5.0); s2.SetKSP(rtol=1e-13)
+    eps.Solve()
+    r = O.eps_krylovschur_nhep(Ao, 4, ncv=24, which=O.which_target_magnitude(-2.0), st=O.ST(Ao, None, "cayley", -2.0, nu=5.0))
+    assert eps.GetConverged() == r.nconv and eps.GetIterationNumber() == r.its
+    for i in range(4):
+        kr, ki = eps.GetEigenvalue(i); j = r.perm[i]
+        assert abs(kr - r.eigr[j]) < 1e-8 * np.hypot(r.eigr[j], r.eigi[j]) and abs(ki - r.eigi[j]) < 1e-8 * np.hypot(r.eigr[j], r.eigi[j])
+        err = eps.ComputeError(i)                                       # convergence is tested on theta, not on lambda
+        assert err < 1e-4 and abs(err - O.eps_compute_error_nhep(Ao, r, i)) < 1e-8
+    with pytest.raises(ks.KsError) as e:
+        s3 = ks.ST(ctx); s3.SetType("cayley"); s3.SetShift(2.0); s3.CayleySetAntishift(-2.0); s3.SetMatrices(A, None); s3.SetUp()
+    assert e.value.rc == 71

@@ -494,3 +494,16 @@ def test_eps_test13_arbitrary_selection_golden():
     assert abs(round(r2.eigr[r2.perm][0], 5) - ref[1][0]) < 1.5e-5
     # without the selection the largest-magnitude solve is free to return +1.98974 or -1.98974 (equal magnitude)
     assert abs(abs(np.array(r2.V.column(r2.perm[0])) @ sx) - 1.0) < 1e-6
+
+
+def test_eps_test1_cayley_golden():
+    """test1_1_ks_cayley: -st_type cayley -eps_target 22 on the GHEP of test1 reprints test1_1.out. Operator
+    (A - 22 B)^-1 (A + 22 B), inner product A + 22 B (STGetBilinearForm_Cayley), back-transformation (nu + theta sigma)/(theta - 1)."""
+    A, B = _test1_pencil()
+    st = O.ST(A, B, "cayley", 22.0)
+    r = O.eps_krylovschur_hep(A, 4, max_it=1500, which=O.which_target_magnitude(22.0), st=st, B=B, conv="norm")
+    assert np.allclose(np.round(r.eigr[r.perm][:4], 5), gi.eigenvalues_line(gi.read("eps/eps_test1_1.out")), atol=1.5e-5)
+    for i in range(4):
+        assert O.eps_compute_error(A, r, i, B=B) < 1e-8
+    # the back-transformation of a complex value is the Moebius map itself
+    assert np.allclose(O.ST(A, B, "cayley", 1.0, nu=1.0).backtransform(2.0, 1.0), (2.0, -1.0))
