@@ -187,11 +187,18 @@ int ks_bv_dot(ks_bv X, ks_bv Y, double *M, int ldm);                            
 int ks_bv_dotvec(ks_bv X, const double *y_dev, double *m);                                       /* ops->dotvec; m NULL -> buffer */
 int ks_bv_dotvec_local(ks_bv X, const double *y_dev, double *m);                                 /* ops->dotvec_local (no reduction) */
 int ks_bv_dotcolumn(ks_bv X, int j, double *q);                                                  /* BVDotColumn bvglobal.c:302 */
+/* split reductions (bvglobal.c:207-300, 343-430, 573-660, 705-790): the Begin calls queue this rank's parts on the device, the first
+   End reduces everything queued with ONE allreduce; Ends in the order of the Begins. Norms: 2-norm (or the B-norm) only. */
+int ks_bv_dotvec_begin(ks_bv X, const double *y_dev, double *m);       int ks_bv_dotvec_end(ks_bv X, const double *y_dev, double *m);
+int ks_bv_dotcolumn_begin(ks_bv X, int j, double *q);                  int ks_bv_dotcolumn_end(ks_bv X, int j, double *q);
+int ks_bv_normvec_begin(ks_bv bv, const double *v_dev, int type, double *val);  int ks_bv_normvec_end(ks_bv bv, const double *v_dev, int type, double *val);
+int ks_bv_normcolumn_begin(ks_bv bv, int j, int type, double *val);    int ks_bv_normcolumn_end(ks_bv bv, int j, int type, double *val);
 int ks_bv_scale(ks_bv bv, double alpha);                                                         /* ops->scale(-1,alpha) */
 int ks_bv_scalecolumn(ks_bv bv, int j, double alpha);                                            /* ops->scale(j,alpha) */
 int ks_bv_norm(ks_bv bv, int type, double *val);                                                 /* ops->norm(-1,type) */
 int ks_bv_normcolumn(ks_bv bv, int j, int type, double *val);                                    /* ops->norm(j,type) */
 int ks_bv_norm_local(ks_bv bv, int j, int type, double *val);                                    /* ops->norm_local */
+int ks_bv_normvec(ks_bv bv, const double *v_dev, int type, double *val);                         /* BVNormVec bvglobal.c:530: norm of a device vector, B-norm when a matrix is set */
 int ks_bv_copy(ks_bv V, ks_bv W);                                                                /* ops->copy */
 int ks_bv_copycolumn(ks_bv V, int j, int i);                                                     /* ops->copycolumn */
 int ks_bv_matmult(ks_bv V, ks_mat A, ks_bv W);                                                   /* ops->matmult (column loop, svec.c:213) */

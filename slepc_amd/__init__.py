@@ -452,6 +452,11 @@ class BV:
         _lib.check(self.ctx.L.ks_bv_norm(self.h, type, C.byref(v)))
         return v.value
 
+    def NormVec(self, v_ptr, type=NORM_2):
+        v = C.c_double()
+        _lib.check(self.ctx.L.ks_bv_normvec(self.h, C.c_void_p(v_ptr), type, C.byref(v)))
+        return v.value
+
     def NormColumn(self, j, type=NORM_2):
         v = C.c_double()
         _lib.check(self.ctx.L.ks_bv_normcolumn(self.h, j, type, C.byref(v)))
@@ -517,6 +522,37 @@ class BV:
         t = C.c_longlong(); l = C.c_int()
         _lib.check(self.ctx.L.ks_bv_gs_passes(self.h, C.byref(t), C.byref(l)))
         return t.value, l.value
+
+    # -- split reductions: Begin queues, the first End reduces everything queued with one allreduce
+    def DotVecBegin(self, v_ptr):
+        out = np.zeros(max(self.k - self.l, 1))
+        _lib.check(self.ctx.L.ks_bv_dotvec_begin(self.h, C.c_void_p(v_ptr), _p(out)))
+        return out                                             # filled by DotVecEnd(v_ptr, out)
+
+    def DotVecEnd(self, v_ptr, out):
+        _lib.check(self.ctx.L.ks_bv_dotvec_end(self.h, C.c_void_p(v_ptr), _p(out)))
+        return out[: self.k - self.l]
+
+    def DotColumnBegin(self, j):
+        out = np.zeros(max(j - self.l, 1))
+        _lib.check(self.ctx.L.ks_bv_dotcolumn_begin(self.h, j, _p(out)))
+        return out
+
+    def DotColumnEnd(self, j, out):
+        _lib.check(self.ctx.L.ks_bv_dotcolumn_end(self.h, j, _p(out)))
+        return out[: j - self.l]
+
+    def NormVecBegin(self, v_ptr, type=NORM_2):
+        _lib.check(self.ctx.L.ks_bv_normvec_begin(self.h, C.c_void_p(v_ptr), type, _p(np.zeros(1))))
+
+    def NormVecEnd(self, v_ptr, type=NORM_2):
+        out = np.zeros(1); _lib.check(self.ctx.L.ks_bv_normvec_end(self.h, C.c_void_p(v_ptr), type, _p(out))); return float(out[0])
+
+    def NormColumnBegin(self, j, type=NORM_2):
+        _lib.check(self.ctx.L.ks_bv_normcolumn_begin(self.h, j, type, _p(np.zeros(1))))
+
+    def NormColumnEnd(self, j, type=NORM_2):
+        out = np.zeros(1); _lib.check(self.ctx.L.ks_bv_normcolumn_end(self.h, j, type, _p(out))); return float(out[0])
 
     def MatLanczos(self, A, T, k, m):
         assert T.flags.f_contiguous and T.dtype == np.float64 and T.shape[1] >= 2

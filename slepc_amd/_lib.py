@@ -77,11 +77,16 @@ _SIG = {
     "ks_bv_dotvec": [vp, vp, dp],
     "ks_bv_dotvec_local": [vp, vp, dp],
     "ks_bv_dotcolumn": [vp, C.c_int, dp],
+    "ks_bv_dotvec_begin": [vp, vp, dp], "ks_bv_dotvec_end": [vp, vp, dp],
+    "ks_bv_dotcolumn_begin": [vp, C.c_int, dp], "ks_bv_dotcolumn_end": [vp, C.c_int, dp],
+    "ks_bv_normvec_begin": [vp, vp, C.c_int, dp], "ks_bv_normvec_end": [vp, vp, C.c_int, dp],
+    "ks_bv_normcolumn_begin": [vp, C.c_int, C.c_int, dp], "ks_bv_normcolumn_end": [vp, C.c_int, C.c_int, dp],
     "ks_bv_scale": [vp, C.c_double],
     "ks_bv_scalecolumn": [vp, C.c_int, C.c_double],
     "ks_bv_norm": [vp, C.c_int, dp],
     "ks_bv_normcolumn": [vp, C.c_int, C.c_int, dp],
     "ks_bv_norm_local": [vp, C.c_int, C.c_int, dp],
+    "ks_bv_normvec": [vp, vp, C.c_int, dp],
     "ks_bv_copy": [vp, vp],
     "ks_bv_copycolumn": [vp, C.c_int, C.c_int],
     "ks_bv_matmult": [vp, vp, vp],

@@ -781,14 +781,20 @@ extern "C" int ks_bv_scalecolumn(ks_bv bv, int j, double alpha)   // bvops.c:341
   return ksk_scale(bv->ctx, ks_bv_col(bv, j), bv->n, alpha);
 }
 
+static int norm_core(ks_bv bv, const double *A, int ncols, int j, int type, double *val, bool reduce);
 static int norm_impl(ks_bv bv, int j, int type, double *val, bool reduce)   // svec.c:164-190, bvlapack.c:37-83
 {
   KS_CHECK(bv && val, KS_ERR_ARG_NULL, "NULL argument");
-  ks_ctx ctx = bv->ctx;
-  KS_HIP(hipSetDevice(ctx->device));
+  KS_HIP(hipSetDevice(bv->ctx->device));
   const double *A; int ncols;
   if (j < 0) { A = bv->array + (size_t)(bv->nc + bv->l) * bv->ld; ncols = bv->k - bv->l; }
   else { KS_CHECK(j < bv->m, KS_ERR_ARG_OUTOFRANGE, "Argument j has wrong value %d, the number of columns is %d", j, bv->m); A = ks_bv_col(bv, j); ncols = 1; }
+  return norm_core(bv, A, ncols, j, type, val, reduce);
+}
+// norm of the ncols columns starting at A (leading dimension of the BV); j >= 0 marks a single vector (2-norm allowed)
+static int norm_core(ks_bv bv, const double *A, int ncols, int j, int type, double *val, bool reduce)
+{
+  ks_ctx ctx = bv->ctx;
   if (ncols <= 0) { *val = 0.0; return KS_SUCCESS; }
   KS_CHECK(ncols <= KS_PSTRIDE - 8, KS_ERR_SUP, "norm over more than %d columns", KS_PSTRIDE - 8);
   const int grid = std::max(1, std::min((bv->n + SW_BLOCK - 1) / SW_BLOCK, std::min(ctx->num_cu * 4, KS_MAX_BLOCKS)));
@@ -838,6 +844,131 @@ extern "C" int ks_bv_normcolumn(ks_bv bv, int j, int type, double *val)      // 
   return norm_impl(bv, j, type, val, true);
 }
 extern "C" int ks_bv_norm_local(ks_bv bv, int j, int type, double *val) { return norm_impl(bv, j, type, val, false); }
+extern "C" int ks_bv_normvec(ks_bv bv, const double *v_dev, int type, double *val)   // BVNormVec bvglobal.c:530-571: B-norm when a matrix is set
+{
+  KS_CHECK(bv && v_dev && val, KS_ERR_ARG_NULL, "NULL argument");
+  KS_HIP(hipSetDevice(bv->ctx->device));
+  if (bv->matrix) return ksb_norm_b(bv, v_dev, val);
+  return norm_core(bv, v_dev, 1, 0, type, val, true);
+}
+
+// ---- split reductions: BVDotVecBegin/End, BVDotColumnBegin/End, BVNormVecBegin/End, BVNormColumnBegin/End (bvglobal.c) ----
+// Begin computes this rank's part into a queue on the device; nothing crosses ranks until the first End, which reduces the
+// whole queue with one allreduce. Ends must come in the order of the Begins (as PetscSplitReduction requires).
+static int split_begin(ks_ctx ctx, int cnt, int kind, double **slot)
+{
+  auto &sp = ctx->split;
+  if (sp.reduced && sp.nread == sp.entries.size()) { sp.entries.clear(); sp.used = 0; sp.nread = 0; sp.reduced = false; }
+  KS_CHECK(!sp.reduced, KS_ERR_ORDER, "Called a Begin operation after an End: finish the pending End calls first");
+  if (!sp.dev) { KS_HIP(hipMalloc(&sp.dev, sizeof(double) * 16384)); sp.cap = 16384; }
+  KS_CHECK(sp.used + cnt <= sp.cap, KS_ERR_ARG_SIZ, "too many values queued in split reductions (%d)", sp.used + cnt);
+  *slot = sp.dev + sp.used;
+  sp.entries.push_back({sp.used, cnt, kind});
+  sp.used += cnt;
+  return KS_SUCCESS;
+}
+static int split_end(ks_ctx ctx, int cnt, int kind, double *out, double deftol)
+{
+  auto &sp = ctx->split;
+  KS_CHECK(sp.nread < sp.entries.size(), KS_ERR_ORDER, "End operation without a matching Begin");
+  if (!sp.reduced) {
+    KS_CALL(ks_allreduce_sum(ctx, sp.dev, sp.used));
+    sp.host.resize(sp.used);
+    KS_HIP(hipMemcpyAsync(sp.host.data(), sp.dev, sizeof(double) * sp.used, hipMemcpyDeviceToHost, ctx->stream));
+    KS_HIP(hipStreamSynchronize(ctx->stream));
+    sp.reduced = true;
+  }
+  const auto e = sp.entries[sp.nread];
+  KS_CHECK(e.cnt == cnt && e.kind == kind, KS_ERR_ORDER, "End operation does not match the Begin at this position (they must come in the same order)");
+  sp.nread++;
+  if (kind == 0) { for (int i = 0; i < cnt; i++) out[i] = sp.host[e.off + i]; }
+  else {
+    const double p = sp.host[e.off];
+    KS_CHECK(p > -deftol, KS_ERR_USER_INPUT, "The inner product is not well defined: indefinite matrix %g", p);
+    out[0] = p < 0.0 ? 0.0 : sqrt(p);
+  }
+  return KS_SUCCESS;
+}
+static int dots_local(ks_bv X, const double *A, int kx, const double *y_dev, double *out)     // out[0..kx) = A(:,0:kx)' y, this rank only
+{
+  ks_ctx ctx = X->ctx;
+  for (int c0 = 0; c0 < kx; c0 += KS_MAX_COLS) {
+    const int nc = std::min(KS_MAX_COLS, kx - c0);
+    if (X->n > 0) { KS_CALL(ksk_dot(X, A + (size_t)c0 * X->ld, X->ld, nc, y_dev, false)); KS_CALL(ksk_reduce_partials(X, nc, out + c0)); }
+    else KS_HIP(hipMemsetAsync(out + c0, 0, sizeof(double) * nc, ctx->stream));
+  }
+  return KS_SUCCESS;
+}
+extern "C" int ks_bv_dotvec_begin(ks_bv X, const double *y_dev, double *m)   // BVDotVecBegin bvglobal.c:207
+{
+  KS_CHECK(X && y_dev && m, KS_ERR_ARG_NULL, "NULL argument");
+  KS_HIP(hipSetDevice(X->ctx->device));
+  const int kx = X->k - X->l;
+  if (kx <= 0) return KS_SUCCESS;
+  KS_CALL(ksb_ipmatmult(X, y_dev, &y_dev));
+  double *slot = nullptr;
+  KS_CALL(split_begin(X->ctx, kx, 0, &slot));
+  return dots_local(X, X->array + (size_t)(X->nc + X->l) * X->ld, kx, y_dev, slot);
+}
+extern "C" int ks_bv_dotvec_end(ks_bv X, const double *y_dev, double *m)     // BVDotVecEnd bvglobal.c:256
+{
+  KS_CHECK(X && m, KS_ERR_ARG_NULL, "NULL argument");
+  (void)y_dev;
+  const int kx = X->k - X->l;
+  if (kx <= 0) return KS_SUCCESS;
+  return split_end(X->ctx, kx, 0, m, 0.0);
+}
+extern "C" int ks_bv_dotcolumn_begin(ks_bv X, int j, double *q)              // BVDotColumnBegin bvglobal.c:343
+{
+  KS_CHECK(X && q, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(j >= 0 && j < X->m, KS_ERR_ARG_OUTOFRANGE, "Index j=%d but BV only has %d columns", j, X->m);
+  const int ksave = X->k; X->k = j;
+  const int rc = ks_bv_dotvec_begin(X, ks_bv_col(X, j), q);
+  X->k = ksave;
+  return rc;
+}
+extern "C" int ks_bv_dotcolumn_end(ks_bv X, int j, double *q)                // BVDotColumnEnd bvglobal.c:395
+{
+  KS_CHECK(X && q, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(j >= 0 && j < X->m, KS_ERR_ARG_OUTOFRANGE, "Index j=%d but BV only has %d columns", j, X->m);
+  const int ksave = X->k; X->k = j;
+  const int rc = ks_bv_dotvec_end(X, nullptr, q);
+  X->k = ksave;
+  return rc;
+}
+static int norm2_begin(ks_bv bv, const double *v_dev)
+{
+  const double *z;
+  KS_CALL(ksb_ipmatmult(bv, v_dev, &z));                                      // x' B x, or x' x
+  double *slot = nullptr;
+  KS_CALL(split_begin(bv->ctx, 1, 1, &slot));
+  return dots_local(bv, z, 1, v_dev, slot);
+}
+extern "C" int ks_bv_normvec_begin(ks_bv bv, const double *v_dev, int type, double *val)   // BVNormVecBegin bvglobal.c:573
+{
+  KS_CHECK(bv && v_dev && val, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(type == KS_NORM_2 || type == KS_NORM_FROBENIUS || bv->matrix, KS_ERR_SUP, "the split form is built for the 2-norm (a SUM reduction)");
+  KS_HIP(hipSetDevice(bv->ctx->device));
+  return norm2_begin(bv, v_dev);
+}
+extern "C" int ks_bv_normvec_end(ks_bv bv, const double *v_dev, int type, double *val)     // BVNormVecEnd bvglobal.c:615
+{
+  KS_CHECK(bv && val, KS_ERR_ARG_NULL, "NULL argument");
+  (void)v_dev; (void)type;
+  return split_end(bv->ctx, 1, 1, val, bv->deftol);
+}
+extern "C" int ks_bv_normcolumn_begin(ks_bv bv, int j, int type, double *val)              // BVNormColumnBegin bvglobal.c:705
+{
+  KS_CHECK(bv && val, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(j >= 0 && j < bv->m, KS_ERR_ARG_OUTOFRANGE, "Argument j has wrong value %d, the number of columns is %d", j, bv->m);
+  return ks_bv_normvec_begin(bv, ks_bv_col(bv, j), type, val);
+}
+extern "C" int ks_bv_normcolumn_end(ks_bv bv, int j, int type, double *val)                // BVNormColumnEnd bvglobal.c:751
+{
+  KS_CHECK(bv && val, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(j >= 0 && j < bv->m, KS_ERR_ARG_OUTOFRANGE, "Argument j has wrong value %d, the number of columns is %d", j, bv->m);
+  return ks_bv_normvec_end(bv, nullptr, type, val);
+}
 
 extern "C" int ks_bv_copy(ks_bv V, ks_bv W)   // svec.c:232-247
 {

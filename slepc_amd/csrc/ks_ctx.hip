@@ -78,6 +78,7 @@ extern "C" int ks_ctx_destroy(ks_ctx ctx)
     if (f) f(ctx->comm.nccl_comm);
   }
   if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+  if (ctx->split.dev) hipFree(ctx->split.dev);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return KS_SUCCESS;

@@ -47,6 +47,10 @@ struct ks_ctx_s {
   KsProfSlot prof[KS_K_COUNT][KS_PROF_VARIANTS];
   std::vector<KsProfPending> pending;
   std::vector<hipEvent_t> event_pool;
+  // split reductions (BVDotVecBegin/End ...): values queued by the Begin calls wait in `dev`; the first End performs ONE
+  // allreduce over all of them (PetscSplitReduction's merged MPI_Allreduce) and the Ends hand the results out in order
+  struct KsSplitEntry { int off, cnt, kind; };
+  struct { double *dev = nullptr; int cap = 0, used = 0; std::vector<double> host; std::vector<KsSplitEntry> entries; size_t nread = 0; bool reduced = false; } split;
   // small pinned host staging area for coefficient transfers
   double *h_pinned = nullptr; size_t h_pinned_len = 0;
 };

@@ -241,3 +241,41 @@ def test_resize_setrandom_insert_copy_vec(ctx):
     with pytest.raises(ks.KsError) as e:
         X.Resize(0)
     assert e.value.rc == 63
+
+
+def test_bv_test10_split_reductions_golden(ctx):
+    """test10.c: BVDotVec / BVDotColumn / BVNormVec / BVNormColumn through their Begin/End forms give exactly what the plain
+    calls give (the program prints the 1-norm of the difference: 0). Here also: Ends interleaved after several Begins, the
+    B-inner product, and the order check."""
+    import slepc_amd as ks
+    assert "BV split ops (5 columns of dimension 10)" in gi.read("bv/test10_1.out") and gi.read("bv/test10_1.out").strip().endswith("0.")
+    n, k = 10, 5
+    X0 = np.zeros((n, k))
+    for j in range(k):
+        for i in range(4):
+            if i + j < n:
+                X0[i + j, j] = 3 * i + j - 2
+    X = ks.BV(ctx, n, k); X.set_dense(X0)
+    v = ks.BV(ctx, n, 1); v.set_column(0, np.ones(n))
+    vp = v.column_ptr(0)
+    z = np.concatenate([X.DotVec(vp), X.DotColumn(2), [X.NormVec(vp), X.NormColumn(0), X.NormColumn(1)]])
+    a = X.DotVecBegin(vp); b = X.DotColumnBegin(2)
+    X.NormVecBegin(vp); X.NormColumnBegin(0); X.NormColumnBegin(1)
+    zs = np.concatenate([X.DotVecEnd(vp, a), X.DotColumnEnd(2, b), [X.NormVecEnd(vp), X.NormColumnEnd(0), X.NormColumnEnd(1)]])
+    assert np.abs(z - zs).sum() == 0.0
+    assert np.allclose(z[:k], X0.T @ np.ones(n)) and np.allclose(z[k: k + 2], X0[:, :2].T @ X0[:, 2])
+    # a second round on the same context, with the inner product of a matrix
+    B = sc.lap1d_csr(sc.GpuBackend(ctx), n)
+    X.SetMatrix(B)
+    n0 = X.NormColumn(0)
+    X.NormColumnBegin(0); a = X.DotVecBegin(vp)
+    assert X.NormColumnEnd(0) == n0 and np.array_equal(X.DotVecEnd(vp, a), X.DotVec(vp))
+    X.SetMatrix(None)
+    # Ends must come in the order of the Begins
+    a = X.DotVecBegin(vp); X.NormColumnBegin(0)
+    with pytest.raises(ks.KsError) as e:
+        X.NormColumnEnd(0)
+    assert e.value.rc == 58
+    X.DotVecEnd(vp, a); X.NormColumnEnd(0)
+    with pytest.raises(ks.KsError):
+        X.NormColumnEnd(0)                                      # nothing pending

@@ -95,6 +95,12 @@ def _worker(rank, world, port, q):
         M = np.zeros((m + 1, m + 1), order="F"); V.SetActiveColumns(0, m + 1); V.Dot(V, M)
         res["orth"] = float(np.abs(M - np.eye(m + 1)).max())
         res["normF"] = V.Norm(ks.NORM_FROBENIUS)
+        # split reductions: two Begins, ONE allreduce at the first End, results as the plain calls
+        V.SetActiveColumns(0, m)
+        a = V.DotVecBegin(V.column_ptr(m)); V.NormColumnBegin(1)
+        d = V.DotVecEnd(V.column_ptr(m), a); nrm1 = V.NormColumnEnd(1)
+        res["split"] = float(max(np.abs(d - V.DotVec(V.column_ptr(m))).max(), abs(nrm1 - V.NormColumn(1))))
+        V.SetActiveColumns(0, m + 1)
         # (3) full Krylov-Schur solve, replicated control flow
         eps = ks.EPS(ctx); eps.SetOperators(A); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(3, 12); eps.Solve()
         res["eig"] = [eps.GetEigenvalue(i)[0] for i in range(3)]
@@ -141,6 +147,7 @@ def test_ranks_sharing_one_gpu_against_oracle(world):
         assert o["passes"] - 1 == V.passes_total() - p0      # the start vector cost one pass on each side
         assert o["orth"] < 1e-13
         assert abs(o["normF"] - np.sqrt(m + 1)) < 1e-12       # global Frobenius norm of an orthonormal basis
+        assert o["split"] < 1e-15
         assert o["nconv"] == r.nconv and o["its"] == r.its
         assert np.allclose(o["eig"], r.eigr[r.perm][:3], rtol=1e-10)
         assert max(o["err"]) < 1e-8
