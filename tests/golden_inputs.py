@@ -120,3 +120,13 @@ def eigenvalue_lines(text):
         if "All requested eigenvalues computed" in line:
             out.append(np.array([float(t) for t in lines[i + 1].replace(",", " ").split()]))
     return out
+
+
+def complex_eigenvalue_lines(text):
+    """As eigenvalue_lines, for values printed as 'a+bi' / 'a-bi' / plain reals (EPSErrorView of a non-symmetric problem)."""
+    out = []
+    lines = text.splitlines()
+    for i, line in enumerate(lines):
+        if "All requested eigenvalues computed" in line:
+            out.append(np.array([complex(t.replace("i", "j")) for t in lines[i + 1].replace(",", " ").split()]))
+    return out

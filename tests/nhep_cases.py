@@ -99,3 +99,17 @@ def config5_pencil_fast(n, mean_nnz=32, seed=42):
     B = sp.diags([np.full(n - 1, 1 / 6), np.full(n, 2 / 3), np.full(n - 1, 1 / 6)], [-1, 0, 1], format="csr")
     B.sort_indices()
     return A, O.CSR(n, B.indptr.astype(np.int32), B.indices.astype(np.int32), B.data)
+
+
+def brusselator(N, alpha=2.0, beta=5.45, delta1=0.008, delta2=0.004, L=0.51302):
+    """The operator of eps/tutorials/ex9.c (MatMult_Brussel :191-226) assembled: [[tau1 T + (beta-1) I, alpha^2 I],
+    [-beta I, tau2 T - alpha^2 I]] with T = tridiag(1,-2,1) of order N, tau_i = delta_i / (h L)^2, h = 1/(N+1)."""
+    import scipy.sparse as sp
+    from oracle import oracle as O
+    h = 1.0 / (N + 1)
+    tau1, tau2 = delta1 / (h * L) ** 2, delta2 / (h * L) ** 2
+    T = sp.diags([np.ones(N - 1), -2.0 * np.ones(N), np.ones(N - 1)], [-1, 0, 1])
+    I = sp.identity(N)
+    S = sp.bmat([[tau1 * T + (beta - 1.0) * I, alpha * alpha * I], [-beta * I, tau2 * T - alpha * alpha * I]]).tocsr()
+    S.sort_indices()
+    return O.CSR(2 * N, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64))

@@ -472,3 +472,23 @@ def test_user_stopping_convergence_and_monitor_callbacks(ctx):
     eps.MonitorSet(lambda *a: 1 / 0)
     with pytest.raises(ks.KsError):
         eps.Solve()
+
+
+@pytest.mark.parametrize("case", ["ex9_1", "ex9_5", "ex9_4"])
+def test_eps_ex9_brusselator_golden(ctx, case):
+    """ex9 (Brusselator wave model): the golden files print conjugate pairs; same selections, counts and values as the oracle."""
+    import slepc_amd as ks
+    n, nev, ncv, which, target, owhich = {"ex9_1": (50, 4, 0, "largest_real", None, "largest_real"),
+                                           "ex9_5": (30, 4, 0, "target_real", -3.0, O.which_target_real(-3.0)),
+                                           "ex9_4": (30, 1, 24, "smallest_imaginary", None, "smallest_imaginary")}[case]
+    Ao = nc.brusselator(n)
+    A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A); eps.SetProblemType(ks.EPS_NHEP); eps.SetDimensions(nev, ncv); eps.SetWhichEigenpairs(which)
+    if target is not None:
+        eps.SetTarget(target)
+    eps.Solve()
+    r = O.eps_krylovschur_nhep(Ao, nev, ncv=ncv or None, which=owhich)
+    lam = np.array([complex(*eps.GetEigenvalue(i)) for i in range(nev)])
+    assert np.allclose(np.round(lam, 5), gi.complex_eigenvalue_lines(gi.read("eps/%s.out" % case))[0], atol=1.5e-5)
+    _check_against_oracle(eps, r, Ao, tol=1e-7)

@@ -507,3 +507,21 @@ def test_eps_test1_cayley_golden():
         assert O.eps_compute_error(A, r, i, B=B) < 1e-8
     # the back-transformation of a complex value is the Moebius map itself
     assert np.allclose(O.ST(A, B, "cayley", 1.0, nu=1.0).backtransform(2.0, 1.0), (2.0, -1.0))
+
+
+def _as_complex(r, k):
+    return np.array([complex(r.eigr[j], r.eigi[j]) for j in r.perm[:k]])
+
+
+def test_eps_ex9_brusselator_golden():
+    """ex9 (Brusselator wave model, non-symmetric, complex conjugate pairs in real arithmetic):
+    suffix 1: -n 50 -eps_nev 4, largest real -> 0.00007+-2.13946i, -0.67386+-2.52812i;
+    suffix 5: -eps_nev 4 -eps_target_real -eps_target -3 (n = 30) -> -3.32597+-3.54263i, -1.78445+-3.02666i;
+    suffix 4: -eps_smallest_imaginary -eps_ncv 24 (n = 30) -> -111.65234."""
+    import nhep_cases as nc
+    r = O.eps_krylovschur_nhep(nc.brusselator(50), 4, which="largest_real")
+    assert np.allclose(np.round(_as_complex(r, 4), 5), gi.complex_eigenvalue_lines(gi.read("eps/ex9_1.out"))[0], atol=1.5e-5)
+    r = O.eps_krylovschur_nhep(nc.brusselator(30), 4, which=O.which_target_real(-3.0))
+    assert np.allclose(np.round(_as_complex(r, 4), 5), gi.complex_eigenvalue_lines(gi.read("eps/ex9_5.out"))[0], atol=1.5e-5)
+    r = O.eps_krylovschur_nhep(nc.brusselator(30), 1, ncv=24, which="smallest_imaginary")
+    assert np.allclose(np.round(_as_complex(r, 1), 5), gi.complex_eigenvalue_lines(gi.read("eps/ex9_4.out"))[0], atol=1.5e-5)
