@@ -132,3 +132,22 @@ def test_eps_test13_arbitrary_selection_golden(ctx):
     eps.SetArbitrarySelection(None)
     eps.Solve()
     assert eps.GetConverged() >= 1
+
+
+def test_eps_ex11_fiedler_restart_parameter_golden(ctx):
+    """ex11 -eps_nev 4 -eps_krylovschur_restart .2 (EPSKrylovSchurSetRestart) with the deflation space of the example."""
+    import slepc_amd as ks
+    S = sc.graph_laplacian_2d(10, 10)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(_mat(ctx, S)); eps.SetProblemType(ks.EPS_HEP); eps.SetWhichEigenpairs("smallest_real"); eps.SetDimensions(4)
+    eps.KrylovSchurSetRestart(0.2); eps.SetDeflationSpace(np.ones((100, 1)))
+    eps.Solve()
+    r = O.eps_krylovschur_hep(_csr(S), 4, which="smallest_real", keep=0.2, deflation=np.ones((100, 1)))
+    # the second copy of the double eigenvalue 0.09789 grows out of rounding noise: the restart in which it passes the test can
+    # differ by one between two summation orders, the values cannot
+    assert eps.GetConverged() >= 4 and abs(eps.GetIterationNumber() - r.its) <= 2
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(4)])
+    assert np.allclose(lam, r.eigr[r.perm][:4], rtol=1e-7)
+    assert np.allclose(np.round(lam[:4], 5), gi.eigenvalue_lines(gi.read("eps/ex11_1.out"))[0], atol=1.5e-5)
+    with pytest.raises(ks.KsError):
+        eps.KrylovSchurSetRestart(0.95)                                   # krylovschur.c:349: must be in [0.1, 0.9]

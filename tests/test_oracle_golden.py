@@ -525,3 +525,11 @@ def test_eps_ex9_brusselator_golden():
     assert np.allclose(np.round(_as_complex(r, 4), 5), gi.complex_eigenvalue_lines(gi.read("eps/ex9_5.out"))[0], atol=1.5e-5)
     r = O.eps_krylovschur_nhep(nc.brusselator(30), 1, ncv=24, which="smallest_imaginary")
     assert np.allclose(np.round(_as_complex(r, 1), 5), gi.complex_eigenvalue_lines(gi.read("eps/ex9_4.out"))[0], atol=1.5e-5)
+
+
+def test_eps_ex11_fiedler_restart_parameter_golden():
+    """ex11 -eps_nev 4 -eps_krylovschur_restart .2: mesh-graph Laplacian (10x10), constant vector deflated, 20 % of the
+    basis kept at each restart -> 0.09789, 0.09789, 0.19577, 0.38197 (the double eigenvalue twice)."""
+    S = sc.graph_laplacian_2d(10, 10)
+    r = O.eps_krylovschur_hep(_csr(S), 4, which="smallest_real", keep=0.2, deflation=np.ones((100, 1)))
+    assert np.allclose(np.round(r.eigr[r.perm][:4], 5), gi.eigenvalue_lines(gi.read("eps/ex11_1.out"))[0], atol=1.5e-5)
