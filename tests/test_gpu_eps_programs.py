@@ -151,3 +151,12 @@ def test_eps_ex11_fiedler_restart_parameter_golden(ctx):
     assert np.allclose(np.round(lam[:4], 5), gi.eigenvalue_lines(gi.read("eps/ex11_1.out"))[0], atol=1.5e-5)
     with pytest.raises(ks.KsError):
         eps.KrylovSchurSetRestart(0.95)                                   # krylovschur.c:349: must be in [0.1, 0.9]
+
+
+def test_no_device_memory_leak_over_many_solver_cycles():
+    """scripts/leak_check.py: 40 create / solve / destroy cycles over the solver variants (deflation, wide basis, sinvert,
+    Cayley, GHEP, block orthogonalisations) leave the free device memory where it was."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "leak_check.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "no leak" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
