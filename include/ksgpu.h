@@ -15,9 +15,9 @@
  *   - every function returns an int error code, 0 = success; non-zero values reuse PETSc's
  *     PetscErrorCode numbers (KS_ERR_*), so an adapter can `return (PetscErrorCode)rc;`
  *   - scalars are real double (PetscScalar), indices 32-bit int (PetscInt default build)
- *   - BV storage is ONE device array of m*ld doubles, column-major, like BVSVEC
+ *   - BV storage is ONE device array of (nc+m)*ld doubles, column-major, like BVSVEC
  *     (src/sys/classes/bv/impls/svec/svec.c:397-565); every op acts on the active window
- *     [l,k) at array+(nc+l)*ld (svec.c:30,47,124); nc (constraints) is always 0 here
+ *     [l,k) at array+(nc+l)*ld (svec.c:30,47,124); nc constraint columns sit in front (ks_bv_insert_constraints)
  *   - Q / M / H arguments are caller-owned HOST column-major arrays, replicated on all ranks
  *     (bvops.c:33-36); q / m coefficient arrays are host arrays, NULL means "use the BV's
  *     device-resident buffer Vec" exactly as in BVMultVec/BVDotVec (svec.c:46,123)
@@ -247,6 +247,7 @@ int ks_eps_set_convergence_test(ks_eps eps, int conv);                    /* EPS
 int ks_eps_set_krylovschur_locking(ks_eps eps, int lock);               /* EPSKrylovSchurSetLocking: 0 = non-locking variant (krylovschur.c:294) */
 int ks_eps_set_random_seed(ks_eps eps, uint64_t seed);
 int ks_eps_set_initial_vector(ks_eps eps, const double *v_host);           /* EPSSetInitialSpace with one vector */
+int ks_eps_set_initial_space(ks_eps eps, int n, const double *const *v_dev);   /* EPSSetInitialSpace epssetup.c:590: device vectors; a Krylov solver uses the first */
 int ks_eps_set_deflation_space(ks_eps eps, int n, const double *const *v_dev); /* EPSSetDeflationSpace epssetup.c:555: n device vectors, copied; used by the next solve only */
 int ks_eps_set_max_steps(ks_eps eps, long long max_steps);                 /* bench harness: stop after this many Arnoldi steps (0 = off) */
 int ks_eps_solve(ks_eps eps);

@@ -796,6 +796,14 @@ class EPS:
     def GetTrueResidual(self):
         v = C.c_int(); _lib.check(self.ctx.L.ks_eps_get_true_residual(self.h, C.byref(v))); return bool(v.value)
 
+    def SetInitialSpace(self, Vmat):
+        """EPSSetInitialSpace with the vectors as the columns of a host matrix (uploaded, passed as device vectors)."""
+        Vmat = np.asarray(Vmat, dtype=np.float64)
+        tmp = BV(self.ctx, Vmat.shape[0], max(Vmat.shape[1], 1))
+        tmp.set_dense(Vmat)
+        ptrs = (C.c_void_p * Vmat.shape[1])(*[tmp.column_ptr(j) for j in range(Vmat.shape[1])])
+        _lib.check(self.ctx.L.ks_eps_set_initial_space(self.h, Vmat.shape[1], ptrs))
+
     def SetDeflationSpace(self, Cmat):
         """EPSSetDeflationSpace with the vectors given as the columns of a host matrix (local rows of this rank)."""
         Cmat = np.asarray(Cmat, dtype=np.float64)

@@ -128,6 +128,7 @@ _SIG = {
     "ks_eps_set_random_seed": [vp, C.c_uint64],
     "ks_eps_set_initial_vector": [vp, dp],
     "ks_eps_set_deflation_space": [vp, C.c_int, C.POINTER(C.c_void_p)],
+    "ks_eps_set_initial_space": [vp, C.c_int, C.POINTER(C.c_void_p)],
     "ks_eps_set_max_steps": [vp, C.c_longlong],
     "ks_eps_solve": [vp],
     "ks_eps_get_converged": [vp, ip],

@@ -521,6 +521,21 @@ extern "C" int ks_eps_set_deflation_space(ks_eps eps, int n, const double *const
   eps->nds = n; eps->solved = false;
   return KS_SUCCESS;
 }
+// EPSSetInitialSpace epssetup.c:590-610 with device vectors. A Krylov solver starts from ONE vector: the first of the
+// space (EPSGetStartVector epssolve.c:853 uses column 0 of the inserted, orthonormalised set), the others are not used.
+extern "C" int ks_eps_set_initial_space(ks_eps eps, int n, const double *const *v_dev)
+{
+  KS_CHECK(eps && eps->A, KS_ERR_ORDER, "set the operators first");
+  KS_CHECK(n >= 0, KS_ERR_ARG_OUTOFRANGE, "Argument n cannot be negative");
+  if (!n) { eps->have_v0 = false; return KS_SUCCESS; }
+  KS_CHECK(v_dev && v_dev[0], KS_ERR_ARG_NULL, "NULL argument");
+  eps->v0.resize(std::max(eps->A->n, 1));
+  KS_HIP(hipSetDevice(eps->ctx->device));
+  KS_HIP(hipMemcpyAsync(eps->v0.data(), v_dev[0], sizeof(double) * eps->A->n, hipMemcpyDeviceToHost, eps->ctx->stream));
+  KS_HIP(hipStreamSynchronize(eps->ctx->stream));
+  eps->have_v0 = true; eps->solved = false;
+  return KS_SUCCESS;
+}
 extern "C" int ks_eps_set_max_steps(ks_eps eps, long long s) { KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL"); eps->max_steps = s > 0 ? s : 0; return KS_SUCCESS; }
 
 // EPSStoppingBasic epsdefault.c:290-307; user functions may call it first, as ex29.c does

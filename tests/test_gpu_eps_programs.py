@@ -160,3 +160,20 @@ def test_no_device_memory_leak_over_many_solver_cycles():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "scripts", "leak_check.py")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "no leak" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_initial_space_of_device_vectors(ctx):
+    """EPSSetInitialSpace: the first vector of the space is the start vector (epssolve.c:853); same run as SetInitialVector."""
+    import slepc_amd as ks
+    S = sc.laplacian2d_csr(13, 11)
+    W = np.random.default_rng(5).standard_normal((S.shape[0], 3))
+    out = []
+    for how in ("vector", "space"):
+        eps = ks.EPS(ctx)
+        eps.SetOperators(_mat(ctx, S)); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(3, 12)
+        eps.SetInitialVector(W[:, 0]) if how == "vector" else eps.SetInitialSpace(W)
+        eps.Solve()
+        out.append((eps.GetIterationNumber(), [eps.GetEigenvalue(i)[0] for i in range(3)]))
+    assert out[0] == out[1]
+    r = O.eps_krylovschur_hep(_csr(S), 3, ncv=12, v0=W[:, 0])
+    assert out[0][0] == r.its and np.allclose(out[0][1], r.eigr[r.perm][:3], rtol=1e-10)
