@@ -295,6 +295,8 @@ int ks_st_get_shift(ks_st st, double *sigma);
 int ks_st_cayley_set_antishift(ks_st st, double nu);                      /* STCayleySetAntishift cayley.c:236 (default: the shift) */
 int ks_st_cayley_get_antishift(ks_st st, double *nu);
 int ks_st_set_matrices(ks_st st, ks_mat A, ks_mat B /* may be NULL */);   /* STSetMatrices */
+enum { KS_KSP_GMRES = 0, KS_KSP_BCGS = 1 };
+int ks_st_set_ksp_type(ks_st st, int type);                                /* KSPSetType on STGetKSP: GMRES (restarted, the shell mode's default) or BiCGStab; both with Jacobi on the left */
 int ks_st_set_ksp(ks_st st, double rtol, int max_it, int restart);        /* KSPSetTolerances / KSPGMRESSetRestart on STGetKSP; 0 keeps */
 int ks_st_setup(ks_st st);                                                /* STSetUp */
 int ks_st_apply(ks_st st, const double *x_dev, double *y_dev);            /* STApply stsolve.c:44 */

@@ -610,6 +610,10 @@ class ST:
     def SetKSP(self, rtol=0.0, max_it=0, restart=0):
         _lib.check(self.ctx.L.ks_st_set_ksp(self.h, rtol, max_it, restart))
 
+    def SetKSPType(self, t):
+        """KSPSetType on the ST's KSP: "gmres" (default) or "bcgs"."""
+        _lib.check(self.ctx.L.ks_st_set_ksp_type(self.h, {"gmres": 0, "bcgs": 1}.get(t, t)))
+
     def SetUp(self):
         _lib.check(self.ctx.L.ks_st_setup(self.h))
 

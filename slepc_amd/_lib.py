@@ -168,6 +168,7 @@ _SIG = {
     "ks_st_cayley_get_antishift": [vp, C.POINTER(C.c_double)],
     "ks_st_set_matrices": [vp, vp, vp],
     "ks_st_set_ksp": [vp, C.c_double, C.c_int, C.c_int],
+    "ks_st_set_ksp_type": [vp, C.c_int],
     "ks_st_setup": [vp],
     "ks_st_apply": [vp, vp, vp],
     "ks_st_backtransform": [vp, C.c_int, dp, dp],

@@ -130,6 +130,60 @@ int gmres_solve(ks_st st, const double *rhs, double *y)
   return KS_SUCCESS;
 }
 
+// Left-preconditioned BiCGStab for P y = rhs (KSPBCGS with PC_LEFT: the iteration runs on D^-1 P, the residual that is tested
+// is the preconditioned one, as for the GMRES above). Two operator applications per iteration, no growing basis: the
+// memory is 7 vectors whatever the iteration count. The dot products of one phase travel in one BVDotVec (one allreduce).
+int bcgs_solve(ks_st st, const double *rhs, double *y)
+{
+  ks_ctx ctx = st->ctx; ks_bv K = st->Kb;
+  const long long n = st->n;
+  double *t1 = ks_bv_col(st->W, 1);
+  double *r = ks_bv_col(K, 0), *rh = ks_bv_col(K, 1), *p = ks_bv_col(K, 2), *v = ks_bv_col(K, 3), *s = ks_bv_col(K, 4), *t = ks_bv_col(K, 5);
+  st->solves++;
+  KS_HIP(hipMemsetAsync(y, 0, sizeof(double) * std::max<long long>(n, 1), ctx->stream));
+  KS_CALL(lincomb(ctx, n, st->dinv, 1.0, rhs, 0.0, nullptr, r));                   // r = D^-1 b (zero initial guess)
+  double beta0 = 0.0;
+  KS_CALL(ks_bv_normcolumn(K, 0, KS_NORM_2, &beta0));
+  st->last_rnorm = beta0;
+  if (beta0 == 0.0) return KS_SUCCESS;
+  const double tol = std::max(st->rtol * beta0, 1e-50);
+  KS_CALL(ksk_copy(ctx, r, rh, n));
+  KS_HIP(hipMemsetAsync(p, 0, sizeof(double) * n, ctx->stream));
+  KS_HIP(hipMemsetAsync(v, 0, sizeof(double) * n, ctx->stream));
+  double rho = 1.0, alpha = 1.0, omega = 1.0, d[2];
+  for (int its = 0; ; its++) {
+    KS_CHECK(its < st->max_it, KS_ERR_NOT_CONVERGED, "KSPSolve has not converged: BiCGStab reached %d iterations, preconditioned residual %g > %g", its, st->last_rnorm, tol);
+    KS_CALL(ks_bv_set_active_columns(K, 0, 1));
+    KS_CALL(ks_bv_dotvec(K, rh, d));                                                 // rho' = (rhat, r)
+    const double rho_new = d[0];
+    KS_CHECK(rho_new != 0.0 && omega != 0.0, KS_ERR_NOT_CONVERGED, "KSPSolve has not converged: BiCGStab breakdown (rho = %g, omega = %g)", rho_new, omega);
+    const double bt = (rho_new / rho) * (alpha / omega);
+    KS_CALL(lincomb(ctx, n, nullptr, 1.0, p, -omega, v, p));                         // p = r + beta (p - omega v)
+    KS_CALL(lincomb(ctx, n, nullptr, bt, p, 1.0, r, p));
+    KS_CALL(apply_P(st, st->dinv, p, v, t1));                                        // v = D^-1 P p
+    KS_CALL(ks_bv_set_active_columns(K, 3, 4));
+    KS_CALL(ks_bv_dotvec(K, rh, d));                                                 // (rhat, v)
+    KS_CHECK(d[0] != 0.0, KS_ERR_NOT_CONVERGED, "KSPSolve has not converged: BiCGStab breakdown ((rhat,v) = 0)");
+    alpha = rho_new / d[0];
+    KS_CALL(lincomb(ctx, n, nullptr, 1.0, r, -alpha, v, s));                         // s = r - alpha v
+    KS_CALL(apply_P(st, st->dinv, s, t, t1));                                        // t = D^-1 P s
+    KS_CALL(ks_bv_set_active_columns(K, 4, 6));
+    KS_CALL(ks_bv_dotvec(K, t, d));                                                  // (s,t), (t,t) in one reduction
+    omega = d[1] != 0.0 ? d[0] / d[1] : 0.0;
+    KS_CALL(lincomb(ctx, n, nullptr, 1.0, y, alpha, p, y));                          // y += alpha p + omega s
+    KS_CALL(lincomb(ctx, n, nullptr, 1.0, y, omega, s, y));
+    KS_CALL(lincomb(ctx, n, nullptr, 1.0, s, -omega, t, r));                         // r = s - omega t
+    rho = rho_new;
+    st->its++;
+    double rn = 0.0;
+    KS_CALL(ks_bv_normcolumn(K, 0, KS_NORM_2, &rn));
+    st->last_rnorm = rn;
+    if (rn <= tol) break;
+  }
+  return KS_SUCCESS;
+}
+int inner_solve(ks_st st, const double *rhs, double *y) { return st->ksp_type == KS_KSP_BCGS ? bcgs_solve(st, rhs, y) : gmres_solve(st, rhs, y); }
+
 int st_shell_mult(void *user, const double *x, double *y) { return ks_st_apply_internal((ks_st)user, x, y); }
 // y = (A + nu B) x, MatMult_Cayley cayley.c:21-44
 int st_bilinear_mult(void *user, const double *x, double *y)
@@ -156,11 +210,12 @@ int ks_st_setup_internal(ks_st st)
     KS_CHECK(st->nu != -st->sigma, KS_ERR_USER_INPUT, "It is not allowed to set the antishift equal to minus the shift (the target)");
   }
   const bool need_solve = (st->type == KS_ST_SINVERT) || (st->type == KS_ST_CAYLEY) || (st->type == KS_ST_SHIFT && B);
-  if (st->W) { int wn = 0; ks_bv_get_sizes(st->W, &wn, nullptr, nullptr, nullptr); if (wn != A->n) { ks_bv_destroy(st->W); ks_bv_destroy(st->K); st->W = st->K = nullptr; if (st->dinv) hipFree(st->dinv); st->dinv = nullptr; } }
+  if (st->W) { int wn = 0; ks_bv_get_sizes(st->W, &wn, nullptr, nullptr, nullptr); if (wn != A->n) { ks_bv_destroy(st->W); ks_bv_destroy(st->K); ks_bv_destroy(st->Kb); st->W = st->K = st->Kb = nullptr; if (st->dinv) hipFree(st->dinv); st->dinv = nullptr; } }
   if (!st->W) KS_CALL(ks_bv_create(ctx, A->n, A->n_global, 3, 0, &st->W));
   if (need_solve) {
     if (st->K) { int km = 0; ks_bv_get_sizes(st->K, nullptr, nullptr, &km, nullptr); if (km != st->restart + 1) { ks_bv_destroy(st->K); st->K = nullptr; } }
     if (!st->K) { KS_CALL(ks_bv_create(ctx, A->n, A->n_global, st->restart + 1, 0, &st->K)); st->K->row_start = A->row_start; }
+    if (st->ksp_type == KS_KSP_BCGS && !st->Kb) { KS_CALL(ks_bv_create(ctx, A->n, A->n_global, 7, 0, &st->Kb)); st->Kb->row_start = A->row_start; }
     if (!st->dinv) KS_HIP(hipMalloc(&st->dinv, sizeof(double) * std::max(A->n, 1)));
     // Jacobi: diag(P)
     double *da = ks_bv_col(st->W, 1), *db = ks_bv_col(st->W, 2);
@@ -190,15 +245,15 @@ int ks_st_apply_internal(ks_st st, const double *x, double *y)     // STApply_Ge
   if (!st->ready) KS_CALL(ks_st_setup_internal(st));
   double *w = ks_bv_col(st->W, 0), *t1 = ks_bv_col(st->W, 1);
   if (st->type == KS_ST_SINVERT) {
-    if (st->B) { KS_CALL(ks_mat_mult_internal(st->B, x, w)); return gmres_solve(st, w, y); }
-    return gmres_solve(st, x, y);
+    if (st->B) { KS_CALL(ks_mat_mult_internal(st->B, x, w)); return inner_solve(st, w, y); }
+    return inner_solve(st, x, y);
   }
   if (st->type == KS_ST_CAYLEY) {                                      // y = (A - sigma B)^-1 (A + nu B) x
     KS_CALL(linop_apply(st, 1.0, st->A, st->nu, st->B, !st->B, nullptr, x, w, t1));
-    return gmres_solve(st, w, y);
+    return inner_solve(st, w, y);
   }
   // shift
-  if (st->B) { KS_CALL(linop_apply(st, 1.0, st->A, -st->sigma, st->B, false, nullptr, x, w, t1)); return gmres_solve(st, w, y); }
+  if (st->B) { KS_CALL(linop_apply(st, 1.0, st->A, -st->sigma, st->B, false, nullptr, x, w, t1)); return inner_solve(st, w, y); }
   return linop_apply(st, 1.0, st->A, -st->sigma, nullptr, st->sigma != 0.0, nullptr, x, y, t1);
 }
 
@@ -232,7 +287,7 @@ extern "C" int ks_st_create(ks_ctx ctx, ks_st *out)
 extern "C" int ks_st_destroy(ks_st st)
 {
   if (!st) return KS_SUCCESS;
-  ks_bv_destroy(st->K); ks_bv_destroy(st->W);
+  ks_bv_destroy(st->K); ks_bv_destroy(st->W); ks_bv_destroy(st->Kb);
   if (st->dinv) hipFree(st->dinv);
   if (st->op) ks_mat_destroy(st->op);
   if (st->bil) ks_mat_destroy(st->bil);
@@ -275,6 +330,13 @@ extern "C" int ks_st_set_ksp(ks_st st, double rtol, int max_it, int restart)   /
   if (rtol > 0.0) st->rtol = rtol;
   if (max_it > 0) st->max_it = max_it;
   if (restart > 0 && restart != st->restart) { st->restart = restart; st->ready = false; }   // a basis wider than 64 columns orthogonalises through the host-driven loop
+  return KS_SUCCESS;
+}
+extern "C" int ks_st_set_ksp_type(ks_st st, int type)              // KSPSetType on STGetKSP: KSPGMRES (default) or KSPBCGS
+{
+  KS_CHECK(st, KS_ERR_ARG_NULL, "ST is NULL");
+  KS_CHECK(type == KS_KSP_GMRES || type == KS_KSP_BCGS, KS_ERR_SUP, "only KSPGMRES and KSPBCGS are built");
+  if (st->ksp_type != type) { st->ksp_type = type; st->ready = false; }
   return KS_SUCCESS;
 }
 extern "C" int ks_st_setup(ks_st st) { KS_CHECK(st, KS_ERR_ARG_NULL, "ST is NULL"); return ks_st_setup_internal(st); }

@@ -334,3 +334,45 @@ def test_cayley_standard_nonsymmetric_and_backtransform(ctx):
     with pytest.raises(ks.KsError) as e:
         s3 = ks.ST(ctx); s3.SetType("cayley"); s3.SetShift(2.0); s3.CayleySetAntishift(-2.0); s3.SetMatrices(A, None); s3.SetUp()
     assert e.value.rc == 71
+
+
+@pytest.mark.parametrize("kind,withB,sigma", [("shift", True, 0.3), ("sinvert", False, 1.3), ("sinvert", True, 0.0), ("sinvert", True, 35.0), ("cayley", True, 35.0)])
+def test_bicgstab_inner_solver_matches_oracle(ctx, kind, withB, sigma):
+    """KSPBCGS as the ST's inner solver (left Jacobi): the operator application agrees with the LU-based oracle, the solver
+    keeps 7 work vectors, and an iteration cap fails loudly."""
+    import slepc_amd as ks
+    Ao, Bo = nc.config5_pencil(3000)
+    if not withB:
+        Bo = None
+    A = _mat(ctx, Ao); B = _mat(ctx, Bo) if withB else None
+    st = ks.ST(ctx)
+    st.SetType(kind); st.SetShift(sigma); st.SetMatrices(A, B); st.SetKSPType("bcgs"); st.SetKSP(rtol=1e-14)
+    st.SetUp()
+    x = np.random.default_rng(3).standard_normal(Ao.n)
+    y = st.Apply(x); y0 = O.ST(Ao, Bo, kind, sigma).apply(x)
+    assert np.linalg.norm(y - y0) <= 1e-10 * np.linalg.norm(y0)
+    stats = st.GetKSPStats()
+    assert stats["solves"] == 1 and 0 < stats["iterations"] < 200 and stats["last_rnorm"] < 1e-10
+    st.SetKSP(max_it=2)
+    with pytest.raises(ks.KsError) as e:
+        st.Apply(x)
+    assert e.value.rc == 91
+
+
+def test_config5_with_bicgstab(ctx):
+    """The config-5 problem (generalized, non-symmetric, shift-and-invert) with BiCGStab inner solves: same eigenvalues as
+    with GMRES and as the LU-based oracle."""
+    import slepc_amd as ks
+    Ao, Bo = nc.config5_pencil(3000)
+    sigma = 36.0
+    lam = {}
+    for ksp in ("gmres", "bcgs"):
+        eps = ks.EPS(ctx)
+        eps.SetOperators(_mat(ctx, Ao), _mat(ctx, Bo)); eps.SetProblemType(ks.EPS_GNHEP); eps.SetDimensions(6, 24); eps.SetTarget(sigma)
+        st = eps.GetST(); st.SetType("sinvert"); st.SetKSPType(ksp); st.SetKSP(rtol=1e-13)
+        eps.Solve()
+        assert eps.GetConverged() >= 6
+        lam[ksp] = np.array([complex(*eps.GetEigenvalue(i)) for i in range(6)])
+    r = O.eps_krylovschur_nhep(Ao, 6, ncv=24, which=O.which_target_magnitude(sigma), st=O.ST(Ao, Bo, "sinvert", sigma))
+    ref = np.array([complex(r.eigr[j], r.eigi[j]) for j in r.perm[:6]])
+    assert np.allclose(lam["bcgs"], lam["gmres"], rtol=1e-9) and np.allclose(lam["bcgs"], ref, rtol=1e-9)
