@@ -824,13 +824,14 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
       if (A->dict_w == 8) hipLaunchKernelGGL((k_spmv_dict<8>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, (const uint4 *)A->dc_codes, A->dc_val, A->dict_nval, A->dc_off, A->dict_noff, x, y, dremap);
       else hipLaunchKernelGGL((k_spmv_dict<16>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, (const uint4 *)A->dc_codes, A->dc_val, A->dict_nval, A->dc_off, A->dict_noff, x, y, dremap);
     } else if (A->use_sell) {
-      static const int remap = getenv("KSGPU_SELL_REMAP") ? 1 : 0;
+      static const int remap_env = getenv("KSGPU_SELL_REMAP") ? atoi(getenv("KSGPU_SELL_REMAP")) : 1;   // each XCD one contiguous range of slices: 179 -> 172 us on the 216^3 Laplacian
       const long long groups = ((long long)A->nslices + 3) / 4;
       long long blocks = std::min<long long>(groups, (long long)ctx->num_cu * 16);
       static const int unr = getenv("KSGPU_SELL_UNR") ? atoi(getenv("KSGPU_SELL_UNR")) : 8;
       static const int bmul = getenv("KSGPU_SELL_BMUL") ? atoi(getenv("KSGPU_SELL_BMUL")) : 4096;   // one 256-row group per block measured fastest
       blocks = std::min<long long>(groups, (long long)ctx->num_cu * bmul);
       const dim3 gr((unsigned)std::max<long long>(blocks, 1));
+      const int remap = (remap_env && blocks == groups && blocks >= 64) ? 1 : 0;     // only with one slice group per workgroup (a strided loop would interleave the ranges again)
       if (unr == 4) hipLaunchKernelGGL((k_spmv_sell<4>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->nslices, A->s_ptr, A->s_len, A->s_col, A->s_val, x, y, remap);
       else if (unr == 2) hipLaunchKernelGGL((k_spmv_sell<2>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->nslices, A->s_ptr, A->s_len, A->s_col, A->s_val, x, y, remap);
       else hipLaunchKernelGGL((k_spmv_sell<8>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->nslices, A->s_ptr, A->s_len, A->s_col, A->s_val, x, y, remap);
