@@ -166,17 +166,72 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_dict(int nrows, const uint4
   }
 }
 
+// Offset-dictionary ELL: the matrix has arbitrary values (variable-coefficient stencils) but still only a few distinct column
+// offsets. The index of an entry shrinks from 4 bytes to 1 (code 255 = padding); the values stay full doubles, stored
+// slice-column-major like SELL-64 so that a wave reads 512 contiguous bytes per entry slot. 7-point stencil: 80 bytes per row
+// instead of 104. Same entry order and fma chain as the other layouts.
+template <int W>
+__global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_odict(int nrows, const unsigned char *__restrict__ codes, const double *__restrict__ vals, const int *__restrict__ doff, int noff,
+                                                           const double *__restrict__ x, double *__restrict__ y, int xcd_remap)
+{
+  __shared__ int so[256];
+  for (int i = threadIdx.x; i < noff; i += SPMV_BLOCK) so[i] = doff[i];
+  __syncthreads();
+  const long long groups = ((long long)nrows + SPMV_BLOCK - 1) / SPMV_BLOCK;
+  long long g0 = 0, g1 = groups, lb = blockIdx.x, nb = gridDim.x;
+  if (xcd_remap) {
+    const long long gper = (groups + 7) / 8;
+    g0 = (blockIdx.x % 8) * gper; g1 = g0 + gper < groups ? g0 + gper : groups;
+    lb = blockIdx.x / 8; nb = gridDim.x / 8;
+  }
+  for (long long g = g0 + lb; g < g1; g += nb) {
+    const long long r = g * SPMV_BLOCK + threadIdx.x;
+    if (r >= nrows) break;
+    unsigned wds[W / 4];
+    if (W == 8) { const uint2 c = *reinterpret_cast<const uint2 *>(codes + r * 8); wds[0] = c.x; wds[1] = c.y; }
+    else { const uint4 c = ksk::ldstream4(reinterpret_cast<const uint4 *>(codes + r * 16)); wds[0] = c.x; wds[1] = c.y; wds[2 % (W / 4)] = c.z; wds[3 % (W / 4)] = c.w; }
+    const double *vb = vals + ((r >> 6) * W) * 64 + (r & 63);
+    double a[W], xv[W];
+#pragma unroll
+    for (int e = 0; e < W; e++) {
+      const unsigned oc = (wds[e >> 2] >> ((e & 3) * 8)) & 0xffu;
+      const bool ok = oc != 255u;
+      a[e] = ok ? ksk::ldstream(vb + (long long)e * 64) : 0.0;
+      xv[e] = ok ? x[r + so[oc]] : 0.0;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < W; e++) acc = fma(a[e], xv[e], acc);
+    y[r] = acc;
+  }
+}
+
 // one thread per row: encode the row's entries against the sorted candidate dictionaries (binary search); entries that
 // are not covered are counted and the first `cap` of them recorded so that the host can extend the dictionaries
 __global__ void k_dict_encode(int n, int W, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
                               const long long *__restrict__ dbits, int nv, const int *__restrict__ doffs, int no,
-                              unsigned short *__restrict__ codes, int *miss, long long *miss_bits, int *miss_off, int cap)
+                              unsigned short *__restrict__ codes, int *miss, long long *miss_bits, int *miss_off, int cap,
+                              unsigned char *__restrict__ codes8, double *__restrict__ vals_out)
 {
+  // nv < 0: offsets-only mode (values kept in full): 1-byte codes into codes8, values into vals_out in slice-column-major order
   const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   const int p0 = rowptr[r], len = rowptr[r + 1] - p0;
   for (int j = 0; j < W; j++) {
     unsigned short code = 0xff00u;                                       // padding
+    if (nv < 0) {
+      unsigned char c8 = 255; double v = 0.0;
+      if (j < len) {
+        const int off = col[p0 + j] - (int)r;
+        int lo = 0, hi = no; while (lo < hi) { const int m = (lo + hi) >> 1; if (doffs[m] < off) lo = m + 1; else hi = m; }
+        if (lo < no && doffs[lo] == off) c8 = (unsigned char)lo;
+        else { if (*(volatile int *)miss < cap) { const int idx = atomicAdd(miss, 1); if (idx < cap) { miss_bits[idx] = 0; miss_off[idx] = off; } } else atomicAdd(miss + 1, 1); c8 = 0; }
+        v = val[p0 + j];
+      }
+      codes8[r * W + j] = c8;
+      vals_out[((r >> 6) * W + j) * 64 + (r & 63)] = v;
+      continue;
+    }
     if (j < len) {
       const long long bits = __double_as_longlong(val[p0 + j]);
       const int off = col[p0 + j] - (int)r;
@@ -560,7 +615,8 @@ int build_dict(ks_mat A)
 {
   ks_ctx ctx = A->ctx;
   const char *force = getenv("KSGPU_SPMV");
-  if (force && strcmp(force, "dict")) return KS_SUCCESS;                 // any other forced layout
+  if (force && strcmp(force, "dict") && strcmp(force, "odict")) return KS_SUCCESS;       // any other forced layout
+  bool value_mode = !(force && !strcmp(force, "odict"));                 // "odict" forces the offsets-only form
   const int n = A->n;
   int *d_int = nullptr;
   KS_HIP(hipMalloc(&d_int, sizeof(int) * 4));
@@ -577,15 +633,21 @@ int build_dict(ks_mat A)
   KS_HIP(hipMalloc(&codes, sizeof(unsigned short) * (size_t)n * W));
   KS_HIP(hipMalloc(&d_bits, sizeof(long long) * 256)); KS_HIP(hipMalloc(&d_offs, sizeof(int) * 256));
   KS_HIP(hipMalloc(&m_bits, sizeof(long long) * cap)); KS_HIP(hipMalloc(&m_off, sizeof(int) * cap));
-  auto cleanup = [&]() { hipFree(d_int); hipFree(codes); hipFree(d_bits); hipFree(d_offs); hipFree(m_bits); hipFree(m_off); };
+  unsigned char *codes8 = nullptr; double *vals_out = nullptr;
+  auto cleanup = [&]() { hipFree(d_int); hipFree(codes); hipFree(d_bits); hipFree(d_offs); hipFree(m_bits); hipFree(m_off); hipFree(codes8); hipFree(vals_out); };
+  const size_t nslot = (size_t)((n + 63) / 64) * 64 * W;
   std::vector<long long> vals; std::vector<int> offs;                   // sorted candidate dictionaries
   bool done = false;
   for (int round = 0; round < 8 && !done; round++) {
     KS_HIP(hipMemsetAsync(d_int, 0, sizeof(int) * 2, ctx->stream));
     if (!vals.empty()) KS_HIP(hipMemcpyAsync(d_bits, vals.data(), sizeof(long long) * vals.size(), hipMemcpyHostToDevice, ctx->stream));
     if (!offs.empty()) KS_HIP(hipMemcpyAsync(d_offs, offs.data(), sizeof(int) * offs.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (!value_mode && !codes8) {
+      KS_HIP(hipMalloc(&codes8, nslot)); KS_HIP(hipMalloc(&vals_out, sizeof(double) * nslot));
+      KS_HIP(hipMemsetAsync(vals_out, 0, sizeof(double) * nslot, ctx->stream));
+    }
     hipLaunchKernelGGL(k_dict_encode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, W, A->d_rowptr, A->d_col, A->d_val,
-                       d_bits, (int)vals.size(), d_offs, (int)offs.size(), codes, d_int, m_bits, m_off, cap);
+                       d_bits, value_mode ? (int)vals.size() : -1, d_offs, (int)offs.size(), codes, d_int, m_bits, m_off, cap, codes8, vals_out);
     int miss[2] = {0, 0};
     KS_HIP(hipMemcpyAsync(miss, d_int, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
     KS_HIP(hipStreamSynchronize(ctx->stream));
@@ -594,11 +656,22 @@ int build_dict(ks_mat A)
     std::vector<long long> mb(got); std::vector<int> mo(got);
     KS_HIP(hipMemcpy(mb.data(), m_bits, sizeof(long long) * got, hipMemcpyDeviceToHost));
     KS_HIP(hipMemcpy(mo.data(), m_off, sizeof(int) * got, hipMemcpyDeviceToHost));
-    vals.insert(vals.end(), mb.begin(), mb.end()); std::sort(vals.begin(), vals.end()); vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+    if (value_mode) { vals.insert(vals.end(), mb.begin(), mb.end()); std::sort(vals.begin(), vals.end()); vals.erase(std::unique(vals.begin(), vals.end()), vals.end()); }
     offs.insert(offs.end(), mo.begin(), mo.end()); std::sort(offs.begin(), offs.end()); offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
-    if (vals.size() > 255 || offs.size() > 256) break;                   // not a dictionary matrix
+    if (value_mode && vals.size() > 255) { value_mode = false; vals.clear(); }        // too many values: keep them in full, compress the indices only
+    if (offs.size() > (value_mode ? 256u : 255u)) break;                 // not a dictionary matrix
   }
   if (!done) { cleanup(); return KS_SUCCESS; }
+  if (!value_mode) {
+    std::vector<int> dof(256, 0);
+    for (size_t i = 0; i < offs.size(); i++) dof[i] = offs[i];
+    KS_HIP(hipMalloc(&A->dc_off, sizeof(int) * 256));
+    KS_HIP(hipMemcpy(A->dc_off, dof.data(), sizeof(int) * 256, hipMemcpyHostToDevice));
+    A->dc_codes8 = codes8; codes8 = nullptr; A->dc_vals = vals_out; vals_out = nullptr;
+    A->use_odict = true; A->dict_w = W; A->dict_nval = 0; A->dict_noff = (int)offs.size();
+    cleanup();
+    return KS_SUCCESS;
+  }
   std::vector<double> dv(256, 0.0); std::vector<int> dof(256, 0);
   for (size_t i = 0; i < vals.size(); i++) memcpy(&dv[i], &vals[i], sizeof(double));
   for (size_t i = 0; i < offs.size(); i++) dof[i] = offs[i];
@@ -771,7 +844,7 @@ extern "C" int ks_mat_destroy(ks_mat A)
   hipFree(A->o_rowptr); hipFree(A->o_col); hipFree(A->o_val); hipFree(A->o_rows);
   hipFree(A->ghost); hipFree(A->send_idx); hipFree(A->send_buf);
   hipFree(A->s_ptr); hipFree(A->s_len); hipFree(A->s_col); hipFree(A->s_val);
-  hipFree(A->dc_codes); hipFree(A->dc_val); hipFree(A->dc_off);
+  hipFree(A->dc_codes); hipFree(A->dc_val); hipFree(A->dc_off); hipFree(A->dc_codes8); hipFree(A->dc_vals);
   hipFree(A->sl_rowptr); hipFree(A->sl_col); hipFree(A->sl_val); hipFree(A->sl_base); hipFree(A->ypart); hipFree(A->diag_cache);
   delete A;
   return KS_SUCCESS;
@@ -780,7 +853,7 @@ extern "C" int ks_mat_destroy(ks_mat A)
 extern "C" int ks_mat_get_layout(ks_mat A, int *layout)     // storage of the diagonal block: KS_MAT_LAYOUT_*
 {
   KS_CHECK(A && layout, KS_ERR_ARG_NULL, "NULL argument");
-  *layout = A->shell_mult ? KS_MAT_LAYOUT_SHELL : (A->use_sliced ? KS_MAT_LAYOUT_SLICED : (A->use_dict ? KS_MAT_LAYOUT_DICT : (A->use_sell ? KS_MAT_LAYOUT_SELL : KS_MAT_LAYOUT_CSR)));
+  *layout = A->shell_mult ? KS_MAT_LAYOUT_SHELL : (A->use_sliced ? KS_MAT_LAYOUT_SLICED : (A->use_dict ? KS_MAT_LAYOUT_DICT : (A->use_odict ? KS_MAT_LAYOUT_ODICT : (A->use_sell ? KS_MAT_LAYOUT_SELL : KS_MAT_LAYOUT_CSR))));
   return KS_SUCCESS;
 }
 extern "C" int ks_mat_get_sizes(ks_mat A, int *n_local, int *n_global, long long *nnz_local)
@@ -807,8 +880,9 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
   }
   {
     const double csr_bytes = 12.0 * A->nnz + 4.0 * (A->n + 1) + 16.0 * A->n;                    // what the CSR algorithm moves
-    KsProfScope ps(ctx, KS_K_SPMV, csr_bytes, A->use_dict ? 16 : (A->use_sell ? 8 : 0),         // variant 16: k_spmv_dict, 8: k_spmv_sell<8>, 0: k_spmv_csr
-                   A->use_dict ? (2.0 * A->dict_w + 16.0) * A->n + 12.0 * A->nnz_o : -1.0);       // the dictionary layout's own compulsory bytes
+    KsProfScope ps(ctx, KS_K_SPMV, csr_bytes, A->use_dict ? 16 : (A->use_odict ? 17 : (A->use_sell ? 8 : 0)),   // variant 16: k_spmv_dict, 17: k_spmv_odict, 8: k_spmv_sell<8>, 0: k_spmv_csr
+                   A->use_dict ? (2.0 * A->dict_w + 16.0) * A->n + 12.0 * A->nnz_o
+                   : (A->use_odict ? 8.0 * A->nnz_d + (A->dict_w + 16.0) * A->n + 12.0 * A->nnz_o : -1.0));   // the dictionary layouts' own compulsory bytes
     if (A->use_sliced) {
       const int per_xcd = std::max(1, std::min((A->n + 255) / 256, (ctx->num_cu / 8) * 8));       // 8 resident workgroups per CU of the XCD
       hipLaunchKernelGGL(k_spmv_sliced, dim3((unsigned)(8 * per_xcd)), dim3(256), 0, ctx->stream, A->n, A->nslice, A->sl_rowptr, A->sl_base, A->sl_col, A->sl_val, x, A->ypart);
@@ -823,6 +897,15 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
       const dim3 gr((unsigned)nblk);
       if (A->dict_w == 8) hipLaunchKernelGGL((k_spmv_dict<8>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, (const uint4 *)A->dc_codes, A->dc_val, A->dict_nval, A->dc_off, A->dict_noff, x, y, dremap);
       else hipLaunchKernelGGL((k_spmv_dict<16>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, (const uint4 *)A->dc_codes, A->dc_val, A->dict_nval, A->dc_off, A->dict_noff, x, y, dremap);
+    } else if (A->use_odict) {
+      static const int oremap_env = getenv("KSGPU_DICT_REMAP") ? atoi(getenv("KSGPU_DICT_REMAP")) : 1;
+      static const int omul = getenv("KSGPU_DICT_BMUL") ? atoi(getenv("KSGPU_DICT_BMUL")) : 64;
+      const long long groups = ((long long)A->n + SPMV_BLOCK - 1) / SPMV_BLOCK;
+      long long nblk = std::max<long long>(1, std::min<long long>(groups, (long long)ctx->num_cu * omul));
+      const int oremap = (oremap_env && nblk >= 64) ? 1 : 0;
+      if (oremap) nblk = std::min<long long>((nblk + 7) / 8, (groups + 7) / 8) * 8;
+      if (A->dict_w == 8) hipLaunchKernelGGL((k_spmv_odict<8>), dim3((unsigned)nblk), dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->dc_codes8, A->dc_vals, A->dc_off, A->dict_noff, x, y, oremap);
+      else hipLaunchKernelGGL((k_spmv_odict<16>), dim3((unsigned)nblk), dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->dc_codes8, A->dc_vals, A->dc_off, A->dict_noff, x, y, oremap);
     } else if (A->use_sell) {
       static const int remap_env = getenv("KSGPU_SELL_REMAP") ? atoi(getenv("KSGPU_SELL_REMAP")) : 1;   // each XCD one contiguous range of slices: 179 -> 172 us on the 216^3 Laplacian
       const long long groups = ((long long)A->nslices + 3) / 4;

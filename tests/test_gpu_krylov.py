@@ -125,9 +125,48 @@ def test_spmv_dictionary_layout(ctx, monkeypatch):
     assert np.allclose(y[ok], ref[ok], rtol=0, atol=1e-13)
     # not dictionary matrices: too many distinct values / rows too long / too many offsets
     val2 = rng.standard_normal(rowptr[-1])
-    assert ks.Mat.from_csr(ctx, rowptr, col, val2).layout() in ("sell", "csr")
+    assert ks.Mat.from_csr(ctx, rowptr, col, val2).layout() == "odict"     # values in full, offsets still coded
     R = sp.random(2000, 2000, density=20 / 2000, random_state=3, format="csr", data_rvs=lambda k: np.ones(k)); R.sort_indices()
     assert ks.Mat.from_csr(ctx, R.indptr, R.indices, R.data).layout() in ("sell", "csr")
+
+
+def test_spmv_offset_dictionary_layout(ctx, monkeypatch):
+    """Variable-coefficient stencils: too many distinct values for the value dictionary, still few column offsets: the index
+    of an entry becomes one byte, the values stay doubles in SELL order. Bit-identical to the SELL result; 13-entry rows;
+    NaN guarded by the padding code; a forced "odict" on a constant-coefficient matrix."""
+    import slepc_amd as ks
+    rng = np.random.default_rng(12)
+    Ao = O.laplacian3d(31, 19, 23)
+    val = rng.standard_normal(Ao.val.shape[0])
+
+    def both(rowptr, col, v):
+        monkeypatch.setenv("KSGPU_SPMV", "sell"); S = ks.Mat.from_csr(ctx, rowptr, col, v); assert S.layout() == "sell"
+        monkeypatch.delenv("KSGPU_SPMV"); D = ks.Mat.from_csr(ctx, rowptr, col, v)
+        return S, D
+    S, D = both(Ao.rowptr, Ao.col, val)
+    assert D.layout() == "odict"
+    x = rng.standard_normal(Ao.n)
+    y = D.mult(x)
+    assert np.array_equal(S.mult(x), y)
+    assert np.abs(y - O.CSR(Ao.n, Ao.rowptr, Ao.col, val).mult(x)).max() < 1e-12
+    assert np.array_equal(S.get_diagonal(), D.get_diagonal()) and S.norm_inf() == D.norm_inf()
+    n = 3000
+    lens = rng.integers(0, 14, n); lens[::5] = 0
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate([np.sort(np.clip(r + rng.choice(np.arange(-40, 41), l, replace=False), 0, n - 1)) for r, l in enumerate(lens)] + [np.empty(0, int)]).astype(np.int32)
+    v2 = rng.standard_normal(rowptr[-1])
+    S, D = both(rowptr, col, v2)
+    assert D.layout() == "odict"
+    xb = rng.standard_normal(n); xb[n - 1] = np.nan
+    y, y0 = D.mult(xb), S.mult(xb)
+    assert np.array_equal(np.isnan(y), np.isnan(y0)) and np.array_equal(y[~np.isnan(y)], y0[~np.isnan(y0)])
+    assert np.all(y[lens == 0] == 0.0)
+    monkeypatch.setenv("KSGPU_SPMV", "odict")
+    L = ks.Mat.laplacian3d(ctx, 20, 13, 11)
+    monkeypatch.delenv("KSGPU_SPMV")
+    assert L.layout() == "odict"
+    xl = rng.standard_normal(20 * 13 * 11)
+    assert np.array_equal(L.mult(xl), ks.Mat.laplacian3d(ctx, 20, 13, 11).mult(xl))          # against the value+offset dictionary
 
 
 def test_spmv_xcd_sliced_layout(ctx, monkeypatch):
