@@ -116,7 +116,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_sell(int nrows, int nslices
 // ---- dictionary ELL ----------------------------------------------------------------------------------
 // Stencil and graph matrices repeat a handful of values at a handful of column offsets (the 7-point Laplacian: 2 values,
 // 7 offsets). When a matrix has at most 255 distinct values (compared bit for bit), at most 256 distinct offsets
-// col - row and rows of at most 16 entries, every entry is stored as two bytes (offset code, value code; value code 255
+// col - row and rows of at most 32 entries, every entry is stored as two bytes (offset code, value code; value code 255
 // marks padding): 16 or 32 bytes per row instead of 12 per entry, one 16-byte load per lane. The dictionaries sit in
 // LDS. Entries keep their CSR order and the products are accumulated in that order with fma, exactly as k_spmv_sell
 // does, so y is bit-identical to the SELL / CSR result.
@@ -189,7 +189,13 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_odict(int nrows, const unsi
     if (r >= nrows) break;
     unsigned wds[W / 4];
     if (W == 8) { const uint2 c = *reinterpret_cast<const uint2 *>(codes + r * 8); wds[0] = c.x; wds[1] = c.y; }
-    else { const uint4 c = ksk::ldstream4(reinterpret_cast<const uint4 *>(codes + r * 16)); wds[0] = c.x; wds[1] = c.y; wds[2 % (W / 4)] = c.z; wds[3 % (W / 4)] = c.w; }
+    else {
+#pragma unroll
+      for (int q = 0; q < W / 16; q++) {
+        const uint4 c = ksk::ldstream4(reinterpret_cast<const uint4 *>(codes + r * W) + q);
+        wds[(4 * q) % (W / 4)] = c.x; wds[(4 * q + 1) % (W / 4)] = c.y; wds[(4 * q + 2) % (W / 4)] = c.z; wds[(4 * q + 3) % (W / 4)] = c.w;
+      }
+    }
     const double *vb = vals + ((r >> 6) * W) * 64 + (r & 63);
     double a[W], xv[W];
 #pragma unroll
@@ -625,8 +631,8 @@ int build_dict(ks_mat A)
   int maxlen = 0;
   KS_HIP(hipMemcpyAsync(&maxlen, d_int + 2, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   KS_HIP(hipStreamSynchronize(ctx->stream));
-  if (maxlen > 16 || maxlen == 0) { hipFree(d_int); return KS_SUCCESS; }
-  const int W = maxlen <= 8 ? 8 : 16;
+  if (maxlen > 32 || maxlen == 0) { hipFree(d_int); return KS_SUCCESS; }
+  const int W = maxlen <= 8 ? 8 : (maxlen <= 16 ? 16 : 32);                // 32: 27-point stencils
   if ((double)W * n > 4.0 * (double)A->nnz_d + 4096.0) { hipFree(d_int); return KS_SUCCESS; }   // mostly padding: nothing to gain
   const int cap = 4096;
   unsigned short *codes = nullptr; long long *d_bits = nullptr, *m_bits = nullptr; int *d_offs = nullptr, *m_off = nullptr;
@@ -896,6 +902,7 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
       if (dremap) nblk = std::min<long long>((nblk + 7) / 8, (groups + 7) / 8) * 8;
       const dim3 gr((unsigned)nblk);
       if (A->dict_w == 8) hipLaunchKernelGGL((k_spmv_dict<8>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, (const uint4 *)A->dc_codes, A->dc_val, A->dict_nval, A->dc_off, A->dict_noff, x, y, dremap);
+      else if (A->dict_w == 32) hipLaunchKernelGGL((k_spmv_dict<32>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, (const uint4 *)A->dc_codes, A->dc_val, A->dict_nval, A->dc_off, A->dict_noff, x, y, dremap);
       else hipLaunchKernelGGL((k_spmv_dict<16>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, (const uint4 *)A->dc_codes, A->dc_val, A->dict_nval, A->dc_off, A->dict_noff, x, y, dremap);
     } else if (A->use_odict) {
       static const int oremap_env = getenv("KSGPU_DICT_REMAP") ? atoi(getenv("KSGPU_DICT_REMAP")) : 1;
@@ -905,6 +912,7 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
       const int oremap = (oremap_env && nblk >= 64) ? 1 : 0;
       if (oremap) nblk = std::min<long long>((nblk + 7) / 8, (groups + 7) / 8) * 8;
       if (A->dict_w == 8) hipLaunchKernelGGL((k_spmv_odict<8>), dim3((unsigned)nblk), dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->dc_codes8, A->dc_vals, A->dc_off, A->dict_noff, x, y, oremap);
+      else if (A->dict_w == 32) hipLaunchKernelGGL((k_spmv_odict<32>), dim3((unsigned)nblk), dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->dc_codes8, A->dc_vals, A->dc_off, A->dict_noff, x, y, oremap);
       else hipLaunchKernelGGL((k_spmv_odict<16>), dim3((unsigned)nblk), dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->dc_codes8, A->dc_vals, A->dc_off, A->dict_noff, x, y, oremap);
     } else if (A->use_sell) {
       static const int remap_env = getenv("KSGPU_SELL_REMAP") ? atoi(getenv("KSGPU_SELL_REMAP")) : 1;   // each XCD one contiguous range of slices: 179 -> 172 us on the 216^3 Laplacian

@@ -90,7 +90,7 @@ struct ks_mat_s {
   // padding it needs is small; val/col stored column-major inside a slice: entry j of row 64s+lane at (sp[s]+j)*64+lane
   bool use_sell = false;
   int nslices = 0; int *s_ptr = nullptr; int *s_len = nullptr; int *s_col = nullptr; double *s_val = nullptr; long long s_entries = 0;
-  // dictionary ELL (few distinct values and few distinct column offsets, rows of at most 16 entries): 2 bytes per entry
+  // dictionary ELL (few distinct values and few distinct column offsets, rows of at most 32 entries): 2 bytes per entry
   bool use_dict = false; int dict_w = 0; int dict_nval = 0, dict_noff = 0;
   unsigned short *dc_codes = nullptr; double *dc_val = nullptr; int *dc_off = nullptr;
   // offset-dictionary ELL: any values, few distinct column offsets: 1 byte per entry for the index, values in SELL order

@@ -169,6 +169,28 @@ def test_spmv_offset_dictionary_layout(ctx, monkeypatch):
     assert np.array_equal(L.mult(xl), ks.Mat.laplacian3d(ctx, 20, 13, 11).mult(xl))          # against the value+offset dictionary
 
 
+def test_spmv_dictionary_layouts_27_point_stencil(ctx, monkeypatch):
+    """Rows of up to 32 entries (27-point stencil: the 64-byte / 32-byte forms), constant and variable coefficients."""
+    import scipy.sparse as sp
+    import slepc_amd as ks
+    nx, ny, nz = 17, 13, 11
+    def tri(n):
+        return sp.diags([np.ones(n - 1), np.ones(n), np.ones(n - 1)], [-1, 0, 1])
+    P = sp.kron(tri(nz), sp.kron(tri(ny), tri(nx))).tocsr(); P.sort_indices()          # the 27-point pattern
+    assert np.diff(P.indptr).max() == 27
+    rng = np.random.default_rng(27)
+    x = rng.standard_normal(P.shape[0])
+    for name, data in (("dict", np.where(P.data > 0, -1.0, 0.0) + 0.0), ("odict", rng.standard_normal(P.nnz))):
+        if name == "dict":
+            data = np.full(P.nnz, -1.0); data[P.indices == np.repeat(np.arange(P.shape[0]), np.diff(P.indptr))] = 26.0
+        monkeypatch.setenv("KSGPU_SPMV", "sell"); S = ks.Mat.from_csr(ctx, P.indptr, P.indices, data)
+        monkeypatch.delenv("KSGPU_SPMV"); D = ks.Mat.from_csr(ctx, P.indptr, P.indices, data)
+        assert D.layout() == name and S.layout() in ("sell", "csr")
+        y = D.mult(x)
+        assert np.array_equal(S.mult(x), y)
+        assert np.abs(y - sp.csr_matrix((data, P.indices, P.indptr), shape=P.shape) @ x).max() < 1e-11
+
+
 def test_spmv_xcd_sliced_layout(ctx, monkeypatch):
     """The XCD-sliced layout (column ranges pinned to XCDs by blockIdx % 8, eight partial results added in fixed order):
     forced on small and ragged matrices incl. empty rows and duplicate entries, and chosen automatically for a
