@@ -177,3 +177,26 @@ def test_initial_space_of_device_vectors(ctx):
     assert out[0] == out[1]
     r = O.eps_krylovschur_hep(_csr(S), 3, ncv=12, v0=W[:, 0])
     assert out[0][0] == r.its and np.allclose(out[0][1], r.eigr[r.perm][:3], rtol=1e-10)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("ptype", ["hep", "nhep"])
+def test_tiny_problems(ctx, n, ptype):
+    """Problems smaller than the default subspace: ncv is clipped to n, the Krylov space is exhausted (breakdown path of
+    BVMatLanczos / BV_OrthogonalizeColumn_Safe), all n eigenvalues come out."""
+    import slepc_amd as ks
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n))
+    if ptype == "hep":
+        M = M + M.T
+    import scipy.sparse as sp
+    S = sp.csr_matrix(M); S.sort_indices()
+    eps = ks.EPS(ctx)
+    eps.SetOperators(_mat(ctx, S)); eps.SetProblemType(ks.EPS_HEP if ptype == "hep" else ks.EPS_NHEP); eps.SetDimensions(1)
+    eps.Solve()
+    assert eps.GetConverged() >= 1 and eps.GetConvergedReason() > 0
+    ev = np.linalg.eigvals(M)
+    top = ev[np.argsort(-np.abs(ev))][0]
+    kr, ki = eps.GetEigenvalue(0)
+    assert abs(abs(complex(kr, ki)) - abs(top)) < 1e-9 * max(1.0, abs(top))
+    assert eps.ComputeError(0) < 1e-7
