@@ -698,6 +698,17 @@ int build_sell(ks_mat A)
   if (force && !strcmp(force, "csr")) return KS_SUCCESS;
   if (A->n == 0 || A->nnz_d == 0) return KS_SUCCESS;
   KS_CALL(build_dict(A));                                   // independent of the SELL decision below; needs the CSR arrays
+  if (A->use_dict || A->use_odict) {
+    // the dictionary form is the only copy kept: diagonal and infinity norm are taken from the CSR arrays before they go
+    KS_HIP(hipMalloc(&A->diag_cache, sizeof(double) * A->n));
+    KS_CALL(ks_mat_get_diagonal_internal(A, A->diag_cache));
+    double nrm = 0.0;
+    KS_CALL(ks_mat_norm_inf_local(A, &nrm));
+    KS_HIP(hipStreamSynchronize(ctx->stream));
+    A->norm_inf_cache = nrm; A->have_cache = true;
+    hipFree(A->d_col); hipFree(A->d_val); A->d_col = nullptr; A->d_val = nullptr;
+    return KS_SUCCESS;
+  }
   const int ns = (A->n + 63) / 64;
   int *width = nullptr;
   KS_HIP(hipMalloc(&width, sizeof(int) * (ns + 1)));
@@ -958,7 +969,7 @@ int ks_mat_get_diagonal_internal(ks_mat A, double *d)
   ks_ctx ctx = A->ctx;
   KS_CHECK(!A->shell_mult, KS_ERR_SUP, "a matrix-free operator has no stored diagonal");
   if (A->n == 0) return KS_SUCCESS;
-  if (A->use_sliced) { KS_HIP(hipMemcpyAsync(d, A->diag_cache, sizeof(double) * A->n, hipMemcpyDeviceToDevice, ctx->stream)); return KS_SUCCESS; }
+  if (A->use_sliced || A->have_cache) { KS_HIP(hipMemcpyAsync(d, A->diag_cache, sizeof(double) * A->n, hipMemcpyDeviceToDevice, ctx->stream)); return KS_SUCCESS; }
   const unsigned nb = (unsigned)((A->n + 255) / 256);
   if (A->use_sell) hipLaunchKernelGGL(k_diag_sell, dim3(nb), dim3(256), 0, ctx->stream, A->n, A->s_ptr, A->s_len, A->s_col, A->s_val, d);
   else hipLaunchKernelGGL(k_diag_csr, dim3(nb), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, d);
@@ -994,7 +1005,7 @@ __global__ void k_rowabs_rows(int nrows, const int *__restrict__ rows, const int
 int ks_mat_norm_inf_local(ks_mat A, double *val)          // this rank's rows only
 {
   ks_ctx ctx = A->ctx;
-  if (A->use_sliced) { *val = A->norm_inf_cache; return KS_SUCCESS; }     // taken before the CSR arrays were released
+  if (A->use_sliced || A->have_cache) { *val = A->norm_inf_cache; return KS_SUCCESS; }     // taken before the CSR arrays were released
   double local = 0.0;
   if (A->n > 0) {
     double *w = nullptr;

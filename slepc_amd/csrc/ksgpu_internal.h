@@ -95,6 +95,7 @@ struct ks_mat_s {
   unsigned short *dc_codes = nullptr; double *dc_val = nullptr; int *dc_off = nullptr;
   // offset-dictionary ELL: any values, few distinct column offsets: 1 byte per entry for the index, values in SELL order
   bool use_odict = false; unsigned char *dc_codes8 = nullptr; double *dc_vals = nullptr;
+  bool have_cache = false;                    // diag_cache / norm_inf_cache hold MatGetDiagonal / the infinity norm (CSR arrays released)
   // XCD-sliced copy of the diagonal block for wide-scatter matrices (columns spread over a vector much larger than one
   // XCD's 4 MiB L2): the columns are cut into nslice = 8*P ranges; slice s is a CSR of its own (rows 0..n-1) and is
   // multiplied only by workgroups with blockIdx % 8 == s % 8, i.e. on one XCD, whose L2 then holds that range of x.
