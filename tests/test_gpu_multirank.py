@@ -106,6 +106,14 @@ def _worker(rank, world, port, q):
         res["eig"] = [eps.GetEigenvalue(i)[0] for i in range(3)]
         res["its"] = eps.GetIterationNumber(); res["nconv"] = eps.GetConverged()
         res["err"] = [eps.ComputeError(i) for i in range(3)]
+        # (4) a deflation space (row-sharded constraint vectors) and a basis wider than the fused kernels (host-driven passes)
+        Cg = np.random.default_rng(5).standard_normal((Aglob.n, 2))
+        e2 = ks.EPS(ctx); e2.SetOperators(A); e2.SetProblemType(ks.EPS_HEP); e2.SetDimensions(3, 12); e2.SetDeflationSpace(Cg[r0:r1]); e2.Solve()
+        res["defl_eig"] = [e2.GetEigenvalue(i)[0] for i in range(3)]; res["defl_its"] = e2.GetIterationNumber()
+        res["defl_cross"] = float(max(abs(np.dot(Cg[r0:r1, 0], e2.GetEigenvector(i))) for i in range(3)))     # local part only: summed by the parent
+        res["defl_cross_vec"] = [[float(np.dot(Cg[r0:r1, c], e2.GetEigenvector(i))) for c in range(2)] for i in range(3)]
+        e3 = ks.EPS(ctx); e3.SetOperators(A); e3.SetProblemType(ks.EPS_HEP); e3.SetDimensions(20, 70); e3.Solve()
+        res["wide_eig"] = [e3.GetEigenvalue(i)[0] for i in range(20)]; res["wide_its"] = e3.GetIterationNumber(); res["wide_nconv"] = e3.GetConverged()
         dist.barrier()
         q.put((rank, res))
     except Exception as e:      # noqa: BLE001
@@ -151,6 +159,15 @@ def test_ranks_sharing_one_gpu_against_oracle(world):
         assert o["nconv"] == r.nconv and o["its"] == r.its
         assert np.allclose(o["eig"], r.eigr[r.perm][:3], rtol=1e-10)
         assert max(o["err"]) < 1e-8
+    Cg = np.random.default_rng(5).standard_normal((A.n, 2))
+    rd = O.eps_krylovschur_hep(A, 3, ncv=12, deflation=Cg)
+    rw = O.eps_krylovschur_hep(A, 20, ncv=70)
+    for rk in range(world):
+        o = out[rk]
+        assert o["defl_its"] == rd.its and np.allclose(o["defl_eig"], rd.eigr[rd.perm][:3], rtol=1e-10)
+        assert o["wide_its"] == rw.its and o["wide_nconv"] == rw.nconv and np.allclose(o["wide_eig"], rw.eigr[rw.perm][:20], rtol=1e-9)
+    cross = np.sum([np.array(out[rk]["defl_cross_vec"]) for rk in range(world)], axis=0)     # global C' x from the ranks' parts
+    assert np.abs(cross).max() < 1e-10
     for rk in range(1, world):
         assert out[0]["eig"] == out[rk]["eig"]               # replicated scalars are bitwise identical on all ranks
 
