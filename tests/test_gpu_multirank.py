@@ -114,6 +114,19 @@ def _worker(rank, world, port, q):
         res["defl_cross_vec"] = [[float(np.dot(Cg[r0:r1, c], e2.GetEigenvector(i))) for c in range(2)] for i in range(3)]
         e3 = ks.EPS(ctx); e3.SetOperators(A); e3.SetProblemType(ks.EPS_HEP); e3.SetDimensions(20, 70); e3.Solve()
         res["wide_eig"] = [e3.GetEigenvalue(i)[0] for i in range(20)]; res["wide_its"] = e3.GetIterationNumber(); res["wide_nconv"] = e3.GetConverged()
+        # (5) generalized non-symmetric shift-and-invert (config-5 shape) across ranks: both matrices sharded by rows, the inner
+        # GMRES + Jacobi solves and the halo exchanges of A and B on the same communicator
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import nhep_cases as nc
+        Ag, Bg = nc.config5_pencil(900)
+        q0, q1 = P.split_ownership(Ag.n, world)[rank]
+        Al = ks.Mat.from_csr(ctx, *P.local_block(Ag.rowptr, Ag.col, Ag.val, q0, q1), row_start=q0, n_global=Ag.n)
+        Bl = ks.Mat.from_csr(ctx, *P.local_block(Bg.rowptr, Bg.col, Bg.val, q0, q1), row_start=q0, n_global=Bg.n)
+        e4 = ks.EPS(ctx); e4.SetOperators(Al, Bl); e4.SetProblemType(ks.EPS_GNHEP); e4.SetDimensions(4, 20); e4.SetTarget(36.0)
+        s4 = e4.GetST(); s4.SetType("sinvert"); s4.SetKSP(rtol=1e-13)
+        e4.Solve()
+        res["c5_eig"] = [list(e4.GetEigenvalue(i)) for i in range(4)]; res["c5_its"] = e4.GetIterationNumber()
+        res["c5_err"] = [e4.ComputeError(i) for i in range(4)]
         dist.barrier()
         q.put((rank, res))
     except Exception as e:      # noqa: BLE001
@@ -166,6 +179,14 @@ def test_ranks_sharing_one_gpu_against_oracle(world):
         o = out[rk]
         assert o["defl_its"] == rd.its and np.allclose(o["defl_eig"], rd.eigr[rd.perm][:3], rtol=1e-10)
         assert o["wide_its"] == rw.its and o["wide_nconv"] == rw.nconv and np.allclose(o["wide_eig"], rw.eigr[rw.perm][:20], rtol=1e-9)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import nhep_cases as nc
+    Ag, Bg = nc.config5_pencil(900)
+    r5 = O.eps_krylovschur_nhep(Ag, 4, ncv=20, which=O.which_target_magnitude(36.0), st=O.ST(Ag, Bg, "sinvert", 36.0))
+    ref5 = np.array([[r5.eigr[j], r5.eigi[j]] for j in r5.perm[:4]])
+    for rk in range(world):
+        assert out[rk]["c5_its"] == r5.its and np.allclose(np.array(out[rk]["c5_eig"]), ref5, rtol=1e-8, atol=1e-9)
+        assert max(out[rk]["c5_err"]) < 1e-6
     cross = np.sum([np.array(out[rk]["defl_cross_vec"]) for rk in range(world)], axis=0)     # global C' x from the ranks' parts
     assert np.abs(cross).max() < 1e-10
     for rk in range(1, world):
