@@ -36,21 +36,21 @@ __global__ void k_reduce_only(const double *__restrict__ partials, int nblocks, 
   if ((int)threadIdx.x < ncols) out[threadIdx.x] = c_lds[threadIdx.x];
 }
 
-// per-column partial reductions for norms: mode 0: sum of squares, 1: sum |x| ; partials[c*G + b]
+// per-column partial reductions for norms: mode 0: sum of squares, 1: sum |x|, 2: sum of (x*inv)^2, 3: max |x| ; partials[c*G + b]
 template <int MODE>
-__global__ __launch_bounds__(SW_BLOCK) void k_colsum(const double *__restrict__ A, long long lda, int n, int ncols, double *__restrict__ partials)
+__global__ __launch_bounds__(SW_BLOCK) void k_colsum(const double *__restrict__ A, long long lda, int n, int ncols, double *__restrict__ partials, double inv = 1.0)
 {
   __shared__ double red[SW_WAVES];
   for (int c = 0; c < ncols; c++) {
     double s = 0.0;
     for (long long r = (long long)blockIdx.x * SW_BLOCK + threadIdx.x; r < n; r += (long long)gridDim.x * SW_BLOCK) {
       const double v = A[(long long)c * lda + r];
-      s += MODE == 0 ? v * v : fabs(v);
+      if (MODE == 0) s += v * v; else if (MODE == 1) s += fabs(v); else if (MODE == 2) s += (v * inv) * (v * inv); else s = fmax(s, fabs(v));
     }
-    s = wave_sum(s);
+    if (MODE == 3) { for (int off = 32; off > 0; off >>= 1) s = fmax(s, __shfl_xor(s, off, 64)); } else s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) { double t = red[0]; for (int w = 1; w < SW_WAVES; w++) t += red[w]; partials[(size_t)c * gridDim.x + blockIdx.x] = t; }
+    if (threadIdx.x == 0) { double t = red[0]; for (int w = 1; w < SW_WAVES; w++) t = MODE == 3 ? fmax(t, red[w]) : t + red[w]; partials[(size_t)c * gridDim.x + blockIdx.x] = t; }
     __syncthreads();
   }
 }
@@ -815,15 +815,46 @@ static int norm_core(ks_bv bv, const double *A, int ncols, int j, int type, doub
     KS_HIP(hipMemcpyAsync(h.data(), bv->coef, sizeof(double) * ncols, hipMemcpyDeviceToHost, ctx->stream));
     KS_HIP(hipStreamSynchronize(ctx->stream));
     if (type == KS_NORM_1) { double mx = 0.0; for (double v : h) mx = std::max(mx, v); *val = mx; }
-    else { double s = 0.0; for (double v : h) s += v; *val = sqrt(s); }
+    else {
+      double s = 0.0; for (double v : h) s += v;
+      *val = sqrt(s);
+      if (!(s < 1e300) || s < 1e-290) {
+        // the plain sum of squares overflowed (or may have flushed to zero): redo it scaled by the largest entry, the
+        // overflow-safe combination the reference gets from lange + MPIU_LAPY2 (bvlapack.c:20-32,60-75)
+        hipLaunchKernelGGL(k_colsum<3>, dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)bv->ld, bv->n, ncols, bv->partials, 1.0);
+        std::vector<double> hm((size_t)grid * ncols);
+        KS_HIP(hipMemcpyAsync(hm.data(), bv->partials, sizeof(double) * hm.size(), hipMemcpyDeviceToHost, ctx->stream));
+        KS_HIP(hipStreamSynchronize(ctx->stream));
+        double mx = 0.0; for (double v : hm) mx = std::max(mx, v);
+        if (reduce && ctx->comm.size > 1) { std::vector<double> all(ctx->comm.size); KS_CALL(ks_comm_allgather_host(ctx, &mx, sizeof(double), all.data())); for (double v : all) mx = std::max(mx, v); }
+        if (mx == 0.0 || !(mx < std::numeric_limits<double>::infinity())) *val = mx;
+        else {
+          hipLaunchKernelGGL(k_colsum<2>, dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)bv->ld, bv->n, ncols, bv->partials, 1.0 / mx);
+          for (int c0 = 0; c0 < ncols; c0 += KS_MAX_COLS) {
+            const int nc = std::min(KS_MAX_COLS, ncols - c0);
+            hipLaunchKernelGGL(k_reduce_only, dim3(1), dim3(1024), 0, ctx->stream, bv->partials + (size_t)c0 * grid, grid, nc, bv->coef + c0);
+          }
+          if (reduce) KS_CALL(ks_allreduce_sum(ctx, bv->coef, ncols));
+          KS_HIP(hipMemcpyAsync(h.data(), bv->coef, sizeof(double) * ncols, hipMemcpyDeviceToHost, ctx->stream));
+          KS_HIP(hipStreamSynchronize(ctx->stream));
+          double s2 = 0.0; for (double v : h) s2 += v;
+          *val = mx * sqrt(s2);
+        }
+      }
+    }
   } else if (type == KS_NORM_INFINITY) {
-    KS_CHECK(!reduce || ctx->comm.size == 1, KS_ERR_SUP, "infinity norm across ranks needs a MAX reduction (not provided)");
     hipLaunchKernelGGL(k_rowsum_max, dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)bv->ld, bv->n, ncols, bv->partials);
     KS_HIP(hipGetLastError());
     h.resize(grid);
     KS_HIP(hipMemcpyAsync(h.data(), bv->partials, sizeof(double) * grid, hipMemcpyDeviceToHost, ctx->stream));
     KS_HIP(hipStreamSynchronize(ctx->stream));
-    double mx = 0.0; for (double v : h) mx = std::max(mx, v); *val = mx;
+    double mx = 0.0; for (double v : h) mx = std::max(mx, v);
+    if (reduce && ctx->comm.size > 1) {                        // MAX across ranks through the host allgather of the provider
+      std::vector<double> all(ctx->comm.size);
+      KS_CALL(ks_comm_allgather_host(ctx, &mx, sizeof(double), all.data()));
+      for (double v : all) mx = std::max(mx, v);
+    }
+    *val = mx;
   } else KS_FAIL(KS_ERR_ARG_WRONG, "unknown norm type %d", type);
   return KS_SUCCESS;
 }

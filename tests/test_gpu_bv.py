@@ -279,3 +279,20 @@ def test_bv_test10_split_reductions_golden(ctx):
     X.DotVecEnd(vp, a); X.NormColumnEnd(0)
     with pytest.raises(ks.KsError):
         X.NormColumnEnd(0)                                      # nothing pending
+
+
+def test_norm_is_overflow_and_underflow_safe(ctx):
+    """BVNormColumn / BVNorm(Frobenius) of entries around 1e+-200: the sum of squares leaves the double range, the norm does not
+    (the reference scales inside lange and combines ranks with hypot, bvlapack.c:20-32,60-75)."""
+    import slepc_amd as ks
+    n = 70001
+    x = np.random.default_rng(2).standard_normal(n)
+    X = ks.BV(ctx, n, 3)
+    X.set_column(0, 1e200 * x); X.set_column(1, 1e-200 * x); X.set_column(2, np.zeros(n))
+    ref = np.linalg.norm(x)
+    assert abs(X.NormColumn(0) / 1e200 / ref - 1.0) < 1e-13
+    assert abs(X.NormColumn(1) / 1e-200 / ref - 1.0) < 1e-13
+    assert X.NormColumn(2) == 0.0
+    X.SetActiveColumns(0, 1)
+    assert abs(X.Norm(ks.NORM_FROBENIUS) / 1e200 / ref - 1.0) < 1e-13
+    assert abs(X.Norm(ks.NORM_INFINITY) - 1e200 * np.abs(x).max()) <= 1e185

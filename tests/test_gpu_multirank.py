@@ -95,6 +95,8 @@ def _worker(rank, world, port, q):
         M = np.zeros((m + 1, m + 1), order="F"); V.SetActiveColumns(0, m + 1); V.Dot(V, M)
         res["orth"] = float(np.abs(M - np.eye(m + 1)).max())
         res["normF"] = V.Norm(ks.NORM_FROBENIUS)
+        res["normInf"] = V.Norm(ks.NORM_INFINITY); res["norm1"] = V.Norm(ks.NORM_1)
+        V.ScaleColumn(3, 1e200); res["big"] = V.NormColumn(3); V.ScaleColumn(3, 1e-200)      # overflow-safe 2-norm across ranks
         # split reductions: two Begins, ONE allreduce at the first End, results as the plain calls
         V.SetActiveColumns(0, m)
         a = V.DotVecBegin(V.column_ptr(m)); V.NormColumnBegin(1)
@@ -169,6 +171,8 @@ def test_ranks_sharing_one_gpu_against_oracle(world):
         assert o["orth"] < 1e-13
         assert abs(o["normF"] - np.sqrt(m + 1)) < 1e-12       # global Frobenius norm of an orthonormal basis
         assert o["split"] < 1e-15
+        assert abs(o["normInf"] - V.Norm(O.NORM_INFINITY)) < 1e-11 and abs(o["norm1"] - V.Norm(O.NORM_1)) < 1e-11
+        assert abs(o["big"] / 1e200 - 1.0) < 1e-13
         assert o["nconv"] == r.nconv and o["its"] == r.its
         assert np.allclose(o["eig"], r.eigr[r.perm][:3], rtol=1e-10)
         assert max(o["err"]) < 1e-8
