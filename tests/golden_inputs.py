@@ -130,3 +130,14 @@ def complex_eigenvalue_lines(text):
         if "All requested eigenvalues computed" in line:
             out.append(np.array([complex(t.replace("i", "j")) for t in lines[i + 1].replace(",", " ").split()]))
     return out
+
+
+def eigenvalues_block(text):
+    """All numbers after 'All requested eigenvalues computed ...' up to the next blank line (EPSErrorView wraps long lists)."""
+    lines = text.splitlines()
+    i = next(k for k, l in enumerate(lines) if "All requested eigenvalues computed" in l) + 1
+    out = []
+    while i < len(lines) and lines[i].strip():
+        out += [float(t) for t in lines[i].replace(",", " ").split()]
+        i += 1
+    return np.array(out)

@@ -346,3 +346,14 @@ def laplacian2d_csr(n, m):
 def test16_converged(re, im, res):
     """eps/tests/test16.c:20-25 MyConvergedAbsolute"""
     return res if re < 0.0 else 100.0 * res
+
+
+def test32_pencil(n):
+    """eps/tests/test32.c:44-56: A = 5-point Laplacian on the n x n grid, B = diag(2 / log(II + 2)) with B(0,1) = B(1,0) = 0.4."""
+    import scipy.sparse as sp
+    N = n * n
+    A = laplacian2d_csr(n, n)
+    B = sp.diags(2.0 / np.log(np.arange(N) + 2.0)).tolil()
+    B[0, 1] = 0.4; B[1, 0] = 0.4
+    B = B.tocsr(); B.sort_indices()
+    return A, B

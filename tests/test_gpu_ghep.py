@@ -181,3 +181,35 @@ def test_eps_test1_true_residual_golden(ctx):
     assert np.allclose(np.round(lam[:4], 5), gi.eigenvalues_line(gi.read("eps/eps_test1_1.out")), atol=1.5e-5)
     assert eps.GetConverged() == r.nconv and eps.GetIterationNumber() == r.its
     assert np.allclose(lam, r.eigr[r.perm], rtol=1e-10)
+
+
+def test_eps_test32_ghep_symmetric_b_golden(ctx):
+    """test32: GHEP with a non-diagonal symmetric B. Suffix 1 (sinvert at 1.02: A - 1.02 B is indefinite, full GMRES) and
+    suffix 3 (nev = 60 of N = 64: ncv = N, a 65-column basis in the B-inner product, the whole space)."""
+    import slepc_amd as ks
+    import scenarios as sc2
+    def csr(S):
+        return O.CSR(S.shape[0], S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.astype(np.float64))
+    A, B = sc2.test32_pencil(18)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(ks.Mat.from_csr(ctx, A.indptr, A.indices, A.data), ks.Mat.from_csr(ctx, B.indptr, B.indices, B.data))
+    eps.SetProblemType(ks.EPS_GHEP); eps.SetDimensions(3); eps.SetTarget(1.02)
+    st = eps.GetST(); st.SetType("sinvert"); st.SetKSP(rtol=1e-13, restart=A.shape[0], max_it=20 * A.shape[0])
+    eps.Solve()
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(3)])
+    assert np.allclose(np.round(lam, 5), gi.eigenvalues_block(gi.read("eps/eps_test32_1.out")), atol=1.5e-5)
+    Ao, Bo = csr(A), csr(B)
+    r = O.eps_krylovschur_hep(Ao, 3, which=O.which_target_magnitude(1.02), st=O.ST(Ao, Bo, "sinvert", 1.02), B=Bo)
+    assert eps.GetIterationNumber() == r.its and np.allclose(lam, r.eigr[r.perm][:3], rtol=1e-9)
+    A, B = sc2.test32_pencil(8)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(ks.Mat.from_csr(ctx, A.indptr, A.indices, A.data), ks.Mat.from_csr(ctx, B.indptr, B.indices, B.data))
+    eps.SetProblemType(ks.EPS_GHEP); eps.SetDimensions(60)
+    eps.GetST().SetKSP(rtol=1e-14, restart=64)
+    eps.Solve()
+    ref = gi.eigenvalues_block(gi.read("eps/eps_test32_3.out"))
+    assert eps.GetDimensions()[1] == 64 and eps.GetConverged() >= 60
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(60)])
+    assert np.allclose(np.round(lam, 5), ref, atol=1.5e-5)
+    X = np.stack([eps.GetEigenvector(i) for i in range(60)], axis=1)
+    assert np.abs(X.T @ (B @ X) - np.eye(60)).max() < 1e-8

@@ -533,3 +533,18 @@ def test_eps_ex11_fiedler_restart_parameter_golden():
     S = sc.graph_laplacian_2d(10, 10)
     r = O.eps_krylovschur_hep(_csr(S), 4, which="smallest_real", keep=0.2, deflation=np.ones((100, 1)))
     assert np.allclose(np.round(r.eigr[r.perm][:4], 5), gi.eigenvalue_lines(gi.read("eps/ex11_1.out"))[0], atol=1.5e-5)
+
+
+def test_eps_test32_ghep_symmetric_b_golden():
+    """test32 (GHEP with a non-diagonal symmetric B): suffix 1: -n 18 -eps_nev 3 -st_type sinvert -eps_target 1.02 ->
+    1.01797, 1.06575, 1.13978; suffix 3: -n 8 -eps_nev 60 (ncv = N = 64: the whole space, a 65-column basis) -> 60 values."""
+    A, B = sc.test32_pencil(18)
+    Ao, Bo = _csr(A), _csr(B)
+    r = O.eps_krylovschur_hep(Ao, 3, which=O.which_target_magnitude(1.02), st=O.ST(Ao, Bo, "sinvert", 1.02), B=Bo)
+    assert np.allclose(np.round(r.eigr[r.perm][:3], 5), gi.eigenvalues_block(gi.read("eps/eps_test32_1.out")), atol=1.5e-5)
+    A, B = sc.test32_pencil(8)
+    Ao, Bo = _csr(A), _csr(B)
+    r = O.eps_krylovschur_hep(Ao, 60, st=O.ST(Ao, Bo, "shift", 0.0), B=Bo)
+    ref = gi.eigenvalues_block(gi.read("eps/eps_test32_3.out"))
+    assert len(ref) == 60 and r.nconv >= 60 and r.ncv == 64
+    assert np.allclose(np.round(r.eigr[r.perm][:60], 5), ref, atol=1.5e-5)
