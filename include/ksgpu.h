@@ -261,6 +261,7 @@ int ks_eps_get_eigenvector_host(ks_eps eps, int i, double *xr_host);       /* n_
    (BV_GetEigenvector bvimpl.h:423-446); any of the four outputs may be NULL */
 int ks_eps_get_eigenpair_host(ks_eps eps, int i, double *eigr, double *eigi, double *xr_host, double *xi_host);
 int ks_eps_get_eigenpair(ks_eps eps, int i, double *eigr, double *eigi, double *xr_dev, double *xi_dev);   /* the same into device vectors of n_local doubles */
+int ks_eps_get_invariant_subspace(ks_eps eps, double *const *v_dev);        /* EPSGetInvariantSubspace epssolve.c:247: nconv device vectors; non-symmetric: before any eigenvector is asked for */
 int ks_eps_get_error_estimate(ks_eps eps, int i, double *errest);
 int ks_eps_compute_error(ks_eps eps, int i, int type, double *error);      /* EPSComputeError epssolve.c:742 */
 /* getters of the settings (EPSGetTolerances, EPSGetWhichEigenpairs, EPSGetTarget, EPSGetConvergenceTest, EPSGetOperators,

@@ -868,6 +868,14 @@ class EPS:
                                                    C.c_void_p(xi_ptr) if xi_ptr else None))
         return kr.value, ki.value
 
+    def GetInvariantSubspace(self):
+        """EPSGetInvariantSubspace as a host matrix (n_local x nconv)."""
+        k = self.GetConverged()
+        tmp = BV(self.ctx, self._A.n, max(k, 1))
+        ptrs = (C.c_void_p * max(k, 1))(*[tmp.column_ptr(j) for j in range(max(k, 1))])
+        _lib.check(self.ctx.L.ks_eps_get_invariant_subspace(self.h, ptrs))
+        return tmp.dense()[:, :k]
+
     def GetBV(self):
         h = C.c_void_p(); _lib.check(self.ctx.L.ks_eps_get_bv(self.h, C.byref(h)))
         return BV(self.ctx, 0, 0, _handle=h)

@@ -140,6 +140,7 @@ _SIG = {
     "ks_eps_get_eigenpair_host": [vp, C.c_int, dp, dp, dp, dp],
     "ks_eps_get_eigenpair": [vp, C.c_int, dp, dp, vp, vp],
     "ks_eps_get_error_estimate": [vp, C.c_int, dp],
+    "ks_eps_get_invariant_subspace": [vp, C.POINTER(C.c_void_p)],
     "ks_eps_compute_error": [vp, C.c_int, C.c_int, dp],
     "ks_eps_get_bv": [vp, C.POINTER(vp)],
     "ks_eps_get_stats": [vp, llp, llp, ip],

@@ -377,6 +377,8 @@ struct ks_eps_s {
   ks_eps_stopping_fn stop_fn = nullptr; void *stop_ctx = nullptr;      // EPSSetStoppingTestFunction; NULL = EPSStoppingBasic
   ks_eps_monitor_fn mon_fn = nullptr; void *mon_ctx = nullptr;         // EPSMonitorSet (one monitor)
   ks_eps_arbitrary_fn arb_fn = nullptr; void *arb_ctx = nullptr;       // EPSSetArbitrarySelection
+  bool problem_type_resolved_hermitian = false;                        // the last solve ran the symmetric (Lanczos) variant
+  bool vectors_done = true;                                            // non-symmetric variant: V holds Schur vectors until the eigenvectors are first asked for (EPS_STATE_EIGENVECTORS)
   int cb_err = 0;                                                      // first non-zero return of a user callback
   bool trueres = false;                                          // EPSSetTrueResidual
   int extraction = KS_EPS_RITZ;                                  // EPSSetExtraction: Ritz or harmonic (krylovschur.c:120)
@@ -686,6 +688,23 @@ static int start_vector(ks_eps eps, int i, bool *breakdown)
   return KS_SUCCESS;
 }
 
+// EPSComputeVectors_Schur epsdefault.c:105-169, run on first use (EPSComputeVectors epssolve.c:... state EPS_STATE_EIGENVECTORS):
+// X = V*Z with Z the normalised eigenvectors of the trimmed quasi-triangular T. Until then V(:,0:nconv) is the orthonormal
+// Schur basis that EPSGetInvariantSubspace hands out.
+static int compute_vectors(ks_eps eps)
+{
+  if (eps->vectors_done) return KS_SUCCESS;
+  ks_bv V = eps->V; DsNhep &ds = eps->dsn;
+  const int nc = eps->nconv;
+  KS_CALL(ks_bv_set_active_columns(V, 0, nc));
+  if (nc) {
+    for (int k = 0; k < nc; k++) k = ds.vectors(k, false, nullptr);
+    KS_CALL(ks_bv_multinplace(V, ds.X.data(), ds.ld, 0, nc));
+  }
+  eps->vectors_done = true;
+  return KS_SUCCESS;
+}
+
 // Non-Hermitian branch of EPSSolve_KrylovSchur_Default (krylovschur.c:227-337 with BVMatArnoldi), the conjugate-pair
 // handling of EPSKrylovConvergence (epskrylov.c:262-287), EPSComputeVectors_Schur (epsdefault.c:105-169) and the
 // pair-aware SlepcSortEigenvalues (slepcsc.c:89-140).
@@ -780,19 +799,20 @@ static int solve_nhep(ks_eps eps, long long passes0)
   }
   ds.truncate(eps->nconv, true);
 
-  // EPSComputeVectors_Schur: X = V*Z with Z the (normalised) eigenvectors of the trimmed quasi-triangular T
+  // the eigenvectors are formed on first use (compute_vectors); V(:,0:nconv) stays the Schur basis until then
   const int nc = eps->nconv;
   KS_CALL(ks_bv_set_active_columns(V, 0, nc));
-  if (nc) {
-    for (int k = 0; k < nc; k++) k = ds.vectors(k, false, nullptr);
-    KS_CALL(ks_bv_multinplace(V, ds.X.data(), ds.ld, 0, nc));
-  }
+  eps->vectors_done = false;
   // EPSComputeValues (epssolve.c:27-41), then conjugate pairs with the positive imaginary part first (:160-175):
   // the inversion of sinvert flips the sign
   if (map) ks_st_backtransform_internal(map, nc, eps->eigr.data(), eps->eigi.data());
   for (int i = 0; i < nc - 1; i++) {
     if (eps->eigi[i] != 0.0) {
-      if (eps->eigi[i] < 0.0) { eps->eigi[i] = -eps->eigi[i]; eps->eigi[i + 1] = -eps->eigi[i + 1]; KS_CALL(ks_bv_scalecolumn(V, i + 1, -1.0)); }
+      if (eps->eigi[i] < 0.0) {                                 // "the next correction only works with eigenvectors" (epssolve.c:166-169)
+        eps->eigi[i] = -eps->eigi[i]; eps->eigi[i + 1] = -eps->eigi[i + 1];
+        KS_CALL(compute_vectors(eps));
+        KS_CALL(ks_bv_scalecolumn(V, i + 1, -1.0));
+      }
       i++;
     }
   }
@@ -876,6 +896,8 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   KS_CALL(ks_bv_set_active_columns(V, 0, ncv + 1));
   KS_CALL(ks_bv_set_matrix(V, ghep ? (cayley ? st->bil : eps->B) : nullptr));   // EPS_SetInnerProduct epsimpl.h:280-292: STGetBilinearForm = B, or A + nu B for STCAYLEY (cayley.c:70-77)
   eps->ghep = ghep;
+  eps->problem_type_resolved_hermitian = (ptype == KS_EPS_HEP || ghep) && eps->extraction != KS_EPS_HARMONIC;
+  eps->vectors_done = true;
   if (eps->nds) {                                                      // process the deflation space (epssetup.c:397-404)
     std::vector<const double *> cp(eps->nds);
     for (int i = 0; i < eps->nds; i++) cp[i] = ks_bv_col(eps->defl, i);
@@ -1020,6 +1042,7 @@ extern "C" int ks_eps_get_eigenvector_host(ks_eps eps, int i, double *xr)
   KS_CHECK(eps && xr, KS_ERR_ARG_NULL, "NULL argument");
   KS_CHECK(eps->solved, KS_ERR_ARG_WRONGSTATE, "Must call EPSSolve() first");
   KS_CHECK(i >= 0 && i < eps->nconv, KS_ERR_ARG_OUTOFRANGE, "The index can be nconv-1 at most, see EPSGetConverged()");
+  KS_CALL(compute_vectors(eps));
   const int k = eps->perm[i];
   // EPSComputeVectors_Hermitian: V already holds the Ritz vectors; pairs: BV_GetEigenvector bvimpl.h:423-446
   return ks_bv_get_column_host(eps->V, eps->eigi[k] < 0.0 ? k - 1 : k, xr);
@@ -1029,6 +1052,7 @@ extern "C" int ks_eps_get_eigenpair_host(ks_eps eps, int i, double *eigr, double
   KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
   KS_CHECK(eps->solved, KS_ERR_ARG_WRONGSTATE, "Must call EPSSolve() first");
   KS_CHECK(i >= 0 && i < eps->nconv, KS_ERR_ARG_OUTOFRANGE, "The index can be nconv-1 at most, see EPSGetConverged()");
+  KS_CALL(compute_vectors(eps));
   const int k = eps->perm[i], nloc = eps->V->n;
   const double im = eps->eigi[k];
   if (eigr) *eigr = eps->eigr[k];
@@ -1046,6 +1070,7 @@ extern "C" int ks_eps_get_eigenpair(ks_eps eps, int i, double *eigr, double *eig
   KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
   KS_CHECK(eps->solved, KS_ERR_ARG_WRONGSTATE, "Must call EPSSolve() first");
   KS_CHECK(i >= 0 && i < eps->nconv, KS_ERR_ARG_OUTOFRANGE, "The index can be nconv-1 at most, see EPSGetConverged()");
+  KS_CALL(compute_vectors(eps));
   const int k = eps->perm[i]; const size_t nloc = eps->V->n;
   const double im = eps->eigi[k];
   ks_ctx ctx = eps->ctx; ks_bv V = eps->V;
@@ -1075,6 +1100,7 @@ extern "C" int ks_eps_compute_error(ks_eps eps, int i, int type, double *error) 
   KS_CHECK(eps && error, KS_ERR_ARG_NULL, "NULL argument");
   KS_CHECK(eps->solved, KS_ERR_ARG_WRONGSTATE, "Must call EPSSolve() first");
   KS_CHECK(i >= 0 && i < eps->nconv, KS_ERR_ARG_OUTOFRANGE, "The index can be nconv-1 at most, see EPSGetConverged()");
+  KS_CALL(compute_vectors(eps));
   const int j = eps->perm[i];
   const double kr = eps->eigr[j], ki = eps->eigi[j];
   ks_bv V = eps->V;
@@ -1114,6 +1140,19 @@ extern "C" int ks_eps_get_problem_type(ks_eps eps, int *type, int *generalized, 
   if (generalized) *generalized = (t == KS_EPS_GHEP || t == KS_EPS_GNHEP);
   if (hermitian) *hermitian = (t == KS_EPS_HEP || t == KS_EPS_GHEP);
   if (positive) *positive = (t == KS_EPS_GHEP);
+  return KS_SUCCESS;
+}
+// EPSGetInvariantSubspace epssolve.c:247-280: an orthonormal basis of the converged invariant subspace into nconv device
+// vectors. Non-symmetric problems: the Schur vectors, which only exist until the eigenvectors are first formed.
+extern "C" int ks_eps_get_invariant_subspace(ks_eps eps, double *const *v_dev)
+{
+  KS_CHECK(eps && v_dev, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(eps->solved, KS_ERR_ARG_WRONGSTATE, "Must call EPSSolve() first");
+  KS_CHECK(!eps->vectors_done || eps->problem_type_resolved_hermitian, KS_ERR_ARG_WRONGSTATE,
+           "EPSGetInvariantSubspace must be called before EPSGetEigenpair,EPSGetEigenvector or EPSComputeError");
+  KS_HIP(hipSetDevice(eps->ctx->device));
+  for (int i = 0; i < eps->nconv; i++) { KS_CHECK(v_dev[i], KS_ERR_ARG_NULL, "vector %d is NULL", i); KS_CALL(ksk_copy(eps->ctx, ks_bv_col(eps->V, i), v_dev[i], eps->V->n)); }
+  KS_HIP(hipStreamSynchronize(eps->ctx->stream));
   return KS_SUCCESS;
 }
 extern "C" int ks_eps_get_bv(ks_eps eps, ks_bv *V) { KS_CHECK(eps && V, KS_ERR_ARG_NULL, "NULL argument"); *V = eps->V; return KS_SUCCESS; }

@@ -492,3 +492,38 @@ def test_eps_ex9_brusselator_golden(ctx, case):
     lam = np.array([complex(*eps.GetEigenvalue(i)) for i in range(nev)])
     assert np.allclose(np.round(lam, 5), gi.complex_eigenvalue_lines(gi.read("eps/%s.out" % case))[0], atol=1.5e-5)
     _check_against_oracle(eps, r, Ao, tol=1e-7)
+
+
+@pytest.mark.parametrize("trueres", [False, True])
+def test_eps_test22_invariant_subspace_golden(ctx, trueres):
+    """test22 (suffix 1): EPSGetInvariantSubspace on the Brusselator problem: an orthonormal basis Q of the converged
+    subspace ("Level of orthogonality below the tolerance"), A Q = Q T with T quasi-triangular; it has to be asked for before
+    the eigenvectors, which are formed on first use."""
+    import slepc_amd as ks
+    Ao = nc.brusselator(30)
+    A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A); eps.SetProblemType(ks.EPS_NHEP); eps.SetDimensions(4); eps.SetWhichEigenpairs("largest_real"); eps.SetTrueResidual(trueres)
+    eps.Solve()
+    txt = gi.read("eps/eps_test22_1.out")
+    lam = np.array([complex(*eps.GetEigenvalue(i)) for i in range(4)])
+    assert np.allclose(np.round(lam, 5), gi.complex_eigenvalue_lines(txt)[0], atol=1.5e-5) and "Level of orthogonality below the tolerance" in txt
+    k = eps.GetConverged()
+    Q = eps.GetInvariantSubspace()
+    assert Q.shape == (Ao.n, k) and np.abs(Q.T @ Q - np.eye(k)).max() < 1e-12
+    S = Ao.to_scipy()
+    T = Q.T @ (S @ Q)
+    assert np.abs(S @ Q - Q @ T).max() < 1e-6 * np.abs(T).max()           # an invariant subspace to the solver's tolerance
+    assert np.abs(np.tril(T, -2)).max() < 1e-7 * np.abs(T).max()          # real Schur form: quasi upper triangular
+    assert np.allclose(np.sort_complex(np.linalg.eigvals(T)), np.sort_complex(np.array([complex(*eps.GetEigenvalue(i)) for i in range(k)])), rtol=1e-9)
+    r = O.eps_krylovschur_nhep(Ao, 4, which="largest_real", trueres=trueres)
+    _check_against_oracle(eps, r, Ao, tol=1e-7)                         # forms the eigenvectors
+    with pytest.raises(ks.KsError) as e:
+        eps.GetInvariantSubspace()
+    assert e.value.rc == 73
+    # symmetric problems: the eigenvectors themselves, at any time
+    L = ks.Mat.laplacian2d(ctx, 12)
+    e2 = ks.EPS(ctx); e2.SetOperators(L); e2.SetProblemType(ks.EPS_HEP); e2.SetDimensions(3); e2.Solve()
+    x0 = e2.GetEigenvector(0)
+    Q2 = e2.GetInvariantSubspace()
+    assert np.abs(Q2.T @ Q2 - np.eye(Q2.shape[1])).max() < 1e-12 and np.abs(abs(Q2.T @ x0).max() - 1.0) < 1e-12

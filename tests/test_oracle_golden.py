@@ -548,3 +548,11 @@ def test_eps_test32_ghep_symmetric_b_golden():
     ref = gi.eigenvalues_block(gi.read("eps/eps_test32_3.out"))
     assert len(ref) == 60 and r.nconv >= 60 and r.ncv == 64
     assert np.allclose(np.round(r.eigr[r.perm][:60], 5), ref, atol=1.5e-5)
+
+
+@pytest.mark.parametrize("trueres", [False, True])
+def test_eps_test22_brusselator_golden(trueres):
+    """test22 -eps_nev 4 -eps_true_residual {{0 1}} (Brusselator n = 30, largest real): the eigenvalue line of test22_1.out."""
+    import nhep_cases as nc
+    r = O.eps_krylovschur_nhep(nc.brusselator(30), 4, which="largest_real", trueres=trueres)
+    assert np.allclose(np.round(_as_complex(r, 4), 5), gi.complex_eigenvalue_lines(gi.read("eps/eps_test22_1.out"))[0], atol=1.5e-5)
