@@ -82,6 +82,7 @@ enum { KS_EPS_HEP = 1, KS_EPS_GHEP = 2, KS_EPS_NHEP = 3, KS_EPS_GNHEP = 4 };   /
 enum { KS_ST_SHIFT = 0, KS_ST_SINVERT = 1, KS_ST_CAYLEY = 2 };   /* STType "shift", "sinvert", "cayley" */
 enum { KS_EPS_ERROR_ABSOLUTE = 0, KS_EPS_ERROR_RELATIVE = 1, KS_EPS_ERROR_BACKWARD = 2 };   /* EPSErrorType */
 enum { KS_EPS_RITZ = 0, KS_EPS_HARMONIC = 1, KS_EPS_HARMONIC_RELATIVE, KS_EPS_HARMONIC_RIGHT, KS_EPS_HARMONIC_LARGEST, KS_EPS_REFINED, KS_EPS_REFINED_HARMONIC };  /* EPSExtraction slepceps.h:94-100; Krylov-Schur offers the first two */
+enum { KS_EPS_BALANCE_NONE = 0, KS_EPS_BALANCE_ONESIDE = 1, KS_EPS_BALANCE_TWOSIDE = 2, KS_EPS_BALANCE_USER = 3 };   /* EPSBalance slepceps.h; the one-sided form is built */
 enum { KS_EPS_CONV_ABS = 0, KS_EPS_CONV_REL = 1, KS_EPS_CONV_NORM = 2, KS_EPS_CONV_USER = 3 };   /* EPSConv slepceps.h:153-156 */
 /* user callbacks of the solver (slepceps.h EPSConvergenceTestFn, EPSStoppingTestFn, EPSMonitorFn); non-zero return = error */
 typedef int (*ks_eps_converged_fn)(ks_eps eps, double eigr, double eigi, double res, double *errest, void *ctx);
@@ -277,6 +278,8 @@ int ks_eps_set_stopping_test_function(ks_eps eps, ks_eps_stopping_fn fn, void *c
 int ks_eps_stopping_basic(ks_eps eps, int its, int max_it, int nconv, int nev, int *reason, void *ctx); /* EPSStoppingBasic epsdefault.c:290 */
 int ks_eps_set_arbitrary_selection(ks_eps eps, ks_eps_arbitrary_fn fn, void *ctx);      /* EPSSetArbitrarySelection epsopts.c:600 (symmetric variant; the DS sorts on rr/ri, krylovschur.c:275-279); NULL disables */
 int ks_eps_monitor_set(ks_eps eps, ks_eps_monitor_fn fn, void *ctx);                    /* EPSMonitorSet (one slot; NULL cancels): called once per restart with the DS-ordered values, untransformed */
+int ks_eps_set_balance(ks_eps eps, int bal, int its, double cutoff);        /* EPSSetBalance epsopts.c:1050 (non-symmetric problems; EPSBuildBalance_Krylov epsdefault.c:370); its / cutoff 0 keep 5 / 1e-8 */
+int ks_eps_get_balance(ks_eps eps, int *bal, int *its, double *cutoff);
 int ks_eps_set_true_residual(ks_eps eps, int trueres);                    /* EPSSetTrueResidual: convergence on ||A x - k B x|| of the Ritz vector (epskrylov.c:256-264) */
 int ks_eps_get_true_residual(ks_eps eps, int *trueres);
 int ks_eps_get_operators(ks_eps eps, ks_mat *A, ks_mat *B);

@@ -938,7 +938,7 @@ def _residual_norm(A, B, kr, ki, xr, xi=None):
     return float(np.hypot(np.linalg.norm(u), np.linalg.norm(w)))
 
 
-def _true_residual(A, B, V, nv, re, im, Zr, Zi=None, purify=None, Bnorm=None):
+def _true_residual(A, B, V, nv, re, im, Zr, Zi=None, purify=None, Bnorm=None, D=None):
     """EPSComputeRitzVector epsdefault.c:313-364 + the residual of epskrylov.c:256-264 (-eps_true_residual)."""
     X = np.array(V.dense())[: V.n, :nv]
     x = X @ Zr[:nv]
@@ -946,6 +946,12 @@ def _true_residual(A, B, V, nv, re, im, Zr, Zi=None, purify=None, Bnorm=None):
         y = purify(x)
         x = y / np.sqrt(y @ (Bnorm if Bnorm is not None else B).mult(y))
     y = X @ Zi[:nv] if Zi is not None else None
+    if D is not None:                                        # fix and normalise when balancing is used (epsdefault.c:336-361)
+        x = x / D
+        y = y / D if y is not None else None
+        nrm = np.hypot(np.linalg.norm(x), np.linalg.norm(y) if y is not None else 0.0)
+        x = x / nrm
+        y = y / nrm if y is not None else None
     return _residual_norm(A, B, re, im, x, y)
 
 
@@ -1231,7 +1237,7 @@ class ST:
 
 def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which="largest_magnitude", keep=0.5,
                          seed=0x12345678, v0=None, max_steps=None, st=None, lock=True, conv="rel", B=None, harmonic=None,
-                         trueres=False, stopping=None, monitor=None):
+                         trueres=False, stopping=None, monitor=None, balance_its=0):
     """EPSSolve_KrylovSchur_Default with the Arnoldi expansion (krylovschur.c:227-337, non-Hermitian branch),
     EPSKrylovConvergence for conjugate pairs (epskrylov.c:262-287), EPSComputeVectors_Schur (epsdefault.c:105-169).
     With st (an ST): the Krylov operator is st.apply, the DS sorts through the back-transformation
@@ -1272,6 +1278,19 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
             V.ScaleColumn(i, 1.0 / norm)
         return lindep or norm == 0.0
 
+    # EPSSetBalance(ONESIDE): EPSBuildBalance_Krylov epsdefault.c:370-434, then the expansion runs on D Op D^-1 (stsolve.c:252-256)
+    D = None
+    base_op = st.apply if st is not None else (lambda x: A.mult(x))
+    if balance_its:
+        D = np.ones(n)
+        scratch = BV(n, 5)
+        for j in range(balance_its):
+            scratch.SetRandomColumn(3, seed + 7919 * (j + 1))
+            z = np.where(np.array(scratch.column(3)) < 0.5, -1.0, 1.0)
+            p = base_op(z / D) * D
+            nz = p != 0.0
+            D[nz] = D[nz] / np.abs(p[nz])
+        bal_op = lambda x: base_op(x / D) * D                # noqa: E731
     assert not start_vector(0)
     l = 0; nconv = 0; its = 0; reason = 0; steps = 0
     while reason == 0:
@@ -1283,7 +1302,9 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
         k0 = nconv + l
         H = ds.A[: nv + 1, :nv]                       # DSGetMat(DS_MAT_A): (n+1) x n with the extra row
         Hs = np.asfortranarray(ds.A)                  # BVMatArnoldi writes through ld = ds.ld
-        if st is None:
+        if D is not None:
+            nv, beta, breakdown = V.MatArnoldiOp(bal_op, Hs, k0, nv)
+        elif st is None:
             nv, beta, breakdown = V.MatArnoldi(A, Hs, k0, nv)
         else:
             nv, beta, breakdown = V.MatArnoldiOp(st.apply, Hs, k0, nv)
@@ -1310,7 +1331,7 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
             if trueres:                                     # epskrylov.c:245,256-264
                 if st is not None and not (st.kind == "shift" or conv == "norm"):
                     re, im = st.backtransform(re, im)
-                resnorm = _true_residual(A, B, V, nv, re, im, ds.X[:, k], ds.X[:, newk] if newk == k + 1 else None)
+                resnorm = _true_residual(A, B, V, nv, re, im, ds.X[:, k], ds.X[:, newk] if newk == k + 1 else None, D=D)
             errest[k] = _converged(conv, re, im, resnorm, nrma, nrmb)
             if marker == -1 and errest[k] >= tol:
                 marker = k
@@ -1365,6 +1386,16 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
     ds.Q[:, :] = Qsave
     if nconv:
         V.MultInPlace(Z, 0, nconv)
+        if D is not None:              # epsdefault.c:130-139: x <- D \ x, BVNormalize with the pairs together
+            i = 0
+            while i < nconv:
+                V.set_column(i, np.array(V.column(i)) / D)
+                if eigi[i] != 0.0 and i + 1 < nconv:
+                    V.set_column(i + 1, np.array(V.column(i + 1)) / D)
+                    nrm = np.hypot(np.linalg.norm(V.column(i)), np.linalg.norm(V.column(i + 1)))
+                    V.ScaleColumn(i, 1.0 / nrm); V.ScaleColumn(i + 1, 1.0 / nrm); i += 2
+                else:
+                    V.ScaleColumn(i, 1.0 / np.linalg.norm(V.column(i))); i += 1
     if st is not None:                 # EPSComputeValues -> EPSBackTransform_Default
         for i in range(nconv):
             eigr[i], eigi[i] = st.backtransform(eigr[i], eigi[i])

@@ -794,6 +794,10 @@ class EPS:
         self._arb_cb = EPS_ARBITRARY_FN(tramp)
         _lib.check(self.ctx.L.ks_eps_set_arbitrary_selection(self.h, C.cast(self._arb_cb, C.c_void_p), None))
 
+    def SetBalance(self, bal="oneside", its=0, cutoff=0.0):
+        """EPSSetBalance: "none" or "oneside" (non-symmetric problems)."""
+        _lib.check(self.ctx.L.ks_eps_set_balance(self.h, {"none": 0, "oneside": 1, "twoside": 2, "user": 3}.get(bal, bal), its, cutoff))
+
     def SetTrueResidual(self, flag=True):
         _lib.check(self.ctx.L.ks_eps_set_true_residual(self.h, int(bool(flag))))
 

@@ -356,6 +356,9 @@ struct ks_eps_s {
   ks_ctx ctx = nullptr;
   ks_mat A = nullptr, B = nullptr;
   ks_mat op = nullptr;                 // operator of the expansion: A itself, or the ST's shell matrix
+  // EPSSetBalance (non-symmetric problems): D from EPSBuildBalance_Krylov, the expansion then runs on D Op D^-1 (STApply with st->D, stsolve.c:252-256)
+  int balance = KS_EPS_BALANCE_NONE, balance_its = 5; double balance_cutoff = 1e-8;
+  double *D = nullptr, *wb = nullptr; int D_n = 0; ks_mat op_inner = nullptr, bal_op = nullptr; bool balanced = false;
   ks_st st = nullptr;                  // owned (EPSGetST)
   ks_bv V = nullptr, W = nullptr;      // basis (ncv+1 columns), work vectors (3 columns)
   int problem_type = 0;               // not set: EPSSetUp picks NHEP (one matrix) or GNHEP (two), epssetup.c:318-322
@@ -399,6 +402,7 @@ extern "C" int ks_eps_destroy(ks_eps eps)
   if (!eps) return KS_SUCCESS;
   ks_bv_destroy(eps->V); ks_bv_destroy(eps->W); ks_bv_destroy(eps->defl);
   ks_st_destroy(eps->st);
+  if (eps->D) hipFree(eps->D); if (eps->wb) hipFree(eps->wb); if (eps->bal_op) ks_mat_destroy(eps->bal_op);
   delete eps;
   return KS_SUCCESS;
 }
@@ -481,6 +485,23 @@ extern "C" int ks_eps_set_true_residual(ks_eps eps, int trueres)            // E
   eps->trueres = trueres != 0; eps->solved = false; return KS_SUCCESS;
 }
 extern "C" int ks_eps_get_true_residual(ks_eps eps, int *trueres) { KS_CHECK(eps && trueres, KS_ERR_ARG_NULL, "NULL argument"); *trueres = eps->trueres ? 1 : 0; return KS_SUCCESS; }
+extern "C" int ks_eps_set_balance(ks_eps eps, int bal, int its, double cutoff)   // EPSSetBalance epsopts.c:1050-1095 (its, cutoff: 0 keeps)
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  KS_CHECK(bal >= KS_EPS_BALANCE_NONE && bal <= KS_EPS_BALANCE_USER, KS_ERR_ARG_OUTOFRANGE, "Invalid value of argument 'bal'");
+  KS_CHECK(bal != KS_EPS_BALANCE_USER, KS_ERR_SUP, "a user-provided balancing matrix is not built");
+  KS_CHECK(its >= 0, KS_ERR_ARG_OUTOFRANGE, "Illegal value of its. Must be >= 0");
+  KS_CHECK(cutoff >= 0.0, KS_ERR_ARG_OUTOFRANGE, "Illegal value of cutoff. Must be >= 0");
+  eps->balance = bal; if (its) eps->balance_its = its; if (cutoff > 0.0) eps->balance_cutoff = cutoff;
+  eps->solved = false;
+  return KS_SUCCESS;
+}
+extern "C" int ks_eps_get_balance(ks_eps eps, int *bal, int *its, double *cutoff)
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  if (bal) *bal = eps->balance; if (its) *its = eps->balance_its; if (cutoff) *cutoff = eps->balance_cutoff;
+  return KS_SUCCESS;
+}
 extern "C" int ks_eps_set_extraction(ks_eps eps, int extr)                  // EPSSetExtraction epsopts.c:968-994; krylovschur.c:120 accepts these two
 {
   KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
@@ -602,6 +623,61 @@ static double converged_estimate(ks_eps eps, double re, double im, double res)
   }
 }
 
+namespace {
+__global__ void k_pw(long long n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out, int mul)
+{
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = mul ? a[i] * b[i] : a[i] / b[i];
+}
+__global__ void k_sign_half(long long n, double *__restrict__ z)
+{
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) z[i] = z[i] < 0.5 ? -1.0 : 1.0;
+}
+__global__ void k_bal_update(long long n, double *__restrict__ D, const double *__restrict__ p)
+{
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) if (p[i] != 0.0) D[i] /= fabs(p[i]);
+}
+__global__ void k_fill(long long n, double *__restrict__ x, double v)
+{
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] = v;
+}
+}
+static int pointwise(ks_eps eps, const double *a, const double *b, double *out, bool mul)     // VecPointwiseMult / VecPointwiseDivide
+{
+  const long long n = eps->V->n;
+  if (!n) return KS_SUCCESS;
+  const unsigned nb = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)eps->ctx->num_cu * 16));
+  hipLaunchKernelGGL(k_pw, dim3(nb), dim3(256), 0, eps->ctx->stream, n, a, b, out, mul ? 1 : 0);
+  KS_HIP(hipGetLastError());
+  return KS_SUCCESS;
+}
+// the balanced operator D Op D^-1 as a matrix-free operator (STApply with st->D, stsolve.c:252-256)
+static int balanced_mult(void *user, const double *x, double *y)
+{
+  ks_eps eps = (ks_eps)user;
+  KS_CALL(pointwise(eps, x, eps->D, eps->wb, false));
+  KS_CALL(ks_mat_mult_internal(eps->op_inner, eps->wb, y));
+  return pointwise(eps, y, eps->D, y, true);
+}
+// EPSBuildBalance_Krylov epsdefault.c:370-434, one-sided form: D <- D ./ |D Op D^-1 z| over balance_its random +-1 vectors
+static int build_balance(ks_eps eps)
+{
+  ks_ctx ctx = eps->ctx; const long long n = eps->V->n;
+  const unsigned nb = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)ctx->num_cu * 16));
+  if (eps->D_n != n) { if (eps->D) hipFree(eps->D); if (eps->wb) hipFree(eps->wb); eps->D = eps->wb = nullptr;
+    KS_HIP(hipMalloc(&eps->D, sizeof(double) * std::max<long long>(n, 1))); KS_HIP(hipMalloc(&eps->wb, sizeof(double) * std::max<long long>(n, 1))); eps->D_n = (int)n; }
+  if (n) hipLaunchKernelGGL(k_fill, dim3(nb), dim3(256), 0, ctx->stream, n, eps->D, 1.0);
+  double *z = ks_bv_col(eps->W, 3), *p = ks_bv_col(eps->W, 4);
+  eps->W->row_start = eps->V->row_start;
+  for (int j = 0; j < eps->balance_its; j++) {
+    KS_CALL(ks_bv_set_random_column(eps->W, 3, eps->seed + 7919ULL * (uint64_t)(j + 1)));           // a random vector of +-1's
+    if (n) hipLaunchKernelGGL(k_sign_half, dim3(nb), dim3(256), 0, ctx->stream, n, z);
+    KS_CALL(balanced_mult(eps, z, p));                                                               // p = D Op (D \ z)
+    if (n) hipLaunchKernelGGL(k_bal_update, dim3(nb), dim3(256), 0, ctx->stream, n, eps->D, p);
+    KS_HIP(hipGetLastError());
+  }
+  return KS_SUCCESS;
+}
+
 // EPSComputeResidualNorm_Private epssolve.c:666-718 (STGetMatrix 0/1 = the user's A and B): || A x - k B x ||_2 for a
 // real eigenvalue, hypot of the two real-arithmetic residuals for a pair (xi_sign * xi is the imaginary part).
 // Work vectors: W columns 0..2.
@@ -665,6 +741,15 @@ static int ritz_vector(ks_eps eps, int nv, const double *Zr, const double *Zi)
   if (Zi) KS_CALL(ks_bv_multvec(V, 1.0, 0.0, y, Zi));
   else KS_HIP(hipMemsetAsync(y, 0, sizeof(double) * V->n, eps->ctx->stream));   // VecSet(y,0.0) epsdefault.c:352
   KS_CALL(ks_bv_set_active_columns(V, ls, ksv));
+  if (eps->balanced) {                                      // fix and normalise the eigenvector when balancing is used (epsdefault.c:336,349,355-361)
+    KS_CALL(pointwise(eps, x, eps->D, x, false));
+    if (Zi) KS_CALL(pointwise(eps, y, eps->D, y, false));
+    double nx = 0.0, ny = 0.0;
+    KS_CALL(ks_bv_normvec(W, x, KS_NORM_2, &nx));
+    if (Zi) KS_CALL(ks_bv_normvec(W, y, KS_NORM_2, &ny));
+    const double nrm = hypot(nx, ny);
+    if (nrm != 0.0) { KS_CALL(ksk_scale(eps->ctx, x, V->n, 1.0 / nrm)); if (Zi) KS_CALL(ksk_scale(eps->ctx, y, V->n, 1.0 / nrm)); }
+  }
   return KS_SUCCESS;
 }
 
@@ -700,6 +785,10 @@ static int compute_vectors(ks_eps eps)
   if (nc) {
     for (int k = 0; k < nc; k++) k = ds.vectors(k, false, nullptr);
     KS_CALL(ks_bv_multinplace(V, ds.X.data(), ds.ld, 0, nc));
+    if (eps->balanced) {                                    // epsdefault.c:130-139: x <- D \ x, then normalise (pairs together)
+      for (int i = 0; i < nc; i++) KS_CALL(pointwise(eps, ks_bv_col(V, i), eps->D, ks_bv_col(V, i), false));
+      KS_CALL(ks_bv_normalize(V, eps->eigi.data()));
+    }
   }
   eps->vectors_done = true;
   return KS_SUCCESS;
@@ -907,6 +996,16 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
     if (rc) return rc;
   }
 
+  // balancing of non-symmetric problems (epssetup.c:383-391): build D, then expand with D Op D^-1
+  eps->balanced = false;
+  if ((ptype == KS_EPS_NHEP || ptype == KS_EPS_GNHEP) && eps->balance != KS_EPS_BALANCE_NONE) {
+    KS_CHECK(eps->balance == KS_EPS_BALANCE_ONESIDE, KS_ERR_SUP, "only one-sided balancing is built (the two-sided form needs the transposed operator)");
+    eps->op_inner = eps->op;
+    KS_CALL(build_balance(eps));
+    if (!eps->bal_op) KS_CALL(ks_mat_create_shell(eps->ctx, A->n, A->row_start, A->n_global, balanced_mult, eps, &eps->bal_op));
+    eps->bal_op->n = A->n; eps->bal_op->row_start = A->row_start; eps->bal_op->n_global = A->n_global;
+    eps->op = eps->bal_op; eps->balanced = true;
+  }
   KS_CHECK(eps->extraction == KS_EPS_RITZ || !ghep, KS_ERR_SUP, "harmonic extraction with a B-inner product is not built");
   KS_CHECK(!eps->arb_fn || ((ptype == KS_EPS_HEP || ghep) && eps->extraction == KS_EPS_RITZ), KS_ERR_SUP, "arbitrary selection is built for the symmetric (Lanczos) variant only");
   if ((ptype != KS_EPS_HEP && !ghep) || eps->extraction == KS_EPS_HARMONIC) return solve_nhep(eps, passes0);   // variant EPS_KS_DEFAULT (krylovschur.c:133-151)
@@ -1151,7 +1250,19 @@ extern "C" int ks_eps_get_invariant_subspace(ks_eps eps, double *const *v_dev)
   KS_CHECK(!eps->vectors_done || eps->problem_type_resolved_hermitian, KS_ERR_ARG_WRONGSTATE,
            "EPSGetInvariantSubspace must be called before EPSGetEigenpair,EPSGetEigenvector or EPSComputeError");
   KS_HIP(hipSetDevice(eps->ctx->device));
-  for (int i = 0; i < eps->nconv; i++) { KS_CHECK(v_dev[i], KS_ERR_ARG_NULL, "vector %d is NULL", i); KS_CALL(ksk_copy(eps->ctx, ks_bv_col(eps->V, i), v_dev[i], eps->V->n)); }
+  for (int i = 0; i < eps->nconv; i++) KS_CHECK(v_dev[i], KS_ERR_ARG_NULL, "vector %d is NULL", i);
+  if (eps->balanced && !eps->vectors_done && eps->nconv) {  // epssolve.c:351-362: Q <- orth(D \ Q)
+    ks_bv T = nullptr;
+    KS_CALL(ks_bv_create(eps->ctx, eps->V->n, eps->V->N, eps->nconv, 0, &T));
+    int rc = KS_SUCCESS;
+    for (int i = 0; i < eps->nconv && !rc; i++) rc = pointwise(eps, ks_bv_col(eps->V, i), eps->D, ks_bv_col(T, i), false);
+    if (!rc) rc = ks_bv_orthogonalize(T, nullptr, 0);
+    for (int i = 0; i < eps->nconv && !rc; i++) rc = ksk_copy(eps->ctx, ks_bv_col(T, i), v_dev[i], eps->V->n);
+    hipStreamSynchronize(eps->ctx->stream);
+    ks_bv_destroy(T);
+    return rc;
+  }
+  for (int i = 0; i < eps->nconv; i++) KS_CALL(ksk_copy(eps->ctx, ks_bv_col(eps->V, i), v_dev[i], eps->V->n));
   KS_HIP(hipStreamSynchronize(eps->ctx->stream));
   return KS_SUCCESS;
 }

@@ -527,3 +527,32 @@ def test_eps_test22_invariant_subspace_golden(ctx, trueres):
     x0 = e2.GetEigenvector(0)
     Q2 = e2.GetInvariantSubspace()
     assert np.abs(Q2.T @ Q2 - np.eye(Q2.shape[1])).max() < 1e-12 and np.abs(abs(Q2.T @ x0).max() - 1.0) < 1e-12
+
+
+def test_eps_test22_balance_oneside_golden(ctx):
+    """test22 suffix 2: -eps_nev 4 -eps_true_residual -eps_balance oneside -eps_tol 1e-7: the expansion runs on D A D^-1 with
+    D from EPSBuildBalance_Krylov; eigenvectors and Ritz vectors are mapped back with D and renormalised; the invariant
+    subspace is re-orthogonalised after the mapping."""
+    import slepc_amd as ks
+    Ao = nc.brusselator(30)
+    A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A); eps.SetProblemType(ks.EPS_NHEP); eps.SetDimensions(4); eps.SetWhichEigenpairs("largest_real")
+    eps.SetTrueResidual(True); eps.SetBalance("oneside"); eps.SetTolerances(1e-7, 0)
+    eps.Solve()
+    lam = np.array([complex(*eps.GetEigenvalue(i)) for i in range(4)])
+    assert np.allclose(np.round(lam, 5), gi.complex_eigenvalue_lines(gi.read("eps/eps_test22_2.out"))[0], atol=1.5e-5)
+    k = eps.GetConverged()
+    Q = eps.GetInvariantSubspace()
+    S = Ao.to_scipy()
+    assert np.abs(Q.T @ Q - np.eye(k)).max() < 1e-12                      # "Level of orthogonality below the tolerance"
+    assert np.abs(S @ Q - Q @ (Q.T @ (S @ Q))).max() < 1e-5 * np.abs(S @ Q).max()
+    r = O.eps_krylovschur_nhep(Ao, 4, tol=1e-7, which="largest_real", trueres=True, balance_its=5)
+    _check_against_oracle(eps, r, Ao, tol=1e-6)
+    # balancing is for non-symmetric problems only; the two-sided form needs the transposed operator
+    eps.SetBalance("twoside")
+    with pytest.raises(ks.KsError) as e:
+        eps.Solve()
+    assert e.value.rc == 56
+    eps.SetBalance("none"); eps.Solve()
+    assert eps.GetConverged() >= 4

@@ -556,3 +556,14 @@ def test_eps_test22_brusselator_golden(trueres):
     import nhep_cases as nc
     r = O.eps_krylovschur_nhep(nc.brusselator(30), 4, which="largest_real", trueres=trueres)
     assert np.allclose(np.round(_as_complex(r, 4), 5), gi.complex_eigenvalue_lines(gi.read("eps/eps_test22_1.out"))[0], atol=1.5e-5)
+
+
+def test_eps_test22_balance_oneside_golden():
+    """test22 suffix 2: -eps_nev 4 -eps_true_residual -eps_balance oneside -eps_tol 1e-7 (Brusselator n = 30)."""
+    import nhep_cases as nc
+    Ao = nc.brusselator(30)
+    r = O.eps_krylovschur_nhep(Ao, 4, tol=1e-7, which="largest_real", trueres=True, balance_its=5)
+    ref = gi.complex_eigenvalue_lines(gi.read("eps/eps_test22_2.out"))[0]
+    assert np.allclose(np.round(_as_complex(r, 4), 5), ref, atol=1.5e-5)
+    for i in range(4):
+        assert O.eps_compute_error_nhep(Ao, r, i) < 1e-6
