@@ -278,6 +278,10 @@ int ks_eps_set_stopping_test_function(ks_eps eps, ks_eps_stopping_fn fn, void *c
 int ks_eps_stopping_basic(ks_eps eps, int its, int max_it, int nconv, int nev, int *reason, void *ctx); /* EPSStoppingBasic epsdefault.c:290 */
 int ks_eps_set_arbitrary_selection(ks_eps eps, ks_eps_arbitrary_fn fn, void *ctx);      /* EPSSetArbitrarySelection epsopts.c:600 (symmetric variant; the DS sorts on rr/ri, krylovschur.c:275-279); NULL disables */
 int ks_eps_monitor_set(ks_eps eps, ks_eps_monitor_fn fn, void *ctx);                    /* EPSMonitorSet (one slot; NULL cancels): called once per restart with the DS-ordered values, untransformed */
+int ks_eps_set_purify(ks_eps eps, int purify);                              /* EPSSetPurify: 0 skips the purification of GHEP eigenvectors (test1_1_ks_nopurify) */
+int ks_eps_get_purify(ks_eps eps, int *purify);
+int ks_eps_set_track_all(ks_eps eps, int trackall);                          /* EPSSetTrackAll: error estimates of all Ritz pairs at every restart (for monitors) */
+int ks_eps_get_krylovschur(ks_eps eps, double *keep, int *lock);             /* EPSKrylovSchurGetRestart / EPSKrylovSchurGetLocking */
 int ks_eps_set_balance(ks_eps eps, int bal, int its, double cutoff);        /* EPSSetBalance epsopts.c:1050 (non-symmetric problems; EPSBuildBalance_Krylov epsdefault.c:370); its / cutoff 0 keep 5 / 1e-8 */
 int ks_eps_get_balance(ks_eps eps, int *bal, int *its, double *cutoff);
 int ks_eps_set_true_residual(ks_eps eps, int trueres);                    /* EPSSetTrueResidual: convergence on ||A x - k B x|| of the Ritz vector (epskrylov.c:256-264) */

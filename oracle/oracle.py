@@ -748,7 +748,7 @@ class EPSResult:
 
 def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which="largest_magnitude",
                         keep=0.5, seed=0x12345678, omp=False, v0=None, orthog=(CGS, REFINE_IFNEEDED, 0.7071),
-                        max_steps=None, monitor=None, lock=True, st=None, B=None, conv="rel", deflation=None, trueres=False, stopping=None, arbitrary=None):
+                        max_steps=None, monitor=None, lock=True, st=None, B=None, conv="rel", deflation=None, trueres=False, stopping=None, arbitrary=None, purify=True):
     """EPSSolve for a symmetric problem with the default Krylov-Schur solver: standard (HEP), or generalized (GHEP,
     B given: the basis carries the B-inner product, EPS_SetInnerProduct epsimpl.h:280-292; the start vector goes
     through the operator, epssolve.c:860-868; the eigenvectors are purified and B-normalised,
@@ -837,7 +837,7 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
             for i in range(ds.l, ds.n):
                 re = eigr[i] if st is None else st.backtransform(eigr[i], 0.0)[0]
                 x = Xall @ ds.Q[:nv, i]
-                if B is not None:                           # purification of EPSComputeRitzVector
+                if B is not None and purify:                # purification of EPSComputeRitzVector
                     y = st.apply(x); x = y / np.sqrt(y @ Bip.mult(y))
                 rr[i], ri[i] = arbitrary(re, 0.0, x, np.zeros(n))
             ds.Sort(eigr, rr, ri)
@@ -856,7 +856,7 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
             if trueres:                                     # epskrylov.c:245,256-264
                 if st is not None and not (st.kind == "shift" or conv == "norm"):
                     re = st.backtransform(re, 0.0)[0]
-                resnorm = _true_residual(A, B, V, nv, re, 0.0, ds.Q[:, kk], purify=st.apply if B is not None else None, Bnorm=Bip)
+                resnorm = _true_residual(A, B, V, nv, re, 0.0, ds.Q[:, kk], purify=st.apply if (B is not None and purify) else None, Bnorm=Bip)
             errest[kk] = _converged(conv, re, 0.0, resnorm, nrma, nrmb)
             if marker == -1 and errest[kk] >= tol:
                 marker = kk
@@ -901,11 +901,14 @@ def eps_krylovschur_hep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which
     if st is not None:                                      # EPSComputeValues (epssolve.c:27-41)
         for i in range(nconv):
             eigr[i] = st.backtransform(eigr[i], 0.0)[0]
-    if B is not None:                                       # EPSComputeVectors_Hermitian: purify, then B-normalise
+    if B is not None and purify:                            # EPSComputeVectors_Hermitian: purify, then B-normalise
         for i in range(nconv):
             V.set_column(i, st.apply(np.array(V.column(i))))
         for i in range(nconv):
             V.ScaleColumn(i, 1.0 / V.NormColumn(i))
+    elif B is not None and st is not None and st.kind == "cayley":      # epsdefault.c:38-47: B-normalise under Cayley
+        for i in range(nconv):
+            x = np.array(V.column(i)); V.set_column(i, x / np.sqrt(x @ B.mult(x)))
     # EPSSolve epilogue: final sort of the converged values (SlepcSortEigenvalues slepcsc.c:89-140, all real)
     perm = list(range(nconv))
     for i in range(nconv - 1, -1, -1):

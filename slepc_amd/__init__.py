@@ -798,6 +798,15 @@ class EPS:
         """EPSSetBalance: "none" or "oneside" (non-symmetric problems)."""
         _lib.check(self.ctx.L.ks_eps_set_balance(self.h, {"none": 0, "oneside": 1, "twoside": 2, "user": 3}.get(bal, bal), its, cutoff))
 
+    def SetPurify(self, flag=True):
+        _lib.check(self.ctx.L.ks_eps_set_purify(self.h, int(bool(flag))))
+
+    def SetTrackAll(self, flag=True):
+        _lib.check(self.ctx.L.ks_eps_set_track_all(self.h, int(bool(flag))))
+
+    def KrylovSchurGet(self):
+        k = C.c_double(); l = C.c_int(); _lib.check(self.ctx.L.ks_eps_get_krylovschur(self.h, C.byref(k), C.byref(l))); return k.value, bool(l.value)
+
     def SetTrueResidual(self, flag=True):
         _lib.check(self.ctx.L.ks_eps_set_true_residual(self.h, int(bool(flag))))
 

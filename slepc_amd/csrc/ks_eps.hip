@@ -383,6 +383,7 @@ struct ks_eps_s {
   bool problem_type_resolved_hermitian = false;                        // the last solve ran the symmetric (Lanczos) variant
   bool vectors_done = true;                                            // non-symmetric variant: V holds Schur vectors until the eigenvectors are first asked for (EPS_STATE_EIGENVECTORS)
   int cb_err = 0;                                                      // first non-zero return of a user callback
+  bool purify = true, trackall = false;                               // EPSSetPurify, EPSSetTrackAll
   bool trueres = false;                                          // EPSSetTrueResidual
   int extraction = KS_EPS_RITZ;                                  // EPSSetExtraction: Ritz or harmonic (krylovschur.c:120)
   int conv = KS_EPS_CONV_REL; double nrma = 0.0, nrmb = 0.0;   // EPSSetConvergenceTest; ||A||_inf, ||B||_inf for CONV_NORM / ERROR_BACKWARD
@@ -485,6 +486,23 @@ extern "C" int ks_eps_set_true_residual(ks_eps eps, int trueres)            // E
   eps->trueres = trueres != 0; eps->solved = false; return KS_SUCCESS;
 }
 extern "C" int ks_eps_get_true_residual(ks_eps eps, int *trueres) { KS_CHECK(eps && trueres, KS_ERR_ARG_NULL, "NULL argument"); *trueres = eps->trueres ? 1 : 0; return KS_SUCCESS; }
+extern "C" int ks_eps_set_purify(ks_eps eps, int purify)                    // EPSSetPurify epsopts.c (generalized symmetric problems)
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  eps->purify = purify != 0; eps->solved = false; return KS_SUCCESS;
+}
+extern "C" int ks_eps_get_purify(ks_eps eps, int *purify) { KS_CHECK(eps && purify, KS_ERR_ARG_NULL, "NULL argument"); *purify = eps->purify ? 1 : 0; return KS_SUCCESS; }
+extern "C" int ks_eps_set_track_all(ks_eps eps, int trackall)                // EPSSetTrackAll epsopts.c: residual estimates of all Ritz pairs at every restart
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  eps->trackall = trackall != 0; return KS_SUCCESS;
+}
+extern "C" int ks_eps_get_krylovschur(ks_eps eps, double *keep, int *lock)   // EPSKrylovSchurGetRestart / GetLocking
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  if (keep) *keep = eps->keep; if (lock) *lock = eps->lock ? 1 : 0;
+  return KS_SUCCESS;
+}
 extern "C" int ks_eps_set_balance(ks_eps eps, int bal, int its, double cutoff)   // EPSSetBalance epsopts.c:1050-1095 (its, cutoff: 0 keeps)
 {
   KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
@@ -731,7 +749,7 @@ static int ritz_vector(ks_eps eps, int nv, const double *Zr, const double *Zi)
   KS_CALL(ks_bv_set_active_columns(V, 0, nv));
   double *x = ks_bv_col(W, 3), *y = ks_bv_col(W, 4);
   KS_CALL(ks_bv_multvec(V, 1.0, 0.0, x, Zr));
-  if (eps->ghep) {                                                                   // eps->purify (epssetup.c:365-373)
+  if (eps->ghep && eps->purify) {                                                    // eps->purify (epssetup.c:365-373)
     double norm = 0.0;
     KS_CALL(ks_mat_mult_internal(eps->op, x, y));
     KS_CALL(ksb_norm_b(V, y, &norm));
@@ -847,7 +865,7 @@ static int solve_nhep(ks_eps eps, long long passes0)
       eps->errest[k] = converged_estimate(eps, re, im, resnorm);
       if (marker == -1 && eps->errest[k] >= eps->tol) marker = k;
       if (newk == k + 1) { eps->errest[k + 1] = eps->errest[k]; k++; }
-      if (marker != -1) break;
+      if (marker != -1 && !eps->trackall) break;               // getall: estimates for every Ritz pair (epskrylov.c:240,280)
     }
     k = (marker != -1) ? marker : nv;
     KS_CHECK(!eps->cb_err, eps->cb_err, "the user's convergence test returned %d", eps->cb_err);
@@ -1056,7 +1074,7 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
       }
       eps->errest[k] = converged_estimate(eps, re, 0.0, resnorm);
       if (marker == -1 && eps->errest[k] >= eps->tol) marker = k;
-      if (marker != -1) break;
+      if (marker != -1 && !eps->trackall) break;               // getall: estimates for every Ritz pair (epskrylov.c:240,280)
     }
     if (marker != -1) k = marker;
     // EPSStoppingBasic
@@ -1091,13 +1109,20 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   // EPSComputeValues (epssolve.c:27-41): map the eigenvalues back through the ST
   const int nc = eps->nconv;
   if (eps->cmp_ds.map) ks_st_backtransform_internal(eps->cmp_ds.map, nc, eps->eigr.data(), eps->eigi.data());
-  if (ghep) {
+  if (ghep && eps->purify) {
     // EPSComputeVectors_Hermitian epsdefault.c:27-49: purification x <- OP x (EPS_Purify epsimpl.h:297-312), then B-normalise
     for (int i = 0; i < nc; i++) {
       KS_CALL(ksk_copy(eps->ctx, ks_bv_col(V, i), ks_bv_col(eps->W, 0), V->n));
       KS_CALL(ks_mat_mult_internal(eps->op, ks_bv_col(eps->W, 0), ks_bv_col(V, i)));
     }
     KS_CALL(ks_bv_normalize(V, nullptr));
+  } else if (ghep && cayley) {
+    // without purification the Lanczos vectors are the eigenvectors; under the Cayley transformation they are orthonormal in
+    // the A + nu B inner product and still have to be B-normalised (epsdefault.c:38-47)
+    KS_CALL(ks_bv_set_matrix(V, eps->B));
+    int rc = ks_bv_normalize(V, nullptr);
+    KS_CALL(ks_bv_set_matrix(V, st->bil));
+    if (rc) return rc;
   }
   // SlepcSortEigenvalues slepcsc.c:89-140 (all eigenvalues real here)
   for (int i = 0; i <= ncv; i++) eps->perm[i] = i;

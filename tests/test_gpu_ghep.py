@@ -213,3 +213,27 @@ def test_eps_test32_ghep_symmetric_b_golden(ctx):
     assert np.allclose(np.round(lam, 5), ref, atol=1.5e-5)
     X = np.stack([eps.GetEigenvector(i) for i in range(60)], axis=1)
     assert np.abs(X.T @ (B @ X) - np.eye(60)).max() < 1e-8
+
+
+def test_eps_test1_nopurify_and_trackall(ctx):
+    """test1_1_ks_nopurify (-eps_purify 0) reprints test1_1.out; EPSSetTrackAll makes every restart report the estimates of all
+    Ritz pairs of the active block to the monitor."""
+    import slepc_amd as ks
+    Ao, Bo = _test1_pencil()
+    A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val); B = ks.Mat.from_csr(ctx, Bo.rowptr, Bo.col, Bo.val)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A, B); eps.SetProblemType(ks.EPS_GHEP); eps.SetDimensions(4); eps.SetTolerances(0.0, 1500)
+    eps.SetConvergenceTest("norm"); eps.SetPurify(False); eps.SetTrackAll(True)
+    eps.GetST().SetKSP(rtol=1e-14)
+    seen = []
+    eps.MonitorSet(lambda its, nconv, er, ei, ee: seen.append((nconv, ee.copy())))
+    eps.Solve()
+    r = O.eps_krylovschur_hep(Ao, 4, max_it=1500, st=O.ST(Ao, Bo, "shift", 0.0), B=Bo, conv="norm", purify=False)
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(eps.GetConverged())])
+    assert np.allclose(np.round(lam[:4], 5), gi.eigenvalues_line(gi.read("eps/eps_test1_1.out")), atol=1.5e-5)
+    assert eps.GetConverged() == r.nconv and eps.GetIterationNumber() == r.its and np.allclose(lam, r.eigr[r.perm], rtol=1e-10)
+    X = np.stack([eps.GetEigenvector(i) for i in range(r.nconv)], axis=1)
+    assert np.abs(X.T @ (Bo.to_scipy() @ X) - np.eye(r.nconv)).max() < 1e-8
+    nconv0, ee0 = seen[0]
+    assert np.all(ee0[nconv0:] > 0.0) and len(ee0) >= 16                # every pair of the first factorisation carries an estimate
+    assert eps.KrylovSchurGet() == (0.5, True)

@@ -567,3 +567,13 @@ def test_eps_test22_balance_oneside_golden():
     assert np.allclose(np.round(_as_complex(r, 4), 5), ref, atol=1.5e-5)
     for i in range(4):
         assert O.eps_compute_error_nhep(Ao, r, i) < 1e-6
+
+
+def test_eps_test1_nopurify_golden():
+    """test1_1_ks_nopurify: -eps_purify 0 reprints test1_1.out: without purification the Lanczos vectors themselves are the
+    (B-orthonormal) eigenvectors."""
+    A, B = _test1_pencil()
+    r = O.eps_krylovschur_hep(A, 4, max_it=1500, st=O.ST(A, B, "shift", 0.0), B=B, conv="norm", purify=False)
+    assert np.allclose(np.round(r.eigr[r.perm][:4], 5), gi.eigenvalues_line(gi.read("eps/eps_test1_1.out")), atol=1.5e-5)
+    X = np.stack([r.V.column(j) for j in range(r.nconv)], axis=1)
+    assert np.abs(X.T @ (B.to_scipy() @ X) - np.eye(r.nconv)).max() < 1e-8
