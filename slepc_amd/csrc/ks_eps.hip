@@ -1022,6 +1022,7 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
     KS_CALL(build_balance(eps));
     if (!eps->bal_op) KS_CALL(ks_mat_create_shell(eps->ctx, A->n, A->row_start, A->n_global, balanced_mult, eps, &eps->bal_op));
     eps->bal_op->n = A->n; eps->bal_op->row_start = A->row_start; eps->bal_op->n_global = A->n_global;
+    eps->bal_op->shell_nosync = !eps->op_inner->shell_mult;         // D A D^-1 on an assembled matrix is three kernel launches: keep the enqueued-ahead run
     eps->op = eps->bal_op; eps->balanced = true;
   }
   KS_CHECK(eps->extraction == KS_EPS_RITZ || !ghep, KS_ERR_SUP, "harmonic extraction with a B-inner product is not built");

@@ -662,7 +662,7 @@ static int krylov_run(ks_bv V, ks_mat A, int k, int *m, double *beta, int *break
   const int m0 = *m;
   int lin = 0;
   double nrm_last = 0.0;
-  if (use_fused(V) && m0 < V->N && !A->shell_mult) {      // a matrix-free operator may synchronise: take it one column at a time
+  if (use_fused(V) && m0 < V->N && (!A->shell_mult || A->shell_nosync)) {      // a matrix-free operator may synchronise: take it one column at a time
     // The whole run is enqueued with the optimistic two-pass program per step; a device-side breakdown, or a
     // column that needs more than the optimistic program, turns the remaining steps into no-ops. In the second
     // case the host completes that one column and re-enqueues the rest of the run.

@@ -116,6 +116,7 @@ struct ks_mat_s {
   double *send_buf = nullptr;
   // matrix-free operator (MATSHELL with MATOP_MULT): y = shell_mult(user, x); may synchronise the host
   int (*shell_mult)(void *user, const double *x_dev, double *y_dev) = nullptr;
+  bool shell_nosync = false;                  // the callback only enqueues work on the context's stream: a Krylov run may be enqueued ahead through it
   void *shell_user = nullptr;
 };
 int ks_mat_get_diagonal_internal(ks_mat A, double *d_dev);
