@@ -144,6 +144,7 @@ typedef int (*ks_shell_mult_fn)(void *user, const double *x_dev, double *y_dev);
 int ks_mat_create_shell(ks_ctx ctx, int n_local, int row_start, int n_global, ks_shell_mult_fn mult, void *user, ks_mat *A);
 int ks_mat_norm_inf(ks_mat A, double *val);                             /* MatNorm(A,NORM_INFINITY) */
 int ks_mat_get_diagonal(ks_mat A, double *d_dev);                      /* MatGetDiagonal (local diagonal block) */
+int ks_mat_shell_set_enqueue_only(ks_mat A, int flag);   /* the callback only enqueues work on the context's stream: Krylov runs are then enqueued ahead through it */
 int ks_mat_destroy(ks_mat A);
 int ks_mat_get_sizes(ks_mat A, int *n_local, int *n_global, long long *nnz_local);
 /* device layout chosen at assembly for the local diagonal block (KSGPU_SPMV=csr|sell|sliced overrides the choice) */

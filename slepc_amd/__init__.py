@@ -228,6 +228,9 @@ class Mat:
         m._cb = cb                      # keep the trampoline alive as long as the matrix
         return m
 
+    def set_enqueue_only(self, flag=True):
+        _lib.check(self.ctx.L.ks_mat_shell_set_enqueue_only(self.h, int(bool(flag))))
+
     def layout(self):
         v = C.c_int(); _lib.check(self.ctx.L.ks_mat_get_layout(self.h, C.byref(v)))
         return ["csr", "sell", "sliced", "shell", "dict", "odict"][v.value]

@@ -47,6 +47,7 @@ _SIG = {
     "ks_mat_get_layout": [vp, ip],
     "ks_mat_load_petsc_binary": [vp, C.c_char_p, C.POINTER(vp)],
     "ks_mat_create_shell": [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(vp)],
+    "ks_mat_shell_set_enqueue_only": [vp, C.c_int],
     "ks_mat_get_diagonal": [vp, vp],
     "ks_mat_norm_inf": [vp, dp],
     "ks_mat_get_sizes": [vp, ip, ip, llp],

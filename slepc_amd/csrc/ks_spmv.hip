@@ -867,6 +867,15 @@ extern "C" int ks_mat_destroy(ks_mat A)
   return KS_SUCCESS;
 }
 
+// A matrix-free operator whose callback only enqueues work on the context's stream (no host synchronisation, no host reads of
+// device results) lets BVMatLanczos / BVMatArnoldi enqueue the whole run ahead, as they do for assembled matrices.
+extern "C" int ks_mat_shell_set_enqueue_only(ks_mat A, int flag)
+{
+  KS_CHECK(A, KS_ERR_ARG_NULL, "Mat is NULL");
+  KS_CHECK(A->shell_mult, KS_ERR_ARG_WRONGSTATE, "not a matrix-free operator");
+  A->shell_nosync = flag != 0;
+  return KS_SUCCESS;
+}
 extern "C" int ks_mat_get_layout(ks_mat A, int *layout)     // storage of the diagonal block: KS_MAT_LAYOUT_*
 {
   KS_CHECK(A && layout, KS_ERR_ARG_NULL, "NULL argument");

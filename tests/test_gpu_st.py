@@ -57,6 +57,15 @@ def test_shell_matrix_drives_arnoldi_and_eps(ctx):
     assert out[0][1] == out[1][1] and out[0][2] == out[1][2]                 # same restarts, steps and passes
     assert np.allclose(out[0][0], out[1][0], rtol=1e-13)
     assert len(calls) > out[1][2]["arnoldi_steps"]
+    # an enqueue-only callback (no host synchronisation inside) keeps the whole run enqueued ahead: same numbers
+    S2 = ks.Mat.shell(ctx, Ao.n, lambda x, y: A.mult_dev(x, y))
+    S2.set_enqueue_only(True)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(S2); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(4, 20)
+    eps.Solve()
+    assert ([eps.GetEigenvalue(i)[0] for i in range(4)], eps.GetIterationNumber(), eps.GetStats()) == out[0]
+    with pytest.raises(ks.KsError):
+        A.set_enqueue_only(True)                                            # not a matrix-free operator
 
 
 @pytest.mark.parametrize("kind,withB,sigma", [("shift", False, 0.7), ("shift", True, 0.3), ("sinvert", False, 1.3), ("sinvert", True, 0.0), ("sinvert", True, 35.0)])
