@@ -232,6 +232,7 @@ int ks_st_setup_internal(ks_st st)
   }
   if (!st->op) KS_CALL(ks_mat_create_shell(ctx, A->n, A->row_start, A->n_global, st_shell_mult, st, &st->op));
   st->op->n = A->n; st->op->row_start = A->row_start; st->op->n_global = A->n_global;
+  st->op->shell_nosync = !need_solve;                         // a plain shift is two kernel launches: Krylov runs stay enqueued ahead
   if (st->type == KS_ST_CAYLEY) {
     if (!st->bil) KS_CALL(ks_mat_create_shell(ctx, A->n, A->row_start, A->n_global, st_bilinear_mult, st, &st->bil));
     st->bil->n = A->n; st->bil->row_start = A->row_start; st->bil->n_global = A->n_global;
