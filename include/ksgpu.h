@@ -284,6 +284,7 @@ int ks_eps_get_purify(ks_eps eps, int *purify);
 int ks_eps_set_track_all(ks_eps eps, int trackall);                          /* EPSSetTrackAll: error estimates of all Ritz pairs at every restart (for monitors) */
 int ks_eps_get_krylovschur(ks_eps eps, double *keep, int *lock);             /* EPSKrylovSchurGetRestart / EPSKrylovSchurGetLocking */
 int ks_eps_set_balance(ks_eps eps, int bal, int its, double cutoff);        /* EPSSetBalance epsopts.c:1050 (non-symmetric problems; EPSBuildBalance_Krylov epsdefault.c:370); its / cutoff 0 keep 5 / 1e-8 */
+int ks_eps_set_balance_matrix(ks_eps eps, const double *D_dev);             /* STSetBalanceMatrix on the solver's ST: EPS_BALANCE_USER with this diagonal (device, n_local, copied) */
 int ks_eps_get_balance(ks_eps eps, int *bal, int *its, double *cutoff);
 int ks_eps_set_true_residual(ks_eps eps, int trueres);                    /* EPSSetTrueResidual: convergence on ||A x - k B x|| of the Ritz vector (epskrylov.c:256-264) */
 int ks_eps_get_true_residual(ks_eps eps, int *trueres);

@@ -810,6 +810,11 @@ class EPS:
     def KrylovSchurGet(self):
         k = C.c_double(); l = C.c_int(); _lib.check(self.ctx.L.ks_eps_get_krylovschur(self.h, C.byref(k), C.byref(l))); return k.value, bool(l.value)
 
+    def SetBalanceMatrix(self, D):
+        """EPS_BALANCE_USER with the diagonal D (host array of the local rows)."""
+        tmp = BV(self.ctx, self._A.n, 1); tmp.set_column(0, _f64(D))
+        _lib.check(self.ctx.L.ks_eps_set_balance_matrix(self.h, C.c_void_p(tmp.column_ptr(0))))
+
     def SetTrueResidual(self, flag=True):
         _lib.check(self.ctx.L.ks_eps_set_true_residual(self.h, int(bool(flag))))
 

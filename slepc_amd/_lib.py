@@ -154,6 +154,7 @@ _SIG = {
     "ks_eps_get_extraction": [vp, C.POINTER(C.c_int)],
     "ks_eps_set_true_residual": [vp, C.c_int],
     "ks_eps_set_balance": [vp, C.c_int, C.c_int, C.c_double],
+    "ks_eps_set_balance_matrix": [vp, vp],
     "ks_eps_set_purify": [vp, C.c_int], "ks_eps_get_purify": [vp, C.POINTER(C.c_int)], "ks_eps_set_track_all": [vp, C.c_int],
     "ks_eps_get_krylovschur": [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)],
     "ks_eps_get_balance": [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)],

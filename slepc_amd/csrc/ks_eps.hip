@@ -507,11 +507,25 @@ extern "C" int ks_eps_set_balance(ks_eps eps, int bal, int its, double cutoff)  
 {
   KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
   KS_CHECK(bal >= KS_EPS_BALANCE_NONE && bal <= KS_EPS_BALANCE_USER, KS_ERR_ARG_OUTOFRANGE, "Invalid value of argument 'bal'");
-  KS_CHECK(bal != KS_EPS_BALANCE_USER, KS_ERR_SUP, "a user-provided balancing matrix is not built");
+  KS_CHECK(bal != KS_EPS_BALANCE_USER || eps->D, KS_ERR_ORDER, "EPS_BALANCE_USER: hand the diagonal over first (STSetBalanceMatrix: ks_eps_set_balance_matrix)");
   KS_CHECK(its >= 0, KS_ERR_ARG_OUTOFRANGE, "Illegal value of its. Must be >= 0");
   KS_CHECK(cutoff >= 0.0, KS_ERR_ARG_OUTOFRANGE, "Illegal value of cutoff. Must be >= 0");
   eps->balance = bal; if (its) eps->balance_its = its; if (cutoff > 0.0) eps->balance_cutoff = cutoff;
   eps->solved = false;
+  return KS_SUCCESS;
+}
+// EPS_BALANCE_USER: the diagonal of the balancing matrix comes from the caller (STSetBalanceMatrix stfunc.c on the solver's ST);
+// n_local positive doubles on the device, copied. Selects KS_EPS_BALANCE_USER.
+extern "C" int ks_eps_set_balance_matrix(ks_eps eps, const double *D_dev)
+{
+  KS_CHECK(eps && eps->A && D_dev, KS_ERR_ORDER, "set the operators first; D must not be NULL");
+  const long long n = eps->A->n;
+  KS_HIP(hipSetDevice(eps->ctx->device));
+  if (eps->D_n != n || !eps->D) { if (eps->D) hipFree(eps->D); if (eps->wb) hipFree(eps->wb); eps->D = eps->wb = nullptr;
+    KS_HIP(hipMalloc(&eps->D, sizeof(double) * std::max<long long>(n, 1))); KS_HIP(hipMalloc(&eps->wb, sizeof(double) * std::max<long long>(n, 1))); eps->D_n = (int)n; }
+  KS_HIP(hipMemcpyAsync(eps->D, D_dev, sizeof(double) * n, hipMemcpyDeviceToDevice, eps->ctx->stream));
+  KS_HIP(hipStreamSynchronize(eps->ctx->stream));
+  eps->balance = KS_EPS_BALANCE_USER; eps->solved = false;
   return KS_SUCCESS;
 }
 extern "C" int ks_eps_get_balance(ks_eps eps, int *bal, int *its, double *cutoff)
@@ -1017,9 +1031,10 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   // balancing of non-symmetric problems (epssetup.c:383-391): build D, then expand with D Op D^-1
   eps->balanced = false;
   if ((ptype == KS_EPS_NHEP || ptype == KS_EPS_GNHEP) && eps->balance != KS_EPS_BALANCE_NONE) {
-    KS_CHECK(eps->balance == KS_EPS_BALANCE_ONESIDE, KS_ERR_SUP, "only one-sided balancing is built (the two-sided form needs the transposed operator)");
+    KS_CHECK(eps->balance == KS_EPS_BALANCE_ONESIDE || eps->balance == KS_EPS_BALANCE_USER, KS_ERR_SUP, "only one-sided and user-provided balancing are built (the two-sided form needs the transposed operator)");
     eps->op_inner = eps->op;
-    KS_CALL(build_balance(eps));
+    if (eps->balance == KS_EPS_BALANCE_ONESIDE) KS_CALL(build_balance(eps));
+    else KS_CHECK(eps->D && eps->D_n == A->n, KS_ERR_ORDER, "EPS_BALANCE_USER: the balancing matrix does not match the operator");
     if (!eps->bal_op) KS_CALL(ks_mat_create_shell(eps->ctx, A->n, A->row_start, A->n_global, balanced_mult, eps, &eps->bal_op));
     eps->bal_op->n = A->n; eps->bal_op->row_start = A->row_start; eps->bal_op->n_global = A->n_global;
     eps->bal_op->shell_nosync = !eps->op_inner->shell_mult;         // D A D^-1 on an assembled matrix is three kernel launches: keep the enqueued-ahead run

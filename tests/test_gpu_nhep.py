@@ -556,3 +556,10 @@ def test_eps_test22_balance_oneside_golden(ctx):
     assert e.value.rc == 56
     eps.SetBalance("none"); eps.Solve()
     assert eps.GetConverged() >= 4
+    # EPS_BALANCE_USER: the caller's diagonal (here a row-norm scaling) instead of the Krylov-built one
+    Dn = 1.0 / np.sqrt(np.asarray(abs(S).sum(axis=1)).ravel())
+    eps.SetBalanceMatrix(Dn); eps.Solve()
+    lam2 = np.array([complex(*eps.GetEigenvalue(i)) for i in range(4)])
+    assert np.allclose(np.sort_complex(lam2), np.sort_complex(lam), rtol=1e-6)
+    for i in range(4):
+        assert eps.ComputeError(i) < 1e-6
