@@ -412,7 +412,13 @@ extern "C" int ks_eps_set_operators(ks_eps eps, ks_mat A, ks_mat B)   // epssetu
 {
   KS_CHECK(eps && A, KS_ERR_ARG_NULL, "NULL argument");
   KS_CHECK(!B || (B->n == A->n && B->n_global == A->n_global), KS_ERR_ARG_INCOMP, "Mismatching dimensions of A (%d) and B (%d)", A->n, B ? B->n : 0);
-  if (eps->V && eps->A && eps->A->n != A->n) { ks_bv_destroy(eps->V); ks_bv_destroy(eps->W); eps->V = eps->W = nullptr; }
+  if (eps->A && eps->A->n != A->n) {                                   // EPSReset (epsbasic.c): everything sized by the old operator goes
+    ks_bv_destroy(eps->V); ks_bv_destroy(eps->W); eps->V = eps->W = nullptr;
+    ks_bv_destroy(eps->defl); eps->defl = nullptr; eps->nds = 0;
+    eps->have_v0 = false; eps->v0.clear();
+    if (eps->D) { hipFree(eps->D); eps->D = nullptr; } if (eps->wb) { hipFree(eps->wb); eps->wb = nullptr; } eps->D_n = 0;
+    if (eps->balance == KS_EPS_BALANCE_USER) eps->balance = KS_EPS_BALANCE_NONE;
+  }
   eps->A = A; eps->B = B; eps->solved = false; eps->nrma = eps->nrmb = 0.0;
   if (eps->st) KS_CALL(ks_st_set_matrices(eps->st, A, B));
   return KS_SUCCESS;
@@ -1020,6 +1026,7 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   eps->problem_type_resolved_hermitian = (ptype == KS_EPS_HEP || ghep) && eps->extraction != KS_EPS_HARMONIC;
   eps->vectors_done = true;
   if (eps->nds) {                                                      // process the deflation space (epssetup.c:397-404)
+    KS_CHECK(eps->defl && eps->defl->n == A->n, KS_ERR_ARG_INCOMP, "the deflation space was set for an operator of another size");
     std::vector<const double *> cp(eps->nds);
     for (int i = 0; i < eps->nds; i++) cp[i] = ks_bv_col(eps->defl, i);
     int kd = eps->nds;

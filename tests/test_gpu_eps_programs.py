@@ -200,3 +200,17 @@ def test_tiny_problems(ctx, n, ptype):
     kr, ki = eps.GetEigenvalue(0)
     assert abs(abs(complex(kr, ki)) - abs(top)) < 1e-9 * max(1.0, abs(top))
     assert eps.ComputeError(0) < 1e-7
+
+
+def test_operator_of_another_size_drops_what_was_sized_by_the_old_one(ctx):
+    """EPSSetOperators with a matrix of another size resets the solver (EPSReset): initial vector, deflation space and a
+    user balancing matrix of the old size are forgotten instead of being read out of bounds."""
+    import slepc_amd as ks
+    S1, S2 = sc.laplacian2d_csr(9, 7), sc.laplacian2d_csr(15, 12)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(_mat(ctx, S1)); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(2)
+    eps.SetInitialVector(np.ones(S1.shape[0])); eps.SetDeflationSpace(np.random.default_rng(0).standard_normal((S1.shape[0], 2)))
+    eps.SetOperators(_mat(ctx, S2))
+    eps.Solve()
+    r = O.eps_krylovschur_hep(_csr(S2), 2)
+    assert eps.GetIterationNumber() == r.its and np.allclose([eps.GetEigenvalue(i)[0] for i in range(2)], r.eigr[r.perm][:2], rtol=1e-10)
