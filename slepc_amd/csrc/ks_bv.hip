@@ -124,7 +124,7 @@ int ks_sweep_grid_for(ks_ctx ctx, int n, int vec, const void *kernel, int force_
   int per_cu = 4;
   if (bmul > 0) per_cu = bmul;
   else if (kernel) {
-    static std::vector<std::pair<const void *, int>> cache;
+    static thread_local std::vector<std::pair<const void *, int>> cache;       // per thread: contexts may live on different threads
     bool found = false;
     for (auto &e : cache) if (e.first == kernel) { per_cu = e.second; found = true; break; }
     if (!found) {
