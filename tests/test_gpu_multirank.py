@@ -129,6 +129,19 @@ def _worker(rank, world, port, q):
         e4.Solve()
         res["c5_eig"] = [list(e4.GetEigenvalue(i)) for i in range(4)]; res["c5_its"] = e4.GetIterationNumber()
         res["c5_err"] = [e4.ComputeError(i) for i in range(4)]
+        # (6) test39.c: one solver, two solves with matrices whose LOCAL sizes differ (the 10x11 2-D Laplacian with one row moved
+        # from rank 1 to rank 0, then the other way); EPSSetOperators drops what was sized by the first matrix
+        L2 = O.laplacian2d(10, 11)
+        e5 = ks.EPS(ctx); e5.SetProblemType(ks.EPS_HEP); e5.SetWhichEigenpairs("smallest_real"); e5.SetDimensions(3)
+        res["t39"] = []
+        for shift in (1, -1):
+            cnt = [b - a for a, b in P.split_ownership(L2.n, world)]
+            cnt[0] += shift; cnt[1] -= shift
+            s0 = sum(cnt[:rank]); s1 = s0 + cnt[rank]
+            Ml = ks.Mat.from_csr(ctx, *P.local_block(L2.rowptr, L2.col, L2.val, s0, s1), row_start=s0, n_global=L2.n)
+            e5.SetOperators(Ml); e5.Solve()
+            res["t39"].append(([e5.GetEigenvalue(i)[0] for i in range(3)], e5.GetIterationNumber(), e5.GetConverged(),
+                               max(e5.ComputeError(i) for i in range(3)), len(e5.GetEigenvector(0)), s1 - s0))
         dist.barrier()
         q.put((rank, res))
     except Exception as e:      # noqa: BLE001
@@ -191,6 +204,17 @@ def test_ranks_sharing_one_gpu_against_oracle(world):
     for rk in range(world):
         assert out[rk]["c5_its"] == r5.its and np.allclose(np.array(out[rk]["c5_eig"]), ref5, rtol=1e-8, atol=1e-9)
         assert max(out[rk]["c5_err"]) < 1e-6
+    import golden_inputs as gi
+    r39 = O.eps_krylovschur_hep(O.laplacian2d(10, 11), 3, which="smallest_real")
+    g39 = gi.eigenvalue_lines(gi.read("eps/eps_test39_1.out"))                  # first and second solve
+    assert len(g39) == 2
+    for rk in range(world):
+        first, second = out[rk]["t39"]
+        for (lam, its, nconv, err, nvec, nloc), gold in zip((first, second), g39):
+            assert its == r39.its and nconv == r39.nconv and err < 1e-8 and nvec == nloc
+            assert np.allclose(lam, r39.eigr[r39.perm][:3], rtol=1e-10)
+            assert np.allclose(np.round(lam, 5), gold, atol=1.5e-5)
+        assert first[5] - second[5] == (2 if rk == 0 else -2 if rk == 1 else 0)
     cross = np.sum([np.array(out[rk]["defl_cross_vec"]) for rk in range(world)], axis=0)     # global C' x from the ranks' parts
     assert np.abs(cross).max() < 1e-10
     for rk in range(1, world):

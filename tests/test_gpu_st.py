@@ -68,6 +68,27 @@ def test_shell_matrix_drives_arnoldi_and_eps(ctx):
         A.set_enqueue_only(True)                                            # not a matrix-free operator
 
 
+def test_eps_ex3_shell_golden(ctx):
+    """ex3.c -eps_nev 4: the 72x72 2-D Laplacian applied by a user callback (matrix-free)."""
+    import slepc_amd as ks
+    Ao = O.laplacian2d(72)
+    A = _mat(ctx, Ao)
+
+    def mult(x, y):
+        A.mult_dev(x, y)
+        ctx.L.ks_ctx_synchronize(ctx.h)
+
+    S = ks.Mat.shell(ctx, Ao.n, mult)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(S); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(4)
+    eps.Solve()
+    r = O.eps_krylovschur_hep(Ao, 4)
+    lam = np.array([eps.GetEigenvalue(i)[0] for i in range(4)])
+    assert eps.GetConverged() == r.nconv and eps.GetIterationNumber() == r.its
+    assert np.allclose(np.round(lam, 5), gi.eigenvalues_line(gi.read("eps/ex3_1.out")), atol=1.5e-5)
+    assert np.allclose(lam, r.eigr[r.perm][:4], rtol=1e-12)
+
+
 @pytest.mark.parametrize("kind,withB,sigma", [("shift", False, 0.7), ("shift", True, 0.3), ("sinvert", False, 1.3), ("sinvert", True, 0.0), ("sinvert", True, 35.0)])
 def test_st_apply_matches_oracle(ctx, kind, withB, sigma):
     import slepc_amd as ks

@@ -212,6 +212,39 @@ def test_eps_test9_golden():
         assert O.eps_compute_error_nhep(A, r, i) < 1e-9
 
 
+def test_eps_ex18_golden():
+    """ex18 -eps_nev 4 (Markov model m=15, EPS_NHEP, user comparison: closest to 0.5 on its right side)
+    -> 0.51928, 0.55740, 0.57028, 0.57143."""
+    import nhep_cases as nc
+    A = O.markov_matrix(15)
+    r = O.eps_krylovschur_nhep(A, 4, which=nc.right_of(0.5))
+    ref = gi.eigenvalues_line(gi.read("eps/ex18_1.out"))
+    assert r.nconv >= 4 and r.reason > 0 and np.all(r.eigi[r.perm][:4] == 0)
+    assert np.allclose(np.round(r.eigr[r.perm][:4], 5), ref, atol=1.5e-5)
+    for i in range(4):
+        assert O.eps_compute_error_nhep(A, r, i) < 1e-8
+
+
+def test_eps_ex3_golden():
+    """ex3 -eps_nev 4 (the 2-D Laplacian of ex2 on a 72x72 grid applied matrix-free, EPS_HEP)
+    -> 7.99630, 7.99074, 7.98519, 7.98150."""
+    A = O.laplacian2d(72)
+    r = O.eps_krylovschur_hep(A, 4)
+    ref = gi.eigenvalues_line(gi.read("eps/ex3_1.out"))
+    assert r.nconv >= 4 and r.reason > 0
+    assert np.allclose(np.round(r.eigr[r.perm][:4], 5), ref, atol=1.5e-5)
+
+
+def test_eps_test39_golden():
+    """test39.c -terse (10x11 2-D Laplacian, 3 smallest, solved twice with the rows distributed differently)
+    -> 0.14916, 0.34896, 0.38564 for both solves."""
+    r39 = O.eps_krylovschur_hep(O.laplacian2d(10, 11), 3, which="smallest_real")
+    g = gi.eigenvalue_lines(gi.read("eps/eps_test39_1.out"))
+    assert len(g) == 2
+    for gold in g:
+        assert np.allclose(np.round(r39.eigr[r39.perm][:3], 5), gold, atol=1.5e-5)
+
+
 def test_eps_nhep_complex_pairs():
     """Conjugate pairs: kept together by DSSort/trexc, by the restart size (DSGetTruncateSize) and by the final sort;
     eigenvalues are true eigenvalues and the real-arithmetic residual of EPSComputeError is below tol."""
