@@ -141,3 +141,9 @@ def eigenvalues_block(text):
         out += [float(t) for t in lines[i].replace(",", " ").split()]
         i += 1
     return np.array(out)
+
+
+def eigenvalues_after(text, marker):
+    """The numbers that follow `marker` on its own line (programs that print their values after a sentence)."""
+    line = next(l for l in text.splitlines() if marker in l)
+    return np.array([float(t) for t in line.split(marker, 1)[1].replace(",", " ").split()])

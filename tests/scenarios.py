@@ -357,3 +357,12 @@ def test32_pencil(n):
     B[0, 1] = 0.4; B[1, 0] = 0.4
     B = B.tocsr(); B.sort_indices()
     return A, B
+
+
+def folded_csr(Ao, target=0.0):
+    """ex24.c MatMult_Fold (ex24.c:192-205) as an explicit matrix: (A - target I)^2, for the CPU side of the comparison."""
+    import scipy.sparse as sp
+    from oracle import oracle as O
+    S = Ao.to_scipy() - target * sp.identity(Ao.n, format="csr")
+    F = (S @ S).tocsr(); F.sort_indices()
+    return O.CSR(Ao.n, F.indptr, F.indices, F.data)

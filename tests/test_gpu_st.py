@@ -89,6 +89,33 @@ def test_eps_ex3_shell_golden(ctx):
     assert np.allclose(lam, r.eigr[r.perm][:4], rtol=1e-12)
 
 
+def test_eps_ex24_spectrum_folding_golden(ctx):
+    """ex24.c: the operator is a callback applying (A - target I)^2 with two products of the library's own SpMV."""
+    import slepc_amd as ks
+    import scenarios as sc
+    Ao = O.laplacian2d(15)
+    A = _mat(ctx, Ao)
+    W = ks.BV(ctx, Ao.n, 1)
+
+    def fold(x, y):                      # target = 0: y = A (A x)
+        A.mult_dev(x, W.column_ptr(0))
+        A.mult_dev(W.column_ptr(0), y)
+
+    S = ks.Mat.shell(ctx, Ao.n, fold)
+    S.set_enqueue_only(True)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(S); eps.SetProblemType(ks.EPS_HEP); eps.SetWhichEigenpairs("smallest_real")
+    eps.SetDimensions(1, 12); eps.SetTolerances(1e-5, 1000)
+    eps.Solve()
+    r = O.eps_krylovschur_hep(sc.folded_csr(Ao, 0.0), 1, ncv=12, max_it=1000, tol=1e-5, which="smallest_real")
+    assert eps.GetConverged() >= 1 and eps.GetConvergedReason() > 0
+    assert abs(eps.GetIterationNumber() - r.its) <= max(2, r.its // 10)      # two products vs the explicit square: rounding only
+    x = eps.GetEigenvector(0)
+    theta = float(x @ Ao.mult(x))
+    assert abs(round(theta, 5) - gi.eigenvalues_after(gi.read("eps/ex24_1.out"), "required tolerance:")[0]) < 1.5e-5
+    assert abs(eps.GetEigenvalue(0)[0] - r.eigr[r.perm][0]) < 1e-5 * abs(r.eigr[r.perm][0]) + 1e-9
+
+
 @pytest.mark.parametrize("kind,withB,sigma", [("shift", False, 0.7), ("shift", True, 0.3), ("sinvert", False, 1.3), ("sinvert", True, 0.0), ("sinvert", True, 35.0)])
 def test_st_apply_matches_oracle(ctx, kind, withB, sigma):
     import slepc_amd as ks

@@ -245,6 +245,18 @@ def test_eps_test39_golden():
         assert np.allclose(np.round(r39.eigr[r39.perm][:3], 5), gold, atol=1.5e-5)
 
 
+def test_eps_ex24_golden():
+    """ex24 -n 15 -eps_nev 1 -eps_ncv 12 -eps_max_it 1000 -eps_tol 1e-5: spectrum folding, the smallest eigenvalue of
+    (A - 0 I)^2 and the Rayleigh quotient of its vector with A (ex24.c:209-221) -> 0.07686."""
+    A = O.laplacian2d(15)
+    r = O.eps_krylovschur_hep(sc.folded_csr(A, 0.0), 1, ncv=12, max_it=1000, tol=1e-5, which="smallest_real")
+    assert r.nconv >= 1 and r.reason > 0
+    x = r.V.column(0)
+    theta = float(x @ A.mult(x))
+    assert abs(round(theta, 5) - gi.eigenvalues_after(gi.read("eps/ex24_1.out"), "required tolerance:")[0]) < 1.5e-5
+    assert np.linalg.norm(A.mult(x) - theta * x) / abs(theta) < 1e-2
+
+
 def test_eps_nhep_complex_pairs():
     """Conjugate pairs: kept together by DSSort/trexc, by the restart size (DSGetTruncateSize) and by the final sort;
     eigenvalues are true eigenvalues and the real-arithmetic residual of EPSComputeError is below tol."""
