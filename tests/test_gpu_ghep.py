@@ -215,6 +215,26 @@ def test_eps_test32_ghep_symmetric_b_golden(ctx):
     assert np.abs(X.T @ (B @ X) - np.eye(60)).max() < 1e-8
 
 
+@pytest.mark.parametrize("ptype", ["ghep", "gnhep"])
+def test_eps_test32_4_every_eigenvalue_golden(ctx, ptype):
+    """test32 suffix 4 / 4_gnhep: -n 8 -eps_nev 64, all 64 eigenvalues of the 64 x 64 pencil (the basis fills the space and the
+    run ends on the breakdown of its last step)."""
+    import slepc_amd as ks
+    import scenarios as sc2
+    A, B = sc2.test32_pencil(8)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(ks.Mat.from_csr(ctx, A.indptr, A.indices, A.data), ks.Mat.from_csr(ctx, B.indptr, B.indices, B.data))
+    eps.SetProblemType(ks.EPS_GHEP if ptype == "ghep" else ks.EPS_GNHEP); eps.SetDimensions(64)
+    eps.GetST().SetKSP(rtol=1e-14, restart=64)
+    eps.Solve()
+    ref = gi.eigenvalues_block(gi.read("eps/eps_test32_4.out"))
+    assert len(ref) == 64 and eps.GetDimensions()[1] == 64 and eps.GetConverged() == 64 and eps.GetConvergedReason() > 0
+    lam = np.array([eps.GetEigenvalue(i) for i in range(64)])
+    assert np.abs(lam[:, 1]).max() == 0.0
+    assert np.allclose(np.round(lam[:, 0], 5), ref, atol=1.5e-5)
+    assert max(eps.ComputeError(i) for i in range(64)) < 1e-8
+
+
 def test_eps_test1_nopurify_and_trackall(ctx):
     """test1_1_ks_nopurify (-eps_purify 0) reprints test1_1.out; EPSSetTrackAll makes every restart report the estimates of all
     Ritz pairs of the active block to the monitor."""

@@ -595,6 +595,16 @@ def test_eps_test32_ghep_symmetric_b_golden():
     assert np.allclose(np.round(r.eigr[r.perm][:60], 5), ref, atol=1.5e-5)
 
 
+def test_eps_test32_4_golden():
+    """test32 -n 8 -eps_nev 64: every eigenvalue of the 64 x 64 pencil, in one cycle that ends on the breakdown of step 64."""
+    A, B = sc.test32_pencil(8)
+    Ao, Bo = _csr(A), _csr(B)
+    r = O.eps_krylovschur_hep(Ao, 64, st=O.ST(Ao, Bo, "shift", 0.0), B=Bo)
+    ref = gi.eigenvalues_block(gi.read("eps/eps_test32_4.out"))
+    assert len(ref) == 64 and r.nconv == 64 and r.ncv == 64 and r.its == 1
+    assert np.allclose(np.round(r.eigr[r.perm][:64], 5), ref, atol=1.5e-5)
+
+
 @pytest.mark.parametrize("trueres", [False, True])
 def test_eps_test22_brusselator_golden(trueres):
     """test22 -eps_nev 4 -eps_true_residual {{0 1}} (Brusselator n = 30, largest real): the eigenvalue line of test22_1.out."""
