@@ -2,22 +2,33 @@
 """bench.py -- Arnoldi steps/s of the Krylov-Schur expansion on MI355X (BASELINE.json metric).
 
 A "step" is one Arnoldi/Lanczos step of EPSSolve_KrylovSchur_Default: BVMatMultColumn (CSR SpMV) +
-BVOrthonormalizeColumn (CGS with refinement, all passes, scaling).  The K timed steps are the first K
-steps of a real Krylov-Schur solve (nev=10, ncv=m=30, tol 1e-8, keep 0.5, largest magnitude), INCLUDING
-its restarts (host DS solve + BVMultInPlace + BVCopyColumn): whole-job throughput, inputs resident in HBM.
+BVOrthonormalizeColumn (CGS with refinement, all passes, scaling).
+
+What is timed.  ONE Krylov-Schur solve (nev=10, ncv=m=30, tol 1e-8, keep 0.5, largest magnitude) runs through
+warm-up, timed region and an instrumented tail without being restarted in between; the phase boundaries sit at restart
+boundaries of that solve (the solver's stopping-test callback, krylovschur.c:289), so the timed region is a whole number
+of restart cycles in steady state - expansion (k = 16..30 here), host projected solve, restart BVMultInPlace +
+BVCopyColumn - and its rate does not depend on --steps:
+  warm-up : the first cycle (k = 1..30) and whole cycles until at least --warmup steps (>= 45) have run;
+  timed   : whole cycles until at least max(--steps, --min-steps) steps have run (--min-steps 200 keeps the region
+            above 200 ms on one GPU); "steps" in the JSON line is the number actually timed;
+  tail    : the same number of steps again with HIP events on every kernel class (untimed): the per-kernel table.
+Inputs and workspace are resident in HBM when the timed region starts.
 
 Workload (config.workload):
   N=1 : BASELINE config 3 - 3-D 7-point Laplacian 216^3 (n = 10 077 696, nnz = 70 263 936)
   N>1 : weak scaling towards config 4 - 432 x 432 x (54 N) grid, each rank owns a 54-plane z-slab
         (10 077 696 rows per GPU; N=8 is the 432^3 = 80.6 M row problem); allreduce of the CGS
         coefficients and the SpMV halo go through RCCL over xGMI.
-Launch: `python bench.py --gpus 1 ...` or
-        `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`.
+Launch: `python bench.py --gpus N ...` starts its N ranks itself (one fresh child process per GPU through
+        torch.distributed.run, before this process touches the GPU); under an existing launcher
+        (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`) it is one of the ranks.
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,33 +38,81 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
 NEV, NCV = 10, 30
+UPD_CLASSES = ["gs_update_fused_dot", "gs_update", "gated_noop"]
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_r02.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this command
 
 
-def make_eps(ks, ctx, A):
-    """EPSCreate + EPSSetOperators + EPSSetDimensions; the basis V (ncv+1 columns) is allocated by the first solve
-    and reused by later ones, so the timed region holds no allocation (inputs and workspace resident in HBM)."""
-    eps = ks.EPS(ctx)
-    eps.SetOperators(A)
-    eps.SetProblemType(ks.EPS_HEP)
-    eps.SetDimensions(NEV, NCV)
-    eps.SetTolerances(1e-8, 1 << 30)
-    return eps
+class Phases:
+    """Stopping-test callback of one solver: moves through warm-up -> timed -> instrumented tail at restart boundaries.
 
+    Every rank runs the same replicated control flow (identical step counts), so the boundaries - which hold a barrier -
+    fall on the same restart everywhere without any extra collective."""
 
-def run_steps(ks, ctx, A, steps, seed, eps=None):
-    """Perform exactly `steps` Arnoldi steps of Krylov-Schur solves on A (fresh solve; restarts on convergence)."""
-    done, passes, restarts, solves = 0, 0, 0, 0
-    if eps is None:
-        eps = make_eps(ks, ctx, A)
-    while done < steps:
-        eps.SetRandomSeed(seed + solves)
-        eps.SetMaxSteps(steps - done)
-        eps.Solve()
-        st = eps.GetStats()
-        if st["arnoldi_steps"] == 0:
-            raise RuntimeError("solver made no progress")
-        done += st["arnoldi_steps"]; passes += st["gs_passes"]; restarts += st["restarts"]; solves += 1
-    return eps, {"steps": done, "gs_passes": passes, "restarts": restarts, "solves": solves}
+    def __init__(self, ks, ctx, eps, barrier, warmup, steps, tail_steps, timed_classes):
+        self.ks, self.ctx, self.eps, self.barrier = ks, ctx, eps, barrier
+        self.warmup, self.steps, self.tail_steps, self.timed_classes = warmup, steps, tail_steps, timed_classes
+        self.phase = 0
+        self.base = 0                 # steps of earlier solves (a solve that converges inside the region is followed by a fresh one)
+        self.marks = {}               # name -> (steps, passes, time)
+        self.cycles = []              # (phase, steps at this restart)
+        self.prof_timed, self.prof_tail = {}, {}
+
+    def _passes(self):
+        return self.eps.GetBV().gs_passes()[0]
+
+    def _mark(self, name, steps):
+        t = self.barrier()
+        self.marks[name] = (steps, self._passes(), t)
+
+    def __call__(self, its, max_it, nconv, nev):
+        steps = self.base + self.eps.GetStats()["arnoldi_steps"]
+        self.cycles.append((self.phase, steps))
+        if self.phase == 0 and steps >= self.warmup:
+            if self.timed_classes is not None:
+                self.ctx.prof_enable(True, classes=self.timed_classes)
+                self.ctx.prof_reset()
+            self.phase = 1
+            self._mark("t0", steps)
+        elif self.phase == 1 and steps - self.marks["t0"][0] >= self.steps:
+            self._mark("t1", steps)
+            if self.tail_steps > 0:
+                self.prof_timed = self.ctx.prof_get(by_variant=True) if self.timed_classes is not None else {}
+                self.ctx.prof_enable(True)
+                self.ctx.prof_reset()
+                self.phase = 2
+            else:
+                if self.timed_classes is not None:
+                    self.prof_timed = self.ctx.prof_get(by_variant=True)
+                self.phase = 3
+                return self.ks.EPS_CONVERGED_USER
+        elif self.phase == 2 and steps - self.marks["t1"][0] >= self.tail_steps:
+            self._mark("t2", steps)
+            self.prof_tail = self.ctx.prof_get(by_variant=True)
+            self.ctx.prof_enable(False)
+            self.phase = 3
+            return self.ks.EPS_CONVERGED_USER
+        return self.eps.StoppingBasic(its, max_it, nconv, nev)
+
+    def run(self, seed):
+        solves = 0
+        while self.phase < 3:
+            self.eps.SetRandomSeed(seed + solves)
+            self.eps.Solve()
+            self.base += self.eps.GetStats()["arnoldi_steps"]
+            solves += 1
+            if solves > 1000:
+                raise RuntimeError("solver made no progress")
+        return solves
+
+    def timed(self, ncv):
+        (s0, p0, t0), (s1, p1, t1) = self.marks["t0"], self.marks["t1"]
+        ends = [s for (ph, s) in self.cycles if ph == 1]                     # restarts inside the timed region (the last one closes it)
+        starts = [s0] + ends[:-1]
+        lens = [e - b for b, e in zip(starts, ends)]
+        # column orthogonalised by a step = number of previous columns k; a cycle of L steps ends at column ncv: k = ncv-L+1 .. ncv
+        ksum = sum(L * (2 * ncv - L + 1) / 2.0 for L in lens)
+        return {"steps": s1 - s0, "seconds": t1 - t0, "gs_passes": p1 - p0, "cycles": len(lens), "cycle_steps": lens,
+                "mean_k": ksum / max(1, s1 - s0)}
 
 
 def cpu_baseline(n_side, max_seconds=30.0):
@@ -81,23 +140,23 @@ def cpu_baseline(n_side, max_seconds=30.0):
     if est <= max_seconds:
         t2 = time.time()
         V.MatLanczos(A, T, m1, NCV)
-        dt = dt6 + (time.time() - t2)
-        steps = NCV
-        # then what a Krylov-Schur cycle costs after a restart: steps k = 16..30 against the kept half of the basis,
-        # repeated (same vectors every time) until about 12 s of CPU work have been sampled
-        k0, cycles = NCV // 2, 0
+        dt_first = dt6 + (time.time() - t2)
+        # the steady state the GPU line times: restart-cycle expansions, steps k = 16..30 against the kept half of the
+        # basis, repeated (same vectors every time) until about 12 s of CPU work have been sampled
+        k0, cycles, dt, steps = NCV // 2, 0, 0.0, 0
         while dt < min(12.0, max_seconds):
             t2 = time.time()
             V.MatLanczos(A, T, k0, NCV)
             dt += time.time() - t2
             steps += NCV - k0; cycles += 1
-        sample = ("first Lanczos run of the %d^3 workload (%d steps, k=1..%d) + %d restart-cycle expansions (k=%d..%d), CGS2; "
-                  "no restart GEMM or projected solve in the CPU sample") % (n_side, NCV, NCV, cycles, k0 + 1, NCV)
+        sample = ("%d restart-cycle expansions (k=%d..%d, CGS2) of the %d^3 workload after its first Lanczos run; no restart GEMM "
+                  "or projected solve in the CPU sample") % (cycles, k0 + 1, NCV, n_side)
+        first = {"value": NCV / dt_first, "unit": "steps/s", "sample": "first Lanczos run, k=1..%d" % NCV}
     else:
-        dt, steps = dt6, m1
+        dt, steps, first = dt6, m1, None
         sample = "first %d Lanczos steps (k=1..%d) of the %d^3 workload (full run estimated %.0f s > budget)" % (m1, m1, n_side, est)
     out = {"value": steps / dt, "unit": "steps/s", "cores": threads, "kind": "port", "sample": sample,
-           "seconds": round(dt, 3), "setup_seconds": round(t1 - t0, 2), "gs_passes": V.passes_total(),
+           "seconds": round(dt, 3), "setup_seconds": round(t1 - t0, 2), "gs_passes": V.passes_total(), "first_cycle": first,
            "same_6_steps_all_cores": {"value": m1 / dt6, "unit": "steps/s", "cores": threads}}
     # one core (the serial build of the oracle), on the first 6 steps only so that it stays within a few seconds
     try:
@@ -118,15 +177,198 @@ def cpu_baseline(n_side, max_seconds=30.0):
     return out
 
 
+def class_table(prof, steps):
+    classes = {}
+    for (name, var), v in prof.items():
+        c = classes.setdefault(name, {"launches": 0, "ms_total": 0.0, "alg": 0.0, "hbm": 0.0})
+        c["launches"] += v["launches"]; c["ms_total"] += v["ms"]; c["alg"] += v["alg_bytes"]; c["hbm"] += v["hbm_bytes"]
+    return [{"class": name, "launches": c["launches"], "ms_total": round(c["ms_total"], 3), "ms_per_step": round(c["ms_total"] / steps, 4),
+             "alg_GBps": round(c["alg"] / c["ms_total"] / 1e6, 1) if c["ms_total"] > 0 else 0.0,
+             "hbm_GBps": round(c["hbm"] / c["ms_total"] / 1e6, 1) if c["ms_total"] > 0 else 0.0}
+            for name, c in sorted(classes.items(), key=lambda kv: -kv[1]["ms_total"])]
+
+
+def update_kernel_roofline(ks, prof_timed):
+    """The k_gs_update<KT,2> symbol with the largest total time IN THE TIMED REGION (HIP events on the library's stream).
+    One symbol = fused launches + final launches + launches that exited at their device-side gate."""
+    sym = {}
+    for (name, var), v in prof_timed.items():
+        if name in UPD_CLASSES and var > 0:
+            e = sym.setdefault(var, {"ms_exec": 0.0, "n_exec": 0, "alg": 0.0, "hbm": 0.0, "ms_noop": 0.0, "n_noop": 0})
+            if name == "gated_noop":
+                e["ms_noop"] += v["ms"]; e["n_noop"] += v["launches"]
+            else:
+                e["ms_exec"] += v["ms"]; e["n_exec"] += v["launches"]; e["alg"] += v["alg_bytes"]; e["hbm"] += v["hbm_bytes"]
+    sym = {k: d for k, d in sym.items() if d["n_exec"]}
+    if not sym:
+        return None
+    kt, d = max(sym.items(), key=lambda kv: kv[1]["ms_exec"])
+    achieved = d["hbm"] / d["ms_exec"] / 1e6          # bytes this kernel must move per launch / its time
+    kname = "k_gs_update<%d, 2>" % kt
+    traffic, tsrc = None, None
+    if os.path.exists(TRAFFIC_FILE):
+        try:
+            tj = json.load(open(TRAFFIC_FILE))
+            traffic = tj.get(kname, {}).get("hbm_bytes_per_executed_launch")
+            tsrc = tj.get("_source")
+        except Exception:      # noqa: BLE001
+            traffic = None
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": tsrc if traffic is not None else None,
+            "kernel": kname, "launches_executed": d["n_exec"], "launches_gated_off": d["n_noop"],
+            "avg_launch_us_executed": round(1e3 * d["ms_exec"] / d["n_exec"], 2),
+            "avg_launch_us_all_launches": round(1e3 * (d["ms_exec"] + d["ms_noop"]) / (d["n_exec"] + d["n_noop"]), 2),
+            "bytes_per_executed_launch": d["hbm"] / d["n_exec"],
+            "survey8d_bytes_per_executed_launch": d["alg"] / d["n_exec"],
+            "survey8d_equivalent_GBps": round(d["alg"] / d["ms_exec"] / 1e6, 1),
+            "note": "HIP events on the library stream over the timed region. achieved = bytes the kernel as designed must move "
+                    "(bytes_per_executed_launch) / its average executed launch. One symbol is launched in two forms (DESIGN.md "
+                    "section 4): the first CGS pass reads k basis columns and the vector, 8n(k+1) bytes, keeps its result in "
+                    "registers and produces the k+1 dot products of the next pass (work the reference pays another 8n(k+1) "
+                    "bytes for, SURVEY 8d: survey8d_*); the final pass reads the same and writes the vector, 8n(k+2). "
+                    "bytes_per_executed_launch is the mean over both forms, as is the PMC figure in traffic (a separate rocprofv3 "
+                    "--pmc run of this command, profiles/). rocprofv3's per-symbol average covers all launches incl. the ones "
+                    "that exit at their device-side gate: compare avg_launch_us_all_launches."}
+
+
+def measure(ks, ctx, A, B, barrier, warmup, steps, min_steps, nev, ncv, ptype, prof=True, tail=True, setup=None, seed=0x12345678):
+    """Run the phased solve on (A, B); returns (Phases, timed dict)."""
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A, B)
+    eps.SetProblemType(ptype)
+    eps.SetDimensions(nev, ncv)
+    eps.SetTolerances(1e-8, 1 << 30)
+    if setup:
+        setup(eps)
+    k_eff = max(steps, min_steps)
+    ph = Phases(ks, ctx, eps, barrier, max(warmup, ncv + ncv // 2), k_eff, k_eff if (prof and tail) else 0, UPD_CLASSES[:2] if prof else None)
+    eps.SetStoppingTestFunction(ph)
+    ph.run(seed)
+    eps.SetStoppingTestFunction(None)
+    return eps, ph, ph.timed(ncv)
+
+
+def spmv_leg(ks, ctx, make_mat, reps=40):
+    """Stand-alone MatMult timing of one device layout (untimed side leg): HIP events around `reps` launches."""
+    import numpy as np
+    A = make_mat()
+    x = ks.BV(ctx, A.n, 2)
+    x.SetRandomColumn(0)
+    for _ in range(5):
+        A.mult_dev(x.column_ptr(0), x.column_ptr(1))
+    ctx.synchronize()
+    ctx.prof_enable(True, classes=["spmv_csr"]); ctx.prof_reset()
+    for _ in range(reps):
+        A.mult_dev(x.column_ptr(0), x.column_ptr(1))
+    ctx.synchronize()
+    p = ctx.prof_get()
+    ctx.prof_enable(False)
+    v = p.get("spmv_csr", {"launches": 0, "ms": 0.0, "alg_bytes": 0.0, "hbm_bytes": 0.0})
+    us = 1e3 * v["ms"] / max(1, v["launches"])
+    out = {"layout": A.layout(), "avg_us": round(us, 2), "survey8d_GBps": round(v["alg_bytes"] / v["ms"] / 1e6, 1) if v["ms"] else None,
+           "own_bytes_GBps": round(v["hbm_bytes"] / v["ms"] / 1e6, 1) if v["ms"] else None,
+           "own_bytes_per_launch": v["hbm_bytes"] / max(1, v["launches"])}
+    del x
+    A.destroy()
+    return out
+
+
+def side_configs(ks, ctx, barrier, args):
+    """The other single-GPU BASELINE configurations, measured with the same phased harness (N=1 only, after the headline)."""
+    import numpy as np
+    out = {}
+    # C2: 2-D 5-pt Laplacian 1000^2, nev 4, m 20
+    try:
+        A = ks.Mat.laplacian2d(ctx, 1000)
+        eps, ph, t = measure(ks, ctx, A, None, barrier, 60, 2000, 0, 4, 20, ks.EPS_HEP)
+        n = A.n
+        rl = update_kernel_roofline(ks, ph.prof_timed)
+        comp = sum(v["hbm_bytes"] for v in ph.prof_tail.values()); ms = sum(v["ms"] for v in ph.prof_tail.values())
+        out["C2"] = {"workload": "2-D 5-pt Laplacian 1000^2 (n=%d), Krylov-Schur nev=4 m=20" % n, "value": t["steps"] / t["seconds"], "unit": "steps/s",
+                     "steps": t["steps"], "us_per_step": 1e6 * t["seconds"] / t["steps"], "mean_k": round(t["mean_k"], 2), "cycles": t["cycles"],
+                     "gs_passes_per_step": t["gs_passes"] / t["steps"], "spmv_layout": A.layout(),
+                     "roofline": rl and {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_us_executed", "bytes_per_executed_launch")},
+                     "basis_MB": round(21 * n * 8 / 1e6, 1),
+                     "note": "the 168 MB basis fits the 256 MB Infinity Cache: rates above the HBM figure are possible and the step is partly latency-bound",
+                     "kernel_classes": class_table(ph.prof_tail, max(1, ph.marks["t2"][0] - ph.marks["t1"][0])) if ph.prof_tail else None}
+        del eps
+        A.destroy()
+    except Exception as e:      # noqa: BLE001
+        out["C2"] = {"value": None, "error": repr(e)}
+    # C5: random nonsymmetric CSR n = 5e6, ~33 nnz/row, generalized, shift-and-invert at target 0, nev 20, m 60
+    if not args.no_c5:
+        try:
+            from slepc_amd.workloads import config5_pencil_arrays
+            n5 = args.c5_n
+            t0 = time.time()
+            (ar, ac, av), (br, bc, bv) = config5_pencil_arrays(n5)
+            A = ks.Mat.from_csr(ctx, ar, ac, av); B = ks.Mat.from_csr(ctx, br, bc, bv)
+            nnz = int(ar[-1]); nnzb = int(br[-1])
+            del ar, ac, av, br, bc, bv
+            tgen = time.time() - t0
+            stref = {}
+
+            def setup(eps):
+                eps.SetTarget(0.0)
+                st = eps.GetST(); st.SetType("sinvert")
+                stref["st"] = st
+            eps, ph, t = measure(ks, ctx, A, B, barrier, 60, 150, 0, 20, 60, ks.EPS_GNHEP, setup=setup)
+            kst = stref["st"].GetKSPStats()
+            tail_steps = max(1, ph.marks["t2"][0] - ph.marks["t1"][0])
+            tab = class_table(ph.prof_tail, tail_steps)
+            sp = ph.prof_tail
+            spmv_ms = sum(v["ms"] for (nm, _), v in sp.items() if nm == "spmv_csr"); spmv_n = sum(v["launches"] for (nm, _), v in sp.items() if nm == "spmv_csr")
+            spmv_alg = sum(v["alg_bytes"] for (nm, _), v in sp.items() if nm == "spmv_csr")
+            its_per_solve = kst["iterations"] / max(1, kst["solves"])
+            out["C5"] = {"workload": "random nonsymmetric CSR n=%d nnz=%d (+ tridiagonal B, nnz=%d), GNHEP shift-and-invert target 0, nev=20 m=60, GMRES(30)+Jacobi inner solves"
+                                     % (n5, nnz, nnzb),
+                         "value": t["steps"] / t["seconds"], "unit": "steps/s", "steps": t["steps"], "ms_per_step": 1e3 * t["seconds"] / t["steps"],
+                         "mean_k": round(t["mean_k"], 2), "cycles": t["cycles"], "inner_iterations_per_step": round(its_per_solve, 2),
+                         "spmv_layout": A.layout(), "setup_seconds": round(tgen, 1),
+                         "roofline": {"bound": "hbm", "kernel": "k_spmv_sliced (+ k_sum_parts) and the small SpMV of B, all MatMult launches of a step",
+                                      "achieved": round(spmv_alg / spmv_ms / 1e6, 1) if spmv_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(spmv_alg / spmv_ms / 1e6 / HBM_PEAK_GBS, 4) if spmv_ms else None,
+                                      "avg_launch_us": round(1e3 * spmv_ms / max(1, spmv_n), 1), "launches_per_step": round(spmv_n / tail_steps, 2),
+                                      "bytes": "SURVEY 8d: 12 nnz + 4(n+1) + 16 n per MatMult; the x gather of a uniformly random matrix is a cache-line "
+                                               "rate, not an HBM rate (DESIGN.md section 4)"},
+                         "kernel_classes": tab}
+            del eps
+            A.destroy(); B.destroy()
+        except Exception as e:      # noqa: BLE001
+            out["C5"] = {"value": None, "error": repr(e)}
+    return out
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as fresh child processes (this process has not
+    touched the GPU) and hand their exit code back. Rank 0's JSON line goes straight to our stdout."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=60)
+    ap.add_argument("--min-steps", type=int, default=200, help="lower bound of the timed region in steps (>= 200 ms on one GPU)")
     ap.add_argument("--side", type=int, default=216, help="grid side per GPU slab (216 -> 10 077 696 rows per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="disable the per-kernel HIP-event timing")
+    ap.add_argument("--no-configs", action="store_true", help="skip the side legs (configs C2 / C5, SpMV layouts)")
+    ap.add_argument("--no-c5", action="store_true")
+    ap.add_argument("--c5-n", type=int, default=5000000)
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
 
     # RCCL / the HIP runtime may print banners on stdout: park stdout on stderr until the one JSON line is due
     sys.stdout.flush()
@@ -140,8 +382,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dist = None
@@ -177,42 +417,17 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+        return time.perf_counter()
 
-    # untimed: allocate the solver workspace and touch every kernel once (one full cycle + a restart),
-    # then the W warmup steps proper: the first W steps of the same solve
-    eps = make_eps(ks, ctx, A)
-    run_steps(ks, ctx, A, NCV + 15, 0x12345678, eps)
-    if args.warmup > 0:
-        run_steps(ks, ctx, A, args.warmup, 0x12345678, eps)
-    barrier()
-    # Timed region. HIP events are recorded only around the Gram-Schmidt update kernel (the dominant kernel
-    # symbol, k_gs_update<KT,2>): timing every launch costs ~6 % of the step rate, this subset ~2 %.
-    upd_classes = ["gs_update_fused_dot", "gs_update", "gated_noop"]
-    if not args.no_prof:
-        ctx.prof_enable(True, classes=upd_classes[:2])
-        ctx.prof_reset()
-    barrier()
-    t0 = time.perf_counter()
-    eps, st = run_steps(ks, ctx, A, args.steps, 0x12345678, eps)
-    barrier()
-    t1 = time.perf_counter()
-    dt = t1 - t0
+    eps, ph, t = measure(ks, ctx, A, None, barrier, args.warmup, args.steps, args.min_steps, NEV, NCV, ks.EPS_HEP, prof=not args.no_prof)
+    dt = t["seconds"]
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    assert st["steps"] == args.steps
-    prof_timed = {} if args.no_prof else ctx.prof_get(by_variant=True)
-
-    # Untimed second pass of the same K steps with events on every kernel class: the per-kernel table.
-    prof = {}
-    if not args.no_prof:
-        ctx.prof_enable(True)
-        ctx.prof_reset()
-        _, st2 = run_steps(ks, ctx, A, args.steps, 0x12345678, eps)
-        barrier()
-        prof = ctx.prof_get(by_variant=True)
-        ctx.prof_enable(False)
+    steps = t["steps"]
+    prof_timed, prof = ph.prof_timed, ph.prof_tail
+    tail_steps = (ph.marks["t2"][0] - ph.marks["t1"][0]) if "t2" in ph.marks else 0
 
     if rank == 0:
         n_local = A.n
@@ -220,77 +435,61 @@ def main():
             "metric": "Arnoldi steps/sec (and GB/s vs HBM roofline), 3D Laplacian n=10M, m=30, 1/2/4/8 GPU",
             # weak scaling: the unit is one Arnoldi step on one GPU's 10 077 696-row shard (the N=1 workload), so the
             # whole job processes world*steps of them; the global solver itself advances steps/dt steps per second
-            "value": world * args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": world * steps / dt, "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": ph.marks["t0"][0],
+            "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "rows_per_gpu": n_local, "nnz_per_gpu": A.nnz, "n_global": A.N, "nev": NEV, "ncv": NCV,
-                       "orthog": "CGS, refine ifneeded eta=0.7071", "gs_passes_per_step": st["gs_passes"] / st["steps"],
-                       "restarts": st["restarts"], "parallelism": "row-slab x%d" % world,
-                       "spmv_layout": A.layout() + (" (2-byte entries: offset code + value code, lossless; y bit-identical to SELL-64; KSGPU_SPMV=sell disables)" if A.layout() == "dict" else ""),
+                       "orthog": "CGS, refine ifneeded eta=0.7071", "gs_passes_per_step": t["gs_passes"] / steps,
+                       "timed_region": "whole restart cycles of one continuing solve in steady state (after the first cycle and %d warm-up steps)" % ph.marks["t0"][0],
+                       "steps_requested": args.steps, "min_steps": args.min_steps, "cycles": t["cycles"], "restarts": t["cycles"],
+                       "steps_per_cycle": round(steps / t["cycles"], 2), "mean_k": round(t["mean_k"], 2), "timed_seconds": round(dt, 4),
+                       "parallelism": "row-slab x%d" % world,
+                       "spmv_layout": A.layout() + (" (2-byte entries: offset code + value code, lossless; y bit-identical to SELL-64; KSGPU_SPMV=sell disables; "
+                                                    "general-matrix layouts: spmv_layouts)" if A.layout() == "dict" else ""),
                        "unit_of_value": "Arnoldi steps on a 10 077 696-row shard, summed over the %d shard(s): value = n_gpus * global_steps_per_s" % world,
-                       "global_steps_per_s": args.steps / dt},
+                       "global_steps_per_s": steps / dt},
         }
-        # step-level algorithmic traffic by the SURVEY 8d formulas (reference-equivalent work) vs time
+        if prof_timed:
+            rl = update_kernel_roofline(ks, prof_timed)
+            if rl:
+                out["roofline"] = rl
         if prof:
             kernels = []
             for (name, var), v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
-                sym = ks.kernel_symbol(name, var)
-                kernels.append({"class": name, "variant": var, "kernel": sym, "launches": v["launches"], "ms_total": round(v["ms"], 3),
+                kernels.append({"class": name, "variant": var, "kernel": ks.kernel_symbol(name, var), "launches": v["launches"], "ms_total": round(v["ms"], 3),
                                 "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
                                 "alg_GBps": round(v["alg_bytes"] / v["ms"] / 1e6, 1) if v["ms"] > 0 else 0.0,
                                 "hbm_GBps": round(v["hbm_bytes"] / v["ms"] / 1e6, 1) if v["ms"] > 0 else 0.0})
-            # roofline: the k_gs_update<KT,2> symbol with the largest total time IN THE TIMED REGION.
-            # One symbol = fused launches + final launches + launches that exited at their device-side gate.
-            sym = {}
-            for (name, var), v in prof_timed.items():
-                if name in upd_classes and var > 0:
-                    e = sym.setdefault(var, {"ms_exec": 0.0, "n_exec": 0, "alg": 0.0, "hbm": 0.0, "ms_noop": 0.0, "n_noop": 0})
-                    if name == "gated_noop":
-                        e["ms_noop"] += v["ms"]; e["n_noop"] += v["launches"]
-                    else:
-                        e["ms_exec"] += v["ms"]; e["n_exec"] += v["launches"]; e["alg"] += v["alg_bytes"]; e["hbm"] += v["hbm_bytes"]
-            kt, d = max(sym.items(), key=lambda kv: kv[1]["ms_exec"])
-            achieved = d["hbm"] / d["ms_exec"] / 1e6          # bytes this kernel must move per launch / its time
-            kname = "k_gs_update<%d, 2>" % kt
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get(kname, {}).get("hbm_bytes_per_executed_launch")
-                except Exception:
-                    traffic = None
-            out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "kernel": kname, "launches_executed": d["n_exec"], "launches_gated_off": d["n_noop"],
-                               "avg_launch_us_executed": round(1e3 * d["ms_exec"] / d["n_exec"], 2),
-                               "avg_launch_us_all_launches": round(1e3 * (d["ms_exec"] + d["ms_noop"]) / (d["n_exec"] + d["n_noop"]), 2),
-                               "bytes_per_executed_launch": d["hbm"] / d["n_exec"],
-                               "survey8d_bytes_per_executed_launch": d["alg"] / d["n_exec"],
-                               "survey8d_equivalent_GBps": round(d["alg"] / d["ms_exec"] / 1e6, 1),
-                               "note": "HIP events on the library stream over the timed region. One symbol is launched in two forms (DESIGN.md "
-                                       "section 4): the first CGS pass reads k basis columns and the vector, 8n(k+1) bytes, keeps its result in "
-                                       "registers and produces the k+1 dot products of the next pass (work the reference pays another 8n(k+1) "
-                                       "bytes for, SURVEY 8d: survey8d_*); the final pass reads the same and writes the vector, 8n(k+2). "
-                                       "bytes_per_executed_launch is the mean over both forms, as is the PMC figure in traffic. rocprofv3's "
-                                       "per-symbol average covers all launches incl. the ones that exit at their device-side gate: compare "
-                                       "avg_launch_us_all_launches."}
             tot_alg = sum(v["alg_bytes"] for v in prof.values()); tot_hbm = sum(v["hbm_bytes"] for v in prof.values())
             tot_ms = sum(v["ms"] for v in prof.values())
-            out["step_traffic"] = {"alg_GB_per_step": round(tot_alg / args.steps / 1e9, 3), "alg_GBps_vs_wall": round(tot_alg / dt / 1e9, 1),
-                                   "frac_of_hbm_peak_alg": round(tot_alg / dt / 1e9 / HBM_PEAK_GBS, 4),
-                                   "compulsory_GB_per_step": round(tot_hbm / args.steps / 1e9, 3), "compulsory_GBps_vs_wall": round(tot_hbm / dt / 1e9, 1),
-                                   "kernel_ms_per_step": round(tot_ms / args.steps, 4)}
-            # every column count has its own compiled kernel, so the per-symbol table is long: all classes, top symbols
-            classes = {}
-            for (name, var), v in prof.items():
-                c = classes.setdefault(name, {"launches": 0, "ms_total": 0.0, "alg": 0.0, "hbm": 0.0})
-                c["launches"] += v["launches"]; c["ms_total"] += v["ms"]; c["alg"] += v["alg_bytes"]; c["hbm"] += v["hbm_bytes"]
-            out["kernel_classes_untimed_instrumented_pass"] = [
-                {"class": name, "launches": c["launches"], "ms_total": round(c["ms_total"], 3), "ms_per_step": round(c["ms_total"] / args.steps, 4),
-                 "alg_GBps": round(c["alg"] / c["ms_total"] / 1e6, 1) if c["ms_total"] > 0 else 0.0,
-                 "hbm_GBps": round(c["hbm"] / c["ms_total"] / 1e6, 1) if c["ms_total"] > 0 else 0.0}
-                for name, c in sorted(classes.items(), key=lambda kv: -kv[1]["ms_total"])]
+            mip_ms = sum(v["ms"] for (nm, _), v in prof.items() if nm in ("bv_multinplace", "bv_copy"))
+            # the tail repeats the timed region's work (same cycle structure) with events on every launch: scale its byte
+            # counts to the timed region's step count and divide by the timed wall time
+            sc = steps / max(1, tail_steps)
+            out["step_traffic"] = {"alg_GB_per_step": round(tot_alg / tail_steps / 1e9, 3), "alg_GBps_vs_wall": round(tot_alg * sc / dt / 1e9, 1),
+                                   "frac_of_hbm_peak_alg": round(tot_alg * sc / dt / 1e9 / HBM_PEAK_GBS, 4),
+                                   "compulsory_GB_per_step": round(tot_hbm / tail_steps / 1e9, 3), "compulsory_GBps_vs_wall": round(tot_hbm * sc / dt / 1e9, 1),
+                                   "frac_of_hbm_peak_compulsory": round(tot_hbm * sc / dt / 1e9 / HBM_PEAK_GBS, 4),
+                                   "kernel_ms_per_step": round(tot_ms / tail_steps, 4)}
+            out["config"]["restart_share_of_kernel_time"] = round(mip_ms / tot_ms, 4) if tot_ms else None
+            out["kernel_classes_untimed_instrumented_pass"] = class_table(prof, tail_steps)
             out["kernels_untimed_instrumented_pass"] = kernels[:12]
+        del eps
+        if world == 1 and not force_dist and not args.no_configs:
+            try:
+                legs = {}
+                for fmt in ("dict", "odict", "sell", "csr"):
+                    os.environ["KSGPU_SPMV"] = fmt
+                    try:
+                        legs[fmt] = spmv_leg(ks, ctx, lambda: ks.Mat.laplacian3d(ctx, side, side, side))
+                    finally:
+                        os.environ.pop("KSGPU_SPMV", None)
+                out["spmv_layouts"] = {"workload": "MatMult of the %d^3 7-pt Laplacian alone, each device layout (KSGPU_SPMV=...)" % side, "legs": legs,
+                                       "note": "dict needs <= 255 distinct values and <= 256 distinct column offsets, odict only the offsets; "
+                                               "sell = SELL-64 for any stencil-like matrix; csr = CSR-vector for ragged ones"}
+            except Exception as e:      # noqa: BLE001
+                out["spmv_layouts"] = {"error": repr(e)}
+            out["configs"] = side_configs(ks, ctx, barrier, args)
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(side)

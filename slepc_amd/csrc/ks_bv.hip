@@ -157,9 +157,9 @@ int ksk_dot(ks_bv bv, const double *A, int lda, int ncols, const double *y, bool
 #define LAUNCH_DOT(KT)                                                                                                                        \
   do {                                                                                                                                        \
     if (v2) { grid = ks_sweep_grid_for(ctx, bv->n, 2, (const void *)k_dot_sweep<KT, 2>, dot_per_cu); bv->last_grid = grid;                                \
-      hipLaunchKernelGGL((k_dot_sweep<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, y, bv->partials, g); } \
+      hipLaunchKernelGGL((k_dot_sweep<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, y, bv->partials, g, &bv->gs->pgrid); } \
     else { grid = ks_sweep_grid_for(ctx, bv->n, 1, (const void *)k_dot_sweep<KT, 1>, dot_per_cu); bv->last_grid = grid;                                   \
-      hipLaunchKernelGGL((k_dot_sweep<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, y, bv->partials, g); }   \
+      hipLaunchKernelGGL((k_dot_sweep<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, y, bv->partials, g, &bv->gs->pgrid); }   \
   } while (0)
   KS_KT_DISPATCH(ncols, LAUNCH_DOT);
 #undef LAUNCH_DOT

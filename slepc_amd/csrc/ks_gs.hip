@@ -129,7 +129,7 @@ __device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict_
 
 // REDUCE: sum block partials -> c (LDS, and global scratch = buffer column 0).  BOOK: run the bookkeeping.
 template <bool REDUCE, bool BOOK>
-__global__ __launch_bounds__(1024) void k_gs_finish(const double *__restrict__ partials, int nblocks, GsArgs a, double *buffer, double *pend, KsGsState *st, KsStepRec *recs)
+__global__ __launch_bounds__(1024) void k_gs_finish(const double *__restrict__ partials, GsArgs a, double *buffer, double *pend, KsGsState *st, KsStepRec *recs)
 {
   __shared__ double c_lds[KS_MAX_COLS + 8];
   const int ncols = a.k + 1;
@@ -144,7 +144,9 @@ __global__ __launch_bounds__(1024) void k_gs_finish(const double *__restrict__ p
   __syncthreads();
   if (!go) return;
   if (REDUCE) {
-    reduce_partials_to_lds(partials, nblocks, ncols, c_lds);
+    // the grid that wrote the partials (not the host's idea of the last launch: sweeps of later columns may have been
+    // enqueued, and gated off, since)
+    reduce_partials_to_lds(partials, st->pgrid, ncols, c_lds);
     if ((int)threadIdx.x < ncols) buffer[threadIdx.x] = c_lds[threadIdx.x];     // scratch c = buffer column 0
   } else {
     if ((int)threadIdx.x < ncols) c_lds[threadIdx.x] = buffer[threadIdx.x];
@@ -228,7 +230,7 @@ __device__ __forceinline__ void upd_tiles(const double *V, long long ld, int n, 
 // v <- v - V(:,0:k) c   [* alpha if final]   and, when st->fuse_dot, partials <- [V(:,0:k) v]^T v  (k+1 values)
 template <int KT, int VEC>
 __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long long ld, int n, int k, double *v, const double *__restrict__ cg,
-                                                        double *__restrict__ partials, const KsGsState *__restrict__ st, int rev)
+                                                        double *__restrict__ partials, const KsGsState *__restrict__ st, int *__restrict__ pgrid, int rev)
 {
   if (!st->do_update) return;
   const bool fuse = st->fuse_dot != 0;
@@ -247,6 +249,7 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long lo
   else if (VEC == 2 && !fuse && npend == 2) upd_tiles<KT, VEC, 2, 0>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
   else upd_tiles<KT, VEC, 0, -1>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
   if (!fuse) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *pgrid = gridDim.x;
   // block combine: partial index i<k <- acc[i]; index k <- acc[KT] (the self dot)
   __shared__ double red[SW_WAVES][KT + 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -282,11 +285,11 @@ int launch_finish(ks_bv bv, const GsArgs &a)
   const bool multi = ks_is_multi(ctx);
   KsProfScope ps(ctx, KS_K_GSFIN, 8.0 * bv->last_grid * (a.k + 1));
   ps.tag(a.col, a.slot, a.k, bv->n);
-  if (!multi) hipLaunchKernelGGL((k_gs_finish<true, true>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, bv->last_grid, a, bv->buffer, bv->pend, bv->gs, bv->recs);
+  if (!multi) hipLaunchKernelGGL((k_gs_finish<true, true>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, a, bv->buffer, bv->pend, bv->gs, bv->recs);
   else {
-    hipLaunchKernelGGL((k_gs_finish<true, false>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, bv->last_grid, a, bv->buffer, bv->pend, bv->gs, bv->recs);
+    hipLaunchKernelGGL((k_gs_finish<true, false>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, a, bv->buffer, bv->pend, bv->gs, bv->recs);
     KS_CALL(ks_allreduce_sum(ctx, bv->buffer, a.k + 1));
-    hipLaunchKernelGGL((k_gs_finish<false, true>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, bv->last_grid, a, bv->buffer, bv->pend, bv->gs, bv->recs);
+    hipLaunchKernelGGL((k_gs_finish<false, true>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, a, bv->buffer, bv->pend, bv->gs, bv->recs);
   }
   KS_HIP(hipGetLastError());
   return KS_SUCCESS;
@@ -312,9 +315,9 @@ int launch_update(ks_bv bv, int col, double *v, int slot)
 #define LAUNCH_UPD(KT)                                                                                                                                 \
   do {                                                                                                                                                 \
     if (v2) { grid = ks_sweep_grid_for(ctx, bv->n, 2, (const void *)k_gs_update<KT, 2>, upd_per_cu); bv->last_grid = grid;                                                        \
-      hipLaunchKernelGGL((k_gs_update<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->pend, bv->partials, bv->gs, rev); } \
+      hipLaunchKernelGGL((k_gs_update<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->pend, bv->partials, bv->gs, &bv->gs->pgrid, rev); } \
     else { grid = ks_sweep_grid_for(ctx, bv->n, 1, (const void *)k_gs_update<KT, 1>, upd_per_cu); bv->last_grid = grid;                                                           \
-      hipLaunchKernelGGL((k_gs_update<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->pend, bv->partials, bv->gs, rev); }   \
+      hipLaunchKernelGGL((k_gs_update<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->pend, bv->partials, bv->gs, &bv->gs->pgrid, rev); }   \
   } while (0)
   KS_KT_DISPATCH(kk, LAUNCH_UPD);
 #undef LAUNCH_UPD

@@ -69,9 +69,10 @@ __device__ __forceinline__ void block_write_partials(double (&acc)[KT], int ncol
 template <int KT, int VEC>
 __global__ __launch_bounds__(SW_BLOCK) void k_dot_sweep(const double *__restrict__ A, long long lda, int n, int ncols,
                                                         const double *__restrict__ y, double *__restrict__ partials,
-                                                        const KsGsState *__restrict__ gate)
+                                                        const KsGsState *__restrict__ gate, int *__restrict__ pgrid)
 {
   if (gate && !gate->active) return;
+  if (pgrid && blockIdx.x == 0 && threadIdx.x == 0) *pgrid = gridDim.x;     // the partials' stride travels with them
   double acc[KT];
 #pragma unroll
   for (int i = 0; i < KT; i++) acc[i] = 0.0;

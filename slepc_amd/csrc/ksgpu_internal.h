@@ -164,6 +164,8 @@ struct KsGsState {
                       // only feeds the next pass's dots keeps its result in registers (writes cost ~5 read-columns of HBM time)
   int store_prev;     // the previous update of this column stored: the coefficients applied so far are in memory
   int npend;          // passes whose coefficients are not in memory yet: the next update applies pend[0..npend) one after the other
+  int pgrid;          // gridDim.x of the sweep that last wrote `partials` (their stride and count): written by that sweep, read by the
+                      // reduction, so a completion program enqueued after later columns' (gated-off) sweeps still reduces with the right grid
   double onrm, nrm, alpha;
   long long passes_total;
 };
@@ -188,7 +190,8 @@ struct ks_bv_s {
   KsStepRec *recs = nullptr;    // m records (one per column)
   long long passes_total_host = 0; int passes_last_host = 0;
   int row_start = 0;            // first global row (reproducible random)
-  int last_grid = 1;            // grid size of the sweep that last wrote `partials`
+  int last_grid = 1;            // grid size of the sweep LAUNCHED last (profiling byte counts, and reductions that directly follow their sweep); the
+                                // Gram-Schmidt bookkeeping reads the grid from KsGsState::pgrid instead
   double *panel = nullptr; size_t panel_len = 0;   // block partials of the MFMA panel dot (grid x 64 x 64 max)
 };
 

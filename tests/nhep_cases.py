@@ -85,20 +85,11 @@ def config5_pencil(n, mean_nnz=32, seed=42):
 
 
 def config5_pencil_fast(n, mean_nnz=32, seed=42):
-    """Vectorised variant for large n: columns drawn WITH replacement (a repeated (i,j) stays as two CSR entries, which
-    MatMult and MatGetDiagonal sum), not sorted inside a row; same value distribution, diagonal + 40, same B."""
-    import scipy.sparse as sp
-    rng = np.random.default_rng(seed)
-    lens = np.clip(rng.poisson(mean_nnz, n), 1, 2 * mean_nnz).astype(np.int64)
-    rowptr = np.concatenate([[0], np.cumsum(lens + 1)]).astype(np.int32)        # + the diagonal entry
-    nnz = int(rowptr[-1])
-    col = rng.integers(0, n, nnz, dtype=np.int32)
-    val = rng.uniform(-1, 1, nnz)
-    col[rowptr[:-1]] = np.arange(n, dtype=np.int32); val[rowptr[:-1]] = 40.0   # first entry of each row: the diagonal
-    A = O.CSR(n, rowptr, col, val)
-    B = sp.diags([np.full(n - 1, 1 / 6), np.full(n, 2 / 3), np.full(n - 1, 1 / 6)], [-1, 0, 1], format="csr")
-    B.sort_indices()
-    return A, O.CSR(n, B.indptr.astype(np.int32), B.indices.astype(np.int32), B.data)
+    """Vectorised variant for large n (slepc_amd/workloads.py, the generator bench.py uses): columns drawn WITH
+    replacement, not sorted inside a row; same value distribution, diagonal + 40, same B."""
+    from slepc_amd.workloads import config5_pencil_arrays
+    (ar, ac, av), (br, bc, bv) = config5_pencil_arrays(n, mean_nnz, seed)
+    return O.CSR(n, ar, ac, av), O.CSR(n, br, bc, bv)
 
 
 def brusselator(N, alpha=2.0, beta=5.45, delta1=0.008, delta2=0.004, L=0.51302):

@@ -393,6 +393,50 @@ def test_breakdown_halts_enqueued_run(ctx):
     assert np.allclose(Tg[:3], To[:3], atol=1e-12)
 
 
+@pytest.mark.parametrize("n", [300001, 700000])
+def test_halted_column_mid_run_reduces_with_its_own_grid(ctx, n):
+    """A column that needs more than the optimistic two-pass program halts the enqueued run; its completion program is
+    enqueued AFTER the (gated-off) sweeps of the later columns, whose kernels have other column tiles and, for
+    131k < n < 1.05M rows, other occupancy-based grids. The partials of the halted column must be reduced with the grid
+    that wrote them. Invariant subspace of dimension 3 at such an n: m = 3 and breakdown, like the oracle."""
+    import slepc_amd as ks
+    Ao = O.CSR(n, np.arange(n + 1), np.arange(n), 1.0 + np.arange(n, dtype=float) / n)
+    Ag = _mat(ctx, Ao)
+    v = np.zeros(n); v[[1, n // 2, n - 7]] = [1.0, 2.0, -1.0]; v /= np.linalg.norm(v)
+    m = 24
+    Vg = ks.BV(ctx, n, m + 1); Vo = O.BV(n, m + 1)
+    Vg.set_column(0, v); Vo.set_column(0, v)
+    Tg = np.zeros((m + 1, 3), order="F"); To = np.zeros((m + 1, 3), order="F")
+    rg = Vg.MatLanczos(Ag, Tg, 0, m); ro = Vo.MatLanczos(Ao, To, 0, m)
+    assert rg[0] == ro[0] == 3 and rg[2] and ro[2]
+    assert np.allclose(Tg[:3], To[:3], atol=1e-12)
+
+
+@pytest.mark.parametrize("n", [300001, 700000])
+def test_third_pass_mid_run_keeps_the_basis_orthonormal(ctx, n):
+    """The same with a start vector that leaks 1e-20 into every other direction: column 3 is what rounding leaves of
+    it, needs the third pass (host completion in the middle of an enqueued run) and the run then goes on. Whatever
+    that column's direction, the basis stays orthonormal and the Lanczos relation holds."""
+    import slepc_amd as ks
+    d = 1.0 + np.arange(n, dtype=float) / n
+    Ao = O.CSR(n, np.arange(n + 1), np.arange(n), d)
+    Ag = _mat(ctx, Ao)
+    v = np.full(n, 1e-20); v[[1, n // 2, n - 7]] = [1.0, 2.0, -1.0]; v /= np.linalg.norm(v)
+    m = 10
+    Vg = ks.BV(ctx, n, m + 1)
+    Vg.set_column(0, v)
+    Tg = np.zeros((m + 1, 3), order="F")
+    rg = Vg.MatLanczos(Ag, Tg, 0, m)
+    mm = rg[0]
+    Vd = Vg.dense()[:, : mm + 1]
+    assert np.abs(Vd[:, :mm].T @ Vd[:, :mm] - np.eye(mm)).max() < 1e-10
+    if not rg[2]:
+        assert mm == m and Vg.gs_passes()[0] > 2 * m        # at least one column took the third pass
+        # full reorthogonalisation: the projected matrix is V^T A V, tridiagonal or not after the junk column
+        H = Vd[:, :mm].T @ (d[:, None] * Vd[:, :mm])
+        assert np.allclose(np.diag(H), Tg[:mm, 0], atol=1e-10)
+
+
 def test_lanczos_argument_checks(ctx):
     import slepc_amd as ks
     Ao = O.laplacian1d(20); Ag = _mat(ctx, Ao)
