@@ -167,6 +167,8 @@ int ks_bv_set_orthogonalization(ks_bv bv, int type, int refine, double eta);    
 int ks_bv_get_array(ks_bv bv, double **dev);                                        /* ops->getarray: device pointer of the m*ld block */
 int ks_bv_get_column(ks_bv bv, int j, double **dev);                                /* ops->getcolumn: device pointer view of column j (j<0: constraint) */
 int ks_bv_get_buffer(ks_bv bv, double **dev);                                       /* BVGetBufferVec bvbasic.c:775: (nc+m)*m device doubles */
+int ks_bv_set_buffer(ks_bv bv, double *dev);                                        /* BVSetBufferVec bvbasic.c:720 on a raw device array of (nc+m)*m doubles (caller-owned; NULL: the library's own) */
+int ks_bv_set_layout(ks_bv bv, int nc, int m);                                      /* mirror of the fields BVSetNumConstraints changes (bvbasic.c:291-296); moves no data */
 int ks_bv_set_column_host(ks_bv bv, int j, const double *host);                     /* H2D of n_local doubles */
 int ks_bv_get_column_host(ks_bv bv, int j, double *host);                           /* D2H, synchronises */
 int ks_bv_get_buffer_host(ks_bv bv, double *host);                                  /* D2H of the (nc+m)*m coefficient buffer */
@@ -206,9 +208,19 @@ int ks_bv_copycolumn(ks_bv V, int j, int i);                                    
 int ks_bv_matmult(ks_bv V, ks_mat A, ks_bv W);                                                   /* ops->matmult (column loop, svec.c:213) */
 int ks_bv_matmultcolumn(ks_bv V, ks_mat A, int j);                                               /* BVMatMultColumn bvops.c:862 */
 
-/* ops->gramschmidt (bvimpl.h:53): replaces BVOrthogonalizeCGS1/MGS1 wholesale (bvorthog.c:134).
-   Fused, device-resident classical Gram-Schmidt of column j against columns [0,j) with the
-   reference's refinement policy; coefficients accumulate in the buffer column j.               */
+/* ops->gramschmidt (bvimpl.h:53): ONE Gram-Schmidt pass, the function BVOrthogonalizeGS1 dispatches to (bvorthog.c:134) in place
+   of BVOrthogonalizeCGS1 (:91-132) / BVOrthogonalizeMGS1 (:52-85), chosen by the BV's orthogonalization type. The caller
+   (BVOrthogonalizeGS :145-217) owns the refinement loop, lindep, BV_CleanCoefficients and BV_SetValue.
+     v_dev NULL : column j against the constraints and columns 0..j-1;  v_dev given: that device vector against columns [-nc, j)
+     which      : MGS only, may be NULL
+     h, c       : HOST arrays of nc+m entries (bv->h, bv->c), or both NULL = column j and the scratch column of the BV's buffer;
+                  the pass ADDS its coefficients to h (BV_AddCoefficients), c holds this pass's coefficients
+     onrm, nrm  : norm before the pass / estimated norm after it (explicit when the estimate breaks down); either may be NULL
+   Returns KS_ERR_USER_INPUT for an invalid inner product (BV_SafeSqrt). Synchronises (the outputs are host scalars).   */
+int ks_bv_gramschmidt_pass(ks_bv bv, int j, double *v_dev, const int *which, double *h, double *c, double *onrm, double *nrm);
+/* The whole of BVOrthogonalizeColumn / BVOrthonormalizeColumn (not ops slots: the entry points a caller uses that drives this
+   library directly): fused, device-resident classical Gram-Schmidt of column j against columns [0,j) with the reference's
+   refinement policy; coefficients accumulate in the buffer column j.                              */
 int ks_bv_orthogonalizecolumn(ks_bv bv, int j, double *H, double *norm, int *lindep);            /* BVOrthogonalizeColumn bvorthog.c:315 */
 int ks_bv_orthonormalizecolumn(ks_bv bv, int j, int replace, double *norm, int *lindep);         /* BVOrthonormalizeColumn bvorthog.c:380 */
 int ks_bv_orthogonalizevec(ks_bv bv, double *v_dev, double *H, double *norm, int *lindep);       /* BVOrthogonalizeVec bvorthog.c:247 */
@@ -236,8 +248,8 @@ int ks_bv_matlanczos(ks_bv V, ks_mat A, double *T, int ldt, int k, int *m, doubl
 /* ---- EPS: Krylov-Schur driver (host side; restates krylovschur.c:227-337) -------------------- */
 int ks_eps_create(ks_ctx ctx, ks_eps *eps);
 int ks_eps_destroy(ks_eps eps);
-int ks_eps_set_operators(ks_eps eps, ks_mat A, ks_mat B /* must be NULL: standard problems only */);
-int ks_eps_set_problem_type(ks_eps eps, int type);                         /* KS_EPS_HEP (Lanczos) | KS_EPS_NHEP (Arnoldi) */
+int ks_eps_set_operators(ks_eps eps, ks_mat A, ks_mat B /* NULL: standard problem */);   /* EPSSetOperators epssetup.c:450 */
+int ks_eps_set_problem_type(ks_eps eps, int type);                         /* KS_EPS_HEP / KS_EPS_GHEP (Lanczos, B-inner product) | KS_EPS_NHEP / KS_EPS_GNHEP (Arnoldi) */
 int ks_eps_set_dimensions(ks_eps eps, int nev, int ncv /*<=0: default*/, int mpd /*<=0: default*/);
 int ks_eps_set_tolerances(ks_eps eps, double tol /*<=0: 1e-8*/, int max_it /*<=0: default*/);
 int ks_eps_set_which_eigenpairs(ks_eps eps, int which);

@@ -65,6 +65,8 @@ _SIG = {
     "ks_bv_get_array": [vp, C.POINTER(vp)],
     "ks_bv_get_column": [vp, C.c_int, C.POINTER(vp)],
     "ks_bv_get_buffer": [vp, C.POINTER(vp)],
+    "ks_bv_set_buffer": [vp, vp],
+    "ks_bv_set_layout": [vp, C.c_int, C.c_int],
     "ks_bv_set_column_host": [vp, C.c_int, dp],
     "ks_bv_get_column_host": [vp, C.c_int, dp],
     "ks_bv_get_buffer_host": [vp, dp],
@@ -92,6 +94,7 @@ _SIG = {
     "ks_bv_copycolumn": [vp, C.c_int, C.c_int],
     "ks_bv_matmult": [vp, vp, vp],
     "ks_bv_matmultcolumn": [vp, vp, C.c_int],
+    "ks_bv_gramschmidt_pass": [vp, C.c_int, vp, ip, dp, dp, dp, dp],
     "ks_bv_orthogonalizecolumn": [vp, C.c_int, dp, dp, ip],
     "ks_bv_orthonormalizecolumn": [vp, C.c_int, C.c_int, dp, ip],
     "ks_bv_orthogonalizevec": [vp, vp, dp, dp, ip],

@@ -261,7 +261,7 @@ extern "C" int ks_bv_destroy(ks_bv bv)
   if (!bv) return KS_SUCCESS;
   hipSetDevice(bv->ctx->device);
   hipStreamSynchronize(bv->ctx->stream);
-  hipFree(bv->array); hipFree(bv->buffer); hipFree(bv->partials); hipFree(bv->coef); hipFree(bv->hc); hipFree(bv->gs); hipFree(bv->recs); hipFree(bv->panel); hipFree(bv->Bx); hipFree(bv->pend);
+  hipFree(bv->array); hipFree(bv->own_buffer ? bv->buffer : bv->buffer_own); hipFree(bv->partials); hipFree(bv->coef); hipFree(bv->hc); hipFree(bv->gs); hipFree(bv->recs); hipFree(bv->panel); hipFree(bv->Bx); hipFree(bv->pend);
   delete bv;
   return KS_SUCCESS;
 }
@@ -283,7 +283,7 @@ extern "C" int ks_bv_resize(ks_bv bv, int m, int copy)
     KS_HIP(hipStreamSynchronize(bv->ctx->stream));
   }
   // swap the storage of the two objects, keep the caller's handle and settings
-  std::swap(bv->array, nb->array); std::swap(bv->buffer, nb->buffer); std::swap(bv->coef, nb->coef); std::swap(bv->coef_len, nb->coef_len);
+  std::swap(bv->array, nb->array); std::swap(bv->buffer, nb->buffer); std::swap(bv->own_buffer, nb->own_buffer); std::swap(bv->buffer_own, nb->buffer_own); std::swap(bv->coef, nb->coef); std::swap(bv->coef_len, nb->coef_len);
   std::swap(bv->hc, nb->hc); std::swap(bv->recs, nb->recs); std::swap(bv->panel, nb->panel); std::swap(bv->panel_len, nb->panel_len);
   std::swap(bv->m, nb->m);
   bv->l = 0; bv->k = m;
@@ -429,6 +429,26 @@ extern "C" int ks_bv_set_orthogonalization(ks_bv bv, int type, int refine, doubl
 
 extern "C" int ks_bv_get_array(ks_bv bv, double **dev) { KS_CHECK(bv && dev, KS_ERR_ARG_NULL, "NULL argument"); *dev = bv->array; return KS_SUCCESS; }
 extern "C" int ks_bv_get_buffer(ks_bv bv, double **dev) { KS_CHECK(bv && dev, KS_ERR_ARG_NULL, "NULL argument"); *dev = bv->buffer; return KS_SUCCESS; }
+// BVSetBufferVec bvbasic.c:720 on a raw device array of (nc+m)*m doubles: the adapter hands over the array of the reference's
+// bv->buffer Vec, so that BV_CleanCoefficients / BV_SetValue / BV_StoreCoefficients of the caller and the kernels of this library
+// work on the same memory. NULL returns to the library's own allocation.
+extern "C" int ks_bv_set_buffer(ks_bv bv, double *dev)
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  if (dev) { if (bv->own_buffer) { bv->buffer_own = bv->buffer; bv->own_buffer = false; } bv->buffer = dev; }
+  else if (!bv->own_buffer) { bv->buffer = bv->buffer_own; bv->buffer_own = nullptr; bv->own_buffer = true; }
+  return KS_SUCCESS;
+}
+// State-only mirror of the reference's BV fields nc / m (BVSetNumConstraints bvbasic.c:260-297 changes them, and shifts the columns,
+// without going through an ops slot): no data moves here. nc + m must equal the number of allocated columns.
+extern "C" int ks_bv_set_layout(ks_bv bv, int nc, int m)
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  KS_CHECK(nc >= 0 && m > 0 && nc + m == bv->nc + bv->m, KS_ERR_ARG_OUTOFRANGE, "nc=%d, m=%d do not add up to the %d allocated columns", nc, m, bv->nc + bv->m);
+  bv->nc = nc; bv->m = m;
+  bv->l = std::min(bv->l, bv->m); bv->k = std::min(bv->k, bv->m);
+  return KS_SUCCESS;
+}
 extern "C" int ks_bv_get_column(ks_bv bv, int j, double **dev)
 {
   KS_CHECK(bv && dev, KS_ERR_ARG_NULL, "NULL argument");

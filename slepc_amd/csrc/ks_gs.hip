@@ -36,8 +36,33 @@ struct GsArgs {
   int krylov;      // inside BVMatLanczos/Arnoldi: lindep halts the rest of the run
   int ldb;         // leading dimension of the coefficient buffer (nc+m)
   int spec_last;   // this is the last slot of the optimistic program: unfinished business halts the run for the host
+  int gs1;         // 0: slot of the device-resident program; 1 / 2: ONE pass with the semantics of the ops->gramschmidt slot
+                   // (BVOrthogonalizeCGS1), without (1) / with (2) the self dot product in c[k]
   double eta, deftol;
 };
+
+// Bookkeeping of ONE classical Gram-Schmidt pass as the reference's slot defines it (BVOrthogonalizeCGS1 bvorthog.c:91-132): the
+// refinement loop, lindep and BV_CleanCoefficients / BV_SetValue stay with the caller. c[0..k) are the reduced dots against the
+// previous columns, c[k] the self dot (a.gs1 == 2). Leaves |v| and the raw estimate |v|^2 - sum c_i^2 in the column's record.
+__device__ void gs1_bookkeep(const GsArgs a, const double *c, double *__restrict__ buffer, double *__restrict__ pend, KsGsState *st, KsStepRec *recs)
+{
+  const int k = a.k;
+  double *H = buffer + (size_t)a.col * a.ldb;
+  double beta = 0.0;
+  st->do_update = 0; st->err = 0;
+  if (a.gs1 == 2) {                                                     // BV_SquareRoot -> BV_SafeSqrt (bvimpl.h:121-141)
+    const double vv = c[k];
+    if (!(vv > -a.deftol)) { st->err = KS_ERR_USER_INPUT; return; }
+    beta = vv < 0.0 ? 0.0 : sqrt(vv);
+  }
+  double sum = 0.0;
+  for (int i = 0; i < k; i++) sum += c[i] * c[i];                      // BV_SquareSum bvimpl.h:347-360
+  for (int i = 0; i < k; i++) { H[i] += c[i]; pend[i] = c[i]; }        // BV_AddCoefficients bvimpl.h:308-322 (the caller cleaned H)
+  st->npend = 1; st->do_update = k > 0 ? 1 : 0; st->fuse_dot = 0; st->scale_now = 0; st->store_now = 1; st->store_prev = 1; st->alpha = 1.0;
+  st->pending_scale = 0; st->more_ = 0; st->expl = 0;
+  KsStepRec r; r.onrm = beta; r.nrm = beta * beta - sum; r.passes = 1; r.lindep = 0; r.expl = 0; r.col = a.col;
+  recs[a.col] = r;
+}
 
 // Bookkeeping for one slot.  Thread 0 only.  c[0..k] are the (globally reduced) dots of the current
 // vector against columns 0..k-1 and itself.
@@ -132,14 +157,14 @@ template <bool REDUCE, bool BOOK>
 __global__ __launch_bounds__(1024) void k_gs_finish(const double *__restrict__ partials, GsArgs a, double *buffer, double *pend, KsGsState *st, KsStepRec *recs)
 {
   __shared__ double c_lds[KS_MAX_COLS + 8];
-  const int ncols = a.k + 1;
+  const int ncols = a.k + (a.gs1 == 1 ? 0 : 1);
   // Slot gating is decided by ONE thread and broadcast through LDS: thread 0 rewrites the state later in
   // this kernel, so letting every wave read it would let a late wave take a different branch around the
   // barriers below.
   __shared__ int go;
   if (threadIdx.x == 0) {
     go = 1;
-    if (BOOK && (!st->active || (a.slot > 1 && !st->expl && !st->more_))) { go = 0; st->do_update = 0; }   // halted run / column already final
+    if (BOOK && !a.gs1 && (!st->active || (a.slot > 1 && !st->expl && !st->more_))) { go = 0; st->do_update = 0; }   // halted run / column already final
   }
   __syncthreads();
   if (!go) return;
@@ -152,7 +177,7 @@ __global__ __launch_bounds__(1024) void k_gs_finish(const double *__restrict__ p
     if ((int)threadIdx.x < ncols) c_lds[threadIdx.x] = buffer[threadIdx.x];
     __syncthreads();
   }
-  if (BOOK && threadIdx.x == 0) gs_bookkeep(a, c_lds, buffer, pend, st, recs);
+  if (BOOK && threadIdx.x == 0) { if (a.gs1) gs1_bookkeep(a, c_lds, buffer, pend, st, recs); else gs_bookkeep(a, c_lds, buffer, pend, st, recs); }
 }
 
 // The tile loop of the update sweep. NP > 0 / FUSE >= 0 fix the number of pending passes and the fused flag at compile
@@ -288,7 +313,7 @@ int launch_finish(ks_bv bv, const GsArgs &a)
   if (!multi) hipLaunchKernelGGL((k_gs_finish<true, true>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, a, bv->buffer, bv->pend, bv->gs, bv->recs);
   else {
     hipLaunchKernelGGL((k_gs_finish<true, false>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, a, bv->buffer, bv->pend, bv->gs, bv->recs);
-    KS_CALL(ks_allreduce_sum(ctx, bv->buffer, a.k + 1));
+    KS_CALL(ks_allreduce_sum(ctx, bv->buffer, a.k + (a.gs1 == 1 ? 0 : 1)));
     hipLaunchKernelGGL((k_gs_finish<false, true>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, a, bv->buffer, bv->pend, bv->gs, bv->recs);
   }
   KS_HIP(hipGetLastError());
@@ -336,7 +361,7 @@ int total_slots(ks_bv bv) { return bv->orthog_ref == KS_BV_ORTHOG_REFINE_IFNEEDE
 int enqueue_gs_slots(ks_bv bv, int j, int normalize, int krylov, int first, int last, bool halt_at_last, bool resolution_and_scale)
 {
   ks_ctx ctx = bv->ctx;
-  GsArgs a; a.k = bv->nc + j; a.col = j; a.refine = bv->orthog_ref; a.normalize = normalize; a.krylov = krylov; a.ldb = bv->nc + bv->m; a.eta = bv->orthog_eta; a.deftol = bv->deftol;
+  GsArgs a; a.gs1 = 0; a.k = bv->nc + j; a.col = j; a.refine = bv->orthog_ref; a.normalize = normalize; a.krylov = krylov; a.ldb = bv->nc + bv->m; a.eta = bv->orthog_eta; a.deftol = bv->deftol;
   double *v = ks_bv_col(bv, j);
   for (int p = first; p <= last; p++) {
     a.slot = p; a.spec_last = (halt_at_last && p == last) ? 1 : 0;
@@ -639,6 +664,72 @@ extern "C" int ks_bv_orthogonalizesomecolumn(ks_bv bv, int j, const int *which, 
   KS_CALL(store_buffer_column(bv, j, hh.data(), bv->nc + j + 1));
   if (norm) *norm = nrm;
   if (H) for (int i = bv->l; i < j; i++) H[i - bv->l] = hh[bv->nc + i];
+  return KS_SUCCESS;
+}
+
+
+// ---- ops->gramschmidt: ONE pass ------------------------------------------------------------------
+// The slot BVOrthogonalizeGS1 dispatches to (bvorthog.c:134, bvimpl.h:53). The caller - BVOrthogonalizeGS, bvorthog.c:145-217 -
+// owns the refinement loop: it cleans the coefficients, calls the slot once per pass (onrm / nrm may be NULL: REFINE_NEVER and the
+// first REFINE_ALWAYS call), compares |nrm| with eta |onrm|, computes lindep and stores the norm next to the coefficients.
+namespace {
+int gs1_fused_column(ks_bv bv, int j, double *onrm, double *nrm)
+{
+  ks_ctx ctx = bv->ctx;
+  const bool need = onrm || nrm;
+  const int k = bv->nc + j;
+  if (k == 0 && !need) return KS_SUCCESS;
+  GsArgs a; a.gs1 = need ? 2 : 1; a.k = k; a.col = j; a.slot = 1; a.refine = bv->orthog_ref; a.normalize = 0; a.krylov = 0; a.ldb = bv->nc + bv->m;
+  a.spec_last = 0; a.eta = bv->orthog_eta; a.deftol = bv->deftol;
+  double *v = ks_bv_col(bv, j);
+  KS_CALL(ksk_dot(bv, ks_bv_col(bv, -bv->nc), bv->ld, k + (need ? 1 : 0), v, false));          // BVDotColumnInc / BVDotColumn
+  KS_CALL(launch_finish(bv, a));
+  if (k > 0) KS_CALL(launch_update(bv, j, v, 2));                                              // BVMultColumn(bv,-1,1,j,c)
+  KsGsState st; KsStepRec rec;
+  KS_CALL(fetch_state(bv, &st, &rec, j, j));
+  ks_prof_resolve_gs(ctx, &rec, j, j);
+  bv->passes_last_host = 1; bv->passes_total_host += 1;
+  if (onrm) *onrm = rec.onrm;
+  if (nrm) {
+    if (rec.nrm <= 0.0) KS_CALL(ks_bv_normcolumn(bv, j, KS_NORM_2, nrm));                      // BV_NormVecOrColumn bvorthog.c:126
+    else *nrm = sqrt(rec.nrm);
+  }
+  return KS_SUCCESS;
+}
+} // namespace
+
+extern "C" int ks_bv_gramschmidt_pass(ks_bv bv, int j, double *v_dev, const int *which, double *h, double *c, double *onrm, double *nrm)
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  KS_CHECK((h == nullptr) == (c == nullptr), KS_ERR_ARG_WRONG, "h and c must both be host arrays or both be NULL (the BV's buffer)");
+  KS_CHECK(v_dev || (j >= 0 && j < bv->m), KS_ERR_ARG_OUTOFRANGE, "Index j=%d but BV only has %d columns", j, bv->m);
+  KS_CHECK(!v_dev || (j >= 0 && j <= bv->m), KS_ERR_ARG_OUTOFRANGE, "Argument j=%d (number of columns to orthogonalize against) out of range", j);
+  KS_CHECK(!v_dev || h, KS_ERR_ARG_WRONG, "orthogonalizing a vector needs host arrays h and c (bv->h, bv->c in BVOrthogonalizeVec)");
+  ks_ctx ctx = bv->ctx;
+  KS_HIP(hipSetDevice(ctx->device));
+  const bool mgs = bv->orthog_type == KS_BV_ORTHOG_MGS;
+  if (!v_dev && !h && !mgs && use_fused(bv)) return gs1_fused_column(bv, j, onrm, nrm);
+  // host-driven pass on the primitive ops (MGS, a vector argument, a B-inner product, a basis wider than the fused kernels)
+  const int len = bv->nc + j;
+  const int ldb = bv->nc + bv->m;
+  std::vector<double> hh(ldb + 1, 0.0), cc(ldb + 1, 0.0);
+  double *hp = h ? h : hh.data(), *cp = c ? c : cc.data();
+  if (!h && len > 0) {                                   // coefficients of column j live in the device buffer
+    KS_HIP(hipMemcpyAsync(hp, bv->buffer + (size_t)j * ldb, sizeof(double) * len, hipMemcpyDeviceToHost, ctx->stream));
+    KS_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  const int lsave = bv->l, ksave = bv->k;
+  bv->l = -bv->nc;
+  if (v_dev) bv->k = j;
+  int rc = mgs ? generic_mgs1(bv, j, v_dev, which, hp, cp, onrm, nrm) : generic_cgs1(bv, j, v_dev, hp, cp, onrm, nrm);
+  bv->l = lsave; bv->k = ksave;
+  if (rc) return rc;
+  bv->passes_last_host = 1; bv->passes_total_host += 1;
+  if (!h && len > 0) {
+    KS_HIP(hipMemcpyAsync(bv->buffer + (size_t)j * ldb, hp, sizeof(double) * len, hipMemcpyHostToDevice, ctx->stream));
+    KS_HIP(hipMemcpyAsync(bv->buffer, cp, sizeof(double) * len, hipMemcpyHostToDevice, ctx->stream));      // scratch column "s" (bvbasic.c:757-769)
+    KS_HIP(hipStreamSynchronize(ctx->stream));
+  }
   return KS_SUCCESS;
 }
 

@@ -182,6 +182,8 @@ struct ks_bv_s {
   double deftol = 10 * 2.220446049250313e-16;
   double *array = nullptr;      // m*ld
   double *buffer = nullptr;     // (nc+m)*m ; column 0 = scratch c
+  bool own_buffer = true;       // false: adopted from the caller (ks_bv_set_buffer: the device array of the reference's bv->buffer Vec)
+  double *buffer_own = nullptr; // the library's own allocation while an adopted one is in use
   double *partials = nullptr;   // [KS_MAX_BLOCKS][KS_PSTRIDE] block partial sums
   double *coef = nullptr;       // device scratch for host-provided q / Q (max(m*m, ...))
   double *hc = nullptr;         // device h,c arrays for orthogonalizevec (2*(nc+m))

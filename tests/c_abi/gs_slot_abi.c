@@ -1,0 +1,127 @@
+/* The ops->gramschmidt slot (include/slepc/private/bvimpl.h:53) driven from C the way its one caller drives it.
+   caller_orthogonalize_column() below restates the CALLER's side - BVOrthogonalizeColumn (bvorthog.c:315-339) around
+   BVOrthogonalizeGS (:145-217) with BV_CleanCoefficients / BV_SetValue on the coefficient buffer - and hands every pass to
+   ks_bv_gramschmidt_pass exactly where the reference calls BVOrthogonalizeGS1 (:176,182,190,198,199): NULL onrm / nrm for
+   REFINE_NEVER and the first REFINE_ALWAYS call, the |nrm| < eta |onrm| loop and lindep on the caller's side.
+   Inputs are dyadic rationals (exact in C and in numpy): column 4 is column 0 plus a 2^-30 perturbation (needs refinement),
+   column 6 = 2 x1 - 3 x2 (dependent), column 8 = 0. The test-suite compares the printed lines with the CPU oracle.
+   usage: gs_slot_abi <refine 0|1|2> [mgs]                                                                                  */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "ksgpu.h"
+
+#define CHK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s failed: %d (%s) %s\n", #call, rc_, ks_error_string(rc_), ks_last_error_message()); return 1; } } while (0)
+
+enum { N = 2000, M = 9 };
+
+static double entry(int i, int j) { return (double)(((i * 37 + j * 101 + ((i * i) % 13) * 7) % 17) - 8) * 0.0625; }
+
+typedef struct { ks_ctx ctx; ks_bv bv; double *buffer; int nc, m; int refine, mgs; double eta; int passes; } Caller;
+
+/* BV_CleanCoefficients(bv,j,NULL) bvimpl.h:289-301: zero column j of the buffer, entries 0..nc+j-1 */
+static int clean_coefficients(Caller *c, int j)
+{
+  double zero[M + 1] = {0};
+  if (c->nc + j > 0) CHK(ks_ctx_memcpy(c->ctx, c->buffer + (size_t)j * (size_t)(c->nc + c->m), zero, sizeof(double) * (size_t)(c->nc + j), 0));
+  return 0;
+}
+/* BV_SetValue(bv,j,k,NULL,value) bvimpl.h:328-340 */
+static int set_value(Caller *c, int j, int k, double value)
+{
+  CHK(ks_ctx_memcpy(c->ctx, c->buffer + (size_t)k * (size_t)(c->nc + c->m) + (size_t)(c->nc + j), &value, sizeof(double), 0));
+  return 0;
+}
+
+static int caller_orthogonalize_column(Caller *c, int j, double *norm, int *lindep)
+{
+  double onrm = 0.0, nrm = 0.0;
+  int l;
+  if (clean_coefficients(c, j)) return 1;
+  switch (c->refine) {
+  case KS_BV_ORTHOG_REFINE_IFNEEDED:
+    CHK(ks_bv_gramschmidt_pass(c->bv, j, NULL, NULL, NULL, NULL, &onrm, &nrm)); c->passes++;
+    l = 1;
+    while (l < 3 && nrm != 0.0 && fabs(nrm) < c->eta * fabs(onrm)) {
+      l++;
+      if (c->mgs) onrm = nrm;                                                              /* bvorthog.c:181-182 */
+      CHK(ks_bv_gramschmidt_pass(c->bv, j, NULL, NULL, NULL, NULL, c->mgs ? NULL : &onrm, &nrm)); c->passes++;
+    }
+    *lindep = !(nrm != 0.0 && fabs(nrm) >= c->eta * fabs(onrm));
+    break;
+  case KS_BV_ORTHOG_REFINE_NEVER:
+    CHK(ks_bv_gramschmidt_pass(c->bv, j, NULL, NULL, NULL, NULL, NULL, NULL)); c->passes++;
+    CHK(ks_bv_normcolumn(c->bv, j, KS_NORM_2, &nrm));
+    *lindep = !(nrm != 0.0);
+    break;
+  default:
+    CHK(ks_bv_gramschmidt_pass(c->bv, j, NULL, NULL, NULL, NULL, NULL, NULL)); c->passes++;
+    CHK(ks_bv_gramschmidt_pass(c->bv, j, NULL, NULL, NULL, NULL, &onrm, &nrm)); c->passes++;
+    *lindep = !(nrm != 0.0 && fabs(nrm) >= c->eta * fabs(onrm));
+    break;
+  }
+  *norm = nrm;
+  if (set_value(c, j, j, *lindep ? 0.0 : nrm)) return 1;
+  return 0;
+}
+
+int main(int argc, char **argv)
+{
+  Caller c;
+  double *col, *x0, *x1, *x2, H[(M + 1) * (M + 1)];
+  int i, j, refine = argc > 1 ? atoi(argv[1]) : 0, mgs = argc > 2 && !strcmp(argv[2], "mgs");
+
+  CHK(ks_ctx_create(0, NULL, &c.ctx));
+  CHK(ks_bv_create(c.ctx, N, N, M, 0, &c.bv));
+  CHK(ks_bv_set_orthogonalization(c.bv, mgs ? KS_BV_ORTHOG_MGS : KS_BV_ORTHOG_CGS, refine, 0.0));
+  CHK(ks_bv_get_buffer(c.bv, &c.buffer));
+  c.nc = 0; c.m = M; c.refine = refine; c.mgs = mgs; c.eta = 0.7071; c.passes = 0;
+
+  col = (double *)malloc(sizeof(double) * N); x0 = (double *)malloc(sizeof(double) * N);
+  x1 = (double *)malloc(sizeof(double) * N); x2 = (double *)malloc(sizeof(double) * N);
+  for (i = 0; i < N; i++) { x0[i] = entry(i, 0); x1[i] = entry(i, 1); x2[i] = entry(i, 2); }
+  for (j = 0; j < M; j++) {
+    for (i = 0; i < N; i++) {
+      if (j == 4) col[i] = x0[i] + ldexp(entry(i, 4), -30);
+      else if (j == 6) col[i] = 2.0 * x1[i] - 3.0 * x2[i];
+      else if (j == 8) col[i] = 0.0;
+      else col[i] = entry(i, j);
+    }
+    CHK(ks_bv_set_column_host(c.bv, j, col));
+  }
+
+  for (j = 0; j < M; j++) {
+    double norm = 0.0; int lindep = 0, before = c.passes;
+    /* the caller sets the window to [-nc, j) around the call (bvorthog.c:327-333) */
+    CHK(ks_bv_set_active_columns(c.bv, 0, M));
+    if (caller_orthogonalize_column(&c, j, &norm, &lindep)) return 1;
+    /* BVOrthonormalizeColumn (bvorthog.c:417-419); a dependent column is zeroed so that both sides go on with the same basis */
+    if (lindep || norm == 0.0) CHK(ks_bv_scalecolumn(c.bv, j, 0.0));
+    else CHK(ks_bv_scalecolumn(c.bv, j, 1.0 / norm));
+    printf("column %d passes %d lindep %d norm %.17g\n", j, c.passes - before, lindep, norm);
+  }
+  CHK(ks_bv_get_buffer_host(c.bv, H));
+  for (j = 0; j < M; j++) {
+    printf("H[:,%d]", j);
+    for (i = 0; i <= j; i++) printf(" %.17g", H[i + j * M]);
+    printf("\n");
+  }
+  /* the vector form of the slot with host h / c (BVOrthogonalizeVec -> bv->h, bv->c, bvorthog.c:247-269): a copy of column 3's
+     original content against the first three (now orthonormal) columns, one pass with both norms */
+  {
+    double h[M] = {0}, cc[M] = {0}, onrm = 0.0, nrm = 0.0, *w;
+    ks_bv W;
+    CHK(ks_bv_create(c.ctx, N, N, 1, 0, &W));
+    for (i = 0; i < N; i++) col[i] = entry(i, 3);
+    CHK(ks_bv_set_column_host(W, 0, col));
+    CHK(ks_bv_get_column(W, 0, &w));
+    CHK(ks_bv_set_active_columns(c.bv, 0, 3));
+    CHK(ks_bv_gramschmidt_pass(c.bv, 3, w, NULL, h, cc, &onrm, &nrm));
+    printf("vector onrm %.17g nrm %.17g h %.17g %.17g %.17g\n", onrm, nrm, h[0], h[1], h[2]);
+    CHK(ks_bv_destroy(W));
+  }
+  free(col); free(x0); free(x1); free(x2);
+  CHK(ks_bv_destroy(c.bv)); CHK(ks_ctx_destroy(c.ctx));
+  return 0;
+}

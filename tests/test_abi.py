@@ -66,16 +66,22 @@ def test_product_does_not_import_oracle():
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
 
 
-def _build_c_example(tmp_path):
+def _build_c_example(tmp_path, name="ex2_abi"):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "ex2_abi")
+    exe = str(tmp_path / name)
     cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
-           os.path.join(root, "tests", "c_abi", "ex2_abi.c"), "-o", exe, "-L" + os.path.join(root, "slepc_amd"), "-l:libksgpu.so",
-           "-Wl,-rpath," + os.path.join(root, "slepc_amd")]
+           os.path.join(root, "tests", "c_abi", name + ".c"), "-o", exe, "-L" + os.path.join(root, "slepc_amd"), "-l:libksgpu.so",
+           "-Wl,-rpath," + os.path.join(root, "slepc_amd"), "-lm"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return exe
+
+
+@pytest.mark.parametrize("name", ["bv_test1_abi", "gs_slot_abi"])
+def test_c_drivers_of_the_bv_slots_compile_as_strict_c99(tmp_path, name):
+    """The C programs that drive the BV-level slots (tests/test_gpu_cabi.py runs them on the GPU) build here."""
+    _build_c_example(tmp_path, name)
 
 
 def test_header_is_plain_c_and_library_links_from_c(tmp_path):
