@@ -234,7 +234,7 @@ int ks_bv_set_matrix(ks_bv bv, ks_mat B);
 int ks_bv_get_matrix(ks_bv bv, ks_mat *B);
 int ks_bv_orthogonalize(ks_bv V, double *R, int ldr);
 int ks_bv_matproject(ks_bv X, ks_mat A /* NULL: identity */, ks_bv Y, double *M, int ldm);   /* BVMatProject bvglobal.c:1014: M = Y^H A X */
-int ks_bv_normalize(ks_bv V, const double *eigi /* may be NULL */);                          /* BVNormalize bvglobal.c:855 */
+int ks_bv_normalize(ks_bv V, const double *eigi /* may be NULL; entry 0 belongs to column l (what the ops->normalize slot receives after svec.c:196's offset) */);   /* BVNormalize bvglobal.c:855 */
 int ks_bv_orthogonalizesomecolumn(ks_bv bv, int j, const int *which, double *H, double *norm, int *lindep); /* bvorthog.c:432 (MGS) */
 int ks_bv_gs_passes(ks_bv bv, long long *passes_total, int *passes_last);                        /* instrumentation */
 

@@ -58,9 +58,18 @@ extern "C" int ks_ctx_create(int device, void *stream, ks_ctx *out)
     KS_FAIL(KS_ERR_GPU, "device %d is %s; libksgpu carries gfx950 code objects only", device, prop.gcnArchName);
   }
   if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
-  else { KS_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+  else {
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; KS_FAIL(KS_ERR_LIB, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(e)); }
+    ctx->own_stream = true;
+  }
   ctx->h_pinned_len = 16384;
-  KS_HIP(hipHostMalloc((void **)&ctx->h_pinned, ctx->h_pinned_len * sizeof(double), hipHostMallocDefault));
+  e = hipHostMalloc((void **)&ctx->h_pinned, ctx->h_pinned_len * sizeof(double), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    KS_FAIL(KS_ERR_MEM, "hipHostMalloc of the staging area failed: %s", hipGetErrorString(e));
+  }
   *out = ctx;
   return KS_SUCCESS;
 }

@@ -1080,7 +1080,11 @@ extern "C" int ks_mat_load_petsc_binary(ks_ctx ctx, const char *path, ks_mat *ou
   KS_CHECK((long long)buf.size() >= 16 + 4 * rows + 12 * nnz, KS_ERR_FILE_UNEXPECTED, "File %s is truncated", path);
   const unsigned char *pl = buf.data() + 16, *pc = pl + 4 * rows, *pv = pc + 4 * nnz;
   std::vector<long long> start(rows + 1, 0);
-  for (long long i = 0; i < rows; i++) start[i + 1] = start[i] + (int32_t)be32(pl + 4 * i);
+  for (long long i = 0; i < rows; i++) {
+    const long long len = (int32_t)be32(pl + 4 * i);
+    KS_CHECK(len >= 0 && len <= cols, KS_ERR_FILE_UNEXPECTED, "Row %lld of %s has length %lld", i, path, len);
+    start[i + 1] = start[i] + len;
+  }
   KS_CHECK(start[rows] == nnz, KS_ERR_FILE_UNEXPECTED, "Row lengths of %s do not add up to its nnz", path);
   const int size = ctx->comm.size, rank = ctx->comm.rank;
   const long long base = rows / size, rem = rows % size;

@@ -198,6 +198,21 @@ def test_matload_and_ex4_rdb200(ctx):
     assert e.value.rc == 79
 
 
+def test_matload_rejects_a_negative_row_length(ctx, tmp_path):
+    """A corrupted file whose row lengths still add up to nnz (one negative, one too long) must be refused before the
+    row pointers are built."""
+    import struct
+    import slepc_amd as ks
+    raw = bytearray(open(gi.matrix_path("rdb200.petsc"), "rb").read())
+    l0 = struct.unpack(">i", raw[16:20])[0]; l1 = struct.unpack(">i", raw[20:24])[0]
+    raw[16:20] = struct.pack(">i", -1); raw[20:24] = struct.pack(">i", l0 + l1 + 1)
+    p = tmp_path / "bad.petsc"
+    p.write_bytes(bytes(raw))
+    with pytest.raises(ks.KsError) as e:
+        ks.Mat.load(ctx, str(p))
+    assert e.value.rc == 79
+
+
 def _bfw(ctx):
     import slepc_amd as ks
     return (ks.Mat.load(ctx, gi.matrix_path("bfw62a.petsc")), ks.Mat.load(ctx, gi.matrix_path("bfw62b.petsc")),
