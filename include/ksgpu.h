@@ -122,6 +122,9 @@ int ks_comm_set_ops(ks_ctx ctx, int rank, int size, const ks_comm_ops *ops, void
 int ks_comm_rank_size(ks_ctx ctx, int *rank, int *size);
 /* device<->host copy on the context's stream (synchronous); kind: 0 = host->device, 1 = device->host */
 int ks_ctx_memcpy(ks_ctx ctx, void *dst, const void *src, size_t bytes, int kind);
+/* the same on a given stream (the `stream` argument a ks_comm_ops callback receives; NULL = the context's): what a provider that
+   stages through the host uses to order itself after the work already enqueued there */
+int ks_ctx_memcpy_stream(ks_ctx ctx, void *dst, const void *src, size_t bytes, int kind, void *stream);
 
 /* ---- Mat: the MatMult(AIJ) slot ------------------------------------------------------------- */
 /* CSR arrays as in PETSc SeqAIJ (i,j,a): rowptr[n_local+1], col[nnz] (GLOBAL column indices),
@@ -263,6 +266,13 @@ int ks_eps_set_random_seed(ks_eps eps, uint64_t seed);
 int ks_eps_set_initial_vector(ks_eps eps, const double *v_host);           /* EPSSetInitialSpace with one vector */
 int ks_eps_set_initial_space(ks_eps eps, int n, const double *const *v_dev);   /* EPSSetInitialSpace epssetup.c:590: device vectors; a Krylov solver uses the first */
 int ks_eps_set_deflation_space(ks_eps eps, int n, const double *const *v_dev); /* EPSSetDeflationSpace epssetup.c:555: n device vectors, copied; used by the next solve only */
+/* DSSetParallel on the solver's DS (dsbasic.c; krylovschur.c:281 DSSynchronize): with KS_DS_PARALLEL_SYNCHRONIZED, after every projected
+   solve rank 0's projected matrix, vectors, eigenvalues and the outcome of the expansion (beta, length, breakdown) are broadcast, so the
+   replicated control flow cannot diverge when a caller-supplied allreduce does not return identical bits on every rank. Default:
+   synchronized (the reference's default is redundant; the broadcast is a few KB per restart). */
+enum { KS_DS_PARALLEL_REDUNDANT = 0, KS_DS_PARALLEL_SYNCHRONIZED = 1 };
+int ks_eps_set_ds_parallel(ks_eps eps, int pmode);
+int ks_eps_get_ds_parallel(ks_eps eps, int *pmode);
 int ks_eps_set_max_steps(ks_eps eps, long long max_steps);                 /* bench harness: stop after this many Arnoldi steps (0 = off) */
 int ks_eps_solve(ks_eps eps);
 int ks_eps_get_converged(ks_eps eps, int *nconv);

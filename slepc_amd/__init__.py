@@ -140,11 +140,12 @@ class Context:
         _lib.check(self.L.ks_comm_set_ops(self.h, rank, size, C.byref(self._ops), None))
         self.rank, self.size = rank, size
 
-    def memcpy_h2d(self, dev_ptr, host_array):
-        _lib.check(self.L.ks_ctx_memcpy(self.h, C.c_void_p(dev_ptr), host_array.ctypes.data_as(C.c_void_p), host_array.nbytes, 0))
+    def memcpy_h2d(self, dev_ptr, host_array, stream=None):
+        """stream: the `stream` argument a communicator callback received (None: the context's own)."""
+        _lib.check(self.L.ks_ctx_memcpy_stream(self.h, C.c_void_p(dev_ptr), host_array.ctypes.data_as(C.c_void_p), host_array.nbytes, 0, C.c_void_p(stream)))
 
-    def memcpy_d2h(self, host_array, dev_ptr):
-        _lib.check(self.L.ks_ctx_memcpy(self.h, host_array.ctypes.data_as(C.c_void_p), C.c_void_p(dev_ptr), host_array.nbytes, 1))
+    def memcpy_d2h(self, host_array, dev_ptr, stream=None):
+        _lib.check(self.L.ks_ctx_memcpy_stream(self.h, host_array.ctypes.data_as(C.c_void_p), C.c_void_p(dev_ptr), host_array.nbytes, 1, C.c_void_p(stream)))
 
     # -- profiling
     def prof_enable(self, on=True, classes=None):
@@ -838,6 +839,11 @@ class EPS:
         tmp.set_dense(Cmat)
         ptrs = (C.c_void_p * Cmat.shape[1])(*[tmp.column_ptr(j) for j in range(Cmat.shape[1])])
         _lib.check(self.ctx.L.ks_eps_set_deflation_space(self.h, Cmat.shape[1], ptrs))
+
+    def SetDSParallel(self, synchronized=True):
+        """DSSetParallel on the solver's DS: broadcast rank 0's projected solve after every restart (default) or trust
+        the redundant computation."""
+        _lib.check(self.ctx.L.ks_eps_set_ds_parallel(self.h, 1 if synchronized else 0))
 
     def SetMaxSteps(self, steps):
         _lib.check(self.ctx.L.ks_eps_set_max_steps(self.h, steps))

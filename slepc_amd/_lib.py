@@ -38,6 +38,7 @@ _SIG = {
     "ks_comm_init_rccl": [vp, C.c_int, C.c_int, C.c_char_p],
     "ks_comm_set_ops": [vp, C.c_int, C.c_int, C.POINTER(CommOps), vp],
     "ks_ctx_memcpy": [vp, vp, vp, C.c_size_t, C.c_int],
+    "ks_ctx_memcpy_stream": [vp, vp, vp, C.c_size_t, C.c_int, vp],
     "ks_comm_rank_size": [vp, ip, ip],
     # mat
     "ks_mat_create_csr": [vp, C.c_int, C.c_int, C.c_int, ip, ip, dp, C.POINTER(vp)],
@@ -134,6 +135,8 @@ _SIG = {
     "ks_eps_set_deflation_space": [vp, C.c_int, C.POINTER(C.c_void_p)],
     "ks_eps_set_initial_space": [vp, C.c_int, C.POINTER(C.c_void_p)],
     "ks_eps_set_max_steps": [vp, C.c_longlong],
+    "ks_eps_set_ds_parallel": [vp, C.c_int],
+    "ks_eps_get_ds_parallel": [vp, ip],
     "ks_eps_solve": [vp],
     "ks_eps_get_converged": [vp, ip],
     "ks_eps_get_iteration_number": [vp, ip],

@@ -63,6 +63,7 @@ extern "C" int ks_ctx_create(int device, void *stream, ks_ctx *out)
     if (e != hipSuccess) { delete ctx; KS_FAIL(KS_ERR_LIB, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(e)); }
     ctx->own_stream = true;
   }
+  { const char *ho = getenv("KSGPU_HALO_OVERLAP"); ctx->halo_overlap = !(ho && atoi(ho) == 0); }   // safety switch of a path no multi-GPU box has run yet
   ctx->h_pinned_len = 16384;
   e = hipHostMalloc((void **)&ctx->h_pinned, ctx->h_pinned_len * sizeof(double), hipHostMallocDefault);
   if (e != hipSuccess) {
@@ -88,8 +89,20 @@ extern "C" int ks_ctx_destroy(ks_ctx ctx)
   }
   if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
   if (ctx->split.dev) hipFree(ctx->split.dev);
+  if (ctx->halo_stream) { hipStreamSynchronize(ctx->halo_stream); hipStreamDestroy(ctx->halo_stream); }
+  if (ctx->ev_x) hipEventDestroy(ctx->ev_x);
+  if (ctx->ev_halo) hipEventDestroy(ctx->ev_halo);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
+  return KS_SUCCESS;
+}
+
+int ks_ctx_halo_stream(ks_ctx ctx)
+{
+  if (ctx->halo_stream) return KS_SUCCESS;
+  KS_HIP(hipStreamCreateWithFlags(&ctx->halo_stream, hipStreamNonBlocking));
+  KS_HIP(hipEventCreateWithFlags(&ctx->ev_x, hipEventDisableTiming));
+  KS_HIP(hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming));
   return KS_SUCCESS;
 }
 
@@ -341,6 +354,16 @@ extern "C" int ks_comm_rank_size(ks_ctx ctx, int *rank, int *size)
   return KS_SUCCESS;
 }
 
+extern "C" int ks_ctx_memcpy_stream(ks_ctx ctx, void *dst, const void *src, size_t bytes, int kind, void *stream)
+{
+  KS_CHECK(ctx && (bytes == 0 || (dst && src)), KS_ERR_ARG_NULL, "NULL argument");
+  KS_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  if (bytes) KS_HIP(hipMemcpyAsync(dst, src, bytes, kind == 0 ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, s));
+  KS_HIP(hipStreamSynchronize(s));
+  return KS_SUCCESS;
+}
+
 extern "C" int ks_ctx_memcpy(ks_ctx ctx, void *dst, const void *src, size_t bytes, int kind)
 {
   KS_CHECK(ctx && (bytes == 0 || (dst && src)), KS_ERR_ARG_NULL, "NULL argument");
@@ -370,12 +393,21 @@ int ks_comm_allgather_host(ks_ctx ctx, const void *send, int bytes, void *recv)
   return KS_SUCCESS;
 }
 
+int ks_comm_bcast0_host(ks_ctx ctx, void *buf, int bytes)
+{
+  if (ctx->comm.size == 1 || bytes <= 0) return KS_SUCCESS;
+  std::vector<char> all((size_t)bytes * ctx->comm.size);
+  KS_CALL(ks_comm_allgather_host(ctx, buf, bytes, all.data()));
+  if (ctx->comm.rank) memcpy(buf, all.data(), (size_t)bytes);
+  return KS_SUCCESS;
+}
+
 int ks_comm_exchange(ks_ctx ctx, int npeers, const int *peers, const void *dev_send, const int *send_off, const int *send_cnt,
-                     void *dev_recv, const int *recv_off, const int *recv_cnt, int elem_bytes)
+                     void *dev_recv, const int *recv_off, const int *recv_cnt, int elem_bytes, hipStream_t stream)
 {
   if (npeers == 0) return KS_SUCCESS;
   KS_CHECK(ctx->comm.ops.exchange, KS_ERR_ORDER, "no communicator");
-  int rc = ctx->comm.ops.exchange(ctx->comm.user, npeers, peers, dev_send, send_off, send_cnt, dev_recv, recv_off, recv_cnt, elem_bytes, (void *)ctx->stream);
+  int rc = ctx->comm.ops.exchange(ctx->comm.user, npeers, peers, dev_send, send_off, send_cnt, dev_recv, recv_off, recv_cnt, elem_bytes, (void *)(stream ? stream : ctx->stream));
   KS_CHECK(rc == 0, KS_ERR_LIB, "neighbour exchange failed (%d)", rc);
   return KS_SUCCESS;
 }

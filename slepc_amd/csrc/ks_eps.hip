@@ -371,6 +371,7 @@ struct ks_eps_s {
   std::vector<double> v0; bool have_v0 = false;
   ks_bv defl = nullptr; int nds = 0;       // deflation space handed over by EPSSetDeflationSpace, consumed by the next solve
   long long max_steps = 0;
+  int ds_parallel = KS_DS_PARALLEL_SYNCHRONIZED;   // DSSetParallel: broadcast rank 0's projected solve after every restart (krylovschur.c:281)
   // results
   std::vector<double> eigr, eigi, errest; std::vector<int> perm;
   int nconv = 0, its = 0, reason = 0;
@@ -597,6 +598,40 @@ extern "C" int ks_eps_set_initial_space(ks_eps eps, int n, const double *const *
   eps->have_v0 = true; eps->solved = false;
   return KS_SUCCESS;
 }
+extern "C" int ks_eps_set_ds_parallel(ks_eps eps, int pmode)
+{
+  KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL");
+  KS_CHECK(pmode == KS_DS_PARALLEL_REDUNDANT || pmode == KS_DS_PARALLEL_SYNCHRONIZED, KS_ERR_ARG_OUTOFRANGE, "unknown DS parallel mode %d", pmode);
+  eps->ds_parallel = pmode;
+  return KS_SUCCESS;
+}
+extern "C" int ks_eps_get_ds_parallel(ks_eps eps, int *pmode) { KS_CHECK(eps && pmode, KS_ERR_ARG_NULL, "NULL argument"); *pmode = eps->ds_parallel; return KS_SUCCESS; }
+
+// DSSynchronize (dsops.c:875 -> DSSynchronize_HEP dshep.c:673-713, DSSynchronize_NHEP dsnhep.c:379): every rank leaves with rank 0's
+// projected matrix, vectors and eigenvalues. The scalars the convergence test and the restart sizes are computed from (beta of the
+// expansion, its length, the breakdown flag) travel in the same message, so the integer control flow that follows is identical on
+// all ranks whatever the allreduce provider returned.
+static int ds_synchronize(ks_eps eps, std::vector<double> *M1, std::vector<double> *M2, double *beta, int *nv, int *breakdown)
+{
+  ks_ctx ctx = eps->ctx;
+  if (ctx->comm.size <= 1 || eps->ds_parallel != KS_DS_PARALLEL_SYNCHRONIZED) return KS_SUCCESS;
+  std::vector<double> pack;
+  pack.reserve(M1->size() + M2->size() + 2 * eps->eigr.size() + 3);
+  pack.insert(pack.end(), M1->begin(), M1->end());
+  pack.insert(pack.end(), M2->begin(), M2->end());
+  pack.insert(pack.end(), eps->eigr.begin(), eps->eigr.end());
+  pack.insert(pack.end(), eps->eigi.begin(), eps->eigi.end());
+  pack.push_back(*beta); pack.push_back((double)*nv); pack.push_back((double)*breakdown);
+  KS_CALL(ks_comm_bcast0_host(ctx, pack.data(), (int)(pack.size() * sizeof(double))));
+  size_t o = 0;
+  std::copy(pack.begin() + o, pack.begin() + o + M1->size(), M1->begin()); o += M1->size();
+  std::copy(pack.begin() + o, pack.begin() + o + M2->size(), M2->begin()); o += M2->size();
+  std::copy(pack.begin() + o, pack.begin() + o + eps->eigr.size(), eps->eigr.begin()); o += eps->eigr.size();
+  std::copy(pack.begin() + o, pack.begin() + o + eps->eigi.size(), eps->eigi.begin()); o += eps->eigi.size();
+  *beta = pack[o]; *nv = (int)pack[o + 1]; *breakdown = (int)pack[o + 2];
+  return KS_SUCCESS;
+}
+
 extern "C" int ks_eps_set_max_steps(ks_eps eps, long long s) { KS_CHECK(eps, KS_ERR_ARG_NULL, "EPS is NULL"); eps->max_steps = s > 0 ? s : 0; return KS_SUCCESS; }
 
 // EPSStoppingBasic epsdefault.c:290-307; user functions may call it first, as ex29.c does
@@ -869,6 +904,7 @@ static int solve_nhep(ks_eps eps, long long passes0)
     info = ds.sort(eps->eigr.data(), eps->eigi.data());
     KS_CHECK(info == 0, KS_ERR_LIB, "reordering of the Schur form failed: blocks too close to swap");
     ds.update_extra_row();
+    KS_CALL(ds_synchronize(eps, &ds.A, &ds.Q, &beta, &nv, &breakdown));      // krylovschur.c:281
 
     // EPSKrylovConvergence(eps,FALSE,nconv,nv-nconv,beta,0.0,1.0,&k)
     int marker = -1, k;
@@ -1084,6 +1120,7 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
       ds.sort(eps->eigr.data(), rr.data(), ri.data());
     } else ds.sort(eps->eigr.data());
     ds.update_extra_row();
+    KS_CALL(ds_synchronize(eps, &ds.T, &ds.Q, &beta, &nv, &breakdown));      // krylovschur.c:281
 
     // EPSKrylovConvergence(eps,FALSE,nconv,nv-nconv,beta,0.0,1.0,&k)
     int marker = -1, k;

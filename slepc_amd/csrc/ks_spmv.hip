@@ -898,11 +898,24 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
   ks_ctx ctx = A->ctx;
   if (A->shell_mult) return A->shell_mult(A->shell_user, x, y);
   const bool multi = ctx->comm.size > 1 && (A->nsend > 0 || A->nghost > 0);
+  // Halo under the diagonal-block product (PETSc: VecScatterBegin / local product / VecScatterEnd in MatMult_MPIAIJ): pack and
+  // neighbour exchange go to the halo stream once x is complete on the main stream; the main stream runs the diagonal block
+  // and only the off-diagonal rows wait for the ghosts. The next product's pack is ordered after this one's off-diagonal rows
+  // through ev_x (recorded on the main stream), so send_buf / ghost are never overwritten while still being read.
+  const bool overlap = multi && ctx->halo_overlap;
   if (multi) {
-    KsProfScope ps(ctx, KS_K_HALO, 8.0 * (A->nsend + A->nghost));
-    if (A->nsend) hipLaunchKernelGGL(k_pack, dim3((A->nsend + 255) / 256), dim3(256), 0, ctx->stream, A->nsend, A->send_idx, x, A->send_buf);
+    hipStream_t hs = ctx->stream;
+    if (overlap) {
+      KS_CALL(ks_ctx_halo_stream(ctx));
+      hs = ctx->halo_stream;
+      KS_HIP(hipEventRecord(ctx->ev_x, ctx->stream));
+      KS_HIP(hipStreamWaitEvent(hs, ctx->ev_x, 0));
+    }
+    KsProfScope ps(ctx, KS_K_HALO, 8.0 * (A->nsend + A->nghost));      // (events on the main stream: with the overlap this times the enqueue only)
+    if (A->nsend) hipLaunchKernelGGL(k_pack, dim3((A->nsend + 255) / 256), dim3(256), 0, hs, A->nsend, A->send_idx, x, A->send_buf);
     KS_CALL(ks_comm_exchange(ctx, (int)A->peers.size(), A->peers.data(), A->send_buf, A->send_off.data(), A->send_cnt.data(),
-                             A->ghost, A->recv_off.data(), A->recv_cnt.data(), (int)sizeof(double)));
+                             A->ghost, A->recv_off.data(), A->recv_cnt.data(), (int)sizeof(double), hs));
+    if (overlap) KS_HIP(hipEventRecord(ctx->ev_halo, hs));
   }
   {
     const double csr_bytes = 12.0 * A->nnz + 4.0 * (A->n + 1) + 16.0 * A->n;                    // what the CSR algorithm moves
@@ -948,6 +961,7 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
       else hipLaunchKernelGGL((k_spmv_sell<8>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->nslices, A->s_ptr, A->s_len, A->s_col, A->s_val, x, y, remap);
     } else
       launch_spmv<false, false>(ctx->stream, ctx->num_cu, A->lanes_per_row, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, nullptr);
+    if (overlap) KS_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_halo, 0));          // also when this rank has no off-diagonal rows: keeps the two streams in step
     if (A->n_orows > 0)
       launch_spmv<true, true>(ctx->stream, ctx->num_cu, 2, A->n_orows, A->o_rowptr, A->o_col, A->o_val, A->ghost, y, A->o_rows);
   }

@@ -37,6 +37,10 @@ struct ks_ctx_s {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // multi-rank MatMult: the halo (pack + neighbour exchange) runs on its own stream under the diagonal-block product;
+  // ev_x orders it after the producer of x on the main stream, ev_halo lets the off-diagonal rows wait for the ghosts
+  hipStream_t halo_stream = nullptr; hipEvent_t ev_x = nullptr, ev_halo = nullptr;
+  bool halo_overlap = true;
   int num_cu = 256;
   char arch[64] = {0};
   size_t mem_total = 0;
@@ -73,7 +77,9 @@ void ks_prof_resolve_gs(ks_ctx ctx, const KsStepRec *recs, int col0, int col1); 
 int ks_allreduce_sum(ks_ctx ctx, double *dev_buf, int count);   // no-op when size==1
 int ks_comm_allgather_host(ks_ctx ctx, const void *send, int bytes, void *recv);
 int ks_comm_exchange(ks_ctx ctx, int npeers, const int *peers, const void *dev_send, const int *send_off, const int *send_cnt,
-                     void *dev_recv, const int *recv_off, const int *recv_cnt, int elem_bytes);
+                     void *dev_recv, const int *recv_off, const int *recv_cnt, int elem_bytes, hipStream_t stream = nullptr);   // nullptr: the context's stream
+int ks_comm_bcast0_host(ks_ctx ctx, void *buf, int bytes);     // every rank leaves with rank 0's bytes (through the provider's host allgather)
+int ks_ctx_halo_stream(ks_ctx ctx);                            // creates the halo stream and its events on first use
 static inline bool ks_is_multi(ks_ctx ctx) { return ctx->comm.size > 1 || ctx->comm.force_collectives; }
 
 // ---- Mat ----------------------------------------------------------------------------------------

@@ -18,13 +18,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _install_gloo_ops(ks, ctx, dist, torch, rank, size):
+def _install_gloo_ops(ks, ctx, dist, torch, rank, size, perturb=False):
+    """Host-staged provider. Every operation orders itself on the stream the library hands it (the halo exchange comes on
+    the halo stream, the reductions on the main one). perturb: rank 1 returns every reduced value one ulp up - an
+    allreduce that is not bitwise identical across ranks, which a caller-supplied provider is allowed to be."""
     def allreduce_sum(ptr, count, stream):
         h = np.empty(count)
-        ctx.memcpy_d2h(h, ptr)
+        ctx.memcpy_d2h(h, ptr, stream)
         t = torch.from_numpy(h)
         dist.all_reduce(t)
-        ctx.memcpy_h2d(ptr, h)
+        if perturb and rank == 1:
+            h[:] = np.nextafter(h, np.inf)
+        ctx.memcpy_h2d(ptr, h, stream)
         return 0
 
     def allgather_host(send, nbytes, recv):
@@ -39,7 +44,7 @@ def _install_gloo_ops(ks, ctx, dist, torch, rank, size):
         for i, p in enumerate(peers):
             if scnt[i]:
                 h = np.empty(scnt[i] * eb, dtype=np.uint8)
-                ctx.memcpy_d2h(h, dsend + soff[i] * eb)
+                ctx.memcpy_d2h(h, dsend + soff[i] * eb, stream)
                 ops.append(dist.P2POp(dist.isend, torch.from_numpy(h), p))
             if rcnt[i]:
                 r = torch.empty(rcnt[i] * eb, dtype=torch.uint8)
@@ -48,7 +53,7 @@ def _install_gloo_ops(ks, ctx, dist, torch, rank, size):
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
         for i, r in recvs:
-            ctx.memcpy_h2d(drecv + roff[i] * eb, r.numpy())
+            ctx.memcpy_h2d(drecv + roff[i] * eb, r.numpy(), stream)
         return 0
 
     ctx.set_comm_ops(rank, size, allreduce_sum, allgather_host, exchange)
@@ -142,6 +147,17 @@ def _worker(rank, world, port, q):
             e5.SetOperators(Ml); e5.Solve()
             res["t39"].append(([e5.GetEigenvalue(i)[0] for i in range(3)], e5.GetIterationNumber(), e5.GetConverged(),
                                max(e5.ComputeError(i) for i in range(3)), len(e5.GetEigenvector(0)), s1 - s0))
+        # (7) an allreduce that differs by one ulp on rank 1: with the projected solve synchronised from rank 0 (the default,
+        # DSSynchronize krylovschur.c:281) every rank still takes the same decisions and reports the same bits
+        ctx2 = ks.Context(0)
+        _install_gloo_ops(ks, ctx2, dist, torch, rank, world, perturb=True)
+        Ap = ks.Mat.laplacian3d(ctx2, nx, ny, nz, z0, z1 - z0)
+        e6 = ks.EPS(ctx2); e6.SetOperators(Ap); e6.SetProblemType(ks.EPS_HEP); e6.SetDimensions(3, 12); e6.Solve()
+        res["pert_eig"] = [e6.GetEigenvalue(i)[0] for i in range(3)]; res["pert_its"] = e6.GetIterationNumber(); res["pert_nconv"] = e6.GetConverged()
+        res["pert_err"] = [e6.ComputeError(i) for i in range(3)]
+        e7 = ks.EPS(ctx2); e7.SetOperators(Ap); e7.SetProblemType(ks.EPS_NHEP); e7.SetDimensions(3, 12); e7.Solve()
+        res["pert_nhep"] = ([list(e7.GetEigenvalue(i)) for i in range(3)], e7.GetIterationNumber(), e7.GetConverged())
+        del e6, e7, Ap
         dist.barrier()
         q.put((rank, res))
     except Exception as e:      # noqa: BLE001
@@ -219,6 +235,10 @@ def test_ranks_sharing_one_gpu_against_oracle(world):
     assert np.abs(cross).max() < 1e-10
     for rk in range(1, world):
         assert out[0]["eig"] == out[rk]["eig"]               # replicated scalars are bitwise identical on all ranks
+        # the perturbed provider: same decisions and the same bits everywhere, because rank 0's projected solve is broadcast
+        assert out[0]["pert_eig"] == out[rk]["pert_eig"] and out[0]["pert_its"] == out[rk]["pert_its"] and out[0]["pert_nconv"] == out[rk]["pert_nconv"]
+        assert out[0]["pert_nhep"] == out[rk]["pert_nhep"]
+    assert out[0]["pert_nconv"] >= 3 and np.allclose(out[0]["pert_eig"], r.eigr[r.perm][:3], rtol=1e-10) and max(out[0]["pert_err"]) < 1e-8
 
 
 def _rccl_worker(q):
