@@ -14,10 +14,15 @@ X.SetActiveColumns(0, 31); Y.SetActiveColumns(0, 31)
 M = np.zeros((31, 31), order="F")
 
 def timed(f, reps=20):
-    f(); ctx.synchronize(); t = time.time()
+    """kernel time only: HIP events of the library's profiler around the panel kernel launches (the wall time of a call also
+    holds the block reduction, the D2H of the result and a stream synchronisation)"""
+    f(); ctx.synchronize()
+    ctx.prof_enable(True, classes=["bv_dot_panel", "bv_multinplace", "bv_mult"]); ctx.prof_reset()
     for _ in range(reps):
         f()
-    ctx.synchronize(); return (time.time() - t) / reps
+    ctx.synchronize()
+    p = ctx.prof_get(); ctx.prof_enable(False)
+    return sum(v["ms"] for v in p.values()) / sum(v["launches"] for v in p.values()) * 1e-3
 
 t = timed(lambda: X.Dot(Y, M)); print("BVDot(X,Y) 31x31: %.0f us  %.2f TB/s (62 columns)" % (t * 1e6, 62 * 8.0 * n / t / 1e12))
 t = timed(lambda: X.Dot(X, M)); print("BVDot(X,X) 31x31: %.0f us  %.2f TB/s of the 31 columns it has to read, %.2f TB/s in BVDot's 62" % (t * 1e6, 31 * 8.0 * n / t / 1e12, 62 * 8.0 * n / t / 1e12))

@@ -9,10 +9,9 @@
 // Layout of one MFMA (wave64): D(16x16) += A(16x4) * B(4x16); lane l supplies A[i=l&15][k=l>>4] and
 // B[k=l>>4][j=l&15] (one f64 each) and owns D[row=(l>>4)+4*reg][col=l&15], reg=0..3.
 //
-// Staging: a row tile (128 rows) of the panels is copied HBM -> LDS with one coalesced 16-byte load per lane
-// (a wave-instruction moves 128 rows of ONE column = 1 KiB contiguous), stored column-major with a row pitch of
-// 130 doubles. With that pitch the MFMA operand reads - 16 different columns x 4 consecutive rows per wave
-// (Dot), or 16 consecutive rows x 4 columns (Mult) - are bank-conflict free for ds_read_b64.
+// No LDS staging: both kernels load their operands straight into the MFMA fragment layout with 16-byte loads (which rows a
+// k-step contracts, and which rows a lane owns, is chosen to fit the loads), so every wave streams its own row chunks with
+// many KiB in flight, like the row sweeps.
 #include "ks_sweeps.cuh"
 #include <algorithm>
 
@@ -20,101 +19,105 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int PB = 256;          // threads per block (4 waves)
-constexpr int TR = 128;          // rows per tile
-constexpr int RP = 130;          // LDS row pitch in doubles (== 2 mod 32: conflict-free Dot operand reads)
-constexpr int RPM = 144;         // pitch for the Mult operand reads (== 16 mod 32)
 
-// 128 rows of one column: lane handles rows r0+2*lane, +1 (zero beyond n or for a padding column)
-__device__ __forceinline__ double2 load_column(const double *__restrict__ src, long long r0, int n, int lane)
+// resident blocks per CU of one kernel symbol (cached: the query costs microseconds per call)
+int occ_blocks(const void *kernel, size_t lds_bytes)
 {
-  const long long r = r0 + 2 * lane;
-  double2 v; v.x = 0.0; v.y = 0.0;
-  if (src) {
-    if (r + 1 < n) v = ksk::ldcol2(src + r);
-    else if (r < n) v.x = src[r];
-  }
-  return v;
-}
-__device__ __forceinline__ void stage_column(const double *__restrict__ src, long long r0, int n, double *dst, int lane)
-{
-  *reinterpret_cast<double2 *>(dst + 2 * lane) = load_column(src, r0, n, lane);
+  static thread_local std::vector<std::pair<const void *, int>> cache;
+  for (auto &e : cache) if (e.first == kernel) return e.second;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, PB, lds_bytes) != hipSuccess || nb < 1) nb = 1;
+  nb = std::min(nb, 8);
+  cache.push_back({kernel, nb});
+  return nb;
 }
 
-// partialsM[b][i*NT16 + j] = sum over the block's rows of Y(r,i) X(r,j)
-// SAME: Y and X are the same columns (a Gram matrix, BVDot(X,X,M) and the CHOL / SVQB orthogonalisations): the panel is
-// read and staged once and serves as both operands - half the HBM bytes, the same MFMA sequence, the same bits.
-template <int MT, int NT, bool SAME>
-__global__ __launch_bounds__(PB) void k_panel_dot_mfma(const double *__restrict__ Y, long long ldy, int my, const double *__restrict__ X, long long ldx, int nx,
-                                                        int n, double *__restrict__ partialsM)
+// SAME (both kernels below): Y and X are the same columns (a Gram matrix, BVDot(X,X,M) and the CHOL / SVQB orthogonalisations): the panel
+// is read once and serves as both operands - half the HBM bytes, the same MFMA sequence, the same bits.
+// ---- BVDot without LDS: loads land directly in MFMA operand layout ------------------------------------------------------------
+// M = Y^T X is a sum over rows, so WHICH rows a k-step contracts is free as long as both operands use the same ones. Lane l
+// (c = l & 15, q = l >> 4) loads the two rows r0+2q, r0+2q+1 of column c of a 16-column tile with one 16-byte load: the .x
+// halves of the wave are exactly the A / B fragments of one v_mfma_f64_16x16x4 (rows r0+{0,2,4,6}), the .y halves those of a
+// second one (rows r0+{1,3,5,7}). One wave-instruction reads 16 columns x 64 contiguous bytes; the next row group reads the
+// other half of the same 128-byte lines, which is why these are plain (L1-allocating) loads: with the nontemporal hint each
+// half line is its own L2 request and the shape reads at 5.4 TB/s, plain at 6.06 (8 columns x 128 B: 6.8, scripts/micro/
+// dot_direct.hip, profiles/r02_micro_dot_direct.txt; the MFMAs cost nothing on top). Nothing is staged, nothing synchronises:
+// every wave streams its own row chunks with U x (MT+NT) KiB in flight, like the row sweeps (the LDS-staged form it replaces
+// could keep only one tile per block in flight and ran at 4 TB/s, profiles/r01e_pmc_panel_kernels_wait_lds.txt). Row order
+// inside a block and the block combine are fixed: deterministic.
+template <int MT, int NT, bool SAME, int U>
+__global__ __launch_bounds__(PB) void k_panel_dot_direct(const double *__restrict__ Y, long long ldy, int my, const double *__restrict__ X, long long ldx, int nx,
+                                                          int n, double *__restrict__ partialsM)
 {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+  extern __shared__ __attribute__((aligned(16))) double lds[];     // MC*NC doubles: the block combine
   constexpr int MC = MT * 16, NC = NT * 16;
-  constexpr int SC = SAME ? MC : MC + NC;               // staged columns
-  double *ldsY = lds, *ldsX = SAME ? lds : lds + MC * RP;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+  const double *py[MT], *px[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++) { const int col = mt * 16 + c; py[mt] = Y + (long long)(col < my ? col : my - 1) * ldy + 2 * q; }   // a padded column repeats the last one: it only
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) { const int col = nt * 16 + c; px[nt] = X + (long long)(col < nx ? col : nx - 1) * ldx + 2 * q; }   // reaches rows / columns of M that are dropped
   d4 acc[MT][NT];
 #pragma unroll
   for (int a = 0; a < MT; a++)
 #pragma unroll
     for (int b = 0; b < NT; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
-  const long long ntiles = ((long long)n + TR - 1) / TR;
-  // software pipeline: the NEXT tile's columns are already in flight (registers) while this tile is multiplied
-  constexpr int CW = SC / (PB / 64);                 // columns staged by one wave
-  constexpr bool PREF = SC <= 64;                    // register budget: prefetch for up to 64 staged columns
-  double2 pre[PREF ? CW : 1];
-  auto colsrc = [&](int c) -> const double * {
-    return (c < MC) ? (c < my ? Y + (long long)c * ldy : nullptr) : (c - MC < nx ? X + (long long)(c - MC) * ldx : nullptr);
-  };
-  if (PREF && (long long)blockIdx.x < ntiles) {
+  constexpr int CH = 8 * U;                                        // rows per chunk
+  const long long nch = ((long long)n + CH - 1) / CH;
+  const long long gw = (long long)blockIdx.x * (PB / 64) + w, GW = (long long)gridDim.x * (PB / 64);
+  for (long long ch = gw; ch < nch; ch += GW) {
+    const long long r0 = ch * CH;
+    double2 a[U][MT], b[U][SAME ? 1 : NT];
+    if (r0 + CH <= n) {
 #pragma unroll
-    for (int q = 0; q < CW; q++) pre[q] = load_column(colsrc(w + q * (PB / 64)), (long long)blockIdx.x * TR, n, lane);
-  }
-  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const long long r0 = t * TR;
-    if (PREF) {
+      for (int u = 0; u < U; u++) {
 #pragma unroll
-      for (int q = 0; q < CW; q++) *reinterpret_cast<double2 *>(lds + (w + q * (PB / 64)) * RP + 2 * lane) = pre[q];
+        for (int mt = 0; mt < MT; mt++) a[u][mt] = *reinterpret_cast<const double2 *>(py[mt] + r0 + 8 * u);
+        if (!SAME) {
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++) b[u][nt] = *reinterpret_cast<const double2 *>(px[nt] + r0 + 8 * u);
+        }
+      }
     } else {
-      for (int c = w; c < SC; c += PB / 64) stage_column(colsrc(c), r0, n, lds + c * RP, lane);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const long long r = r0 + 8 * u + 2 * q;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) { double2 v; v.x = r < n ? py[mt][r0 + 8 * u] : 0.0; v.y = r + 1 < n ? py[mt][r0 + 8 * u + 1] : 0.0; a[u][mt] = v; }
+        if (!SAME) {
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++) { double2 v; v.x = r < n ? px[nt][r0 + 8 * u] : 0.0; v.y = r + 1 < n ? px[nt][r0 + 8 * u + 1] : 0.0; b[u][nt] = v; }
+        }
+      }
     }
-    __syncthreads();
-    if (PREF && t + gridDim.x < ntiles) {
+    __builtin_amdgcn_sched_barrier(0);                             // all loads of the chunk in flight before the first product waits
 #pragma unroll
-      for (int q = 0; q < CW; q++) pre[q] = load_column(colsrc(w + q * (PB / 64)), (t + gridDim.x) * TR, n, lane);
-    }
-#pragma unroll
-    for (int ks = 0; ks < TR / 4 / 4; ks++) {          // wave w owns rows [32w, 32w+32) of the tile: 8 k-steps of 4 rows
-      const int rr = w * (TR / 4) + ks * 4 + (lane >> 4);
-      double a[MT], b[NT];
-#pragma unroll
-      for (int mt = 0; mt < MT; mt++) a[mt] = ldsY[(mt * 16 + (lane & 15)) * RP + rr];
-#pragma unroll
-      for (int nt = 0; nt < NT; nt++) b[nt] = ldsX[(nt * 16 + (lane & 15)) * RP + rr];
+    for (int u = 0; u < U; u++)
 #pragma unroll
       for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; nt++) {
+          const double2 bb = SAME ? a[u][nt] : b[u][SAME ? 0 : nt];
+          acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][mt].x, bb.x, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][mt].y, bb.y, acc[mt][nt], 0, 0, 0);
+        }
+  }
+  // combine the four waves in wave order through one MC x NC buffer, then one block partial to HBM
+  for (int ww = 0; ww < PB / 64; ww++) {
+    if (w == ww) {
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+          for (int reg = 0; reg < 4; reg++) {
+            const int i = mt * 16 + q + 4 * reg, j = nt * 16 + c;
+            if (ww == 0) lds[i * NC + j] = acc[mt][nt][reg]; else lds[i * NC + j] += acc[mt][nt][reg];
+          }
     }
     __syncthreads();
   }
-  // combine the four waves through LDS (reuse the staging area), then one block partial to HBM
-  double *red = lds;            // [w][MC*NC]
-#pragma unroll
-  for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-      for (int reg = 0; reg < 4; reg++) {
-        const int i = mt * 16 + (lane >> 4) + 4 * reg, j = nt * 16 + (lane & 15);
-        red[(w * MC + i) * NC + j] = acc[mt][nt][reg];
-      }
-  __syncthreads();
-  for (int e = threadIdx.x; e < MC * NC; e += PB) {
-    double s = red[e];
-#pragma unroll
-    for (int ww = 1; ww < PB / 64; ww++) s += red[ww * MC * NC + e];
-    partialsM[(size_t)blockIdx.x * MC * NC + e] = s;
-  }
+  for (int e = threadIdx.x; e < MC * NC; e += PB) partialsM[(size_t)blockIdx.x * MC * NC + e] = lds[e];
 }
 
 // out (my x nx, column-major, contiguous) = sum over blocks of the padded MC x NC row-major block partials
@@ -129,70 +132,86 @@ __global__ void k_reduce_blocks(const double *__restrict__ partialsM, int nblock
   out[i + (size_t)j * my] = s;
 }
 
-// C(:,0:nout) = beta*C + alpha*A(:,0:kin)*Q, computed transposed on the matrix cores:
-//   D[i][j] = sum_k Q[k][i] * A[row j][k]   (i = output column, j = row inside a 16-row group)
-// so that a store instruction writes, for each of 4 output columns, 16 consecutive rows (one 128-byte line).
-// KT4 = ceil(kin/4) k-steps, NT = ceil(nout/16) output column tiles. Q fragments live in registers for the whole
-// sweep. The A tile is complete in LDS before any output row of the tile is written: in-place safe.
-template <int KS4, int NT>
-__global__ __launch_bounds__(PB) void k_panel_mult_mfma(const double *A, long long lda, int n, int kin, const double *__restrict__ Q, int qsk, int qsi, int nout,
-                                                         double alpha, double beta, double *C, long long ldc)
+// C(:,0:nout) = beta*C + alpha*A(:,0:kin)*Q, computed transposed on the matrix cores and without LDS:
+//   D[i][j] = sum_k Q[k][i] * A[row j][k]   (i = output column, j = row slot)
+// Lane l (j = l & 15, kq = l >> 4) loads the two rows R+2j, R+2j+1 of column 4*ks + kq with one 16-byte load: a wave-instruction
+// reads 4 columns x 256 contiguous bytes (whole 128-byte lines), its .x halves are the B fragment of the k-step for the even
+// rows of a 32-row group, its .y halves the one for the odd rows. The Q fragments live in registers for the whole sweep. A lane
+// ends up owning rows R+2j, R+2j+1 of output columns i = kq + 4*reg (+16 per tile): one 16-byte store each, 256 contiguous
+// bytes per column and instruction. A 32-row group is private to one wave and all its loads are complete before its first
+// store (the products need them), so C may alias columns of A (BVMultInPlace). U groups per iteration keep U x KS4 KiB in flight.
+template <int KS4, int NT, int U>
+__global__ __launch_bounds__(PB) void k_panel_mult_direct(const double *A, long long lda, int n, int kin, const double *__restrict__ Q, int qsk, int qsi, int nout,
+                                                           double alpha, double beta, double *C, long long ldc, int vecC)
 {
-  extern __shared__ __attribute__((aligned(16))) double lds[];   // KS4*4 columns x RPM
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  // A-operand fragments of Q^T: lane supplies Qt[i=l&15][k=l>>4] = Q[k][i]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, kq = lane >> 4;
+  // A-operand fragments of Q^T: lane supplies Qt[i=j][k=kq] = Q[k][i]
   double qf[KS4][NT];
 #pragma unroll
   for (int ks = 0; ks < KS4; ks++)
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
-      const int k = ks * 4 + (lane >> 4), i = nt * 16 + (lane & 15);
+      const int k = ks * 4 + kq, i = nt * 16 + j;
       qf[ks][nt] = (k < kin && i < nout) ? Q[(size_t)k * qsk + (size_t)i * qsi] : 0.0;   // Q(k,i): strides (1,ldq), or (ldq,1) for the transposed form
     }
-  const long long ntiles = ((long long)n + TR - 1) / TR;
-  // software pipeline: the next tile's KS4 columns of this wave are in flight while the current tile is multiplied
-  double2 pre[KS4];
-  if ((long long)blockIdx.x < ntiles) {
+  const double *pa[KS4];
 #pragma unroll
-    for (int q = 0; q < KS4; q++) { const int c = w + q * (PB / 64); pre[q] = load_column(c < kin ? A + (long long)c * lda : nullptr, (long long)blockIdx.x * TR, n, lane); }
-  }
-  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const long long r0 = t * TR;
+  for (int ks = 0; ks < KS4; ks++) { const int k = ks * 4 + kq; pa[ks] = A + (long long)(k < kin ? k : kin - 1) * lda + 2 * j; }   // a padded column repeats the last one; its Q entries are zero
+  constexpr int CH = 32 * U;
+  const long long nch = ((long long)n + CH - 1) / CH;
+  const long long gw = (long long)blockIdx.x * (PB / 64) + w, GW = (long long)gridDim.x * (PB / 64);
+  for (long long ch = gw; ch < nch; ch += GW) {
+    const long long r0 = ch * CH;
+    double2 v[U][KS4];
+    if (r0 + CH <= n) {
 #pragma unroll
-    for (int q = 0; q < KS4; q++) *reinterpret_cast<double2 *>(lds + (w + q * (PB / 64)) * RPM + 2 * lane) = pre[q];
-    __syncthreads();
-    if (t + gridDim.x < ntiles) {
+      for (int u = 0; u < U; u++)
 #pragma unroll
-      for (int q = 0; q < KS4; q++) { const int c = w + q * (PB / 64); pre[q] = load_column(c < kin ? A + (long long)c * lda : nullptr, (t + gridDim.x) * TR, n, lane); }
-    }
-    // wave w owns row groups 2w, 2w+1 (16 rows each) of the 128-row tile
+        for (int ks = 0; ks < KS4; ks++) v[u][ks] = ksk::ldcol2(pa[ks] + r0 + 32 * u);
+    } else {
 #pragma unroll
-    for (int g = 0; g < 2; g++) {
-      const int rg = (2 * w + g) * 16;
-      d4 acc[NT];
+      for (int u = 0; u < U; u++) {
+        const long long r = r0 + 32 * u + 2 * j;
 #pragma unroll
-      for (int nt = 0; nt < NT; nt++) acc[nt] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int ks = 0; ks < KS4; ks++) {
-        const double bfrag = lds[(ks * 4 + (lane >> 4)) * RPM + rg + (lane & 15)];     // B[k][j] = A[row j][k]
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[ks][nt], bfrag, acc[nt], 0, 0, 0);
+        for (int ks = 0; ks < KS4; ks++) { double2 t; t.x = r < n ? pa[ks][r0 + 32 * u] : 0.0; t.y = r + 1 < n ? pa[ks][r0 + 32 * u + 1] : 0.0; v[u][ks] = t; }
       }
-      const long long row = r0 + rg + (lane & 15);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      d4 e[NT], o[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) { e[nt] = (d4){0.0, 0.0, 0.0, 0.0}; o[nt] = (d4){0.0, 0.0, 0.0, 0.0}; }
+#pragma unroll
+      for (int ks = 0; ks < KS4; ks++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+          e[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[ks][nt], v[u][ks].x, e[nt], 0, 0, 0);
+          o[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(qf[ks][nt], v[u][ks].y, o[nt], 0, 0, 0);
+        }
+      const long long row = r0 + 32 * u + 2 * j;
       if (row < n) {
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
           for (int reg = 0; reg < 4; reg++) {
-            const int col = nt * 16 + (lane >> 4) + 4 * reg;
+            const int col = nt * 16 + kq + 4 * reg;
             if (col < nout) {
               double *c = C + (long long)col * ldc + row;
-              *c = (beta == 0.0) ? alpha * acc[nt][reg] : fma(alpha, acc[nt][reg], beta * (*c));
+              if (vecC && row + 1 < n) {
+                double2 r;
+                if (beta == 0.0) { r.x = alpha * e[nt][reg]; r.y = alpha * o[nt][reg]; }
+                else { const double2 old = *reinterpret_cast<const double2 *>(c); r.x = fma(alpha, e[nt][reg], beta * old.x); r.y = fma(alpha, o[nt][reg], beta * old.y); }
+                ksk::ks_d2v rv; rv.x = r.x; rv.y = r.y;
+                __builtin_nontemporal_store(rv, reinterpret_cast<ksk::ks_d2v *>(c));      // written once, re-read much later: keep it out of the way of the input stream
+              } else {
+                c[0] = (beta == 0.0) ? alpha * e[nt][reg] : fma(alpha, e[nt][reg], beta * c[0]);
+                if (row + 1 < n) c[1] = (beta == 0.0) ? alpha * o[nt][reg] : fma(alpha, o[nt][reg], beta * c[1]);
+              }
             }
           }
       }
     }
-    __syncthreads();
   }
 }
 
@@ -206,35 +225,36 @@ int ksp_dot_mfma(ks_bv bv, const double *Y, int ldy, int my, const double *X, in
   KS_CHECK(my >= 1 && my <= 64 && nx >= 1 && nx <= 64, KS_ERR_PLIB, "panel dot %dx%d", my, nx);
   KS_CHECK(ldy % 2 == 0 && ldx % 2 == 0 && (((uintptr_t)Y | (uintptr_t)X) & 15) == 0, KS_ERR_SUP, "MFMA panel kernels need 16-byte aligned columns");
   const int MT = (my + 15) / 16, NT = (nx + 15) / 16, MC = MT * 16, NC = NT * 16;
-  const long long ntiles = ((long long)n + TR - 1) / TR;
   const bool same = (Y == X && ldy == ldx && my == nx);
-  const size_t lds_bytes = std::max<size_t>((size_t)(same ? MC : MC + NC) * RP, (size_t)4 * MC * NC) * sizeof(double);
-  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (150 * 1024) / lds_bytes));
-  const int grid = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)ctx->num_cu * per_cu));
-  const size_t need = (size_t)grid * MC * NC;
-  if (bv->panel_len < need) {
-    if (bv->panel) hipFree(bv->panel);
-    bv->panel = nullptr; bv->panel_len = 0;
-    KS_HIP(hipMalloc(&bv->panel, need * sizeof(double)));
-    bv->panel_len = need;
+  int grid = 1;
+  {
+    // row chunks of 8U rows per wave; U so that one wave keeps about 16 KiB in flight whatever the tile counts
+    const int streams = same ? MT : MT + NT;
+    const int U = streams <= 2 ? 8 : (streams <= 4 ? 4 : 2);
+    const long long nch = ((long long)n + 8 * U - 1) / (8 * U);
+    const size_t lds_bytes = (size_t)MC * NC * sizeof(double);
+    KsProfScope ps(ctx, KS_K_BVDOT, 8.0 * n * (my + nx), 0, same ? 8.0 * n * my : -1.0);
+#define DOTD_LAUNCH(M_, N_, S_, U_) do { \
+      const int nb = occ_blocks((const void *)k_panel_dot_direct<M_, N_, S_, U_>, lds_bytes); \
+      grid = (int)std::max<long long>(1, std::min<long long>((nch + 3) / 4, (long long)ctx->num_cu * nb)); \
+      const size_t need = (size_t)grid * MC * NC; \
+      if (bv->panel_len < need) { if (bv->panel) hipFree(bv->panel); bv->panel = nullptr; bv->panel_len = 0; KS_HIP(hipMalloc(&bv->panel, need * sizeof(double))); bv->panel_len = need; } \
+      hipLaunchKernelGGL((k_panel_dot_direct<M_, N_, S_, U_>), dim3(grid), dim3(PB), lds_bytes, ctx->stream, Y, (long long)ldy, my, X, (long long)ldx, nx, n, bv->panel); } while (0)
+#define DOTD_CASE(M_, N_, U_) case (M_) * 8 + (N_): DOTD_LAUNCH(M_, N_, false, U_); break;
+    if (same) {
+      switch (MT) { case 1: DOTD_LAUNCH(1, 1, true, 8); break; case 2: DOTD_LAUNCH(2, 2, true, 8); break; case 3: DOTD_LAUNCH(3, 3, true, 4); break; default: DOTD_LAUNCH(4, 4, true, 4); break; }
+    } else
+    switch (MT * 8 + NT) {
+      DOTD_CASE(1, 1, 8) DOTD_CASE(1, 2, 4) DOTD_CASE(1, 3, 4) DOTD_CASE(1, 4, 2)
+      DOTD_CASE(2, 1, 4) DOTD_CASE(2, 2, 4) DOTD_CASE(2, 3, 2) DOTD_CASE(2, 4, 2)
+      DOTD_CASE(3, 1, 4) DOTD_CASE(3, 2, 2) DOTD_CASE(3, 3, 2) DOTD_CASE(3, 4, 2)
+      DOTD_CASE(4, 1, 2) DOTD_CASE(4, 2, 2) DOTD_CASE(4, 3, 2) DOTD_CASE(4, 4, 2)
+      default: KS_FAIL(KS_ERR_PLIB, "bad tile counts");
+    }
+#undef DOTD_CASE
+#undef DOTD_LAUNCH
+    (void)U;
   }
-  KsProfScope ps(ctx, KS_K_BVDOT, 8.0 * n * (my + nx), 0, same ? 8.0 * n * my : -1.0);
-#define DOT_LAUNCH(M_, N_, S_) do { \
-    KS_HIP(hipFuncSetAttribute((const void *)k_panel_dot_mfma<M_, N_, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-    hipLaunchKernelGGL((k_panel_dot_mfma<M_, N_, S_>), dim3(grid), dim3(PB), lds_bytes, ctx->stream, Y, (long long)ldy, my, X, (long long)ldx, nx, n, bv->panel); } while (0)
-#define DOT_CASE(M_, N_) case (M_) * 8 + (N_): DOT_LAUNCH(M_, N_, false); break;
-  if (same) {
-    switch (MT) { case 1: DOT_LAUNCH(1, 1, true); break; case 2: DOT_LAUNCH(2, 2, true); break; case 3: DOT_LAUNCH(3, 3, true); break; default: DOT_LAUNCH(4, 4, true); break; }
-  } else
-  switch (MT * 8 + NT) {
-    DOT_CASE(1, 1) DOT_CASE(1, 2) DOT_CASE(1, 3) DOT_CASE(1, 4)
-    DOT_CASE(2, 1) DOT_CASE(2, 2) DOT_CASE(2, 3) DOT_CASE(2, 4)
-    DOT_CASE(3, 1) DOT_CASE(3, 2) DOT_CASE(3, 3) DOT_CASE(3, 4)
-    DOT_CASE(4, 1) DOT_CASE(4, 2) DOT_CASE(4, 3) DOT_CASE(4, 4)
-    default: KS_FAIL(KS_ERR_PLIB, "bad tile counts");
-  }
-#undef DOT_CASE
-#undef DOT_LAUNCH
   KS_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_reduce_blocks, dim3((MC * NC + 255) / 256), dim3(256), 0, ctx->stream, bv->panel, grid, MC, NC, my, nx, M_dev);
   KS_HIP(hipGetLastError());
@@ -248,19 +268,19 @@ int ksp_mult_mfma(ks_ctx ctx, int kclass, const double *A, int lda, int n, int k
 {
   KS_CHECK(kin >= 1 && kin <= 64 && nout >= 1 && nout <= 64, KS_ERR_PLIB, "panel mult %dx%d", kin, nout);
   const int KS4 = ((kin + 15) / 16) * 4, NT = (nout + 15) / 16;      // k-steps rounded to 16 inner columns
-  const long long ntiles = ((long long)n + TR - 1) / TR;
-  const size_t lds_bytes = (size_t)KS4 * 4 * RPM * sizeof(double);
-  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (150 * 1024) / lds_bytes));
-  const int grid = (int)std::max<long long>(1, std::min<long long>(ntiles, (long long)ctx->num_cu * per_cu));
+  const int vecC = (ldc % 2 == 0 && (((uintptr_t)C) & 15) == 0) ? 1 : 0;
+  int grid = 1;
   KsProfScope ps(ctx, kclass, 8.0 * n * (kin + nout * (beta == 0.0 ? 1 : 2)), KS4 * 4);
-#define MULT_CASE(K_, N_) case (K_) * 8 + (N_): \
-    KS_HIP(hipFuncSetAttribute((const void *)k_panel_mult_mfma<K_, N_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-    hipLaunchKernelGGL((k_panel_mult_mfma<K_, N_>), dim3(grid), dim3(PB), lds_bytes, ctx->stream, A, (long long)lda, n, kin, Qdev, qsk, qsi, nout, alpha, beta, C, (long long)ldc); break;
+#define MULT_CASE(K_, N_, U_) case (K_) * 8 + (N_): { \
+    const int nb = occ_blocks((const void *)k_panel_mult_direct<K_, N_, U_>, 0); \
+    const long long nch = ((long long)n + 32 * (U_) - 1) / (32 * (U_)); \
+    grid = (int)std::max<long long>(1, std::min<long long>((nch + 3) / 4, (long long)ctx->num_cu * nb)); \
+    hipLaunchKernelGGL((k_panel_mult_direct<K_, N_, U_>), dim3(grid), dim3(PB), 0, ctx->stream, A, (long long)lda, n, kin, Qdev, qsk, qsi, nout, alpha, beta, C, (long long)ldc, vecC); } break;
   switch (KS4 * 8 + NT) {
-    MULT_CASE(4, 1) MULT_CASE(4, 2) MULT_CASE(4, 3) MULT_CASE(4, 4)
-    MULT_CASE(8, 1) MULT_CASE(8, 2) MULT_CASE(8, 3) MULT_CASE(8, 4)
-    MULT_CASE(12, 1) MULT_CASE(12, 2) MULT_CASE(12, 3) MULT_CASE(12, 4)
-    MULT_CASE(16, 1) MULT_CASE(16, 2) MULT_CASE(16, 3) MULT_CASE(16, 4)
+    MULT_CASE(4, 1, 4) MULT_CASE(4, 2, 4) MULT_CASE(4, 3, 4) MULT_CASE(4, 4, 2)
+    MULT_CASE(8, 1, 2) MULT_CASE(8, 2, 2) MULT_CASE(8, 3, 2) MULT_CASE(8, 4, 2)
+    MULT_CASE(12, 1, 2) MULT_CASE(12, 2, 2) MULT_CASE(12, 3, 1) MULT_CASE(12, 4, 1)
+    MULT_CASE(16, 1, 1) MULT_CASE(16, 2, 1) MULT_CASE(16, 3, 1) MULT_CASE(16, 4, 1)
     default: KS_FAIL(KS_ERR_PLIB, "bad tile counts");
   }
 #undef MULT_CASE
