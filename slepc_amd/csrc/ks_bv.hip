@@ -119,8 +119,7 @@ bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 // round of dispatch. Measured on MI355X: +5 % on the register-heavy update kernel versus a fixed 4 blocks/CU.
 int ks_sweep_grid_for(ks_ctx ctx, int n, int vec, const void *kernel, int force_per_cu)
 {
-  static const int bmul_env = getenv("KSGPU_SWEEP_BMUL") ? atoi(getenv("KSGPU_SWEEP_BMUL")) : 0;
-  const int bmul = force_per_cu > 0 ? force_per_cu : bmul_env;
+  const int bmul = force_per_cu;
   int per_cu = 4;
   if (bmul > 0) per_cu = bmul;
   else if (kernel) {
@@ -150,16 +149,17 @@ int ksk_dot(ks_bv bv, const double *A, int lda, int ncols, const double *y, bool
   // Every wave keeps all ncols column loads of its tile in flight (ncols KiB); about 120 KiB per CU saturate the HBM path,
   // more resident blocks only add concurrent DRAM streams: 1 block per CU at 30 columns (6.34 TB/s, 4 blocks: 6.20), more for
   // narrow sweeps.
-  static const int dot_env = getenv("KSGPU_DOT_PERCU") ? atoi(getenv("KSGPU_DOT_PERCU")) : 0;
-  const int dot_per_cu = dot_env ? dot_env : std::max(1, std::min(4, (30 + ncols - 1) / ncols));
+  const int dot_per_cu = std::max(1, std::min(4, (30 + ncols - 1) / ncols));
   const KsGsState *g = gate ? bv->gs : nullptr;
+  const int plain = ks_basis_is_cache_resident((size_t)(bv->nc + bv->m), (size_t)bv->ld);
+  const int rev = bv->sweep_dir; bv->sweep_dir ^= 1;            // snake over the basis with the sweeps before and after (ks_gs.hip launch_update)
   KsProfScope ps(ctx, KS_K_DOT, 8.0 * bv->n * (ncols + (y >= A && y < A + (size_t)ncols * lda ? 0 : 1)), ks_kt_for(ncols));
 #define LAUNCH_DOT(KT)                                                                                                                        \
   do {                                                                                                                                        \
     if (v2) { grid = ks_sweep_grid_for(ctx, bv->n, 2, (const void *)k_dot_sweep<KT, 2>, dot_per_cu); bv->last_grid = grid;                                \
-      hipLaunchKernelGGL((k_dot_sweep<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, y, bv->partials, g, &bv->gs->pgrid); } \
+      hipLaunchKernelGGL((k_dot_sweep<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, y, bv->partials, g, &bv->gs->pgrid, rev, plain); } \
     else { grid = ks_sweep_grid_for(ctx, bv->n, 1, (const void *)k_dot_sweep<KT, 1>, dot_per_cu); bv->last_grid = grid;                                   \
-      hipLaunchKernelGGL((k_dot_sweep<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, y, bv->partials, g, &bv->gs->pgrid); }   \
+      hipLaunchKernelGGL((k_dot_sweep<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, y, bv->partials, g, &bv->gs->pgrid, rev, plain); }   \
   } while (0)
   KS_KT_DISPATCH(ncols, LAUNCH_DOT);
 #undef LAUNCH_DOT

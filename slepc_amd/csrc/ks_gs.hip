@@ -41,14 +41,18 @@ struct GsArgs {
   double eta, deftol;
 };
 
+// What thread 0 decides and the other lanes then carry out in parallel (the O(k) global-memory loops of BV_AddCoefficients and of
+// the pending-coefficient copy took a third of the kernel when one lane ran them: every iteration a dependent global access).
+struct BookPlan { int hmode; int pslot; };      // hmode 0: leave H, 1: H = c (first pass: BV_CleanCoefficients + add), 2: H += c; pslot: row of `pend` that receives c, -1: none
+
 // Bookkeeping of ONE classical Gram-Schmidt pass as the reference's slot defines it (BVOrthogonalizeCGS1 bvorthog.c:91-132): the
 // refinement loop, lindep and BV_CleanCoefficients / BV_SetValue stay with the caller. c[0..k) are the reduced dots against the
 // previous columns, c[k] the self dot (a.gs1 == 2). Leaves |v| and the raw estimate |v|^2 - sum c_i^2 in the column's record.
-__device__ void gs1_bookkeep(const GsArgs a, const double *c, double *__restrict__ buffer, double *__restrict__ pend, KsGsState *st, KsStepRec *recs)
+__device__ void gs1_bookkeep(const GsArgs a, const double *c, KsGsState *st, KsStepRec *recs, BookPlan *plan)
 {
   const int k = a.k;
-  double *H = buffer + (size_t)a.col * a.ldb;
   double beta = 0.0;
+  plan->hmode = 0; plan->pslot = -1;
   st->do_update = 0; st->err = 0;
   if (a.gs1 == 2) {                                                     // BV_SquareRoot -> BV_SafeSqrt (bvimpl.h:121-141)
     const double vv = c[k];
@@ -57,7 +61,7 @@ __device__ void gs1_bookkeep(const GsArgs a, const double *c, double *__restrict
   }
   double sum = 0.0;
   for (int i = 0; i < k; i++) sum += c[i] * c[i];                      // BV_SquareSum bvimpl.h:347-360
-  for (int i = 0; i < k; i++) { H[i] += c[i]; pend[i] = c[i]; }        // BV_AddCoefficients bvimpl.h:308-322 (the caller cleaned H)
+  plan->hmode = 2; plan->pslot = 0;                                    // BV_AddCoefficients bvimpl.h:308-322 (the caller cleaned H)
   st->npend = 1; st->do_update = k > 0 ? 1 : 0; st->fuse_dot = 0; st->scale_now = 0; st->store_now = 1; st->store_prev = 1; st->alpha = 1.0;
   st->pending_scale = 0; st->more_ = 0; st->expl = 0;
   KsStepRec r; r.onrm = beta; r.nrm = beta * beta - sum; r.passes = 1; r.lindep = 0; r.expl = 0; r.col = a.col;
@@ -66,10 +70,11 @@ __device__ void gs1_bookkeep(const GsArgs a, const double *c, double *__restrict
 
 // Bookkeeping for one slot.  Thread 0 only.  c[0..k] are the (globally reduced) dots of the current
 // vector against columns 0..k-1 and itself.
-__device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict__ buffer, double *__restrict__ pend, KsGsState *st, KsStepRec *recs)
+__device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict__ buffer, KsGsState *st, KsStepRec *recs, BookPlan *plan)
 {
   const int k = a.k;
   int upd = 0, fuse = 0, scal = 0;
+  plan->hmode = 0; plan->pslot = -1;
   double *H = buffer + (size_t)a.col * a.ldb;    // H(:,col): buffer column col, entries nc+i (bvbasic.c:784-786)
   bool process = true, finalize = false, after_update = false;
   double nrm = st->nrm, onrm = st->onrm;
@@ -97,13 +102,12 @@ __device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict_
     // BV_SquareSum (bvimpl.h:347-360) and BV_AddCoefficients (bvimpl.h:308-322)
     double sum = 0.0;
     for (int i = 0; i < k; i++) sum += c[i] * c[i];
-    if (st->pass == 1) for (int i = 0; i < k; i++) H[i] = c[i];         // BV_CleanCoefficients + add
-    else for (int i = 0; i < k; i++) H[i] += c[i];
+    plan->hmode = st->pass == 1 ? 1 : 2;                                 // BV_CleanCoefficients + add / BV_AddCoefficients, by the other lanes
     // coefficients the next update applies to the vector AS IT IS IN MEMORY: the passes since it was last written back,
     // kept apart so that the update can subtract them one pass after the other - adding c2 to c1 first would round the
     // correction away exactly when refinement is needed (|c2| ~ eps |c1|)
     if (st->store_prev) st->npend = 0;
-    { double *pp = pend + (size_t)st->npend * KS_PSTRIDE; for (int i = 0; i < k; i++) pp[i] = c[i]; st->npend++; }
+    plan->pslot = st->npend; st->npend++;
     upd = 1;
     if (a.refine == KS_BV_ORTHOG_REFINE_NEVER) {
       // one pass, then explicit norm (bvorthog.c:189-195)
@@ -177,13 +181,23 @@ __global__ __launch_bounds__(1024) void k_gs_finish(const double *__restrict__ p
     if ((int)threadIdx.x < ncols) c_lds[threadIdx.x] = buffer[threadIdx.x];
     __syncthreads();
   }
-  if (BOOK && threadIdx.x == 0) { if (a.gs1) gs1_bookkeep(a, c_lds, buffer, pend, st, recs); else gs_bookkeep(a, c_lds, buffer, pend, st, recs); }
+  if (BOOK) {
+    __shared__ BookPlan plan;
+    if (threadIdx.x == 0) { if (a.gs1) gs1_bookkeep(a, c_lds, st, recs, &plan); else gs_bookkeep(a, c_lds, buffer, st, recs, &plan); }
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i < a.k) {
+      double *H = buffer + (size_t)a.col * a.ldb;
+      if (plan.hmode == 1) H[i] = c_lds[i]; else if (plan.hmode == 2) H[i] += c_lds[i];
+      if (plan.pslot >= 0) pend[(size_t)plan.pslot * KS_PSTRIDE + i] = c_lds[i];
+    }
+  }
 }
 
 // The tile loop of the update sweep. NP > 0 / FUSE >= 0 fix the number of pending passes and the fused flag at compile
 // time (coefficients preloaded, pass loop unrolled) for the two shapes every CGS2 step runs: the first pass (one pending
 // pass, fused dots, nothing written) and the final pass (two pending passes, scaled store). NP = 0 / FUSE = -1: runtime.
-template <int KT, int VEC, int NP, int FUSE>
+template <int KT, int VEC, int NP, int FUSE, bool PLAIN>
 __device__ __forceinline__ void upd_tiles(const double *V, long long ld, int n, int k, double *v, const double *__restrict__ cg, int npend_rt, bool fuse_rt,
                                           bool scal, bool store, double alpha, int rev, double (&acc)[KT + 1])
 {
@@ -205,7 +219,7 @@ __device__ __forceinline__ void upd_tiles(const double *V, long long ld, int n, 
       double2 s = *reinterpret_cast<const double2 *>(v + r);
       double2 xv[KT];
 #pragma unroll
-      for (int i = 0; i < KT; i++) { const int ii = i < k ? i : (k > 0 ? k - 1 : 0); xv[i] = ldcol2(V + (long long)ii * ld + r); }
+      for (int i = 0; i < KT; i++) { const int ii = i < k ? i : (k > 0 ? k - 1 : 0); xv[i] = ldbasis2<PLAIN>(V + (long long)ii * ld + r); }
       // pass by pass, exactly as if each pass had stored its result
       if (NP > 0) {
 #pragma unroll
@@ -255,7 +269,7 @@ __device__ __forceinline__ void upd_tiles(const double *V, long long ld, int n, 
 // v <- v - V(:,0:k) c   [* alpha if final]   and, when st->fuse_dot, partials <- [V(:,0:k) v]^T v  (k+1 values)
 template <int KT, int VEC>
 __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long long ld, int n, int k, double *v, const double *__restrict__ cg,
-                                                        double *__restrict__ partials, const KsGsState *__restrict__ st, int *__restrict__ pgrid, int rev)
+                                                        double *__restrict__ partials, const KsGsState *__restrict__ st, int *__restrict__ pgrid, int rev, int plain)
 {
   if (!st->do_update) return;
   const bool fuse = st->fuse_dot != 0;
@@ -270,9 +284,13 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long lo
   double acc[KT + 1];
 #pragma unroll
   for (int i = 0; i <= KT; i++) acc[i] = 0.0;
-  if (VEC == 2 && fuse && npend == 1 && !scal) upd_tiles<KT, VEC, 1, 1>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
-  else if (VEC == 2 && !fuse && npend == 2) upd_tiles<KT, VEC, 2, 0>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
-  else upd_tiles<KT, VEC, 0, -1>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
+  if (VEC == 2 && plain) {                // basis resident in the Infinity Cache: plain loads (ks_sweeps.cuh)
+    if (fuse && npend == 1 && !scal) upd_tiles<KT, VEC, 1, 1, true>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
+    else if (!fuse && npend == 2) upd_tiles<KT, VEC, 2, 0, true>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
+    else upd_tiles<KT, VEC, 0, -1, false>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
+  } else if (VEC == 2 && fuse && npend == 1 && !scal) upd_tiles<KT, VEC, 1, 1, false>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
+  else if (VEC == 2 && !fuse && npend == 2) upd_tiles<KT, VEC, 2, 0, false>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
+  else upd_tiles<KT, VEC, 0, -1, false>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
   if (!fuse) return;
   if (blockIdx.x == 0 && threadIdx.x == 0) *pgrid = gridDim.x;
   // block combine: partial index i<k <- acc[i]; index k <- acc[KT] (the self dot)
@@ -328,21 +346,22 @@ int launch_update(ks_bv bv, int col, double *v, int slot)
   const bool v2 = (bv->ld % 2 == 0) && aligned16(V) && aligned16(v);
   int grid = 1;
   const int kk = std::max(k, 1);
-  static const bool snake = !getenv("KSGPU_NO_SNAKE");
   // blocks per CU of the update sweep: measured on MI355X at n = 1e7, k = 16..30: 1 block (4 waves, k KiB in flight each)
   // per CU is fastest (fewer concurrent DRAM streams), as long as every block still gets many tiles
-  static const int upd_env = getenv("KSGPU_UPD_PERCU") ? atoi(getenv("KSGPU_UPD_PERCU")) : 0;
   const long long ntl = ((long long)bv->n + 511) / 512;
-  const int upd_per_cu = upd_env ? upd_env : (ntl >= 16LL * ctx->num_cu ? 1 : (ntl >= 8LL * ctx->num_cu ? 2 : 0));
-  const int rev = (snake && (slot & 1)) ? 1 : 0;     // dot: forward, update 1: backward, update 2: forward, update 3: backward
+  const int upd_per_cu = ntl >= 16LL * ctx->num_cu ? 1 : (ntl >= 8LL * ctx->num_cu ? 2 : 0);
+  (void)slot;
+  const int plain = ks_basis_is_cache_resident((size_t)(bv->nc + bv->m), (size_t)bv->ld);
+  const int rev = bv->sweep_dir; bv->sweep_dir ^= 1;   // every sweep over the basis runs opposite to the one before it (dot sweeps included): it starts on
+                                                       // the tail the previous one left in the 256 MB Infinity Cache (about a tenth of a 2.4 GB basis)
   KsProfScope ps(ctx, KS_K_UPD_FUSED, 8.0 * bv->n * (k + 2), ks_kt_for(kk));
   ps.tag(col, slot, k, bv->n);
 #define LAUNCH_UPD(KT)                                                                                                                                 \
   do {                                                                                                                                                 \
     if (v2) { grid = ks_sweep_grid_for(ctx, bv->n, 2, (const void *)k_gs_update<KT, 2>, upd_per_cu); bv->last_grid = grid;                                                        \
-      hipLaunchKernelGGL((k_gs_update<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->pend, bv->partials, bv->gs, &bv->gs->pgrid, rev); } \
+      hipLaunchKernelGGL((k_gs_update<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->pend, bv->partials, bv->gs, &bv->gs->pgrid, rev, plain); } \
     else { grid = ks_sweep_grid_for(ctx, bv->n, 1, (const void *)k_gs_update<KT, 1>, upd_per_cu); bv->last_grid = grid;                                                           \
-      hipLaunchKernelGGL((k_gs_update<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->pend, bv->partials, bv->gs, &bv->gs->pgrid, rev); }   \
+      hipLaunchKernelGGL((k_gs_update<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->pend, bv->partials, bv->gs, &bv->gs->pgrid, rev, plain); }   \
   } while (0)
   KS_KT_DISPATCH(kk, LAUNCH_UPD);
 #undef LAUNCH_UPD
@@ -390,8 +409,7 @@ int enqueue_fused_gs(ks_bv bv, int j, int normalize, int krylov)
   KS_CALL(ksk_dot(bv, ks_bv_col(bv, -bv->nc), bv->ld, bv->nc + j + 1, ks_bv_col(bv, j), krylov != 0));
   const int ns = spec_slots(bv), nt = total_slots(bv);
   const bool whole = (ns >= nt) && bv->orthog_ref == KS_BV_ORTHOG_REFINE_NEVER;
-  static const bool optimistic = !getenv("KSGPU_NO_OPTIMISTIC");
-  if (whole || !optimistic) return enqueue_gs_slots(bv, j, normalize, krylov, 1, nt, false, true);
+  if (whole) return enqueue_gs_slots(bv, j, normalize, krylov, 1, nt, false, true);
   return enqueue_gs_slots(bv, j, normalize, krylov, 1, ns, true, false);
 }
 

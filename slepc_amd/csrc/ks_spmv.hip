@@ -579,7 +579,7 @@ int build_sliced(ks_mat A)
     KS_HIP(hipMemcpyAsync(&h, cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream)); KS_HIP(hipStreamSynchronize(ctx->stream)); hipFree(cnt);
     if ((double)h < 0.5 * (double)A->nnz_d) return KS_SUCCESS;
   }
-  const int max_slice_rows = getenv("KSGPU_SLICE_ROWS") ? std::max(4096, atoi(getenv("KSGPU_SLICE_ROWS"))) : 786432;   // 6 MiB of x per slice: the 5 MiB slices of the 40 MB probe ran at the L2 rate
+  const int max_slice_rows = 786432;   // 6 MiB of x per slice: the 5 MiB slices of the 40 MB probe ran at the L2 rate
   int P = (int)(((long long)n + 8LL * max_slice_rows - 1) / (8LL * max_slice_rows)); if (P < 1) P = 1;
   KS_CHECK(P <= 8, KS_ERR_SUP, "sliced SpMV layout supports up to %d local rows", 64 * max_slice_rows);
   const int S = 8 * P, sc = (n + S - 1) / S;
@@ -927,8 +927,7 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
       hipLaunchKernelGGL(k_spmv_sliced, dim3((unsigned)(8 * per_xcd)), dim3(256), 0, ctx->stream, A->n, A->nslice, A->sl_rowptr, A->sl_base, A->sl_col, A->sl_val, x, A->ypart);
       hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)std::min((A->n + 255) / 256, ctx->num_cu * 8)), dim3(256), 0, ctx->stream, A->n, A->ypart, y);
     } else if (A->use_dict) {
-      static const int dremap_env = getenv("KSGPU_DICT_REMAP") ? atoi(getenv("KSGPU_DICT_REMAP")) : 1;
-      static const int dmul = getenv("KSGPU_DICT_BMUL") ? atoi(getenv("KSGPU_DICT_BMUL")) : 64;
+      const int dremap_env = 1, dmul = 64;
       const long long groups = ((long long)A->n + SPMV_BLOCK - 1) / SPMV_BLOCK;
       long long nblk = std::max<long long>(1, std::min<long long>(groups, (long long)ctx->num_cu * dmul));
       const int dremap = (dremap_env && nblk >= 64) ? 1 : 0;               // small matrices: nothing to pin
@@ -938,8 +937,7 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
       else if (A->dict_w == 32) hipLaunchKernelGGL((k_spmv_dict<32>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, (const uint4 *)A->dc_codes, A->dc_val, A->dict_nval, A->dc_off, A->dict_noff, x, y, dremap);
       else hipLaunchKernelGGL((k_spmv_dict<16>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, (const uint4 *)A->dc_codes, A->dc_val, A->dict_nval, A->dc_off, A->dict_noff, x, y, dremap);
     } else if (A->use_odict) {
-      static const int oremap_env = getenv("KSGPU_DICT_REMAP") ? atoi(getenv("KSGPU_DICT_REMAP")) : 1;
-      static const int omul = getenv("KSGPU_DICT_BMUL") ? atoi(getenv("KSGPU_DICT_BMUL")) : 64;
+      const int oremap_env = 1, omul = 64;
       const long long groups = ((long long)A->n + SPMV_BLOCK - 1) / SPMV_BLOCK;
       long long nblk = std::max<long long>(1, std::min<long long>(groups, (long long)ctx->num_cu * omul));
       const int oremap = (oremap_env && nblk >= 64) ? 1 : 0;
@@ -948,17 +946,14 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
       else if (A->dict_w == 32) hipLaunchKernelGGL((k_spmv_odict<32>), dim3((unsigned)nblk), dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->dc_codes8, A->dc_vals, A->dc_off, A->dict_noff, x, y, oremap);
       else hipLaunchKernelGGL((k_spmv_odict<16>), dim3((unsigned)nblk), dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->dc_codes8, A->dc_vals, A->dc_off, A->dict_noff, x, y, oremap);
     } else if (A->use_sell) {
-      static const int remap_env = getenv("KSGPU_SELL_REMAP") ? atoi(getenv("KSGPU_SELL_REMAP")) : 1;   // each XCD one contiguous range of slices: 179 -> 172 us on the 216^3 Laplacian
+      const int remap_env = 1;   // each XCD one contiguous range of slices: 179 -> 172 us on the 216^3 Laplacian
       const long long groups = ((long long)A->nslices + 3) / 4;
       long long blocks = std::min<long long>(groups, (long long)ctx->num_cu * 16);
-      static const int unr = getenv("KSGPU_SELL_UNR") ? atoi(getenv("KSGPU_SELL_UNR")) : 8;
-      static const int bmul = getenv("KSGPU_SELL_BMUL") ? atoi(getenv("KSGPU_SELL_BMUL")) : 4096;   // one 256-row group per block measured fastest
+      const int bmul = 4096;   // one 256-row group per block measured fastest
       blocks = std::min<long long>(groups, (long long)ctx->num_cu * bmul);
       const dim3 gr((unsigned)std::max<long long>(blocks, 1));
       const int remap = (remap_env && blocks == groups && blocks >= 64) ? 1 : 0;     // only with one slice group per workgroup (a strided loop would interleave the ranges again)
-      if (unr == 4) hipLaunchKernelGGL((k_spmv_sell<4>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->nslices, A->s_ptr, A->s_len, A->s_col, A->s_val, x, y, remap);
-      else if (unr == 2) hipLaunchKernelGGL((k_spmv_sell<2>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->nslices, A->s_ptr, A->s_len, A->s_col, A->s_val, x, y, remap);
-      else hipLaunchKernelGGL((k_spmv_sell<8>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->nslices, A->s_ptr, A->s_len, A->s_col, A->s_val, x, y, remap);
+      hipLaunchKernelGGL((k_spmv_sell<8>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->nslices, A->s_ptr, A->s_len, A->s_col, A->s_val, x, y, remap);
     } else
       launch_spmv<false, false>(ctx->stream, ctx->num_cu, A->lanes_per_row, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, nullptr);
     if (overlap) KS_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_halo, 0));          // also when this rank has no off-diagonal rows: keeps the two streams in step

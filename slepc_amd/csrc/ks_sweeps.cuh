@@ -19,21 +19,20 @@ namespace ksk {
 
 // Streaming (read-once) 16-byte load of a basis column: `global_load_dwordx4 ... nt`. The panel V is far larger
 // than L2 + Infinity Cache and every element is used once per sweep, so the nontemporal hint keeps the stream from
-// displacing the vector being updated; measured +6 % steps/s on MI355X (n = 1e7). -DKSGPU_NO_NT_LOADS restores
-// plain loads for A/B runs.
+// displacing the vector being updated; measured +6 % steps/s on MI355X (n = 1e7).
 typedef double ks_d2v __attribute__((ext_vector_type(2)));
-#ifndef KSGPU_NO_NT_LOADS
 __device__ __forceinline__ double2 ldcol2(const double *p) { const ks_d2v t = __builtin_nontemporal_load(reinterpret_cast<const ks_d2v *>(p)); double2 v; v.x = t.x; v.y = t.y; return v; }
 __device__ __forceinline__ double ldstream(const double *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ int ldstream(const int *p) { return __builtin_nontemporal_load(p); }
 typedef unsigned ks_u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 ldstream4(const uint4 *p) { const ks_u4v t = __builtin_nontemporal_load(reinterpret_cast<const ks_u4v *>(p)); uint4 v; v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w; return v; }
-#else
-__device__ __forceinline__ uint4 ldstream4(const uint4 *p) { return *p; }
-__device__ __forceinline__ double2 ldcol2(const double *p) { return *reinterpret_cast<const double2 *>(p); }
-__device__ __forceinline__ double ldstream(const double *p) { return *p; }
-__device__ __forceinline__ int ldstream(const int *p) { return *p; }
-#endif
+
+// A basis that fits the 256 MB Infinity Cache (config 2: 21 columns x 1e6 rows = 168 MB) is re-read from there by every sweep:
+// plain loads then, the nontemporal hint only costs (measured +4.5 % steps/s on config 2, -7 % on config 3 with plain loads,
+// profiles/r01e_other_configs_probe.txt). Chosen per launch from the size of the BV's storage.
+__device__ __forceinline__ double2 ldplain2(const double *p) { return *reinterpret_cast<const double2 *>(p); }
+template <bool PLAIN> __device__ __forceinline__ double2 ldbasis2(const double *p) { return PLAIN ? ldplain2(p) : ldcol2(p); }
+static inline int ks_basis_is_cache_resident(size_t columns, size_t ld) { return columns * ld * sizeof(double) <= (size_t)200 * 1000 * 1000; }
 
 constexpr int SW_BLOCK = 256;
 constexpr int SW_WAVES = SW_BLOCK / 64;
@@ -66,26 +65,20 @@ __device__ __forceinline__ void block_write_partials(double (&acc)[KT], int ncol
 }
 
 // partials <- A(:,0:ncols)^T y        (gemv-C of BVDotVec_BLAS_Private, bvblas.c:240-261)
-template <int KT, int VEC>
-__global__ __launch_bounds__(SW_BLOCK) void k_dot_sweep(const double *__restrict__ A, long long lda, int n, int ncols,
-                                                        const double *__restrict__ y, double *__restrict__ partials,
-                                                        const KsGsState *__restrict__ gate, int *__restrict__ pgrid)
+template <int KT, int VEC, bool PLAIN>
+__device__ __forceinline__ void dot_tiles(const double *__restrict__ A, long long lda, int n, int ncols, const double *__restrict__ y, int rev, double (&acc)[KT])
 {
-  if (gate && !gate->active) return;
-  if (pgrid && blockIdx.x == 0 && threadIdx.x == 0) *pgrid = gridDim.x;     // the partials' stride travels with them
-  double acc[KT];
-#pragma unroll
-  for (int i = 0; i < KT; i++) acc[i] = 0.0;
   const long long tile = (long long)SW_BLOCK * VEC;
   const long long ntiles = ((long long)n + tile - 1) / tile;
-  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  for (long long t0 = blockIdx.x; t0 < ntiles; t0 += gridDim.x) {
+    const long long t = rev ? ntiles - 1 - t0 : t0;
     const long long r = t * tile + (long long)threadIdx.x * VEC;
     if (VEC == 2) {
       if (r + 1 < n) {
         // all KT column loads of the tile are issued back to back (KT KiB in flight per wave), then the products
         double2 xv[KT];
 #pragma unroll
-        for (int i = 0; i < KT; i++) { const int ii = i < ncols ? i : ncols - 1; xv[i] = ldcol2(A + (long long)ii * lda + r); }
+        for (int i = 0; i < KT; i++) { const int ii = i < ncols ? i : ncols - 1; xv[i] = ldbasis2<PLAIN>(A + (long long)ii * lda + r); }
         const double2 yv = *reinterpret_cast<const double2 *>(y + r);
         __builtin_amdgcn_sched_barrier(0);              // keep the scheduler from folding the loads back into a 2-deep load/fma chain
 #pragma unroll
@@ -103,6 +96,20 @@ __global__ __launch_bounds__(SW_BLOCK) void k_dot_sweep(const double *__restrict
       }
     }
   }
+}
+
+template <int KT, int VEC>
+__global__ __launch_bounds__(SW_BLOCK) void k_dot_sweep(const double *__restrict__ A, long long lda, int n, int ncols,
+                                                        const double *__restrict__ y, double *__restrict__ partials,
+                                                        const KsGsState *__restrict__ gate, int *__restrict__ pgrid, int rev, int plain)
+{
+  if (gate && !gate->active) return;
+  if (pgrid && blockIdx.x == 0 && threadIdx.x == 0) *pgrid = gridDim.x;     // the partials' stride travels with them
+  double acc[KT];
+#pragma unroll
+  for (int i = 0; i < KT; i++) acc[i] = 0.0;
+  if (VEC == 2 && plain) dot_tiles<KT, VEC, true>(A, lda, n, ncols, y, rev, acc);
+  else dot_tiles<KT, VEC, false>(A, lda, n, ncols, y, rev, acc);
   block_write_partials<KT>(acc, ncols, partials);
 }
 
@@ -172,9 +179,8 @@ __device__ __forceinline__ void reduce_partials_to_lds(const double *__restrict_
 // bypass the caches), then steps of 8
 static inline int ks_kt_for(int ncols)
 {
-  static const int gran = getenv("KSGPU_KT_GRAN") ? atoi(getenv("KSGPU_KT_GRAN")) : 1;     // A/B switch: 4 = pad to multiples of 4
-  if (ncols <= 1) return gran > 1 ? gran : 1;
-  if (ncols <= 32) return gran > 1 ? (ncols + gran - 1) / gran * gran : ncols;
+  if (ncols <= 1) return 1;
+  if (ncols <= 32) return ncols;
   return (ncols + 7) / 8 * 8 > 64 ? 64 : (ncols + 7) / 8 * 8;
 }
 

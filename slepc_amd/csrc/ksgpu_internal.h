@@ -198,6 +198,8 @@ struct ks_bv_s {
   KsStepRec *recs = nullptr;    // m records (one per column)
   long long passes_total_host = 0; int passes_last_host = 0;
   int row_start = 0;            // first global row (reproducible random)
+  int sweep_dir = 0;            // direction of the next row sweep over the basis: consecutive sweeps alternate (forward / backward), so each starts
+                                // on the rows the previous one left in the Infinity Cache
   int last_grid = 1;            // grid size of the sweep LAUNCHED last (profiling byte counts, and reductions that directly follow their sweep); the
                                 // Gram-Schmidt bookkeeping reads the grid from KsGsState::pgrid instead
   double *panel = nullptr; size_t panel_len = 0;   // block partials of the MFMA panel dot (grid x 64 x 64 max)
