@@ -98,6 +98,7 @@ enum { KS_EPS_CONVERGED_TOL = 1, KS_EPS_CONVERGED_USER = 2, KS_EPS_DIVERGED_ITS 
 int ks_ctx_create(int device, void *stream, ks_ctx *ctx);
 int ks_ctx_destroy(ks_ctx ctx);
 int ks_ctx_synchronize(ks_ctx ctx);
+int ks_ctx_sync_count(ks_ctx ctx, long long *count);   /* instrumentation: host waits on the context's stream made by the library so far */
 int ks_ctx_device_info(ks_ctx ctx, char *arch, int arch_len, int *num_cu, size_t *mem_total);
 
 /* Row-wise distribution (PetscLayout, bvbasic.c:129-134).  Reductions inside BV ops

@@ -99,6 +99,9 @@ class Context:
     def synchronize(self):
         _lib.check(self.L.ks_ctx_synchronize(self.h))
 
+    def sync_count(self):
+        v = C.c_longlong(); _lib.check(self.L.ks_ctx_sync_count(self.h, C.byref(v))); return v.value
+
     def device_info(self):
         arch = C.create_string_buffer(64); ncu = C.c_int(); mem = C.c_size_t()
         _lib.check(self.L.ks_ctx_device_info(self.h, arch, 64, C.byref(ncu), C.byref(mem)))

@@ -33,6 +33,7 @@ _SIG = {
     "ks_ctx_create": [C.c_int, vp, C.POINTER(vp)],
     "ks_ctx_destroy": [vp],
     "ks_ctx_synchronize": [vp],
+    "ks_ctx_sync_count": [vp, llp],
     "ks_ctx_device_info": [vp, C.c_char_p, C.c_int, ip, C.POINTER(C.c_size_t)],
     "ks_comm_get_unique_id": [C.c_char_p],
     "ks_comm_init_rccl": [vp, C.c_int, C.c_int, C.c_char_p],

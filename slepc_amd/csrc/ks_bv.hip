@@ -212,14 +212,14 @@ static int stage_coefs(ks_bv bv, const double *host, size_t len, double **dev)
 {
   ks_ctx ctx = bv->ctx;
   if (len > bv->coef_len) {                                 // a wider coefficient block than this BV's own m x m: grow the scratch
-    KS_HIP(hipStreamSynchronize(ctx->stream));
+    KS_HIP(ks_sync(ctx));
     hipFree(bv->coef); bv->coef = nullptr; bv->coef_len = 0;
     KS_HIP(hipMalloc(&bv->coef, (len + 64) * sizeof(double)));
     bv->coef_len = len + 64;
   }
   // the pinned area may still be in use by an earlier async copy: make the copy synchronous w.r.t. the host
   KS_HIP(hipMemcpyAsync(bv->coef, host, len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_HIP(ks_sync(ctx));
   *dev = bv->coef;
   return KS_SUCCESS;
 }
@@ -251,7 +251,7 @@ extern "C" int ks_bv_create(ks_ctx ctx, int n_local, int n_global, int m, int ld
   KS_HIP(hipMemsetAsync(bv->gs, 0, sizeof(KsGsState), ctx->stream));
   KS_HIP(hipMalloc(&bv->recs, (size_t)(m + 1) * sizeof(KsStepRec)));
   KS_HIP(hipMemsetAsync(bv->recs, 0, (size_t)(m + 1) * sizeof(KsStepRec), ctx->stream));
-  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_HIP(ks_sync(ctx));
   *out = bv;
   return KS_SUCCESS;
 }
@@ -260,7 +260,7 @@ extern "C" int ks_bv_destroy(ks_bv bv)
 {
   if (!bv) return KS_SUCCESS;
   hipSetDevice(bv->ctx->device);
-  hipStreamSynchronize(bv->ctx->stream);
+  ks_sync(bv->ctx);
   hipFree(bv->array); hipFree(bv->own_buffer ? bv->buffer : bv->buffer_own); hipFree(bv->partials); hipFree(bv->coef); hipFree(bv->hc); hipFree(bv->gs); hipFree(bv->recs); hipFree(bv->panel); hipFree(bv->Bx); hipFree(bv->pend);
   delete bv;
   return KS_SUCCESS;
@@ -280,7 +280,7 @@ extern "C" int ks_bv_resize(ks_bv bv, int m, int copy)
   if (copy) {
     const int mc = std::min(m, bv->m);
     for (int j = 0; j < mc; j++) { int rc = ksk_copy(bv->ctx, ks_bv_col(bv, j), ks_bv_col(nb, j), bv->n); if (rc) { ks_bv_destroy(nb); return rc; } }
-    KS_HIP(hipStreamSynchronize(bv->ctx->stream));
+    KS_HIP(ks_sync(bv->ctx));
   }
   // swap the storage of the two objects, keep the caller's handle and settings
   std::swap(bv->array, nb->array); std::swap(bv->buffer, nb->buffer); std::swap(bv->own_buffer, nb->own_buffer); std::swap(bv->buffer_own, nb->buffer_own); std::swap(bv->coef, nb->coef); std::swap(bv->coef_len, nb->coef_len);
@@ -464,7 +464,7 @@ extern "C" int ks_bv_set_column_host(ks_bv bv, int j, const double *host)
   KS_CHECK(j >= 0 && j < bv->m, KS_ERR_ARG_OUTOFRANGE, "column %d out of range", j);
   KS_HIP(hipSetDevice(bv->ctx->device));
   KS_HIP(hipMemcpyAsync(ks_bv_col(bv, j), host, sizeof(double) * bv->n, hipMemcpyHostToDevice, bv->ctx->stream));
-  KS_HIP(hipStreamSynchronize(bv->ctx->stream));
+  KS_HIP(ks_sync(bv->ctx));
   return KS_SUCCESS;
 }
 
@@ -474,7 +474,7 @@ extern "C" int ks_bv_get_column_host(ks_bv bv, int j, double *host)
   KS_CHECK(j >= -bv->nc && j < bv->m, KS_ERR_ARG_OUTOFRANGE, "column %d out of range", j);
   KS_HIP(hipSetDevice(bv->ctx->device));
   KS_HIP(hipMemcpyAsync(host, ks_bv_col(bv, j), sizeof(double) * bv->n, hipMemcpyDeviceToHost, bv->ctx->stream));
-  KS_HIP(hipStreamSynchronize(bv->ctx->stream));
+  KS_HIP(ks_sync(bv->ctx));
   return KS_SUCCESS;
 }
 
@@ -483,7 +483,7 @@ extern "C" int ks_bv_get_buffer_host(ks_bv bv, double *host)
   KS_CHECK(bv && host, KS_ERR_ARG_NULL, "NULL argument");
   KS_HIP(hipSetDevice(bv->ctx->device));
   KS_HIP(hipMemcpyAsync(host, bv->buffer, sizeof(double) * (bv->nc + bv->m) * bv->m, hipMemcpyDeviceToHost, bv->ctx->stream));
-  KS_HIP(hipStreamSynchronize(bv->ctx->stream));
+  KS_HIP(ks_sync(bv->ctx));
   return KS_SUCCESS;
 }
 
@@ -527,7 +527,7 @@ static int panel_mult(ks_ctx ctx, int kclass, const double *A, int lda, int n, i
   }
   if (alias) {
     for (int j = 0; j < nout && !rc; j++) rc = ksk_copy(ctx, T + (size_t)j * ldt, C + (size_t)j * ldc, n);
-    hipStreamSynchronize(ctx->stream);
+    ks_sync(ctx);
     hipFree(T);
   }
   return rc;
@@ -669,7 +669,7 @@ int ksb_norm_b(ks_bv bv, const double *x, double *val)              // BVNorm_Pr
   else KS_HIP(hipMemsetAsync(bv->coef, 0, sizeof(double), ctx->stream));
   KS_CALL(ks_allreduce_sum(ctx, bv->coef, 1));
   KS_HIP(hipMemcpyAsync(&p, bv->coef, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_HIP(ks_sync(ctx));
   KS_CHECK(p > -bv->deftol, KS_ERR_USER_INPUT, "The inner product is not well defined: indefinite matrix %g", p);
   *val = p < 0.0 ? 0.0 : sqrt(p);
   return KS_SUCCESS;
@@ -692,7 +692,7 @@ static int dotvec_impl(ks_bv X, const double *y_dev, double *m, bool reduce)
     else KS_HIP(hipMemsetAsync(out + c0, 0, sizeof(double) * nc, ctx->stream));
   }
   if (reduce) KS_CALL(ks_allreduce_sum(ctx, out, kx));
-  if (m) { KS_HIP(hipMemcpyAsync(m, out, sizeof(double) * kx, hipMemcpyDeviceToHost, ctx->stream)); KS_HIP(hipStreamSynchronize(ctx->stream)); }
+  if (m) { KS_HIP(hipMemcpyAsync(m, out, sizeof(double) * kx, hipMemcpyDeviceToHost, ctx->stream)); KS_HIP(ks_sync(ctx)); }
   return KS_SUCCESS;
 }
 extern "C" int ks_bv_dotvec(ks_bv X, const double *y_dev, double *m) { return dotvec_impl(X, y_dev, m, true); }          // bvglobal.c:151
@@ -756,7 +756,7 @@ int ksb_dot_range(ks_bv X, int xs, int xe, ks_bv Y, int ys, int ye, double *M, i
   KS_CALL(ks_allreduce_sum(ctx, X->coef, my * nx));
   std::vector<double> tmp((size_t)my * nx);
   KS_HIP(hipMemcpyAsync(tmp.data(), X->coef, sizeof(double) * my * nx, hipMemcpyDeviceToHost, ctx->stream));
-  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_HIP(ks_sync(ctx));
   double *C = M + (size_t)xs * ldm + ys;
   for (int j = 0; j < nx; j++) memcpy(C + (size_t)j * ldm, tmp.data() + (size_t)j * my, sizeof(double) * my);
   return KS_SUCCESS;
@@ -833,7 +833,7 @@ static int norm_core(ks_bv bv, const double *A, int ncols, int j, int type, doub
     if (reduce) KS_CALL(ks_allreduce_sum(ctx, bv->coef, ncols));     // sum of squares / abs sums add across ranks
     h.resize(ncols);
     KS_HIP(hipMemcpyAsync(h.data(), bv->coef, sizeof(double) * ncols, hipMemcpyDeviceToHost, ctx->stream));
-    KS_HIP(hipStreamSynchronize(ctx->stream));
+    KS_HIP(ks_sync(ctx));
     if (type == KS_NORM_1) { double mx = 0.0; for (double v : h) mx = std::max(mx, v); *val = mx; }
     else {
       double s = 0.0; for (double v : h) s += v;
@@ -844,7 +844,7 @@ static int norm_core(ks_bv bv, const double *A, int ncols, int j, int type, doub
         hipLaunchKernelGGL(k_colsum<3>, dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)bv->ld, bv->n, ncols, bv->partials, 1.0);
         std::vector<double> hm((size_t)grid * ncols);
         KS_HIP(hipMemcpyAsync(hm.data(), bv->partials, sizeof(double) * hm.size(), hipMemcpyDeviceToHost, ctx->stream));
-        KS_HIP(hipStreamSynchronize(ctx->stream));
+        KS_HIP(ks_sync(ctx));
         double mx = 0.0; for (double v : hm) mx = std::max(mx, v);
         if (reduce && ctx->comm.size > 1) { std::vector<double> all(ctx->comm.size); KS_CALL(ks_comm_allgather_host(ctx, &mx, sizeof(double), all.data())); for (double v : all) mx = std::max(mx, v); }
         if (mx == 0.0 || !(mx < std::numeric_limits<double>::infinity())) *val = mx;
@@ -856,7 +856,7 @@ static int norm_core(ks_bv bv, const double *A, int ncols, int j, int type, doub
           }
           if (reduce) KS_CALL(ks_allreduce_sum(ctx, bv->coef, ncols));
           KS_HIP(hipMemcpyAsync(h.data(), bv->coef, sizeof(double) * ncols, hipMemcpyDeviceToHost, ctx->stream));
-          KS_HIP(hipStreamSynchronize(ctx->stream));
+          KS_HIP(ks_sync(ctx));
           double s2 = 0.0; for (double v : h) s2 += v;
           *val = mx * sqrt(s2);
         }
@@ -867,7 +867,7 @@ static int norm_core(ks_bv bv, const double *A, int ncols, int j, int type, doub
     KS_HIP(hipGetLastError());
     h.resize(grid);
     KS_HIP(hipMemcpyAsync(h.data(), bv->partials, sizeof(double) * grid, hipMemcpyDeviceToHost, ctx->stream));
-    KS_HIP(hipStreamSynchronize(ctx->stream));
+    KS_HIP(ks_sync(ctx));
     double mx = 0.0; for (double v : h) mx = std::max(mx, v);
     if (reduce && ctx->comm.size > 1) {                        // MAX across ranks through the host allgather of the provider
       std::vector<double> all(ctx->comm.size);
@@ -926,7 +926,7 @@ static int split_end(ks_ctx ctx, int cnt, int kind, double *out, double deftol)
     KS_CALL(ks_allreduce_sum(ctx, sp.dev, sp.used));
     sp.host.resize(sp.used);
     KS_HIP(hipMemcpyAsync(sp.host.data(), sp.dev, sizeof(double) * sp.used, hipMemcpyDeviceToHost, ctx->stream));
-    KS_HIP(hipStreamSynchronize(ctx->stream));
+    KS_HIP(ks_sync(ctx));
     sp.reduced = true;
   }
   const auto e = sp.entries[sp.nread];

@@ -79,7 +79,7 @@ extern "C" int ks_ctx_destroy(ks_ctx ctx)
 {
   if (!ctx) return KS_SUCCESS;
   hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
+  ks_sync(ctx);
   for (auto &p : ctx->pending) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
   for (auto &e : ctx->event_pool) hipEventDestroy(e);
   if (ctx->comm.nccl_comm && ctx->comm.rccl_lib) {
@@ -109,7 +109,14 @@ int ks_ctx_halo_stream(ks_ctx ctx)
 extern "C" int ks_ctx_synchronize(ks_ctx ctx)
 {
   KS_CHECK(ctx, KS_ERR_ARG_NULL, "ctx is NULL");
-  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_HIP(ks_sync(ctx));
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_ctx_sync_count(ks_ctx ctx, long long *count)
+{
+  KS_CHECK(ctx && count, KS_ERR_ARG_NULL, "NULL argument");
+  *count = ctx->nsync;
   return KS_SUCCESS;
 }
 
@@ -158,7 +165,7 @@ int ks_prof_end(ks_ctx ctx, size_t index)
 int ks_prof_flush(ks_ctx ctx)
 {
   if (ctx->pending.empty()) return KS_SUCCESS;
-  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_HIP(ks_sync(ctx));
   for (auto &p : ctx->pending) {
     float ms = 0.f;
     if (!p.done) { (void)hipGetLastError(); }
@@ -289,7 +296,7 @@ static int rccl_allgather_host(void *user, const void *send, int bytes, void *re
   if (hipMemcpyAsync(d + (size_t)bytes * ctx->comm.size, send, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = 2;
   if (!rc) rc = g_rccl.allgather(d + (size_t)bytes * ctx->comm.size, d, (size_t)bytes, NCCL_INT8, ctx->comm.nccl_comm, ctx->stream);
   if (!rc && hipMemcpyAsync(recv, d, (size_t)bytes * ctx->comm.size, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = 3;
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = 4;
+  if (ks_sync(ctx) != hipSuccess && !rc) rc = 4;
   hipFree(d);
   return rc;
 }
@@ -369,7 +376,7 @@ extern "C" int ks_ctx_memcpy(ks_ctx ctx, void *dst, const void *src, size_t byte
   KS_CHECK(ctx && (bytes == 0 || (dst && src)), KS_ERR_ARG_NULL, "NULL argument");
   KS_HIP(hipSetDevice(ctx->device));
   if (bytes) KS_HIP(hipMemcpyAsync(dst, src, bytes, kind == 0 ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, ctx->stream));
-  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_HIP(ks_sync(ctx));
   return KS_SUCCESS;
 }
 

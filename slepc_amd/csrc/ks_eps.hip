@@ -531,7 +531,7 @@ extern "C" int ks_eps_set_balance_matrix(ks_eps eps, const double *D_dev)
   if (eps->D_n != n || !eps->D) { if (eps->D) hipFree(eps->D); if (eps->wb) hipFree(eps->wb); eps->D = eps->wb = nullptr;
     KS_HIP(hipMalloc(&eps->D, sizeof(double) * std::max<long long>(n, 1))); KS_HIP(hipMalloc(&eps->wb, sizeof(double) * std::max<long long>(n, 1))); eps->D_n = (int)n; }
   KS_HIP(hipMemcpyAsync(eps->D, D_dev, sizeof(double) * n, hipMemcpyDeviceToDevice, eps->ctx->stream));
-  KS_HIP(hipStreamSynchronize(eps->ctx->stream));
+  KS_HIP(ks_sync(eps->ctx));
   eps->balance = KS_EPS_BALANCE_USER; eps->solved = false;
   return KS_SUCCESS;
 }
@@ -594,7 +594,7 @@ extern "C" int ks_eps_set_initial_space(ks_eps eps, int n, const double *const *
   eps->v0.resize(std::max(eps->A->n, 1));
   KS_HIP(hipSetDevice(eps->ctx->device));
   KS_HIP(hipMemcpyAsync(eps->v0.data(), v_dev[0], sizeof(double) * eps->A->n, hipMemcpyDeviceToHost, eps->ctx->stream));
-  KS_HIP(hipStreamSynchronize(eps->ctx->stream));
+  KS_HIP(ks_sync(eps->ctx));
   eps->have_v0 = true; eps->solved = false;
   return KS_SUCCESS;
 }
@@ -1113,7 +1113,7 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
         double re = eps->eigr[i], im0 = 0.0;
         if (eps->cmp_ds.map) ks_st_backtransform_internal(eps->cmp_ds.map, 1, &re, &im0);
         KS_CALL(ritz_vector(eps, nv, ds.Q.data() + (size_t)i * ds.ld, nullptr));       // DSVectors(X,i) = Q(:,i) for DSHEP
-        KS_HIP(hipStreamSynchronize(eps->ctx->stream));
+        KS_HIP(ks_sync(eps->ctx));
         const int rc = eps->arb_fn(re, im0, ks_bv_col(eps->W, 3), ks_bv_col(eps->W, 4), &rr[i], &ri[i], eps->arb_ctx);
         KS_CHECK(!rc, rc, "the user's arbitrary selection function returned %d", rc);
       }
@@ -1267,7 +1267,7 @@ extern "C" int ks_eps_get_eigenpair(ks_eps eps, int i, double *eigr, double *eig
     if (im == 0.0) KS_HIP(hipMemsetAsync(xi_dev, 0, nloc * sizeof(double), ctx->stream));
     else { KS_CALL(ksk_copy(ctx, ks_bv_col(V, kr + 1), xi_dev, nloc)); if (im < 0.0) KS_CALL(ksk_scale(ctx, xi_dev, nloc, -1.0)); }
   }
-  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_HIP(ks_sync(ctx));
   return KS_SUCCESS;
 }
 extern "C" int ks_eps_get_error_estimate(ks_eps eps, int i, double *errest)
@@ -1343,12 +1343,12 @@ extern "C" int ks_eps_get_invariant_subspace(ks_eps eps, double *const *v_dev)
     for (int i = 0; i < eps->nconv && !rc; i++) rc = pointwise(eps, ks_bv_col(eps->V, i), eps->D, ks_bv_col(T, i), false);
     if (!rc) rc = ks_bv_orthogonalize(T, nullptr, 0);
     for (int i = 0; i < eps->nconv && !rc; i++) rc = ksk_copy(eps->ctx, ks_bv_col(T, i), v_dev[i], eps->V->n);
-    hipStreamSynchronize(eps->ctx->stream);
+    ks_sync(eps->ctx);
     ks_bv_destroy(T);
     return rc;
   }
   for (int i = 0; i < eps->nconv; i++) KS_CALL(ksk_copy(eps->ctx, ks_bv_col(eps->V, i), v_dev[i], eps->V->n));
-  KS_HIP(hipStreamSynchronize(eps->ctx->stream));
+  KS_HIP(ks_sync(eps->ctx));
   return KS_SUCCESS;
 }
 extern "C" int ks_eps_get_bv(ks_eps eps, ks_bv *V) { KS_CHECK(eps && V, KS_ERR_ARG_NULL, "NULL argument"); *V = eps->V; return KS_SUCCESS; }

@@ -36,6 +36,8 @@ struct GsArgs {
   int krylov;      // inside BVMatLanczos/Arnoldi: lindep halts the rest of the run
   int ldb;         // leading dimension of the coefficient buffer (nc+m)
   int spec_last;   // this is the last slot of the optimistic program: unfinished business halts the run for the host
+  int bmat;        // B-inner product (BVSetMatrix): the dots of every pass are taken with B*v, recomputed by an SpMV before each slot, so an
+                   // update never carries the next pass's dots and always writes the vector back
   int gs1;         // 0: slot of the device-resident program; 1 / 2: ONE pass with the semantics of the ops->gramschmidt slot
                    // (BVOrthogonalizeCGS1), without (1) / with (2) the self dot product in c[k]
   double eta, deftol;
@@ -142,6 +144,7 @@ __device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict_
     if (a.krylov && lindep) st->active = 0;          // bvkrylov.c:92-95: stop the expansion
     st->more_ = 0;
   }
+  if (a.bmat) fuse = 0;
   st->nrm = nrm; st->onrm = onrm;
   st->do_update = upd; st->fuse_dot = fuse; st->scale_now = scal;
   if (upd) {
@@ -377,18 +380,30 @@ int launch_update(ks_bv bv, int col, double *v, int slot)
 int spec_slots(ks_bv bv) { return bv->orthog_ref == KS_BV_ORTHOG_REFINE_NEVER ? 1 : 2; }
 int total_slots(ks_bv bv) { return bv->orthog_ref == KS_BV_ORTHOG_REFINE_IFNEEDED ? 3 : (bv->orthog_ref == KS_BV_ORTHOG_REFINE_ALWAYS ? 2 : 1); }
 
+// h = V(:,-nc:j+1)^T z with z = v, or z = B v for a B-inner product (BVDotColumnInc bvorthog.c:32-47 with l = -nc: nc+j+1 dots
+// including (v,z); BV_IPMatMult bvimpl.h:147-158 inside the dotvec slot, svec.c:117-120)
+int enqueue_dots(ks_bv bv, int j, int krylov)
+{
+  const double *z = ks_bv_col(bv, j);
+  KS_CALL(ksb_ipmatmult(bv, z, &z));
+  return ksk_dot(bv, ks_bv_col(bv, -bv->nc), bv->ld, bv->nc + j + 1, z, krylov != 0);
+}
+
 int enqueue_gs_slots(ks_bv bv, int j, int normalize, int krylov, int first, int last, bool halt_at_last, bool resolution_and_scale)
 {
   ks_ctx ctx = bv->ctx;
-  GsArgs a; a.gs1 = 0; a.k = bv->nc + j; a.col = j; a.refine = bv->orthog_ref; a.normalize = normalize; a.krylov = krylov; a.ldb = bv->nc + bv->m; a.eta = bv->orthog_eta; a.deftol = bv->deftol;
+  const bool bmat = bv->matrix != nullptr;
+  GsArgs a; a.gs1 = 0; a.bmat = bmat ? 1 : 0; a.k = bv->nc + j; a.col = j; a.refine = bv->orthog_ref; a.normalize = normalize; a.krylov = krylov; a.ldb = bv->nc + bv->m; a.eta = bv->orthog_eta; a.deftol = bv->deftol;
   double *v = ks_bv_col(bv, j);
   for (int p = first; p <= last; p++) {
     a.slot = p; a.spec_last = (halt_at_last && p == last) ? 1 : 0;
+    if (bmat) KS_CALL(enqueue_dots(bv, j, krylov));          // every pass takes its dots with B v afresh (a pass that turns out not to be needed gates itself off in the bookkeeping)
     KS_CALL(launch_finish(bv, a));
     KS_CALL(launch_update(bv, j, v, p));
   }
   if (resolution_and_scale) {
     a.slot = last + 1; a.spec_last = 0;     // resolves an explicit-norm request of the last update
+    if (bmat) KS_CALL(enqueue_dots(bv, j, krylov));
     KS_CALL(launch_finish(bv, a));
     if (normalize) {
       KsProfScope ps(ctx, KS_K_SCALE, 0.0);
@@ -405,8 +420,7 @@ int enqueue_gs_slots(ks_bv bv, int j, int normalize, int krylov, int first, int 
 int enqueue_fused_gs(ks_bv bv, int j, int normalize, int krylov)
 {
   KS_CHECK(bv->nc + j + 1 <= KS_MAX_COLS, KS_ERR_SUP, "fused Gram-Schmidt supports at most %d columns", KS_MAX_COLS);
-  // h = V(:,-nc:j+1)^T v  (BVDotColumnInc bvorthog.c:32-47 with l = -nc: nc+j+1 dots including (v,v))
-  KS_CALL(ksk_dot(bv, ks_bv_col(bv, -bv->nc), bv->ld, bv->nc + j + 1, ks_bv_col(bv, j), krylov != 0));
+  if (!bv->matrix) KS_CALL(enqueue_dots(bv, j, krylov));      // with a matrix every slot starts with its own B v and dots
   const int ns = spec_slots(bv), nt = total_slots(bv);
   const bool whole = (ns >= nt) && bv->orthog_ref == KS_BV_ORTHOG_REFINE_NEVER;
   if (whole) return enqueue_gs_slots(bv, j, normalize, krylov, 1, nt, false, true);
@@ -436,7 +450,7 @@ int fetch_state(ks_bv bv, KsGsState *st, KsStepRec *recs, int j0, int j1)
   ks_ctx ctx = bv->ctx;
   KS_HIP(hipMemcpyAsync(st, bv->gs, sizeof(KsGsState), hipMemcpyDeviceToHost, ctx->stream));
   if (recs && j1 >= j0) KS_HIP(hipMemcpyAsync(recs, bv->recs + j0, sizeof(KsStepRec) * (j1 - j0 + 1), hipMemcpyDeviceToHost, ctx->stream));
-  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_HIP(ks_sync(ctx));
   if (st->err) KS_FAIL(st->err, "Invalid inner product (BV_SafeSqrt): negative v^H v");
   return KS_SUCCESS;
 }
@@ -458,7 +472,7 @@ int generic_norm(ks_bv bv, int j, double *v, double *nrm)     // BV_NormVecOrCol
   KS_CALL(ks_allreduce_sum(bv->ctx, bv->coef, 1));
   double s = 0.0;
   KS_HIP(hipMemcpyAsync(&s, bv->coef, sizeof(double), hipMemcpyDeviceToHost, bv->ctx->stream));
-  KS_HIP(hipStreamSynchronize(bv->ctx->stream));
+  KS_HIP(ks_sync(bv->ctx));
   *nrm = sqrt(s);
   return KS_SUCCESS;
 }
@@ -477,12 +491,12 @@ int generic_mgs1(ks_bv bv, int j, double *v, const int *which, double *hh, doubl
     KS_CALL(ksk_reduce_partials(bv, 1, bv->coef));
     KS_CALL(ks_allreduce_sum(bv->ctx, bv->coef, 1));
     KS_HIP(hipMemcpyAsync(&dot, bv->coef, sizeof(double), hipMemcpyDeviceToHost, bv->ctx->stream));
-    KS_HIP(hipStreamSynchronize(bv->ctx->stream));
+    KS_HIP(ks_sync(bv->ctx));
     cc[bv->nc + i] = dot;                                                   // BV_SetValue(bv,i,0,c,dot)
     // VecAXPY(w,-dot,vi)
     double mdot = dot;
     KS_HIP(hipMemcpyAsync(bv->coef + 8, &mdot, sizeof(double), hipMemcpyHostToDevice, bv->ctx->stream));
-    KS_HIP(hipStreamSynchronize(bv->ctx->stream));
+    KS_HIP(ks_sync(bv->ctx));
     KS_CALL(ksk_multvec(bv, ks_bv_col(bv, i), bv->ld, 1, -1.0, 1.0, bv->coef + 8, w));
   }
   if (nrm) KS_CALL(generic_norm(bv, j, v, nrm));
@@ -570,11 +584,11 @@ int generic_gs(ks_bv bv, int j, double *v, const int *which, double *hh, double 
 int store_buffer_column(ks_bv bv, int j, const double *hh, int len)
 {
   KS_HIP(hipMemcpyAsync(bv->buffer + (size_t)j * (bv->nc + bv->m), hh, sizeof(double) * len, hipMemcpyHostToDevice, bv->ctx->stream));
-  KS_HIP(hipStreamSynchronize(bv->ctx->stream));
+  KS_HIP(ks_sync(bv->ctx));
   return KS_SUCCESS;
 }
 
-bool use_fused(ks_bv bv) { return bv->orthog_type == KS_BV_ORTHOG_CGS && bv->nc + bv->m <= KS_MAX_COLS && !bv->matrix && !getenv("KSGPU_NO_FUSED_GS"); }   // B-inner products need B*v between the sweeps: host-driven passes
+bool use_fused(ks_bv bv) { return bv->orthog_type == KS_BV_ORTHOG_CGS && bv->nc + bv->m <= KS_MAX_COLS && !getenv("KSGPU_NO_FUSED_GS"); }
 
 // Orthogonalize column j; fused or generic. Returns norm/lindep on the host (synchronises).
 int orthogonalize_column(ks_bv bv, int j, int normalize, double *H, double *norm, int *lindep)
@@ -597,7 +611,7 @@ int orthogonalize_column(ks_bv bv, int j, int normalize, double *H, double *norm
     if (lindep) *lindep = rec.lindep;
     if (H && j > bv->l) {   // BV_StoreCoefficients bvimpl.h:403-415: entries l..j-1
       KS_HIP(hipMemcpyAsync(H, bv->buffer + (size_t)j * (bv->nc + bv->m) + bv->nc + bv->l, sizeof(double) * (j - bv->l), hipMemcpyDeviceToHost, ctx->stream));
-      KS_HIP(hipStreamSynchronize(ctx->stream));
+      KS_HIP(ks_sync(ctx));
     }
     return KS_SUCCESS;
   }
@@ -697,10 +711,12 @@ int gs1_fused_column(ks_bv bv, int j, double *onrm, double *nrm)
   const bool need = onrm || nrm;
   const int k = bv->nc + j;
   if (k == 0 && !need) return KS_SUCCESS;
-  GsArgs a; a.gs1 = need ? 2 : 1; a.k = k; a.col = j; a.slot = 1; a.refine = bv->orthog_ref; a.normalize = 0; a.krylov = 0; a.ldb = bv->nc + bv->m;
+  GsArgs a; a.bmat = bv->matrix ? 1 : 0; a.gs1 = need ? 2 : 1; a.k = k; a.col = j; a.slot = 1; a.refine = bv->orthog_ref; a.normalize = 0; a.krylov = 0; a.ldb = bv->nc + bv->m;
   a.spec_last = 0; a.eta = bv->orthog_eta; a.deftol = bv->deftol;
   double *v = ks_bv_col(bv, j);
-  KS_CALL(ksk_dot(bv, ks_bv_col(bv, -bv->nc), bv->ld, k + (need ? 1 : 0), v, false));          // BVDotColumnInc / BVDotColumn
+  const double *z = v;
+  KS_CALL(ksb_ipmatmult(bv, v, &z));                                                             // B v for a B-inner product
+  KS_CALL(ksk_dot(bv, ks_bv_col(bv, -bv->nc), bv->ld, k + (need ? 1 : 0), z, false));          // BVDotColumnInc / BVDotColumn
   KS_CALL(launch_finish(bv, a));
   if (k > 0) KS_CALL(launch_update(bv, j, v, 2));                                              // BVMultColumn(bv,-1,1,j,c)
   KsGsState st; KsStepRec rec;
@@ -734,7 +750,7 @@ extern "C" int ks_bv_gramschmidt_pass(ks_bv bv, int j, double *v_dev, const int 
   double *hp = h ? h : hh.data(), *cp = c ? c : cc.data();
   if (!h && len > 0) {                                   // coefficients of column j live in the device buffer
     KS_HIP(hipMemcpyAsync(hp, bv->buffer + (size_t)j * ldb, sizeof(double) * len, hipMemcpyDeviceToHost, ctx->stream));
-    KS_HIP(hipStreamSynchronize(ctx->stream));
+    KS_HIP(ks_sync(ctx));
   }
   const int lsave = bv->l, ksave = bv->k;
   bv->l = -bv->nc;
@@ -746,7 +762,7 @@ extern "C" int ks_bv_gramschmidt_pass(ks_bv bv, int j, double *v_dev, const int 
   if (!h && len > 0) {
     KS_HIP(hipMemcpyAsync(bv->buffer + (size_t)j * ldb, hp, sizeof(double) * len, hipMemcpyHostToDevice, ctx->stream));
     KS_HIP(hipMemcpyAsync(bv->buffer, cp, sizeof(double) * len, hipMemcpyHostToDevice, ctx->stream));      // scratch column "s" (bvbasic.c:757-769)
-    KS_HIP(hipStreamSynchronize(ctx->stream));
+    KS_HIP(ks_sync(ctx));
   }
   return KS_SUCCESS;
 }
@@ -840,7 +856,7 @@ static int krylov_run(ks_bv V, ks_mat A, int k, int *m, double *beta, int *break
   if (breakdown) *breakdown = lin;
   buf.resize((size_t)V->m * (V->nc + V->m));
   KS_HIP(hipMemcpyAsync(buf.data(), V->buffer, sizeof(double) * buf.size(), hipMemcpyDeviceToHost, ctx->stream));   // VecGetArrayRead(buf) bvkrylov.c:103,215
-  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_HIP(ks_sync(ctx));
   return KS_SUCCESS;
 }
 

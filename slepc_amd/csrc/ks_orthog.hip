@@ -90,7 +90,7 @@ int tsqr_r(ks_bv V, int s, int nc, double *R, int ldr)
   int rc = hipGetLastError() == hipSuccess ? KS_SUCCESS : KS_ERR_LIB;
   std::vector<double> h((size_t)nb * nc * nc);
   if (!rc && hipMemcpyAsync(h.data(), dR, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = KS_ERR_LIB;
-  if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = KS_ERR_LIB;
+  if (!rc && ks_sync(ctx) != hipSuccess) rc = KS_ERR_LIB;
   hipFree(dR);
   KS_CHECK(!rc, KS_ERR_LIB, "TSQR panel kernel failed");
   for (long long b = 1; b < nb; b++) ksd::tsqr_combine(nc, h.data(), nc, h.data() + (size_t)b * nc * nc, nc);

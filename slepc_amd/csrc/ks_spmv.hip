@@ -448,7 +448,7 @@ int build_halo_plan(ks_mat A, const std::vector<int> &garray)
                            d_sidx, A->send_off.data(), A->send_cnt.data(), (int)sizeof(int)));
   std::vector<int> sidx(std::max(nsend, 1));
   KS_HIP(hipMemcpyAsync(sidx.data(), d_sidx, sizeof(int) * nsend, hipMemcpyDeviceToHost, ctx->stream));
-  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_HIP(ks_sync(ctx));
   for (int i = 0; i < nsend; i++) { sidx[i] -= A->row_start; KS_CHECK(sidx[i] >= 0 && sidx[i] < A->n, KS_ERR_PLIB, "peer requested a row this rank does not own"); }
   KS_HIP(hipMemcpy(d_sidx, sidx.data(), sizeof(int) * nsend, hipMemcpyHostToDevice));
   A->send_idx = d_sidx; A->nsend = nsend;
@@ -473,7 +473,7 @@ int compact_offdiag_rows(ks_mat A)
   KS_HIP(hipMalloc(&rows, sizeof(int) * std::max(norows, 1))); KS_HIP(hipMalloc(&rp_c, sizeof(int) * (norows + 1)));
   hipLaunchKernelGGL(k_compact_rows, dim3((A->n + 255) / 256), dim3(256), 0, ctx->stream, A->n, A->o_rowptr, pos, rows, rp_c);
   int last = (int)A->nnz_o; KS_HIP(hipMemcpyAsync(rp_c + norows, &last, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_HIP(ks_sync(ctx));
   hipFree(flag); hipFree(pos); hipFree(A->o_rowptr);
   A->o_rowptr = rp_c; A->o_rows = rows; A->n_orows = norows;
   return KS_SUCCESS;
@@ -576,7 +576,7 @@ int build_sliced(ks_mat A)
     unsigned long long *cnt = nullptr, h = 0;
     KS_HIP(hipMalloc(&cnt, sizeof(unsigned long long))); KS_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL(k_far_entries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, n / 16, A->d_rowptr, A->d_col, cnt);
-    KS_HIP(hipMemcpyAsync(&h, cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream)); KS_HIP(hipStreamSynchronize(ctx->stream)); hipFree(cnt);
+    KS_HIP(hipMemcpyAsync(&h, cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream)); KS_HIP(ks_sync(ctx)); hipFree(cnt);
     if ((double)h < 0.5 * (double)A->nnz_d) return KS_SUCCESS;
   }
   const int max_slice_rows = 786432;   // 6 MiB of x per slice: the 5 MiB slices of the 40 MB probe ran at the L2 rate
@@ -592,21 +592,21 @@ int build_sliced(ks_mat A)
     KS_CALL(exclusive_scan_int(ctx->stream, cnt + (size_t)s * (n + 1), A->sl_rowptr + (size_t)s * (n + 1), n + 1));
     int tot = 0;
     KS_HIP(hipMemcpyAsync(&tot, A->sl_rowptr + (size_t)s * (n + 1) + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    KS_HIP(hipStreamSynchronize(ctx->stream));
+    KS_HIP(ks_sync(ctx));
     base[s + 1] = base[s] + tot;
   }
   hipFree(cnt);
   KS_CHECK(base[S] == A->nnz_d, KS_ERR_PLIB, "slice counts do not add up (%lld vs %lld)", base[S], A->nnz_d);
   KS_HIP(hipMalloc(&A->sl_base, sizeof(long long) * (S + 1)));
   KS_HIP(hipMemcpyAsync(A->sl_base, base.data(), sizeof(long long) * (S + 1), hipMemcpyHostToDevice, ctx->stream));
-  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_HIP(ks_sync(ctx));
   KS_HIP(hipMalloc(&A->sl_col, sizeof(int) * A->nnz_d)); KS_HIP(hipMalloc(&A->sl_val, sizeof(double) * A->nnz_d));
   hipLaunchKernelGGL(k_slice_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, S, sc, A->d_rowptr, A->d_col, A->d_val, A->sl_rowptr, A->sl_base, A->sl_col, A->sl_val);
   KS_HIP(hipMalloc(&A->ypart, sizeof(double) * 8 * (size_t)n));
   // diagonal and infinity norm are taken from the CSR arrays before they are released
   KS_HIP(hipMalloc(&A->diag_cache, sizeof(double) * n));
   KS_CALL(ks_mat_get_diagonal_internal(A, A->diag_cache));
-  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_HIP(ks_sync(ctx));
   KS_HIP(hipGetLastError());
   double nrm = 0.0;
   KS_CALL(ks_mat_norm_inf_local(A, &nrm));                 // local rows only: no collective inside the (per-rank) layout choice
@@ -630,7 +630,7 @@ int build_dict(ks_mat A)
   hipLaunchKernelGGL(k_max_rowlen, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, A->d_rowptr, d_int + 2);
   int maxlen = 0;
   KS_HIP(hipMemcpyAsync(&maxlen, d_int + 2, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_HIP(ks_sync(ctx));
   if (maxlen > 32 || maxlen == 0) { hipFree(d_int); return KS_SUCCESS; }
   const int W = maxlen <= 8 ? 8 : (maxlen <= 16 ? 16 : 32);                // 32: 27-point stencils
   if ((double)W * n > 4.0 * (double)A->nnz_d + 4096.0) { hipFree(d_int); return KS_SUCCESS; }   // mostly padding: nothing to gain
@@ -656,7 +656,7 @@ int build_dict(ks_mat A)
                        d_bits, value_mode ? (int)vals.size() : -1, d_offs, (int)offs.size(), codes, d_int, m_bits, m_off, cap, codes8, vals_out);
     int miss[2] = {0, 0};
     KS_HIP(hipMemcpyAsync(miss, d_int, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
-    KS_HIP(hipStreamSynchronize(ctx->stream));
+    KS_HIP(ks_sync(ctx));
     if (miss[0] == 0) { done = true; break; }
     const int got = std::min(miss[0], cap);
     std::vector<long long> mb(got); std::vector<int> mo(got);
@@ -704,7 +704,7 @@ int build_sell(ks_mat A)
     KS_CALL(ks_mat_get_diagonal_internal(A, A->diag_cache));
     double nrm = 0.0;
     KS_CALL(ks_mat_norm_inf_local(A, &nrm));
-    KS_HIP(hipStreamSynchronize(ctx->stream));
+    KS_HIP(ks_sync(ctx));
     A->norm_inf_cache = nrm; A->have_cache = true;
     hipFree(A->d_col); hipFree(A->d_val); A->d_col = nullptr; A->d_val = nullptr;
     return KS_SUCCESS;
@@ -726,7 +726,7 @@ int build_sell(ks_mat A)
   KS_HIP(hipMalloc(&A->s_col, sizeof(int) * entries));
   KS_HIP(hipMalloc(&A->s_val, sizeof(double) * entries));
   hipLaunchKernelGGL(k_sell_fill, dim3((ns + 3) / 4), dim3(256), 0, ctx->stream, A->n, ns, A->d_rowptr, A->d_col, A->d_val, A->s_ptr, A->s_col, A->s_val);
-  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_HIP(ks_sync(ctx));
   KS_HIP(hipGetLastError());
   A->use_sell = true; A->nslices = ns; A->s_entries = entries;
   // the CSR copy of the diagonal block is no longer needed on the device
@@ -810,7 +810,7 @@ extern "C" int ks_mat_create_laplacian3d(ks_ctx ctx, int nx, int ny, int nz, int
   KS_HIP(hipMalloc(&A->d_col, sizeof(int) * std::max(nnzd, 1))); KS_HIP(hipMalloc(&A->d_val, sizeof(double) * std::max(nnzd, 1)));
   KS_HIP(hipMalloc(&A->o_col, sizeof(int) * std::max(nnzo, 1))); KS_HIP(hipMalloc(&A->o_val, sizeof(double) * std::max(nnzo, 1)));
   hipLaunchKernelGGL(k_lap3d_fill, dim3(nb), dim3(256), 0, ctx->stream, nx, ny, nz, z0, nzl, A->d_rowptr, A->d_col, A->d_val, A->o_rowptr, A->o_col, A->o_val);
-  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_HIP(ks_sync(ctx));
   A->lanes_per_row = pick_lanes(A->nnz_d, A->n);
   // ghost columns: the plane below (owned by the previous slab) then the plane above
   std::vector<int> garray;
@@ -845,7 +845,7 @@ extern "C" int ks_mat_create_laplacian2d(ks_ctx ctx, int n, int m, ks_mat *out)
   A->nnz = A->nnz_d = nnz;
   KS_HIP(hipMalloc(&A->d_col, sizeof(int) * nnz)); KS_HIP(hipMalloc(&A->d_val, sizeof(double) * nnz));
   hipLaunchKernelGGL(k_lap2d_fill, dim3(nb), dim3(256), 0, ctx->stream, n, m, A->d_rowptr, A->d_col, A->d_val);
-  KS_HIP(hipStreamSynchronize(ctx->stream));
+  KS_HIP(ks_sync(ctx));
   A->lanes_per_row = pick_lanes(A->nnz_d, A->n);
   { int rc = build_sell(A); if (rc) { ks_mat_destroy(A); return rc; } }
   *out = A;
@@ -856,7 +856,7 @@ extern "C" int ks_mat_destroy(ks_mat A)
 {
   if (!A) return KS_SUCCESS;
   hipSetDevice(A->ctx->device);
-  hipStreamSynchronize(A->ctx->stream);
+  ks_sync(A->ctx);
   hipFree(A->d_rowptr); hipFree(A->d_col); hipFree(A->d_val);
   hipFree(A->o_rowptr); hipFree(A->o_col); hipFree(A->o_val); hipFree(A->o_rows);
   hipFree(A->ghost); hipFree(A->send_idx); hipFree(A->send_buf);
@@ -1033,7 +1033,7 @@ int ks_mat_norm_inf_local(ks_mat A, double *val)          // this rank's rows on
     else hipLaunchKernelGGL(k_rowabs_csr, dim3(nb), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_val, w, 0);
     if (A->n_orows > 0) hipLaunchKernelGGL(k_rowabs_rows, dim3((unsigned)((A->n_orows + 255) / 256)), dim3(256), 0, ctx->stream, A->n_orows, A->o_rows, A->o_rowptr, A->o_val, w);
     std::vector<double> h(A->n);
-    int rc = hipGetLastError() == hipSuccess && hipMemcpyAsync(h.data(), w, sizeof(double) * A->n, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess ? 0 : 1;
+    int rc = hipGetLastError() == hipSuccess && hipMemcpyAsync(h.data(), w, sizeof(double) * A->n, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && ks_sync(ctx) == hipSuccess ? 0 : 1;
     hipFree(w);
     KS_CHECK(!rc, KS_ERR_LIB, "row-sum kernel failed");
     for (double v : h) local = std::max(local, v);
@@ -1133,7 +1133,7 @@ extern "C" int ks_mat_mult_host(ks_mat A, const double *x_host, double *y_host)
   KS_HIP(hipMalloc(&x, sizeof(double) * std::max(A->n_global, 1))); KS_HIP(hipMalloc(&y, sizeof(double) * std::max(A->n, 1)));
   KS_HIP(hipMemcpy(x, x_host, sizeof(double) * A->n_global, hipMemcpyHostToDevice));
   int rc = ks_mat_mult_internal(A, x, y);
-  if (!rc) { hipStreamSynchronize(A->ctx->stream); hipMemcpy(y_host, y, sizeof(double) * A->n, hipMemcpyDeviceToHost); }
+  if (!rc) { ks_sync(A->ctx); hipMemcpy(y_host, y, sizeof(double) * A->n, hipMemcpyDeviceToHost); }
   hipFree(x); hipFree(y);
   return rc;
 }

@@ -41,6 +41,7 @@ struct ks_ctx_s {
   // ev_x orders it after the producer of x on the main stream, ev_halo lets the off-diagonal rows wait for the ghosts
   hipStream_t halo_stream = nullptr; hipEvent_t ev_x = nullptr, ev_halo = nullptr;
   bool halo_overlap = true;
+  long long nsync = 0;              // host synchronisations of the context's stream made by the library (ks_ctx_sync_count)
   int num_cu = 256;
   char arch[64] = {0};
   size_t mem_total = 0;
@@ -58,6 +59,9 @@ struct ks_ctx_s {
   // small pinned host staging area for coefficient transfers
   double *h_pinned = nullptr; size_t h_pinned_len = 0;
 };
+
+// every host wait on the context's stream goes through here, so that tests can assert that a call enqueues without waiting
+static inline hipError_t ks_sync(ks_ctx ctx) { ctx->nsync++; return hipStreamSynchronize(ctx->stream); }
 
 int ks_prof_begin(ks_ctx ctx, int kclass, int variant, double alg_bytes, double hbm_bytes);   // records start event when profiling
 int ks_prof_end(ks_ctx ctx, size_t index);

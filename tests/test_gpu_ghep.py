@@ -257,3 +257,33 @@ def test_eps_test1_nopurify_and_trackall(ctx):
     nconv0, ee0 = seen[0]
     assert np.all(ee0[nconv0:] > 0.0) and len(ee0) >= 16                # every pair of the first factorisation carries an estimate
     assert eps.KrylovSchurGet() == (0.5, True)
+
+
+@pytest.mark.parametrize("refine", [0, 1, 2])
+def test_binner_product_lanczos_is_enqueued_without_host_waits(ctx, refine):
+    """A basis with BVSetMatrix runs the device-resident Gram-Schmidt program too: every pass takes its dots with B v from an
+    SpMV of its own inside the enqueued run. Same tridiagonal, pass counts and B-orthonormal basis as the oracle, and the
+    whole run of m steps costs two host waits (state + coefficient buffer), not one per pass."""
+    import slepc_amd as ks
+    Ao = O.laplacian2d(40, 30); Bo = O.laplacian1d(Ao.n)
+    Bo = O.CSR(Ao.n, Bo.rowptr, Bo.col, np.where(Bo.col == np.repeat(np.arange(Ao.n), np.diff(Bo.rowptr)), 4.0, 1.0))   # tridiag(1, 4, 1): positive definite
+    A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val); B = ks.Mat.from_csr(ctx, Bo.rowptr, Bo.col, Bo.val)
+    m = 14
+    Vg = ks.BV(ctx, Ao.n, m + 1); Vo = O.BV(Ao.n, m + 1)
+    Vg.SetOrthogonalization(ks.CGS, refine); Vo.SetOrthogonalization(O.CGS, refine)
+    Vg.SetMatrix(B); Vo.SetMatrix(Bo)
+    for V in (Vg, Vo):
+        V.SetRandomColumn(0)
+        _, nrm, _ = V.OrthogonalizeColumn(0); V.ScaleColumn(0, 1.0 / nrm)
+    Tg = np.zeros((m + 1, 3), order="F"); To = np.zeros((m + 1, 3), order="F")
+    p0g, p0o = Vg.gs_passes()[0], Vo.passes_total()
+    s0 = ctx.sync_count()
+    rg = Vg.MatLanczos(A, Tg, 0, m)
+    waits = ctx.sync_count() - s0
+    ro = Vo.MatLanczos(Ao, To, 0, m)
+    assert rg[0] == ro[0] == m and not rg[2]
+    assert Vg.gs_passes()[0] - p0g == Vo.passes_total() - p0o
+    assert np.abs(Tg - To).max() < 1e-10 and abs(rg[1] - ro[1]) < 1e-10
+    Vd = Vg.dense()
+    assert np.abs(Vd.T @ (Bo.to_scipy() @ Vd) - np.eye(m + 1)).max() < (1e-6 if refine == 1 else 1e-12)
+    assert waits <= 3, waits
