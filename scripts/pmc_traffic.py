@@ -1,8 +1,8 @@
-"""Build profiles/traffic_r01.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the same command:
+"""Build profiles/traffic_rNN.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the same command:
 HBM bytes per EXECUTED launch of every sweep / SpMV / panel kernel symbol. FETCH_SIZE counts KiB and, on gfx950, only
 half of the bytes of a 128-B request (x2 correction calibrated in profiles/r01b_pmc_calibration_and_mfma_summary.txt);
 launches that exit at their device-side gate (fetch < 1 MB) are counted but excluded from the per-launch mean.
-usage: pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json>"""
+usage: pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json> [source description]"""
 import csv, glob, json, re, sys, collections
 
 def load(d, counter):
@@ -30,5 +30,7 @@ for name, f in sorted(fetch.items()):
     res[name] = {"launches_total": len(f), "launches_executed": len(ex), "fetch_bytes_per_executed_launch": fb,
                  "write_bytes_per_executed_launch": wb, "hbm_bytes_per_executed_launch": fb + wb,
                  "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes, x2 gfx950 correction for FETCH_SIZE"}
+if len(sys.argv) > 4:
+    res["_source"] = sys.argv[4]
 json.dump(res, open(sys.argv[3], "w"), indent=1)
 print("wrote", sys.argv[3], len(res), "kernel symbols")
