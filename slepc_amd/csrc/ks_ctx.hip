@@ -88,6 +88,7 @@ extern "C" int ks_ctx_destroy(ks_ctx ctx)
     if (f) f(ctx->comm.nccl_comm);
   }
   if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+  if (ctx->comm.ag_dev) hipFree(ctx->comm.ag_dev);
   if (ctx->split.dev) hipFree(ctx->split.dev);
   if (ctx->halo_stream) { hipStreamSynchronize(ctx->halo_stream); hipStreamDestroy(ctx->halo_stream); }
   if (ctx->ev_x) hipEventDestroy(ctx->ev_x);
@@ -290,8 +291,14 @@ static int rccl_allreduce_sum(void *user, double *dev_buf, int count, void *stre
 static int rccl_allgather_host(void *user, const void *send, int bytes, void *recv)
 {
   ks_ctx ctx = (ks_ctx)user;
-  char *d = nullptr;
-  if (hipMalloc(&d, (size_t)bytes * (ctx->comm.size + 1)) != hipSuccess) return 1;
+  const size_t need = (size_t)bytes * (ctx->comm.size + 1);
+  if (ctx->comm.ag_len < need) {
+    if (ctx->comm.ag_dev) hipFree(ctx->comm.ag_dev);
+    ctx->comm.ag_dev = nullptr; ctx->comm.ag_len = 0;
+    if (hipMalloc(&ctx->comm.ag_dev, need) != hipSuccess) return 1;
+    ctx->comm.ag_len = need;
+  }
+  char *d = ctx->comm.ag_dev;
   int rc = 0;
   if (hipMemcpyAsync(d + (size_t)bytes * ctx->comm.size, send, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = 2;
   if (!rc) rc = g_rccl.allgather(d + (size_t)bytes * ctx->comm.size, d, (size_t)bytes, NCCL_INT8, ctx->comm.nccl_comm, ctx->stream);

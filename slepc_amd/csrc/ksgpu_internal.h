@@ -28,6 +28,7 @@ struct KsComm {
   // native RCCL (resolved with dlopen so that a process that already holds librccl reuses it)
   void *rccl_lib = nullptr;
   void *nccl_comm = nullptr;
+  char *ag_dev = nullptr; size_t ag_len = 0;   // device staging of the host allgather (kept: the projected solve is broadcast through it at every restart)
   // active provider (RCCL fills these with its own implementations)
   ks_comm_ops ops = {nullptr, nullptr, nullptr};
   void *user = nullptr;
