@@ -478,7 +478,7 @@ def main():
         if world == 1 and not force_dist and not args.no_configs:
             try:
                 legs = {}
-                for fmt in ("dict", "odict", "sell", "csr"):
+                for fmt in ("dict", "odict", "sell", "csr", "csrvec"):
                     os.environ["KSGPU_SPMV"] = fmt
                     try:
                         legs[fmt] = spmv_leg(ks, ctx, lambda: ks.Mat.laplacian3d(ctx, side, side, side))
@@ -486,7 +486,7 @@ def main():
                         os.environ.pop("KSGPU_SPMV", None)
                 out["spmv_layouts"] = {"workload": "MatMult of the %d^3 7-pt Laplacian alone, each device layout (KSGPU_SPMV=...)" % side, "legs": legs,
                                        "note": "dict needs <= 255 distinct values and <= 256 distinct column offsets, odict only the offsets; "
-                                               "sell = SELL-64 for any stencil-like matrix; csr = CSR-vector for ragged ones"}
+                                               "sell = SELL-64 for any stencil-like matrix; csr = 256-row blocks of CSR streamed through LDS, for ragged ones; csrvec = the CSR-vector kernel it replaced"}
             except Exception as e:      # noqa: BLE001
                 out["spmv_layouts"] = {"error": repr(e)}
             out["configs"] = side_configs(ks, ctx, barrier, args)

@@ -73,6 +73,48 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_csr(int nrows, const int *_
   }
 }
 
+
+// ---- CSR, row blocks streamed through LDS ("coalesced CSR row-block loads") -----------------------------------------------------
+// A workgroup takes 256 consecutive rows; their entries are ONE contiguous run of col / val, which it streams in chunks of 1024
+// with fully coalesced nontemporal loads (lane e of a chunk loads entry e: no lane idles on a short row, no row length is a
+// multiple of anything), gathers x for each entry (4 independent gathers per lane in flight) and parks value and x in LDS;
+// then every row (= thread) runs the reference's own loop over its segment: acc = fma(val, x, acc) in entry order, so the
+// result has the bits of the SELL / dictionary kernels. LDS slots are skewed by one per 32 so that rows whose length is a
+// multiple of 32 do not put a whole wave on one bank. The general-matrix kernel: ragged rows, empty rows, rows longer than a
+// chunk; the CSR-vector kernel above keeps the small matrices and the compressed off-diagonal block.
+constexpr int CS_EPT = 4, CS_CHUNK = 256 * CS_EPT;    // 1024-entry chunks: 212 us on the 216^3 Laplacian (512: 224, 2048: 252)
+__device__ __forceinline__ int cs_slot(int e) { return e + (e >> 5); }
+__global__ __launch_bounds__(256) void k_spmv_csr_stream(int n, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
+                                                         const double *__restrict__ x, double *__restrict__ y)
+{
+  __shared__ double sa[CS_CHUNK + CS_CHUNK / 32], sx[CS_CHUNK + CS_CHUNK / 32];
+  __shared__ int erange[2];
+  const int tid = threadIdx.x;
+  for (long long R0 = (long long)blockIdx.x * 256; R0 < n; R0 += (long long)gridDim.x * 256) {
+    const long long r = R0 + tid;
+    const bool has = r < n;
+    const int p0 = has ? ksk::ldstream(rp + r) : 0, p1 = has ? ksk::ldstream(rp + r + 1) : 0;
+    if (tid == 0) erange[0] = p0;
+    if (has && (r == n - 1 || tid == 255)) erange[1] = p1;
+    __syncthreads();
+    const int E0 = erange[0], E1 = erange[1];
+    double acc = 0.0;
+    for (int e0 = E0; e0 < E1; e0 += CS_CHUNK) {
+      int c[CS_EPT]; double a[CS_EPT];
+#pragma unroll
+      for (int u = 0; u < CS_EPT; u++) { const int e = e0 + u * 256 + tid; const bool ok = e < E1; c[u] = ok ? ksk::ldstream(col + e) : -1; a[u] = ok ? ksk::ldstream(val + e) : 0.0; }
+#pragma unroll
+      for (int u = 0; u < CS_EPT; u++) { const int sl = cs_slot(u * 256 + tid); sa[sl] = a[u]; sx[sl] = c[u] >= 0 ? x[c[u]] : 0.0; }
+      __syncthreads();
+      const int lo = max(p0, e0), hi = min(p1, e0 + CS_CHUNK);
+      for (int p = lo; p < hi; p++) { const int sl = cs_slot(p - e0); acc = fma(sa[sl], sx[sl], acc); }
+      __syncthreads();
+    }
+    if (has) y[r] = acc;
+    __syncthreads();                       // erange is rewritten by the next row block
+  }
+}
+
 // ---- sliced ELL (SELL-64) ---------------------------------------------------------------------------
 // lane <-> row: every val/col load of a wavefront is one contiguous 512 B / 256 B run, the x gather of a
 // stencil matrix is contiguous too (consecutive rows -> consecutive columns), y is stored 512 B per wave,
@@ -695,6 +737,7 @@ int build_sell(ks_mat A)
   if (A->use_sliced) return KS_SUCCESS;
   ks_ctx ctx = A->ctx;
   const char *force = getenv("KSGPU_SPMV");
+  if (force && !strcmp(force, "csrvec")) { A->force_csr_vector = true; return KS_SUCCESS; }     // the CSR-vector kernel at any size (A/B against the row-block kernel)
   if (force && !strcmp(force, "csr")) return KS_SUCCESS;
   if (A->n == 0 || A->nnz_d == 0) return KS_SUCCESS;
   KS_CALL(build_dict(A));                                   // independent of the SELL decision below; needs the CSR arrays
@@ -954,6 +997,9 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
       const dim3 gr((unsigned)std::max<long long>(blocks, 1));
       const int remap = (remap_env && blocks == groups && blocks >= 64) ? 1 : 0;     // only with one slice group per workgroup (a strided loop would interleave the ranges again)
       hipLaunchKernelGGL((k_spmv_sell<8>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->nslices, A->s_ptr, A->s_len, A->s_col, A->s_val, x, y, remap);
+    } else if (A->n >= 2048 && !A->force_csr_vector) {
+      const unsigned nb = (unsigned)std::min<long long>(((long long)A->n + 255) / 256, (long long)ctx->num_cu * 8);
+      hipLaunchKernelGGL(k_spmv_csr_stream, dim3(nb), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, x, y);
     } else
       launch_spmv<false, false>(ctx->stream, ctx->num_cu, A->lanes_per_row, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, nullptr);
     if (overlap) KS_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_halo, 0));          // also when this rank has no off-diagonal rows: keeps the two streams in step

@@ -97,6 +97,7 @@ struct ks_mat_s {
   // diagonal block (columns owned by this rank, LOCAL column indices)
   int *d_rowptr = nullptr; int *d_col = nullptr; double *d_val = nullptr; long long nnz_d = 0;
   int lanes_per_row = 8;
+  bool force_csr_vector = false;   // KSGPU_SPMV=csrvec
   // sliced-ELL copy of the diagonal block (slice = 64 rows = one wavefront), chosen at assembly when the
   // padding it needs is small; val/col stored column-major inside a slice: entry j of row 64s+lane at (sp[s]+j)*64+lane
   bool use_sell = false;

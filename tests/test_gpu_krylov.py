@@ -57,7 +57,37 @@ def test_spmv_random_csr_ragged(ctx, n, mean):
     assert np.all(y[lens == 0] == 0.0)
 
 
-@pytest.mark.parametrize("fmt", ["csr", "sell"])
+def test_spmv_csr_row_block_kernel(ctx, monkeypatch):
+    """The general-matrix kernel (256-row blocks streamed through LDS): rows longer than a 1024-entry chunk, rows whose length
+    is a multiple of 32, empty rows, a last block that is not full; the same bits as the CSR-vector kernel's reference sum order
+    is not promised, the oracle's entry-order fma chain is: compare with the oracle to rounding and with the SELL kernel
+    bit for bit where SELL applies."""
+    import slepc_amd as ks
+    rng = np.random.default_rng(21)
+    n = 5000
+    lens = rng.integers(0, 40, n); lens[::9] = 0; lens[7] = 1500; lens[2048] = 2600; lens[100:164] = 32; lens[n - 1] = 64
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate([np.sort(rng.choice(n, l, replace=False)) for l in lens] + [np.empty(0, int)]).astype(np.int32)
+    val = rng.uniform(-1, 1, rowptr[-1])
+    Ao = O.CSR(n, rowptr, col, val)
+    x = rng.standard_normal(n)
+    y0 = Ao.mult(x)
+    monkeypatch.setenv("KSGPU_SPMV", "csr")
+    A = ks.Mat.from_csr(ctx, rowptr, col, val); assert A.layout() == "csr"
+    y = A.mult(x)
+    assert np.allclose(y, y0, rtol=0, atol=1e-12) and np.all(y[lens == 0] == 0.0)
+    monkeypatch.setenv("KSGPU_SPMV", "csrvec")
+    yv = ks.Mat.from_csr(ctx, rowptr, col, val).mult(x)
+    assert np.allclose(yv, y0, rtol=0, atol=1e-12)
+    # a stencil: bit-identical to the SELL kernel (same entry order, same fma chain)
+    Lo = O.laplacian3d(40, 30, 20)
+    xs = rng.standard_normal(Lo.n)
+    monkeypatch.setenv("KSGPU_SPMV", "csr"); yc = ks.Mat.laplacian3d(ctx, 40, 30, 20).mult(xs)
+    monkeypatch.setenv("KSGPU_SPMV", "sell"); ys = ks.Mat.laplacian3d(ctx, 40, 30, 20).mult(xs)
+    assert np.array_equal(yc, ys)
+
+
+@pytest.mark.parametrize("fmt", ["csr", "csrvec", "sell"])
 def test_spmv_both_layouts(ctx, monkeypatch, fmt):
     """The CSR-vector kernel and the SELL-64 kernel (layout picked at assembly, KSGPU_SPMV forces one) agree with
     the oracle on a stencil matrix and on a ragged matrix with empty rows and NaN-free padding semantics."""
