@@ -433,3 +433,38 @@ def test_config5_with_bicgstab(ctx):
     r = O.eps_krylovschur_nhep(Ao, 6, ncv=24, which=O.which_target_magnitude(sigma), st=O.ST(Ao, Bo, "sinvert", sigma))
     ref = np.array([complex(r.eigr[j], r.eigi[j]) for j in r.perm[:6]])
     assert np.allclose(lam["bcgs"], lam["gmres"], rtol=1e-9) and np.allclose(lam["bcgs"], ref, rtol=1e-9)
+
+
+def test_config5_at_its_stated_size_step_capped(ctx):
+    """BASELINE config 5 at its real n = 5 * 10^6 (1.65e8 nonzeros, XCD-sliced layout, generalized shift-and-invert at the
+    config's target 0, nev 20, m 60), capped at one full cycle plus a restart cycle. Too large for the LU oracle and, at
+    target 0, far from converged after 90 steps, so the checks are size-independent properties: STApply satisfies
+    (A - sigma B) y = B x to the inner tolerance on a random vector (host arithmetic), one linear solve per Arnoldi step at
+    the iteration count the spectrum predicts (rho(D^-1 R) = 0.08: 8), the Arnoldi basis is orthonormal to rounding."""
+    import slepc_amd as ks
+    from slepc_amd.workloads import config5_pencil_arrays
+    import scipy.sparse as sp
+    n = 5_000_000
+    (ar, ac, av), (br, bc, bv) = config5_pencil_arrays(n)
+    A = ks.Mat.from_csr(ctx, ar, ac, av); B = ks.Mat.from_csr(ctx, br, bc, bv)
+    assert A.layout() == "sliced" and A.nnz == int(ar[-1])
+    Sa = sp.csr_matrix((av, ac, ar), shape=(n, n)); Sb = sp.csr_matrix((bv, bc, br), shape=(n, n))
+    st = ks.ST(ctx); st.SetType("sinvert"); st.SetShift(0.0); st.SetMatrices(A, B)
+    x = np.random.default_rng(11).standard_normal(n)
+    y = st.Apply(x)
+    rhs = Sb @ x
+    assert np.linalg.norm(Sa @ y - rhs) <= 1e-7 * np.linalg.norm(rhs)          # KSP rtol 1e-8 on the preconditioned residual
+    del st, Sa, Sb
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A, B); eps.SetProblemType(ks.EPS_GNHEP); eps.SetDimensions(20, 60); eps.SetTarget(0.0)
+    s = eps.GetST(); s.SetType("sinvert")
+    eps.SetMaxSteps(90)
+    eps.Solve()
+    stats = eps.GetStats(); k = s.GetKSPStats()
+    assert stats["arnoldi_steps"] == 90 and stats["restarts"] == 2
+    assert k["solves"] == 90 and 7.0 <= k["iterations"] / k["solves"] <= 9.0
+    V = eps.GetBV()
+    m = 31                                                                       # columns in use after the capped second cycle: check the leading block
+    V.SetActiveColumns(0, m)
+    M = np.zeros((m, m), order="F"); V.Dot(V, M)
+    assert np.abs(M - np.eye(m)).max() < 1e-12
