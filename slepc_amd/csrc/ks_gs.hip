@@ -160,8 +160,9 @@ __device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict_
 }
 
 // REDUCE: sum block partials -> c (LDS, and global scratch = buffer column 0).  BOOK: run the bookkeeping.
+constexpr int GF_BLOCK = 1024;    // 16 waves gather the block partials in parallel (256 threads: 10.5 instead of 7.7 us per launch)
 template <bool REDUCE, bool BOOK>
-__global__ __launch_bounds__(1024) void k_gs_finish(const double *__restrict__ partials, GsArgs a, double *buffer, double *pend, KsGsState *st, KsStepRec *recs)
+__global__ __launch_bounds__(GF_BLOCK) void k_gs_finish(const double *__restrict__ partials, GsArgs a, double *buffer, double *pend, KsGsState *st, KsStepRec *recs)
 {
   __shared__ double c_lds[KS_MAX_COLS + 8];
   const int ncols = a.k + (a.gs1 == 1 ? 0 : 1);
@@ -331,11 +332,11 @@ int launch_finish(ks_bv bv, const GsArgs &a)
   const bool multi = ks_is_multi(ctx);
   KsProfScope ps(ctx, KS_K_GSFIN, 8.0 * bv->last_grid * (a.k + 1));
   ps.tag(a.col, a.slot, a.k, bv->n);
-  if (!multi) hipLaunchKernelGGL((k_gs_finish<true, true>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, a, bv->buffer, bv->pend, bv->gs, bv->recs);
+  if (!multi) hipLaunchKernelGGL((k_gs_finish<true, true>), dim3(1), dim3(GF_BLOCK), 0, ctx->stream, bv->partials, a, bv->buffer, bv->pend, bv->gs, bv->recs);
   else {
-    hipLaunchKernelGGL((k_gs_finish<true, false>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, a, bv->buffer, bv->pend, bv->gs, bv->recs);
+    hipLaunchKernelGGL((k_gs_finish<true, false>), dim3(1), dim3(GF_BLOCK), 0, ctx->stream, bv->partials, a, bv->buffer, bv->pend, bv->gs, bv->recs);
     KS_CALL(ks_allreduce_sum(ctx, bv->buffer, a.k + (a.gs1 == 1 ? 0 : 1)));
-    hipLaunchKernelGGL((k_gs_finish<false, true>), dim3(1), dim3(1024), 0, ctx->stream, bv->partials, a, bv->buffer, bv->pend, bv->gs, bv->recs);
+    hipLaunchKernelGGL((k_gs_finish<false, true>), dim3(1), dim3(GF_BLOCK), 0, ctx->stream, bv->partials, a, bv->buffer, bv->pend, bv->gs, bv->recs);
   }
   KS_HIP(hipGetLastError());
   return KS_SUCCESS;

@@ -1,4 +1,4 @@
-"""Row-wise distribution helpers (host logic shared by bench.py and the multi-rank tests).
+"""Row-wise distribution helpers (host logic of the multi-rank tests).
 
 The path shards exactly like the reference: contiguous row blocks per rank (PetscLayout,
 src/sys/classes/bv/interface/bvbasic.c:129-134), small dense matrices replicated."""
