@@ -217,9 +217,19 @@ static int stage_coefs(ks_bv bv, const double *host, size_t len, double **dev)
     KS_HIP(hipMalloc(&bv->coef, (len + 64) * sizeof(double)));
     bv->coef_len = len + 64;
   }
-  // the pinned area may still be in use by an earlier async copy: make the copy synchronous w.r.t. the host
-  KS_HIP(hipMemcpyAsync(bv->coef, host, len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  KS_HIP(ks_sync(ctx));
+  if (len <= KS_PINNED_H2D_DOUBLES) {
+    // through one of two pinned halves, no host wait: the event of a half says when the upload that last used it has left
+    const int h = ctx->h2d_next; ctx->h2d_next ^= 1;
+    if (!ctx->ev_h2d[h]) KS_HIP(hipEventCreateWithFlags(&ctx->ev_h2d[h], hipEventDisableTiming));
+    else KS_HIP(hipEventSynchronize(ctx->ev_h2d[h]));
+    double *pin = ctx->h_pinned + KS_PINNED_D2H_BYTES / sizeof(double) + (size_t)h * KS_PINNED_H2D_DOUBLES;
+    memcpy(pin, host, len * sizeof(double));
+    KS_HIP(hipMemcpyAsync(bv->coef, pin, len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    KS_HIP(hipEventRecord(ctx->ev_h2d[h], ctx->stream));
+  } else {
+    KS_HIP(hipMemcpyAsync(bv->coef, host, len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    KS_HIP(ks_sync(ctx));                               // pageable source: the caller may reuse it at once
+  }
   *dev = bv->coef;
   return KS_SUCCESS;
 }
@@ -243,12 +253,14 @@ extern "C" int ks_bv_create(ks_ctx ctx, int n_local, int n_global, int m, int ld
   KS_HIP(hipMemsetAsync(bv->array, 0, cells * sizeof(double), ctx->stream));
   KS_HIP(hipMalloc(&bv->buffer, (size_t)m * m * sizeof(double)));
   KS_HIP(hipMemsetAsync(bv->buffer, 0, (size_t)m * m * sizeof(double), ctx->stream));
-  KS_HIP(hipMalloc(&bv->partials, (size_t)KS_MAX_BLOCKS * KS_PSTRIDE * sizeof(double)));
+  KS_HIP(hipMalloc(&bv->partials_base, (size_t)2 * KS_MAX_BLOCKS * KS_PSTRIDE * sizeof(double)));
+  bv->partials = bv->partials_base; bv->partials_alt = bv->partials_base + (size_t)KS_MAX_BLOCKS * KS_PSTRIDE;
   KS_HIP(hipMalloc(&bv->coef, bv->coef_len * sizeof(double)));
   KS_HIP(hipMalloc(&bv->hc, (size_t)2 * (m + 8) * sizeof(double)));
   KS_HIP(hipMalloc(&bv->pend, sizeof(double) * 3 * KS_PSTRIDE)); KS_HIP(hipMemsetAsync(bv->pend, 0, sizeof(double) * 3 * KS_PSTRIDE, ctx->stream));
-  KS_HIP(hipMalloc(&bv->gs, sizeof(KsGsState)));
-  KS_HIP(hipMemsetAsync(bv->gs, 0, sizeof(KsGsState), ctx->stream));
+  KS_HIP(hipMalloc(&bv->gs_base, 2 * sizeof(KsGsState)));
+  KS_HIP(hipMemsetAsync(bv->gs_base, 0, 2 * sizeof(KsGsState), ctx->stream));
+  bv->gs = bv->gs_base; bv->gs_alt = bv->gs_base + 1;
   KS_HIP(hipMalloc(&bv->recs, (size_t)(m + 1) * sizeof(KsStepRec)));
   KS_HIP(hipMemsetAsync(bv->recs, 0, (size_t)(m + 1) * sizeof(KsStepRec), ctx->stream));
   KS_HIP(ks_sync(ctx));
@@ -261,7 +273,7 @@ extern "C" int ks_bv_destroy(ks_bv bv)
   if (!bv) return KS_SUCCESS;
   hipSetDevice(bv->ctx->device);
   ks_sync(bv->ctx);
-  hipFree(bv->array); hipFree(bv->own_buffer ? bv->buffer : bv->buffer_own); hipFree(bv->partials); hipFree(bv->coef); hipFree(bv->hc); hipFree(bv->gs); hipFree(bv->recs); hipFree(bv->panel); hipFree(bv->Bx); hipFree(bv->pend);
+  hipFree(bv->array); hipFree(bv->own_buffer ? bv->buffer : bv->buffer_own); hipFree(bv->partials_base); hipFree(bv->coef); hipFree(bv->hc); hipFree(bv->gs_base); hipFree(bv->recs); hipFree(bv->panel); hipFree(bv->Bx); hipFree(bv->pend);
   delete bv;
   return KS_SUCCESS;
 }

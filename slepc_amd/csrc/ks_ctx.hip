@@ -64,7 +64,7 @@ extern "C" int ks_ctx_create(int device, void *stream, ks_ctx *out)
     ctx->own_stream = true;
   }
   { const char *ho = getenv("KSGPU_HALO_OVERLAP"); ctx->halo_overlap = !(ho && atoi(ho) == 0); }   // safety switch of a path no multi-GPU box has run yet
-  ctx->h_pinned_len = 16384;
+  ctx->h_pinned_len = KS_PINNED_D2H_BYTES / sizeof(double) + 2 * KS_PINNED_H2D_DOUBLES;
   e = hipHostMalloc((void **)&ctx->h_pinned, ctx->h_pinned_len * sizeof(double), hipHostMallocDefault);
   if (e != hipSuccess) {
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
@@ -88,6 +88,7 @@ extern "C" int ks_ctx_destroy(ks_ctx ctx)
     if (f) f(ctx->comm.nccl_comm);
   }
   if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+  for (int i = 0; i < 2; i++) if (ctx->ev_h2d[i]) hipEventDestroy(ctx->ev_h2d[i]);
   if (ctx->comm.ag_dev) hipFree(ctx->comm.ag_dev);
   if (ctx->split.dev) hipFree(ctx->split.dev);
   if (ctx->halo_stream) { hipStreamSynchronize(ctx->halo_stream); hipStreamDestroy(ctx->halo_stream); }

@@ -45,16 +45,27 @@ struct GsArgs {
 
 // What thread 0 decides and the other lanes then carry out in parallel (the O(k) global-memory loops of BV_AddCoefficients and of
 // the pending-coefficient copy took a third of the kernel when one lane ran them: every iteration a dependent global access).
-struct BookPlan { int hmode; int pslot; };      // hmode 0: leave H, 1: H = c (first pass: BV_CleanCoefficients + add), 2: H += c; pslot: row of `pend` that receives c, -1: none
+struct BookPlan {
+  int hmode;          // 0: leave H, 1: H = c (first pass: BV_CleanCoefficients + add), 2: H += c
+  int pslot;          // row of `pend` that receives c, -1: none
+  int set_hk;         // BV_SetValue: H[k] = hk
+  int set_rec;        // the column's record is final: recs[col] = rec
+  double hk;
+  KsStepRec rec;
+};
+// The bookkeeping functions below are PURE: they read the reduced coefficients c and a private copy of the state and return the new
+// state and a plan. Whoever runs them applies the side effects: the 1-block k_gs_finish, or - single rank, the common case - the
+// prologue of the update kernel itself, where EVERY workgroup runs the same bookkeeping on the same inputs (same decisions) and
+// workgroup 0 alone writes the state, the coefficients and the record back (one launch and one dependent-kernel boundary less per pass).
 
 // Bookkeeping of ONE classical Gram-Schmidt pass as the reference's slot defines it (BVOrthogonalizeCGS1 bvorthog.c:91-132): the
 // refinement loop, lindep and BV_CleanCoefficients / BV_SetValue stay with the caller. c[0..k) are the reduced dots against the
 // previous columns, c[k] the self dot (a.gs1 == 2). Leaves |v| and the raw estimate |v|^2 - sum c_i^2 in the column's record.
-__device__ void gs1_bookkeep(const GsArgs a, const double *c, KsGsState *st, KsStepRec *recs, BookPlan *plan)
+__device__ void gs1_bookkeep(const GsArgs a, const double *c, KsGsState *st, BookPlan *plan)
 {
   const int k = a.k;
   double beta = 0.0;
-  plan->hmode = 0; plan->pslot = -1;
+  plan->hmode = 0; plan->pslot = -1; plan->set_hk = 0; plan->set_rec = 0;
   st->do_update = 0; st->err = 0;
   if (a.gs1 == 2) {                                                     // BV_SquareRoot -> BV_SafeSqrt (bvimpl.h:121-141)
     const double vv = c[k];
@@ -67,17 +78,16 @@ __device__ void gs1_bookkeep(const GsArgs a, const double *c, KsGsState *st, KsS
   st->npend = 1; st->do_update = k > 0 ? 1 : 0; st->fuse_dot = 0; st->scale_now = 0; st->store_now = 1; st->store_prev = 1; st->alpha = 1.0;
   st->pending_scale = 0; st->more_ = 0; st->expl = 0;
   KsStepRec r; r.onrm = beta; r.nrm = beta * beta - sum; r.passes = 1; r.lindep = 0; r.expl = 0; r.col = a.col;
-  recs[a.col] = r;
+  plan->rec = r; plan->set_rec = 1;
 }
 
 // Bookkeeping for one slot.  Thread 0 only.  c[0..k] are the (globally reduced) dots of the current
 // vector against columns 0..k-1 and itself.
-__device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict__ buffer, KsGsState *st, KsStepRec *recs, BookPlan *plan)
+__device__ void gs_bookkeep(const GsArgs a, const double *c, KsGsState *st, BookPlan *plan)
 {
   const int k = a.k;
   int upd = 0, fuse = 0, scal = 0;
-  plan->hmode = 0; plan->pslot = -1;
-  double *H = buffer + (size_t)a.col * a.ldb;    // H(:,col): buffer column col, entries nc+i (bvbasic.c:784-786)
+  plan->hmode = 0; plan->pslot = -1; plan->set_hk = 0; plan->set_rec = 0;
   bool process = true, finalize = false, after_update = false;
   double nrm = st->nrm, onrm = st->onrm;
 
@@ -135,12 +145,12 @@ __device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict_
     int lindep;
     if (a.refine == KS_BV_ORTHOG_REFINE_NEVER) lindep = (nrm == 0.0);                                       // bvorthog.c:193
     else lindep = !(nrm != 0.0 && fabs(nrm) >= a.eta * fabs(onrm));                                          // bvorthog.c:186,201
-    H[k] = lindep ? 0.0 : nrm;                                                                               // BV_SetValue bvorthog.c:209-214
+    plan->set_hk = 1; plan->hk = lindep ? 0.0 : nrm;                                                         // BV_SetValue bvorthog.c:209-214
     const double alpha = (nrm != 1.0 && nrm != 0.0) ? 1.0 / nrm : 1.0;                                       // bvorthog.c:417-419
     st->alpha = alpha; st->lindep = lindep;
     if (a.normalize && alpha != 1.0) { if (after_update) st->pending_scale = 1; else scal = 1; }
     KsStepRec r; r.nrm = nrm; r.onrm = onrm; r.passes = st->pass; r.lindep = lindep; r.expl = after_update ? 1 : 0; r.col = a.col;
-    recs[a.col] = r;
+    plan->rec = r; plan->set_rec = 1;
     if (a.krylov && lindep) st->active = 0;          // bvkrylov.c:92-95: stop the expansion
     st->more_ = 0;
   }
@@ -157,6 +167,18 @@ __device__ void gs_bookkeep(const GsArgs a, const double *c, double *__restrict_
   // a pass or an explicit norm after them, stop every later kernel of the run and tell the host which column to
   // complete (the pending update itself still runs: it gates on do_update only).
   if (a.spec_last && (st->more_ || st->expl)) { st->active = 0; st->halt_col = a.col; }
+}
+
+// the global-memory side of a plan: H(:,col) (entries nc+i, bvbasic.c:784-786), the pending coefficients, BV_SetValue; all lanes
+__device__ __forceinline__ void apply_plan(const GsArgs &a, const BookPlan &plan, const double *c, double *__restrict__ buffer, double *__restrict__ pend)
+{
+  const int i = threadIdx.x;
+  double *H = buffer + (size_t)a.col * a.ldb;
+  if (i < a.k) {
+    if (plan.hmode == 1) H[i] = c[i]; else if (plan.hmode == 2) H[i] += c[i];
+    if (plan.pslot >= 0) pend[(size_t)plan.pslot * KS_PSTRIDE + i] = c[i];
+  }
+  if (i == 0 && plan.set_hk) H[a.k] = plan.hk;
 }
 
 // REDUCE: sum block partials -> c (LDS, and global scratch = buffer column 0).  BOOK: run the bookkeeping.
@@ -187,14 +209,14 @@ __global__ __launch_bounds__(GF_BLOCK) void k_gs_finish(const double *__restrict
   }
   if (BOOK) {
     __shared__ BookPlan plan;
-    if (threadIdx.x == 0) { if (a.gs1) gs1_bookkeep(a, c_lds, st, recs, &plan); else gs_bookkeep(a, c_lds, buffer, st, recs, &plan); }
-    __syncthreads();
-    const int i = threadIdx.x;
-    if (i < a.k) {
-      double *H = buffer + (size_t)a.col * a.ldb;
-      if (plan.hmode == 1) H[i] = c_lds[i]; else if (plan.hmode == 2) H[i] += c_lds[i];
-      if (plan.pslot >= 0) pend[(size_t)plan.pslot * KS_PSTRIDE + i] = c_lds[i];
+    if (threadIdx.x == 0) {
+      KsGsState s = *st;
+      if (a.gs1) gs1_bookkeep(a, c_lds, &s, &plan); else gs_bookkeep(a, c_lds, &s, &plan);
+      *st = s;
+      if (plan.set_rec) recs[a.col] = plan.rec;
     }
+    __syncthreads();
+    apply_plan(a, plan, c_lds, buffer, pend);
   }
 }
 
@@ -271,16 +293,69 @@ __device__ __forceinline__ void upd_tiles(const double *V, long long ld, int n, 
 }
 
 // v <- v - V(:,0:k) c   [* alpha if final]   and, when st->fuse_dot, partials <- [V(:,0:k) v]^T v  (k+1 values)
+// What the update kernel needs to carry the bookkeeping of its own slot (single rank): the partials of the sweep before it, the
+// state to read and the state to write (ping-pong: workgroup 0 writes the new state while the others may still be reading the old
+// one), and where the plan's global side goes. fold == nullptr: the bookkeeping ran in k_gs_finish and the state is read in place.
+struct FoldArgs {
+  GsArgs a;
+  const double *partials_in;     // written by the previous sweep (its grid is in st_in->pgrid)
+  const KsGsState *st_in;
+  KsGsState *st_out;
+  double *buffer, *pend;
+  KsStepRec *recs;
+};
+
 template <int KT, int VEC>
-__global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long long ld, int n, int k, double *v, const double *__restrict__ cg,
-                                                        double *__restrict__ partials, const KsGsState *__restrict__ st, int *__restrict__ pgrid, int rev, int plain)
+__global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long long ld, int n, int k, double *v, const double *__restrict__ cg_global,
+                                                        double *__restrict__ partials, const KsGsState *__restrict__ st, int *__restrict__ pgrid, int rev, int plain,
+                                                        int folded, FoldArgs fa)
 {
-  if (!st->do_update) return;
-  const bool fuse = st->fuse_dot != 0;
-  const bool scal = st->scale_now != 0;
-  const bool store = st->store_now != 0;
-  const int npend = st->npend;
-  const double alpha = st->alpha;
+  __shared__ double c_lds[KS_MAX_COLS + 8];
+  __shared__ double spend[3 * KS_PSTRIDE];           // the pending passes' coefficients as this launch applies them
+  __shared__ KsGsState s_sh;
+  __shared__ BookPlan plan_sh;
+  __shared__ int go_sh;
+  bool fuse, scal, store; int npend; double alpha;
+  const double *cg = cg_global;
+  if (folded) {
+    // ---- prologue: every workgroup runs the slot's bookkeeping on the same inputs ----
+    const GsArgs &a = fa.a;
+    if (threadIdx.x == 0) {
+      KsGsState s = *fa.st_in;
+      int go = 1;
+      if (!s.active || (a.slot > 1 && !s.expl && !s.more_)) { go = 0; s.do_update = 0; }     // halted run / column already final
+      s_sh = s; go_sh = go;
+    }
+    __syncthreads();
+    if (!go_sh) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) *fa.st_out = s_sh;                             // the chain of states goes on through a launch that does nothing
+      return;
+    }
+    const int ncols = a.k + 1;
+    reduce_partials_to_lds(fa.partials_in, s_sh.pgrid, ncols, c_lds);
+    if (threadIdx.x == 0) {
+      KsGsState s = s_sh;
+      gs_bookkeep(a, c_lds, &s, &plan_sh);
+      if (s.do_update && s.fuse_dot) s.pgrid = gridDim.x;                                     // the grid of the partials this launch is about to write
+      s_sh = s;
+    }
+    __syncthreads();
+    // coefficients of the passes this update applies: older ones from memory (written by earlier launches), this slot's from c
+    for (int p = 0; p < s_sh.npend; p++)
+      if ((int)threadIdx.x < a.k) spend[p * KS_PSTRIDE + threadIdx.x] = (p == plan_sh.pslot) ? c_lds[threadIdx.x] : fa.pend[(size_t)p * KS_PSTRIDE + threadIdx.x];
+    if (blockIdx.x == 0) {
+      apply_plan(a, plan_sh, c_lds, fa.buffer, fa.pend);
+      if ((int)threadIdx.x < ncols) fa.buffer[threadIdx.x] = c_lds[threadIdx.x];             // scratch c = buffer column 0
+      if (threadIdx.x == 0) { *fa.st_out = s_sh; if (plan_sh.set_rec) fa.recs[a.col] = plan_sh.rec; }
+    }
+    __syncthreads();
+    if (!s_sh.do_update) return;
+    fuse = s_sh.fuse_dot != 0; scal = s_sh.scale_now != 0; store = s_sh.store_now != 0; npend = s_sh.npend; alpha = s_sh.alpha;
+    cg = spend;
+  } else {
+    if (!st->do_update) return;
+    fuse = st->fuse_dot != 0; scal = st->scale_now != 0; store = st->store_now != 0; npend = st->npend; alpha = st->alpha;
+  }
 
   // ALL k column loads of a tile are issued back to back (k x 1 KiB in flight per wave), then the update; the fused form
   // keeps the row panel V(r,0:k) in registers and also accumulates the next pass's dots (and writes nothing unless an
@@ -296,7 +371,7 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long lo
   else if (VEC == 2 && !fuse && npend == 2) upd_tiles<KT, VEC, 2, 0, false>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
   else upd_tiles<KT, VEC, 0, -1, false>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
   if (!fuse) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *pgrid = gridDim.x;
+  if (!folded && blockIdx.x == 0 && threadIdx.x == 0) *pgrid = gridDim.x;        // (folded: already part of the state workgroup 0 wrote)
   // block combine: partial index i<k <- acc[i]; index k <- acc[KT] (the self dot)
   __shared__ double red[SW_WAVES][KT + 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -342,7 +417,8 @@ int launch_finish(ks_bv bv, const GsArgs &a)
   return KS_SUCCESS;
 }
 
-int launch_update(ks_bv bv, int col, double *v, int slot)
+// fold: the slot's GsArgs when the kernel carries its own bookkeeping (single rank), nullptr after a k_gs_finish launch
+int launch_update(ks_bv bv, int col, double *v, int slot, const GsArgs *fold = nullptr)
 {
   ks_ctx ctx = bv->ctx;
   const int k = bv->nc + col;
@@ -360,16 +436,21 @@ int launch_update(ks_bv bv, int col, double *v, int slot)
                                                        // the tail the previous one left in the 256 MB Infinity Cache (about a tenth of a 2.4 GB basis)
   KsProfScope ps(ctx, KS_K_UPD_FUSED, 8.0 * bv->n * (k + 2), ks_kt_for(kk));
   ps.tag(col, slot, k, bv->n);
+  FoldArgs fa; memset(&fa, 0, sizeof(fa));
+  const int folded = fold ? 1 : 0;
+  double *pout = bv->partials;                     // where fused dots go
+  if (folded) { fa.a = *fold; fa.partials_in = bv->partials; fa.st_in = bv->gs; fa.st_out = bv->gs_alt; fa.buffer = bv->buffer; fa.pend = bv->pend; fa.recs = bv->recs; pout = bv->partials_alt; }
 #define LAUNCH_UPD(KT)                                                                                                                                 \
   do {                                                                                                                                                 \
     if (v2) { grid = ks_sweep_grid_for(ctx, bv->n, 2, (const void *)k_gs_update<KT, 2>, upd_per_cu); bv->last_grid = grid;                                                        \
-      hipLaunchKernelGGL((k_gs_update<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->pend, bv->partials, bv->gs, &bv->gs->pgrid, rev, plain); } \
+      hipLaunchKernelGGL((k_gs_update<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->pend, pout, bv->gs, &bv->gs->pgrid, rev, plain, folded, fa); } \
     else { grid = ks_sweep_grid_for(ctx, bv->n, 1, (const void *)k_gs_update<KT, 1>, upd_per_cu); bv->last_grid = grid;                                                           \
-      hipLaunchKernelGGL((k_gs_update<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->pend, bv->partials, bv->gs, &bv->gs->pgrid, rev, plain); }   \
+      hipLaunchKernelGGL((k_gs_update<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->pend, pout, bv->gs, &bv->gs->pgrid, rev, plain, folded, fa); }   \
   } while (0)
   KS_KT_DISPATCH(kk, LAUNCH_UPD);
 #undef LAUNCH_UPD
   KS_HIP(hipGetLastError());
+  if (folded) { std::swap(bv->gs, bv->gs_alt); std::swap(bv->partials, bv->partials_alt); }      // what the next launch reads
   return KS_SUCCESS;
 }
 
@@ -394,13 +475,14 @@ int enqueue_gs_slots(ks_bv bv, int j, int normalize, int krylov, int first, int 
 {
   ks_ctx ctx = bv->ctx;
   const bool bmat = bv->matrix != nullptr;
+  const bool fold = !ks_is_multi(ctx);                        // multi-rank: the allreduce sits between the reduction and the bookkeeping (launch_finish)
   GsArgs a; a.gs1 = 0; a.bmat = bmat ? 1 : 0; a.k = bv->nc + j; a.col = j; a.refine = bv->orthog_ref; a.normalize = normalize; a.krylov = krylov; a.ldb = bv->nc + bv->m; a.eta = bv->orthog_eta; a.deftol = bv->deftol;
   double *v = ks_bv_col(bv, j);
   for (int p = first; p <= last; p++) {
     a.slot = p; a.spec_last = (halt_at_last && p == last) ? 1 : 0;
     if (bmat) KS_CALL(enqueue_dots(bv, j, krylov));          // every pass takes its dots with B v afresh (a pass that turns out not to be needed gates itself off in the bookkeeping)
-    KS_CALL(launch_finish(bv, a));
-    KS_CALL(launch_update(bv, j, v, p));
+    if (fold) KS_CALL(launch_update(bv, j, v, p, &a));       // the update kernel runs the slot's bookkeeping in its prologue
+    else { KS_CALL(launch_finish(bv, a)); KS_CALL(launch_update(bv, j, v, p)); }
   }
   if (resolution_and_scale) {
     a.slot = last + 1; a.spec_last = 0;     // resolves an explicit-norm request of the last update
@@ -446,12 +528,31 @@ int begin_run(ks_bv bv)
 
 struct HostGs { KsGsState st; };
 
-int fetch_state(ks_bv bv, KsGsState *st, KsStepRec *recs, int j0, int j1)
+// One host wait for everything the host wants to know after an enqueued run: the device state, the records of columns j0..j1 and
+// (coef_out) the whole coefficient buffer, all copied into the context's pinned area by copies enqueued back to back. Between a
+// Lanczos run and the restart this wait, the host's projected solve and the upload of Q are all the GPU idles for; copies into
+// pageable memory, each with a wait of its own, made that 135 us per restart (config 2: 10 % of the time).
+int fetch_state(ks_bv bv, KsGsState *st, KsStepRec *recs, int j0, int j1, double *coef_out = nullptr, size_t coef_len = 0)
 {
   ks_ctx ctx = bv->ctx;
-  KS_HIP(hipMemcpyAsync(st, bv->gs, sizeof(KsGsState), hipMemcpyDeviceToHost, ctx->stream));
-  if (recs && j1 >= j0) KS_HIP(hipMemcpyAsync(recs, bv->recs + j0, sizeof(KsStepRec) * (j1 - j0 + 1), hipMemcpyDeviceToHost, ctx->stream));
-  KS_HIP(ks_sync(ctx));
+  const size_t nrec = (recs && j1 >= j0) ? (size_t)(j1 - j0 + 1) : 0;
+  const size_t off_rec = (sizeof(KsGsState) + 63) / 64 * 64, off_coef = (off_rec + nrec * sizeof(KsStepRec) + 63) / 64 * 64;
+  const size_t need = off_coef + coef_len * sizeof(double);
+  char *pin = (char *)ctx->h_pinned;
+  if (need <= KS_PINNED_D2H_BYTES) {
+    KS_HIP(hipMemcpyAsync(pin, bv->gs, sizeof(KsGsState), hipMemcpyDeviceToHost, ctx->stream));
+    if (nrec) KS_HIP(hipMemcpyAsync(pin + off_rec, bv->recs + j0, sizeof(KsStepRec) * nrec, hipMemcpyDeviceToHost, ctx->stream));
+    if (coef_len) KS_HIP(hipMemcpyAsync(pin + off_coef, bv->buffer, sizeof(double) * coef_len, hipMemcpyDeviceToHost, ctx->stream));
+    KS_HIP(ks_sync(ctx));
+    memcpy(st, pin, sizeof(KsGsState));
+    if (nrec) memcpy(recs, pin + off_rec, sizeof(KsStepRec) * nrec);
+    if (coef_len) memcpy(coef_out, pin + off_coef, sizeof(double) * coef_len);
+  } else {                                            // a basis too wide for the pinned area: pageable destinations
+    KS_HIP(hipMemcpyAsync(st, bv->gs, sizeof(KsGsState), hipMemcpyDeviceToHost, ctx->stream));
+    if (nrec) KS_HIP(hipMemcpyAsync(recs, bv->recs + j0, sizeof(KsStepRec) * nrec, hipMemcpyDeviceToHost, ctx->stream));
+    if (coef_len) KS_HIP(hipMemcpyAsync(coef_out, bv->buffer, sizeof(double) * coef_len, hipMemcpyDeviceToHost, ctx->stream));
+    KS_HIP(ks_sync(ctx));
+  }
   if (st->err) KS_FAIL(st->err, "Invalid inner product (BV_SafeSqrt): negative v^H v");
   return KS_SUCCESS;
 }
@@ -791,6 +892,7 @@ static int krylov_run(ks_bv V, ks_mat A, int k, int *m, double *beta, int *break
   const int m0 = *m;
   int lin = 0;
   double nrm_last = 0.0;
+  bool buf_fresh = false;                            // buf already holds the coefficient buffer as the run left it
   if (use_fused(V) && m0 < V->N && (!A->shell_mult || A->shell_nosync)) {      // a matrix-free operator may synchronise: take it one column at a time
     // The whole run is enqueued with the optimistic two-pass program per step; a device-side breakdown, or a
     // column that needs more than the optimistic program, turns the remaining steps into no-ops. In the second
@@ -803,7 +905,9 @@ static int krylov_run(ks_bv V, ks_mat A, int k, int *m, double *beta, int *break
         KS_CALL(enqueue_fused_gs(V, j + 1, 1, 1));
       }
       KsGsState st; std::vector<KsStepRec> recs(m0 - j0);
-      KS_CALL(fetch_state(V, &st, recs.data(), j0 + 1, m0));
+      buf.resize((size_t)V->m * (V->nc + V->m));
+      KS_CALL(fetch_state(V, &st, recs.data(), j0 + 1, m0, buf.data(), buf.size()));          // the coefficient buffer travels with the state (VecGetArrayRead(buf) bvkrylov.c:103,215)
+      buf_fresh = true;
       const int hc = st.halt_col;                    // column awaiting completion, or -1
       if (ctx->prof_on) {
         // columns after a halt never ran (0 passes, everything gated off); the flagged column ran both optimistic
@@ -822,6 +926,7 @@ static int krylov_run(ks_bv V, ks_mat A, int k, int *m, double *beta, int *break
         if (j + 1 == hc) {
           // rare path: finish column hc on the device (remaining passes, explicit norm, scaling), then go on
           KsStepRec rec;
+          buf_fresh = false;                         // the completion (and whatever is enqueued after it) writes the buffer again
           KS_CALL(enqueue_gs_completion(V, hc, 1, 1));
           KS_CALL(fetch_state(V, &st, &rec, hc, hc));
           ks_prof_resolve_gs(ctx, &rec, hc, hc);
@@ -855,9 +960,11 @@ static int krylov_run(ks_bv V, ks_mat A, int k, int *m, double *beta, int *break
   }
   if (beta) *beta = nrm_last;
   if (breakdown) *breakdown = lin;
-  buf.resize((size_t)V->m * (V->nc + V->m));
-  KS_HIP(hipMemcpyAsync(buf.data(), V->buffer, sizeof(double) * buf.size(), hipMemcpyDeviceToHost, ctx->stream));   // VecGetArrayRead(buf) bvkrylov.c:103,215
-  KS_HIP(ks_sync(ctx));
+  if (!buf_fresh) {
+    buf.resize((size_t)V->m * (V->nc + V->m));
+    KS_HIP(hipMemcpyAsync(buf.data(), V->buffer, sizeof(double) * buf.size(), hipMemcpyDeviceToHost, ctx->stream));   // VecGetArrayRead(buf) bvkrylov.c:103,215
+    KS_HIP(ks_sync(ctx));
+  }
   return KS_SUCCESS;
 }
 

@@ -57,8 +57,10 @@ struct ks_ctx_s {
   // allreduce over all of them (PetscSplitReduction's merged MPI_Allreduce) and the Ends hand the results out in order
   struct KsSplitEntry { int off, cnt, kind; };
   struct { double *dev = nullptr; int cap = 0, used = 0; std::vector<double> host; std::vector<KsSplitEntry> entries; size_t nread = 0; bool reduced = false; } split;
-  // small pinned host staging area for coefficient transfers
+  // pinned host staging: [0, KS_PINNED_D2H_BYTES) results coming back (state, records, coefficient buffer), then two halves of
+  // KS_PINNED_H2D_DOUBLES doubles for coefficient uploads (alternating; an event per half says when its last upload has left)
   double *h_pinned = nullptr; size_t h_pinned_len = 0;
+  hipEvent_t ev_h2d[2] = {nullptr, nullptr}; int h2d_next = 0;
 };
 
 // every host wait on the context's stream goes through here, so that tests can assert that a call enqueues without waiting
@@ -196,11 +198,13 @@ struct ks_bv_s {
   double *buffer = nullptr;     // (nc+m)*m ; column 0 = scratch c
   bool own_buffer = true;       // false: adopted from the caller (ks_bv_set_buffer: the device array of the reference's bv->buffer Vec)
   double *buffer_own = nullptr; // the library's own allocation while an adopted one is in use
-  double *partials = nullptr;   // [KS_MAX_BLOCKS][KS_PSTRIDE] block partial sums
+  double *partials = nullptr;   // [KS_MAX_BLOCKS][KS_PSTRIDE] block partial sums: the CURRENT one of two buffers (an update kernel that carries the
+                                // bookkeeping reads the current one in its prologue while its fused dots go to the other; the host swaps the pointers)
+  double *partials_alt = nullptr, *partials_base = nullptr;
   double *coef = nullptr;       // device scratch for host-provided q / Q (max(m*m, ...))
   double *hc = nullptr;         // device h,c arrays for orthogonalizevec (2*(nc+m))
   size_t coef_len = 0;
-  KsGsState *gs = nullptr;
+  KsGsState *gs = nullptr, *gs_alt = nullptr, *gs_base = nullptr;   // current / other device state (same ping-pong), allocation
   KsStepRec *recs = nullptr;    // m records (one per column)
   long long passes_total_host = 0; int passes_last_host = 0;
   int row_start = 0;            // first global row (reproducible random)
@@ -211,6 +215,8 @@ struct ks_bv_s {
   double *panel = nullptr; size_t panel_len = 0;   // block partials of the MFMA panel dot (grid x 64 x 64 max)
 };
 
+constexpr size_t KS_PINNED_D2H_BYTES = 65536;
+constexpr size_t KS_PINNED_H2D_DOUBLES = 4096;
 constexpr int KS_MAX_COLS   = 64;     // max columns handled by the register-tiled sweeps (k+1 <= 64)
 constexpr int KS_PSTRIDE    = 72;     // doubles per block in the partials array
 constexpr int KS_MAX_BLOCKS = 4096;
