@@ -257,6 +257,7 @@ extern "C" int ks_bv_create(ks_ctx ctx, int n_local, int n_global, int m, int ld
   bv->partials = bv->partials_base; bv->partials_alt = bv->partials_base + (size_t)KS_MAX_BLOCKS * KS_PSTRIDE;
   KS_HIP(hipMalloc(&bv->coef, bv->coef_len * sizeof(double)));
   KS_HIP(hipMalloc(&bv->hc, (size_t)2 * (m + 8) * sizeof(double)));
+  KS_HIP(hipMalloc(&bv->cred, (size_t)KS_PSTRIDE * sizeof(double)));
   KS_HIP(hipMalloc(&bv->pend, sizeof(double) * 3 * KS_PSTRIDE)); KS_HIP(hipMemsetAsync(bv->pend, 0, sizeof(double) * 3 * KS_PSTRIDE, ctx->stream));
   KS_HIP(hipMalloc(&bv->gs_base, 2 * sizeof(KsGsState)));
   KS_HIP(hipMemsetAsync(bv->gs_base, 0, 2 * sizeof(KsGsState), ctx->stream));
@@ -273,7 +274,7 @@ extern "C" int ks_bv_destroy(ks_bv bv)
   if (!bv) return KS_SUCCESS;
   hipSetDevice(bv->ctx->device);
   ks_sync(bv->ctx);
-  hipFree(bv->array); hipFree(bv->own_buffer ? bv->buffer : bv->buffer_own); hipFree(bv->partials_base); hipFree(bv->coef); hipFree(bv->hc); hipFree(bv->gs_base); hipFree(bv->recs); hipFree(bv->panel); hipFree(bv->Bx); hipFree(bv->pend);
+  hipFree(bv->array); hipFree(bv->own_buffer ? bv->buffer : bv->buffer_own); hipFree(bv->partials_base); hipFree(bv->coef); hipFree(bv->hc); hipFree(bv->cred); hipFree(bv->gs_base); hipFree(bv->recs); hipFree(bv->panel); hipFree(bv->Bx); hipFree(bv->pend);
   delete bv;
   return KS_SUCCESS;
 }

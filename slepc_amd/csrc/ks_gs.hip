@@ -169,6 +169,15 @@ __device__ void gs_bookkeep(const GsArgs a, const double *c, KsGsState *st, Book
   if (a.spec_last && (st->more_ || st->expl)) { st->active = 0; st->halt_col = a.col; }
 }
 
+constexpr int GF_BLOCK = 1024;    // 16 waves gather the block partials in parallel (256 threads: 10.5 instead of 7.7 us per launch)
+// out[i] = sum over the blocks of partials[i][.], i < ncols, with the grid the producing sweep left in the state
+__global__ __launch_bounds__(GF_BLOCK) void k_reduce_state(const double *__restrict__ partials, const KsGsState *__restrict__ st, int ncols, double *__restrict__ out)
+{
+  __shared__ double c_lds[KS_MAX_COLS + 8];
+  reduce_partials_to_lds(partials, st->pgrid, ncols, c_lds);
+  if ((int)threadIdx.x < ncols) out[threadIdx.x] = c_lds[threadIdx.x];
+}
+
 // the global-memory side of a plan: H(:,col) (entries nc+i, bvbasic.c:784-786), the pending coefficients, BV_SetValue; all lanes
 __device__ __forceinline__ void apply_plan(const GsArgs &a, const BookPlan &plan, const double *c, double *__restrict__ buffer, double *__restrict__ pend)
 {
@@ -182,7 +191,6 @@ __device__ __forceinline__ void apply_plan(const GsArgs &a, const BookPlan &plan
 }
 
 // REDUCE: sum block partials -> c (LDS, and global scratch = buffer column 0).  BOOK: run the bookkeeping.
-constexpr int GF_BLOCK = 1024;    // 16 waves gather the block partials in parallel (256 threads: 10.5 instead of 7.7 us per launch)
 template <bool REDUCE, bool BOOK>
 __global__ __launch_bounds__(GF_BLOCK) void k_gs_finish(const double *__restrict__ partials, GsArgs a, double *buffer, double *pend, KsGsState *st, KsStepRec *recs)
 {
@@ -299,6 +307,7 @@ __device__ __forceinline__ void upd_tiles(const double *V, long long ld, int n, 
 struct FoldArgs {
   GsArgs a;
   const double *partials_in;     // written by the previous sweep (its grid is in st_in->pgrid)
+  const double *cred;            // multi-rank: the partials already summed over blocks and ranks (k+1 values), nullptr: reduce partials_in here
   const KsGsState *st_in;
   KsGsState *st_out;
   double *buffer, *pend;
@@ -332,7 +341,8 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long lo
       return;
     }
     const int ncols = a.k + 1;
-    reduce_partials_to_lds(fa.partials_in, s_sh.pgrid, ncols, c_lds);
+    if (fa.cred) { if ((int)threadIdx.x < ncols) c_lds[threadIdx.x] = fa.cred[threadIdx.x]; __syncthreads(); }
+    else reduce_partials_to_lds(fa.partials_in, s_sh.pgrid, ncols, c_lds);
     if (threadIdx.x == 0) {
       KsGsState s = s_sh;
       gs_bookkeep(a, c_lds, &s, &plan_sh);
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long lo
       if ((int)threadIdx.x < a.k) spend[p * KS_PSTRIDE + threadIdx.x] = (p == plan_sh.pslot) ? c_lds[threadIdx.x] : fa.pend[(size_t)p * KS_PSTRIDE + threadIdx.x];
     if (blockIdx.x == 0) {
       apply_plan(a, plan_sh, c_lds, fa.buffer, fa.pend);
-      if ((int)threadIdx.x < ncols) fa.buffer[threadIdx.x] = c_lds[threadIdx.x];             // scratch c = buffer column 0
+      if ((int)threadIdx.x < ncols && !(a.col == 0 && (int)threadIdx.x <= a.k)) fa.buffer[threadIdx.x] = c_lds[threadIdx.x];   // scratch c = buffer column 0 (column 0's own coefficients live there: apply_plan has just written them)
       if (threadIdx.x == 0) { *fa.st_out = s_sh; if (plan_sh.set_rec) fa.recs[a.col] = plan_sh.rec; }
     }
     __syncthreads();
@@ -417,7 +427,19 @@ int launch_finish(ks_bv bv, const GsArgs &a)
   return KS_SUCCESS;
 }
 
-// fold: the slot's GsArgs when the kernel carries its own bookkeeping (single rank), nullptr after a k_gs_finish launch
+// multi-rank first half of a slot: the 1-block reduction of the block partials into buffer[0..k], then the allreduce; the update
+// kernel's prologue takes the bookkeeping from there
+int launch_reduce_allreduce(ks_bv bv, const GsArgs &a)
+{
+  ks_ctx ctx = bv->ctx;
+  KsProfScope ps(ctx, KS_K_GSFIN, 8.0 * bv->last_grid * (a.k + 1));
+  ps.tag(a.col, a.slot, a.k, bv->n);
+  hipLaunchKernelGGL(k_reduce_state, dim3(1), dim3(GF_BLOCK), 0, ctx->stream, bv->partials, bv->gs, a.k + 1, bv->cred);
+  KS_HIP(hipGetLastError());
+  return ks_allreduce_sum(ctx, bv->cred, a.k + 1);
+}
+
+// fold: the slot's GsArgs when the kernel carries its own bookkeeping, nullptr after a k_gs_finish launch
 int launch_update(ks_bv bv, int col, double *v, int slot, const GsArgs *fold = nullptr)
 {
   ks_ctx ctx = bv->ctx;
@@ -439,7 +461,7 @@ int launch_update(ks_bv bv, int col, double *v, int slot, const GsArgs *fold = n
   FoldArgs fa; memset(&fa, 0, sizeof(fa));
   const int folded = fold ? 1 : 0;
   double *pout = bv->partials;                     // where fused dots go
-  if (folded) { fa.a = *fold; fa.partials_in = bv->partials; fa.st_in = bv->gs; fa.st_out = bv->gs_alt; fa.buffer = bv->buffer; fa.pend = bv->pend; fa.recs = bv->recs; pout = bv->partials_alt; }
+  if (folded) { fa.a = *fold; fa.cred = ks_is_multi(ctx) ? bv->cred : nullptr; fa.partials_in = bv->partials; fa.st_in = bv->gs; fa.st_out = bv->gs_alt; fa.buffer = bv->buffer; fa.pend = bv->pend; fa.recs = bv->recs; pout = bv->partials_alt; }
 #define LAUNCH_UPD(KT)                                                                                                                                 \
   do {                                                                                                                                                 \
     if (v2) { grid = ks_sweep_grid_for(ctx, bv->n, 2, (const void *)k_gs_update<KT, 2>, upd_per_cu); bv->last_grid = grid;                                                        \
@@ -475,12 +497,13 @@ int enqueue_gs_slots(ks_bv bv, int j, int normalize, int krylov, int first, int 
 {
   ks_ctx ctx = bv->ctx;
   const bool bmat = bv->matrix != nullptr;
-  const bool fold = !ks_is_multi(ctx);                        // multi-rank: the allreduce sits between the reduction and the bookkeeping (launch_finish)
+  const bool fold = true, multi = ks_is_multi(ctx);
   GsArgs a; a.gs1 = 0; a.bmat = bmat ? 1 : 0; a.k = bv->nc + j; a.col = j; a.refine = bv->orthog_ref; a.normalize = normalize; a.krylov = krylov; a.ldb = bv->nc + bv->m; a.eta = bv->orthog_eta; a.deftol = bv->deftol;
   double *v = ks_bv_col(bv, j);
   for (int p = first; p <= last; p++) {
     a.slot = p; a.spec_last = (halt_at_last && p == last) ? 1 : 0;
     if (bmat) KS_CALL(enqueue_dots(bv, j, krylov));          // every pass takes its dots with B v afresh (a pass that turns out not to be needed gates itself off in the bookkeeping)
+    if (multi) KS_CALL(launch_reduce_allreduce(bv, a));      // ranks: block partials -> buffer[0..k], summed over the ranks (bvblas.c:255)
     if (fold) KS_CALL(launch_update(bv, j, v, p, &a));       // the update kernel runs the slot's bookkeeping in its prologue
     else { KS_CALL(launch_finish(bv, a)); KS_CALL(launch_update(bv, j, v, p)); }
   }

@@ -203,6 +203,8 @@ struct ks_bv_s {
   double *partials_alt = nullptr, *partials_base = nullptr;
   double *coef = nullptr;       // device scratch for host-provided q / Q (max(m*m, ...))
   double *hc = nullptr;         // device h,c arrays for orthogonalizevec (2*(nc+m))
+  double *cred = nullptr;       // [KS_PSTRIDE] multi-rank: the pass's dots summed over blocks and ranks, read by every workgroup of the update kernel
+                                // (not the buffer's scratch column: workgroup 0 writes H(:,0) there while the others may still be reading)
   size_t coef_len = 0;
   KsGsState *gs = nullptr, *gs_alt = nullptr, *gs_base = nullptr;   // current / other device state (same ping-pong), allocation
   KsStepRec *recs = nullptr;    // m records (one per column)

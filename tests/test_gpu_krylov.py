@@ -277,6 +277,9 @@ def test_fused_gs_matches_oracle(ctx, refine, n, m):
     for j in range(m):
         ng, lg = Vg.OrthonormalizeColumn(j)
         no, lo = Vo.OrthonormalizeColumn(j)
+        if j == 0:
+            # BV_SetValue(bv,0,0,NULL,nrm): column 0 of the buffer is both column 0's coefficient column and the scratch column
+            assert Vg.buffer()[0, 0] == ng and np.array(Vo.buffer)[0, 0] == no
         assert lg == lo
         assert Vg.gs_passes()[1] == Vo.passes_last(), (j, Vg.gs_passes(), Vo.passes_last())
         # the norm comes from beta^2 - sum(h^2): its ABSOLUTE accuracy is eps*||x_j||, whatever is left of x_j
