@@ -69,13 +69,19 @@ static int caller_orthogonalize_column(Caller *c, int j, double *norm, int *lind
 int main(int argc, char **argv)
 {
   Caller c;
+  ks_bv bufbv;
   double *col, *x0, *x1, *x2, H[(M + 1) * (M + 1)];
   int i, j, refine = argc > 1 ? atoi(argv[1]) : 0, mgs = argc > 2 && !strcmp(argv[2], "mgs");
 
   CHK(ks_ctx_create(0, NULL, &c.ctx));
   CHK(ks_bv_create(c.ctx, N, N, M, 0, &c.bv));
   CHK(ks_bv_set_orthogonalization(c.bv, mgs ? KS_BV_ORTHOG_MGS : KS_BV_ORTHOG_CGS, refine, 0.0));
-  CHK(ks_bv_get_buffer(c.bv, &c.buffer));
+  /* as the adapter does with the device array of the reference's bv->buffer Vec (HipksSync): the library adopts a caller-owned
+     coefficient buffer; here the storage of a helper BV stands in for that Vec */
+  CHK(ks_bv_create(c.ctx, M * M, M * M, 1, 0, &bufbv));
+  CHK(ks_bv_get_column(bufbv, 0, &c.buffer));
+  CHK(ks_bv_set_buffer(c.bv, c.buffer));
+  { double *chk = NULL; CHK(ks_bv_get_buffer(c.bv, &chk)); if (chk != c.buffer) { fprintf(stderr, "the adopted buffer is not in use\n"); return 3; } }
   c.nc = 0; c.m = M; c.refine = refine; c.mgs = mgs; c.eta = 0.7071; c.passes = 0;
 
   col = (double *)malloc(sizeof(double) * N); x0 = (double *)malloc(sizeof(double) * N);
@@ -122,7 +128,43 @@ int main(int argc, char **argv)
     printf("vector onrm %.17g nrm %.17g h %.17g %.17g %.17g\n", onrm, nrm, h[0], h[1], h[2]);
     CHK(ks_bv_destroy(W));
   }
+  /* constraints as the interface layer sets them up: storage of nc + m columns, the constraint vectors in front, then only the
+     FIELDS change (BVSetNumConstraints bvbasic.c:291-296, mirrored with ks_bv_set_layout); the slot then orthogonalizes column 0
+     against columns -nc..-1 and its coefficients go to rows 0..nc-1 of buffer column 0 (BV_AddCoefficients with nc+j entries) */
+  {
+    enum { NC = 2, MM = 3 };
+    ks_bv W; double *wbuf, hc0[NC + MM], nrm = 0.0, onrm = 0.0, dots[NC + MM], *w0;
+    double zero[NC + MM] = {0};
+    CHK(ks_bv_create(c.ctx, N, N, NC + MM, 0, &W));
+    for (j = 0; j < NC; j++) {                      /* two orthonormal constraint vectors: e_j-like blocks */
+      double s = 1.0 / sqrt((double)(N / 2));
+      for (i = 0; i < N; i++) col[i] = ((i % 2) == j) ? s : 0.0;
+      CHK(ks_bv_set_column_host(W, j, col));
+    }
+    for (i = 0; i < N; i++) col[i] = entry(i, 5);
+    CHK(ks_bv_set_column_host(W, NC, col));         /* becomes regular column 0 */
+    for (i = 0; i < N; i++) col[i] = entry(i, 6);
+    CHK(ks_bv_set_column_host(W, NC + 1, col));     /* regular column 1 */
+    CHK(ks_bv_set_layout(W, NC, MM));
+    CHK(ks_bv_get_buffer(W, &wbuf));
+    /* column 0: one pass against the two constraints, then normalise (its own coefficient column is the scratch column: the
+       reference's BV_AddCoefficients adds that column to itself for j = 0, so nothing is read from it here) */
+    CHK(ks_ctx_memcpy(c.ctx, wbuf, zero, sizeof(double) * NC, 0));
+    CHK(ks_bv_gramschmidt_pass(W, 0, NULL, NULL, NULL, NULL, &onrm, &nrm));
+    CHK(ks_bv_scalecolumn(W, 0, 1.0 / nrm));
+    /* column 1 against the constraints and column 0: BV_CleanCoefficients(bv,1,NULL) = nc+1 entries of buffer column 1 */
+    CHK(ks_ctx_memcpy(c.ctx, wbuf + (NC + MM), zero, sizeof(double) * (NC + 1), 0));
+    CHK(ks_bv_gramschmidt_pass(W, 1, NULL, NULL, NULL, NULL, &onrm, &nrm));
+    CHK(ks_ctx_memcpy(c.ctx, hc0, wbuf + (NC + MM), sizeof(double) * (NC + 1), 1));
+    /* what is left of column 1 is orthogonal to the constraints and to column 0: look at the same storage as plain columns */
+    CHK(ks_bv_set_layout(W, 0, NC + MM));
+    CHK(ks_bv_set_active_columns(W, 0, NC + 1));
+    CHK(ks_bv_get_column(W, NC + 1, &w0));
+    CHK(ks_bv_dotvec(W, w0, dots));
+    printf("constraints onrm %.17g nrm %.17g h %.17g %.17g %.17g residual_dots %.3e %.3e %.3e\n", onrm, nrm, hc0[0], hc0[1], hc0[2], dots[0], dots[1], dots[2]);
+    CHK(ks_bv_destroy(W));
+  }
   free(col); free(x0); free(x1); free(x2);
-  CHK(ks_bv_destroy(c.bv)); CHK(ks_ctx_destroy(c.ctx));
+  CHK(ks_bv_destroy(c.bv)); CHK(ks_bv_destroy(bufbv)); CHK(ks_ctx_destroy(c.ctx));
   return 0;
 }

@@ -98,3 +98,15 @@ def test_gramschmidt_slot_replayed_from_c_matches_the_oracle(tmp_path, refine, m
     assert np.allclose([float(vec[6]), float(vec[7]), float(vec[8])], h, rtol=1e-12, atol=1e-12)
     assert abs(float(vec[2]) - np.linalg.norm(w)) < 1e-11
     assert abs(float(vec[4]) - np.linalg.norm(w - Q @ h)) < 1e-9
+    # constraints through the state mirror (ks_bv_set_layout) and an adopted coefficient buffer (ks_bv_set_buffer)
+    con = [ln.split() for ln in out.splitlines() if ln.startswith("constraints")][0]
+    ent = lambda j: (((i * 37 + j * 101 + ((i * i) % 13) * 7) % 17) - 8) * 0.0625      # noqa: E731
+    w5, w6 = ent(5), ent(6)
+    sc = 1.0 / np.sqrt(n / 2)
+    c0 = np.where(i % 2 == 0, sc, 0.0); c1 = np.where(i % 2 == 1, sc, 0.0)
+    q0 = w5 - (c0 @ w5) * c0 - (c1 @ w5) * c1; q0 /= np.linalg.norm(q0)
+    h = np.array([c0 @ w6, c1 @ w6, q0 @ w6])
+    assert abs(float(con[2]) - np.linalg.norm(w6)) < 1e-11
+    assert np.allclose([float(con[6]), float(con[7]), float(con[8])], h, rtol=0, atol=1e-11)
+    assert abs(float(con[4]) - np.linalg.norm(w6 - h[0] * c0 - h[1] * c1 - h[2] * q0)) < 1e-9
+    assert max(abs(float(con[10])), abs(float(con[11])), abs(float(con[12]))) < 1e-12
