@@ -487,6 +487,15 @@ class BV:
         _lib.check(self.ctx.L.ks_bv_orthogonalizecolumn(self.h, j, _p(H), C.byref(nrm), C.byref(lin)))
         return H[: max(j - self.l, 0)], nrm.value, bool(lin.value)
 
+    def GramSchmidtPass(self, j, want_onrm=True, want_nrm=True):
+        """ops->gramschmidt: ONE pass on column j with the coefficients in the buffer; returns (onrm, nrm), None where not asked for."""
+        o = C.c_double(); nr = C.c_double()
+        _lib.check(self.ctx.L.ks_bv_gramschmidt_pass(self.h, j, None, None, None, None, C.byref(o) if want_onrm else None, C.byref(nr) if want_nrm else None))
+        return (o.value if want_onrm else None), (nr.value if want_nrm else None)
+
+    def buffer_ptr(self):
+        p = C.c_void_p(); _lib.check(self.ctx.L.ks_bv_get_buffer(self.h, C.byref(p))); return p.value
+
     def SetMatrix(self, B):
         """BVSetMatrix(bv,B,PETSC_FALSE); B a Mat (kept alive here) or None."""
         self._B = B
