@@ -451,7 +451,7 @@ int launch_update(ks_bv bv, int col, double *v, int slot, const GsArgs *fold = n
   // blocks per CU of the update sweep: measured on MI355X at n = 1e7, k = 16..30: 1 block (4 waves, k KiB in flight each)
   // per CU is fastest (fewer concurrent DRAM streams), as long as every block still gets many tiles
   const long long ntl = ((long long)bv->n + 511) / 512;
-  const int upd_per_cu = ntl >= 16LL * ctx->num_cu ? 1 : (ntl >= 8LL * ctx->num_cu ? 2 : 0);
+  const int upd_per_cu = ntl >= 16LL * ctx->num_cu ? 1 : (ntl >= 4LL * ctx->num_cu ? 2 : 0);
   (void)slot;
   const int plain = ks_basis_is_cache_resident((size_t)(bv->nc + bv->m), (size_t)bv->ld);
   const int rev = bv->sweep_dir; bv->sweep_dir ^= 1;   // every sweep over the basis runs opposite to the one before it (dot sweeps included): it starts on
