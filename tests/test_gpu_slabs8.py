@@ -142,3 +142,74 @@ def test_eight_slabs_of_the_config4_geometry_against_the_oracle():
     # the leading Ritz values after 60 steps approach the top of the spectrum of the 432 x 432 x 16 Laplacian from below
     lam_max = max(O.laplacian_eigenvalues((nx, ny, p * world)))
     assert all(0.9 * lam_max < v <= lam_max + 1e-9 for v in out[0]["ritz"][0])
+
+
+def _rank_c4(rank, world, comm, out):
+    try:
+        import slepc_amd as ks
+        nx = ny = 432; p = 54; nz = p * world                       # BASELINE config 4: 432^3 = 80 621 568 rows in 8 z-slabs of 54 planes
+        ctx = ks.Context(0)
+        comm.install(ctx, rank)
+        A = ks.Mat.laplacian3d(ctx, nx, ny, nz, rank * p, p)
+        res = {"n": A.n, "N": A.N, "nnz": A.nnz, "layout": A.layout()}
+        # an analytic eigenvector of the Dirichlet Laplacian (ex19.c:19-45), this rank's slab of it
+        a, b, c = 3, 5, 7
+        sx = np.sin(np.pi * a * np.arange(1, nx + 1) / (nx + 1)); sy = np.sin(np.pi * b * np.arange(1, ny + 1) / (ny + 1))
+        sz = np.sin(np.pi * c * np.arange(rank * p + 1, (rank + 1) * p + 1) / (nz + 1))
+        v = (sz[:, None, None] * sy[None, :, None] * sx[None, None, :]).ravel()
+        lam = 4.0 * (np.sin(a * np.pi / (2 * (nx + 1))) ** 2 + np.sin(b * np.pi / (2 * (ny + 1))) ** 2 + np.sin(c * np.pi / (2 * (nz + 1))) ** 2)
+        X = ks.BV(ctx, A.n, 2, N=A.N)
+        X.set_column(0, v)
+        A.mult_dev(X.column_ptr(0), X.column_ptr(1))
+        res["spmv_err"] = float(np.abs(X.column(1) - lam * v).max())      # the planes next to a slab boundary need the neighbours' halos
+        del X, v
+        eps = ks.EPS(ctx); eps.SetOperators(A); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(10, 30); eps.SetMaxSteps(45)
+        last = {}
+        eps.MonitorSet(lambda its, nconv, er, ei, ee: last.update(ritz=list(er[:10])))
+        eps.Solve()
+        st = eps.GetStats()
+        res["eps"] = (eps.GetIterationNumber(), st["arnoldi_steps"], st["gs_passes"], st["restarts"])
+        res["ritz"] = last["ritz"]
+        V = eps.GetBV(); V.SetActiveColumns(0, 16)
+        M = np.zeros((16, 16), order="F"); V.Dot(V, M)
+        res["orth"] = float(np.abs(M - np.eye(16)).max())
+        del eps
+        A.destroy()
+        ctx.close()
+        out[rank] = res
+    except Exception:      # noqa: BLE001
+        import traceback
+        out[rank] = {"error": traceback.format_exc()}
+        try:
+            comm.bar.abort()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+@pytest.mark.timeout(900)
+def test_config4_at_its_stated_size_in_eight_shards():
+    """BASELINE config 4 itself - the 432^3 Laplacian, 80.6 M rows, eight z-slabs of 54 planes (10 077 696 rows per shard, the
+    per-GPU workload of bench.py --gpus 8) - with the eight ranks as threads of one process on one GPU (20 GB of bases).
+    No CPU oracle at this size: the sharded product is checked on an analytic eigenvector (A v = lambda v to rounding, which
+    the planes next to the slab boundaries only satisfy with the neighbours' halos), the solver through size-independent
+    properties: identical integer control flow and identical Ritz values on all eight ranks after a full cycle and a restart
+    cycle, every Ritz value inside the analytic spectrum, an orthonormal basis across the shards."""
+    from oracle import oracle as O
+    world = 8
+    comm = ThreadComm(world)
+    out = [None] * world
+    th = [threading.Thread(target=_rank_c4, args=(r, world, comm, out)) for r in range(world)]
+    for t in th: t.start()
+    for t in th: t.join(800)
+    for r in range(world):
+        assert out[r] is not None and "error" not in out[r], (r, out[r])
+    lam_max = 4.0 * 3 * np.sin(432 * np.pi / (2 * 433)) ** 2
+    for r in range(world):
+        o = out[r]
+        assert o["n"] == 10_077_696 and o["N"] == 80_621_568 and o["layout"] == "dict"
+        assert o["spmv_err"] < 1e-12
+        assert o["eps"] == out[0]["eps"] and o["ritz"] == out[0]["ritz"]
+        assert o["orth"] < 1e-13
+    assert out[0]["eps"][1] == 45 and out[0]["eps"][3] == 2
+    assert all(0.8 * lam_max < v <= lam_max + 1e-9 for v in out[0]["ritz"])
+    assert sum(o["nnz"] for o in out) == 7 * 80_621_568 - 6 * 432 * 432
