@@ -175,14 +175,14 @@ int ksk_reduce_partials(ks_bv bv, int ncols, double *out_dev)
   return KS_SUCCESS;
 }
 
-int ksk_multvec(ks_bv bv, const double *A, int lda, int ncols, double alpha, double beta, const double *q_dev, double *y)
+int ksk_multvec(ks_bv bv, const double *A, int lda, int ncols, double alpha, double beta, const double *q_dev, double *y, const KsGsState *gate)
 {
   ks_ctx ctx = bv->ctx;
   const bool v2 = (lda % 2 == 0) && aligned16(A) && aligned16(y);
   const int grid = sweep_grid(ctx, bv->n, v2 ? 2 : 1);
   KsProfScope ps(ctx, KS_K_UPD, 8.0 * bv->n * (ncols + 2));
-  if (v2) hipLaunchKernelGGL((k_multvec<2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, alpha, beta, q_dev, y);
-  else hipLaunchKernelGGL((k_multvec<1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, alpha, beta, q_dev, y);
+  if (v2) hipLaunchKernelGGL((k_multvec<2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, alpha, beta, q_dev, y, gate);
+  else hipLaunchKernelGGL((k_multvec<1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, alpha, beta, q_dev, y, gate);
   KS_HIP(hipGetLastError());
   return KS_SUCCESS;
 }
@@ -258,6 +258,7 @@ extern "C" int ks_bv_create(ks_ctx ctx, int n_local, int n_global, int m, int ld
   KS_HIP(hipMalloc(&bv->coef, bv->coef_len * sizeof(double)));
   KS_HIP(hipMalloc(&bv->hc, (size_t)2 * (m + 8) * sizeof(double)));
   KS_HIP(hipMalloc(&bv->cred, (size_t)KS_PSTRIDE * sizeof(double)));
+  KS_HIP(hipMalloc(&bv->cw, (size_t)(m + 8) * sizeof(double)));
   KS_HIP(hipMalloc(&bv->pend, sizeof(double) * 3 * KS_PSTRIDE)); KS_HIP(hipMemsetAsync(bv->pend, 0, sizeof(double) * 3 * KS_PSTRIDE, ctx->stream));
   KS_HIP(hipMalloc(&bv->gs_base, 2 * sizeof(KsGsState)));
   KS_HIP(hipMemsetAsync(bv->gs_base, 0, 2 * sizeof(KsGsState), ctx->stream));
@@ -274,7 +275,7 @@ extern "C" int ks_bv_destroy(ks_bv bv)
   if (!bv) return KS_SUCCESS;
   hipSetDevice(bv->ctx->device);
   ks_sync(bv->ctx);
-  hipFree(bv->array); hipFree(bv->own_buffer ? bv->buffer : bv->buffer_own); hipFree(bv->partials_base); hipFree(bv->coef); hipFree(bv->hc); hipFree(bv->cred); hipFree(bv->gs_base); hipFree(bv->recs); hipFree(bv->panel); hipFree(bv->Bx); hipFree(bv->pend);
+  hipFree(bv->array); hipFree(bv->own_buffer ? bv->buffer : bv->buffer_own); hipFree(bv->partials_base); hipFree(bv->coef); hipFree(bv->hc); hipFree(bv->cred); hipFree(bv->cw); hipFree(bv->gs_base); hipFree(bv->recs); hipFree(bv->panel); hipFree(bv->Bx); hipFree(bv->pend);
   delete bv;
   return KS_SUCCESS;
 }
@@ -297,7 +298,7 @@ extern "C" int ks_bv_resize(ks_bv bv, int m, int copy)
   }
   // swap the storage of the two objects, keep the caller's handle and settings
   std::swap(bv->array, nb->array); std::swap(bv->buffer, nb->buffer); std::swap(bv->own_buffer, nb->own_buffer); std::swap(bv->buffer_own, nb->buffer_own); std::swap(bv->coef, nb->coef); std::swap(bv->coef_len, nb->coef_len);
-  std::swap(bv->hc, nb->hc); std::swap(bv->recs, nb->recs); std::swap(bv->panel, nb->panel); std::swap(bv->panel_len, nb->panel_len);
+  std::swap(bv->hc, nb->hc); std::swap(bv->cw, nb->cw); std::swap(bv->recs, nb->recs); std::swap(bv->panel, nb->panel); std::swap(bv->panel_len, nb->panel_len);
   std::swap(bv->m, nb->m);
   bv->l = 0; bv->k = m;
   return ks_bv_destroy(nb);

@@ -1041,8 +1041,8 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   else { if (nev < 500) ncv = std::min(n, std::max(2 * nev, nev + 15)); else { mpd = 500; ncv = std::min(n, nev + mpd); } }
   if (!mpd) mpd = ncv;
   KS_CHECK(ncv <= nev + mpd, KS_ERR_USER_INPUT, "The value of ncv must not be larger than nev+mpd");
-  // ncv + 1 > 64 columns: the basis is wider than the register-tiled fused kernels; Gram-Schmidt then runs the host-driven pass loop
-  // over 64-column chunks and the panel products are blocked (ks_bv.hip)
+  // ncv + 1 > 64 columns: the basis is wider than the register-tiled fused kernels; Gram-Schmidt then runs its slot program over
+  // 64-column chunks (ks_gs.hip, still enqueued as a whole) and the panel products are blocked (ks_bv.hip)
   eps->ncv = ncv; eps->mpd = mpd;
   eps->max_it = eps->max_it_user ? eps->max_it_user : std::max(100, 2 * n / ncv);
   if (eps->V) { int vm = 0; ks_bv_get_sizes(eps->V, nullptr, nullptr, &vm, nullptr); if (vm != ncv + 1 || eps->V->nc) { ks_bv_destroy(eps->V); eps->V = nullptr; } }

@@ -38,6 +38,8 @@ struct GsArgs {
   int spec_last;   // this is the last slot of the optimistic program: unfinished business halts the run for the host
   int bmat;        // B-inner product (BVSetMatrix): the dots of every pass are taken with B*v, recomputed by an SpMV before each slot, so an
                    // update never carries the next pass's dots and always writes the vector back
+  int wide;        // more than 64 previous columns: dots and updates run over 64-column chunks, the reduced coefficients live in bv->cw, the
+                   // update never carries dots and the 1/nrm scaling is a kernel of its own
   int gs1;         // 0: slot of the device-resident program; 1 / 2: ONE pass with the semantics of the ops->gramschmidt slot
                    // (BVOrthogonalizeCGS1), without (1) / with (2) the self dot product in c[k]
   double eta, deftol;
@@ -120,6 +122,7 @@ __device__ void gs_bookkeep(const GsArgs a, const double *c, KsGsState *st, Book
     // correction away exactly when refinement is needed (|c2| ~ eps |c1|)
     if (st->store_prev) st->npend = 0;
     plan->pslot = st->npend; st->npend++;
+    if (a.wide) plan->pslot = -1;                                      // chunked updates read the coefficients from bv->cw
     upd = 1;
     if (a.refine == KS_BV_ORTHOG_REFINE_NEVER) {
       // one pass, then explicit norm (bvorthog.c:189-195)
@@ -148,13 +151,13 @@ __device__ void gs_bookkeep(const GsArgs a, const double *c, KsGsState *st, Book
     plan->set_hk = 1; plan->hk = lindep ? 0.0 : nrm;                                                         // BV_SetValue bvorthog.c:209-214
     const double alpha = (nrm != 1.0 && nrm != 0.0) ? 1.0 / nrm : 1.0;                                       // bvorthog.c:417-419
     st->alpha = alpha; st->lindep = lindep;
-    if (a.normalize && alpha != 1.0) { if (after_update) st->pending_scale = 1; else scal = 1; }
+    if (a.normalize && alpha != 1.0) { if (after_update || a.wide) st->pending_scale = 1; else scal = 1; }
     KsStepRec r; r.nrm = nrm; r.onrm = onrm; r.passes = st->pass; r.lindep = lindep; r.expl = after_update ? 1 : 0; r.col = a.col;
     plan->rec = r; plan->set_rec = 1;
     if (a.krylov && lindep) st->active = 0;          // bvkrylov.c:92-95: stop the expansion
     st->more_ = 0;
   }
-  if (a.bmat) fuse = 0;
+  if (a.bmat || a.wide) fuse = 0;
   st->nrm = nrm; st->onrm = onrm;
   st->do_update = upd; st->fuse_dot = fuse; st->scale_now = scal;
   if (upd) {
@@ -189,6 +192,37 @@ __device__ __forceinline__ void apply_plan(const GsArgs &a, const BookPlan &plan
   }
   if (i == 0 && plan.set_hk) H[a.k] = plan.hk;
 }
+
+// ---- wide bases: the same slot program over 64-column chunks ------------------------------------------------------------------
+// k + 1 > 64 coefficients do not fit the register-tiled sweeps or the update kernel's prologue. The slot then runs as: dot sweeps over
+// 64-column chunks, each reduced into bv->cw (k_reduce_only), [allreduce], this 1-block bookkeeping kernel on the k + 1 reduced
+// coefficients (same pure bookkeeping function), gated k_multvec updates chunk by chunk with the coefficients read from bv->cw, and
+// the scaling as a kernel of its own - all enqueued, nothing waits for the host.
+__global__ __launch_bounds__(1024) void k_gs_finish_wide(const double *__restrict__ cw, GsArgs a, double *buffer, KsGsState *st, KsStepRec *recs)
+{
+  extern __shared__ double cw_lds[];
+  __shared__ int go;
+  __shared__ BookPlan plan;
+  if (threadIdx.x == 0) {
+    go = 1;
+    if (!st->active || (a.slot > 1 && !st->expl && !st->more_)) { go = 0; st->do_update = 0; }
+  }
+  __syncthreads();
+  if (!go) return;
+  for (int i = threadIdx.x; i <= a.k; i += blockDim.x) cw_lds[i] = cw[i];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    KsGsState s = *st;
+    gs_bookkeep(a, cw_lds, &s, &plan);
+    *st = s;
+    if (plan.set_rec) recs[a.col] = plan.rec;
+  }
+  __syncthreads();
+  double *H = buffer + (size_t)a.col * a.ldb;
+  for (int i = threadIdx.x; i < a.k; i += blockDim.x) { if (plan.hmode == 1) H[i] = cw_lds[i]; else if (plan.hmode == 2) H[i] += cw_lds[i]; }
+  if (threadIdx.x == 0 && plan.set_hk) H[a.k] = plan.hk;
+}
+__global__ void k_gs_clear_pending_scale(KsGsState *st) { st->pending_scale = 0; }
 
 // REDUCE: sum block partials -> c (LDS, and global scratch = buffer column 0).  BOOK: run the bookkeeping.
 template <bool REDUCE, bool BOOK>
@@ -493,15 +527,66 @@ int enqueue_dots(ks_bv bv, int j, int krylov)
   return ksk_dot(bv, ks_bv_col(bv, -bv->nc), bv->ld, bv->nc + j + 1, z, krylov != 0);
 }
 
+// wide bases: the dots of a pass over 64-column chunks of [V(:,-nc:j), v] (the last column is the vector itself: the self dot),
+// each chunk reduced into its part of bv->cw, then summed over the ranks
+int enqueue_dots_wide(ks_bv bv, int j, int krylov)
+{
+  const double *z = ks_bv_col(bv, j);
+  KS_CALL(ksb_ipmatmult(bv, z, &z));
+  const int total = bv->nc + j + 1;
+  for (int c0 = 0; c0 < total; c0 += KS_MAX_COLS) {
+    const int nq = std::min(KS_MAX_COLS, total - c0);
+    KS_CALL(ksk_dot(bv, ks_bv_col(bv, -bv->nc) + (size_t)c0 * bv->ld, bv->ld, nq, z, krylov != 0));
+    KS_CALL(ksk_reduce_partials(bv, nq, bv->cw + c0));
+  }
+  return ks_allreduce_sum(bv->ctx, bv->cw, total);
+}
+int launch_finish_wide(ks_bv bv, const GsArgs &a)
+{
+  ks_ctx ctx = bv->ctx;
+  hipLaunchKernelGGL(k_gs_finish_wide, dim3(1), dim3(1024), sizeof(double) * (a.k + 8), ctx->stream, bv->cw, a, bv->buffer, bv->gs, bv->recs);
+  KS_HIP(hipGetLastError());
+  return KS_SUCCESS;
+}
+// v -= V(:,-nc:j) c chunk by chunk, each launch gated on the bookkeeping's do_update
+int enqueue_update_wide(ks_bv bv, int j)
+{
+  const int k = bv->nc + j;
+  for (int c0 = 0; c0 < k; c0 += KS_MAX_COLS) {
+    const int nq = std::min(KS_MAX_COLS, k - c0);
+    KS_CALL(ksk_multvec(bv, ks_bv_col(bv, -bv->nc) + (size_t)c0 * bv->ld, bv->ld, nq, -1.0, 1.0, bv->cw + c0, ks_bv_col(bv, j), bv->gs));
+  }
+  return KS_SUCCESS;
+}
+int enqueue_scale_if(ks_bv bv, int j, bool clear)
+{
+  ks_ctx ctx = bv->ctx;
+  KsProfScope ps(ctx, KS_K_SCALE, 0.0);
+  ps.tag(j, 0, j, bv->n);
+  const int grid = std::max(1, std::min((bv->n + 255) / 256, ctx->num_cu * 4));
+  hipLaunchKernelGGL(k_scale_if, dim3(grid), dim3(256), 0, ctx->stream, ks_bv_col(bv, j), bv->n, bv->gs);
+  if (clear) hipLaunchKernelGGL(k_gs_clear_pending_scale, dim3(1), dim3(1), 0, ctx->stream, bv->gs);
+  KS_HIP(hipGetLastError());
+  return KS_SUCCESS;
+}
+
 int enqueue_gs_slots(ks_bv bv, int j, int normalize, int krylov, int first, int last, bool halt_at_last, bool resolution_and_scale)
 {
   ks_ctx ctx = bv->ctx;
   const bool bmat = bv->matrix != nullptr;
   const bool fold = true, multi = ks_is_multi(ctx);
-  GsArgs a; a.gs1 = 0; a.bmat = bmat ? 1 : 0; a.k = bv->nc + j; a.col = j; a.refine = bv->orthog_ref; a.normalize = normalize; a.krylov = krylov; a.ldb = bv->nc + bv->m; a.eta = bv->orthog_eta; a.deftol = bv->deftol;
+  const bool wide = bv->nc + j + 1 > KS_MAX_COLS;
+  GsArgs a; a.gs1 = 0; a.wide = wide ? 1 : 0; a.bmat = bmat ? 1 : 0; a.k = bv->nc + j; a.col = j; a.refine = bv->orthog_ref; a.normalize = normalize; a.krylov = krylov; a.ldb = bv->nc + bv->m; a.eta = bv->orthog_eta; a.deftol = bv->deftol;
   double *v = ks_bv_col(bv, j);
   for (int p = first; p <= last; p++) {
     a.slot = p; a.spec_last = (halt_at_last && p == last) ? 1 : 0;
+    if (wide) {
+      KS_CALL(enqueue_dots_wide(bv, j, krylov));
+      KS_CALL(launch_finish_wide(bv, a));
+      KS_CALL(enqueue_update_wide(bv, j));
+      if (normalize) KS_CALL(enqueue_scale_if(bv, j, true));
+      continue;
+    }
     if (bmat) KS_CALL(enqueue_dots(bv, j, krylov));          // every pass takes its dots with B v afresh (a pass that turns out not to be needed gates itself off in the bookkeeping)
     if (multi) KS_CALL(launch_reduce_allreduce(bv, a));      // ranks: block partials -> buffer[0..k], summed over the ranks (bvblas.c:255)
     if (fold) KS_CALL(launch_update(bv, j, v, p, &a));       // the update kernel runs the slot's bookkeeping in its prologue
@@ -509,15 +594,12 @@ int enqueue_gs_slots(ks_bv bv, int j, int normalize, int krylov, int first, int 
   }
   if (resolution_and_scale) {
     a.slot = last + 1; a.spec_last = 0;     // resolves an explicit-norm request of the last update
-    if (bmat) KS_CALL(enqueue_dots(bv, j, krylov));
-    KS_CALL(launch_finish(bv, a));
-    if (normalize) {
-      KsProfScope ps(ctx, KS_K_SCALE, 0.0);
-      ps.tag(j, 0, j, bv->n);
-      const int grid = std::max(1, std::min((bv->n + 255) / 256, ctx->num_cu * 4));
-      hipLaunchKernelGGL(k_scale_if, dim3(grid), dim3(256), 0, ctx->stream, v, bv->n, bv->gs);
-      KS_HIP(hipGetLastError());
+    if (wide) { KS_CALL(enqueue_dots_wide(bv, j, krylov)); KS_CALL(launch_finish_wide(bv, a)); }
+    else {
+      if (bmat) KS_CALL(enqueue_dots(bv, j, krylov));
+      KS_CALL(launch_finish(bv, a));
     }
+    if (normalize) KS_CALL(enqueue_scale_if(bv, j, wide));
   }
   return KS_SUCCESS;
 }
@@ -525,8 +607,8 @@ int enqueue_gs_slots(ks_bv bv, int j, int normalize, int krylov, int first, int 
 // Optimistic program of column j (against columns 0..j-1).
 int enqueue_fused_gs(ks_bv bv, int j, int normalize, int krylov)
 {
-  KS_CHECK(bv->nc + j + 1 <= KS_MAX_COLS, KS_ERR_SUP, "fused Gram-Schmidt supports at most %d columns", KS_MAX_COLS);
-  if (!bv->matrix) KS_CALL(enqueue_dots(bv, j, krylov));      // with a matrix every slot starts with its own B v and dots
+  KS_CHECK(bv->nc + j + 1 <= 8000, KS_ERR_SUP, "device-resident Gram-Schmidt supports at most 8000 columns");
+  if (!bv->matrix && bv->nc + j + 1 <= KS_MAX_COLS) KS_CALL(enqueue_dots(bv, j, krylov));      // with a matrix, or more than 64 coefficients, every slot starts with its own dots
   const int ns = spec_slots(bv), nt = total_slots(bv);
   const bool whole = (ns >= nt) && bv->orthog_ref == KS_BV_ORTHOG_REFINE_NEVER;
   if (whole) return enqueue_gs_slots(bv, j, normalize, krylov, 1, nt, false, true);
@@ -713,7 +795,7 @@ int store_buffer_column(ks_bv bv, int j, const double *hh, int len)
   return KS_SUCCESS;
 }
 
-bool use_fused(ks_bv bv) { return bv->orthog_type == KS_BV_ORTHOG_CGS && bv->nc + bv->m <= KS_MAX_COLS && !getenv("KSGPU_NO_FUSED_GS"); }
+bool use_fused(ks_bv bv) { return bv->orthog_type == KS_BV_ORTHOG_CGS && bv->nc + bv->m <= 8000 && !getenv("KSGPU_NO_FUSED_GS"); }
 
 // Orthogonalize column j; fused or generic. Returns norm/lindep on the host (synchronises).
 int orthogonalize_column(ks_bv bv, int j, int normalize, double *H, double *norm, int *lindep)
@@ -836,7 +918,7 @@ int gs1_fused_column(ks_bv bv, int j, double *onrm, double *nrm)
   const bool need = onrm || nrm;
   const int k = bv->nc + j;
   if (k == 0 && !need) return KS_SUCCESS;
-  GsArgs a; a.bmat = bv->matrix ? 1 : 0; a.gs1 = need ? 2 : 1; a.k = k; a.col = j; a.slot = 1; a.refine = bv->orthog_ref; a.normalize = 0; a.krylov = 0; a.ldb = bv->nc + bv->m;
+  GsArgs a; a.wide = 0; a.bmat = bv->matrix ? 1 : 0; a.gs1 = need ? 2 : 1; a.k = k; a.col = j; a.slot = 1; a.refine = bv->orthog_ref; a.normalize = 0; a.krylov = 0; a.ldb = bv->nc + bv->m;
   a.spec_last = 0; a.eta = bv->orthog_eta; a.deftol = bv->deftol;
   double *v = ks_bv_col(bv, j);
   const double *z = v;
@@ -867,7 +949,7 @@ extern "C" int ks_bv_gramschmidt_pass(ks_bv bv, int j, double *v_dev, const int 
   ks_ctx ctx = bv->ctx;
   KS_HIP(hipSetDevice(ctx->device));
   const bool mgs = bv->orthog_type == KS_BV_ORTHOG_MGS;
-  if (!v_dev && !h && !mgs && use_fused(bv)) return gs1_fused_column(bv, j, onrm, nrm);
+  if (!v_dev && !h && !mgs && use_fused(bv) && bv->nc + j + 1 <= KS_MAX_COLS) return gs1_fused_column(bv, j, onrm, nrm);
   // host-driven pass on the primitive ops (MGS, a vector argument, a B-inner product, a basis wider than the fused kernels)
   const int len = bv->nc + j;
   const int ldb = bv->nc + bv->m;

@@ -116,8 +116,9 @@ __global__ __launch_bounds__(SW_BLOCK) void k_dot_sweep(const double *__restrict
 // y = beta*y + alpha*A(:,0:ncols) q   (gemv-N of BVMultVec_BLAS_Private, bvblas.c:56-67); q on device
 template <int VEC>
 __global__ __launch_bounds__(SW_BLOCK) void k_multvec(const double *__restrict__ A, long long lda, int n, int ncols, double alpha, double beta,
-                                                      const double *__restrict__ q, double *__restrict__ y)
+                                                      const double *__restrict__ q, double *__restrict__ y, const KsGsState *__restrict__ gate)
 {
+  if (gate && !gate->do_update) return;           // a chunk of a device-resident Gram-Schmidt update (wide bases): runs only when the bookkeeping asked for it
   const long long tile = (long long)SW_BLOCK * VEC;
   const long long ntiles = ((long long)n + tile - 1) / tile;
   for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {

@@ -203,6 +203,7 @@ struct ks_bv_s {
   double *partials_alt = nullptr, *partials_base = nullptr;
   double *coef = nullptr;       // device scratch for host-provided q / Q (max(m*m, ...))
   double *hc = nullptr;         // device h,c arrays for orthogonalizevec (2*(nc+m))
+  double *cw = nullptr;         // [nc+m+1] wide bases (more than 64 previous columns): the pass's reduced dots, chunk after chunk
   double *cred = nullptr;       // [KS_PSTRIDE] multi-rank: the pass's dots summed over blocks and ranks, read by every workgroup of the update kernel
                                 // (not the buffer's scratch column: workgroup 0 writes H(:,0) there while the others may still be reading)
   size_t coef_len = 0;
@@ -228,7 +229,7 @@ static inline double *ks_bv_col(ks_bv bv, int j) { return bv->array + (size_t)(b
 // kernel launchers (ks_bv_kernels.hip / ks_gs.hip)
 int ksk_dot(ks_bv bv, const double *A, int lda, int ncols, const double *y, bool gate);      // partials <- A(:,0:ncols)^T y
 int ksk_reduce_partials(ks_bv bv, int ncols, double *out_dev);                                // out[i] = sum_b partials[b][i]
-int ksk_multvec(ks_bv bv, const double *A, int lda, int ncols, double alpha, double beta, const double *q_dev, double *y);
+int ksk_multvec(ks_bv bv, const double *A, int lda, int ncols, double alpha, double beta, const double *q_dev, double *y, const KsGsState *gate = nullptr);
 int ksk_scale(ks_ctx ctx, double *x, size_t n, double alpha);
 int ksk_copy(ks_ctx ctx, const double *src, double *dst, size_t n);
 

@@ -93,3 +93,38 @@ def test_solver_with_a_wide_basis(ctx, ptype, nev, ncv):
         w = np.hypot(r.eigr[j], r.eigi[j] if ptype == "nhep" else 0.0)
         assert abs(kr - r.eigr[j]) <= 1e-9 * w and (ptype == "hep" or abs(ki - r.eigi[j]) <= 1e-9 * w)
         assert eps.ComputeError(i) < 1e-7
+
+
+@pytest.mark.parametrize("withb", [False, True])
+def test_wide_lanczos_is_enqueued_without_host_waits(ctx, withb):
+    """More than 64 previous columns: the Gram-Schmidt slot program runs over 64-column chunks (chunked dot sweeps reduced into a
+    device array, one bookkeeping launch, gated chunked updates, scaling as its own launch), still enqueued as a whole. The
+    columns below 64 of the same run take the register-tiled path. Tridiagonal, pass counts and orthonormal basis as the
+    oracle; two host waits for a run of 100 steps, also in a B-inner product."""
+    import slepc_amd as ks
+    Ao = O.laplacian2d(60, 50)
+    A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
+    m = 100
+    Vg = ks.BV(ctx, Ao.n, m + 1); Vo = O.BV(Ao.n, m + 1)
+    Bo = None
+    if withb:
+        L = O.laplacian1d(Ao.n)
+        Bo = O.CSR(Ao.n, L.rowptr, L.col, np.where(L.col == np.repeat(np.arange(Ao.n), np.diff(L.rowptr)), 4.0, 1.0))
+        B = ks.Mat.from_csr(ctx, Bo.rowptr, Bo.col, Bo.val)
+        Vg.SetMatrix(B); Vo.SetMatrix(Bo)
+    for V in (Vg, Vo):
+        V.SetRandomColumn(0)
+        _, nrm, _ = V.OrthogonalizeColumn(0); V.ScaleColumn(0, 1.0 / nrm)
+    Tg = np.zeros((m + 1, 3), order="F"); To = np.zeros((m + 1, 3), order="F")
+    p0g, p0o = Vg.gs_passes()[0], Vo.passes_total()
+    s0 = ctx.sync_count()
+    rg = Vg.MatLanczos(A, Tg, 0, m)
+    waits = ctx.sync_count() - s0
+    ro = Vo.MatLanczos(Ao, To, 0, m)
+    assert rg[0] == ro[0] == m and not rg[2]
+    assert Vg.gs_passes()[0] - p0g == Vo.passes_total() - p0o
+    assert np.abs(Tg - To).max() < 1e-9 and abs(rg[1] - ro[1]) < 1e-9
+    Vd = Vg.dense()
+    G = Vd.T @ (Bo.to_scipy() @ Vd) if withb else Vd.T @ Vd
+    assert np.abs(G - np.eye(m + 1)).max() < 1e-11
+    assert waits <= 3, waits
