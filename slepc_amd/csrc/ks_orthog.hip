@@ -155,8 +155,15 @@ extern "C" int ks_bv_orthogonalize(ks_bv V, double *R, int ldr)       // BVOrtho
   if (nact <= 0) return KS_SUCCESS;
   KS_HIP(hipSetDevice(V->ctx->device));
   if (V->orthog_block == KS_BV_ORTHOG_BLOCK_GS) return orthogonalize_gs(V, R, ldr);
-  KS_CHECK(nact <= 64 || V->orthog_block == KS_BV_ORTHOG_BLOCK_CHOL || V->orthog_block == KS_BV_ORTHOG_BLOCK_SVQB, KS_ERR_SUP,
-           "TSQR block orthogonalization of %d columns (max 64: the running R factor lives in LDS); use GS, CHOL or SVQB", nact);
+  if (nact > 64 && (V->orthog_block == KS_BV_ORTHOG_BLOCK_TSQR || V->orthog_block == KS_BV_ORTHOG_BLOCK_TSQRCHOL)) {
+    // the running R factor of the TSQR kernel lives in LDS (64 columns): wider windows go panel by panel, every panel first
+    // block-orthogonalised against everything before it (the leading-columns step below), then factored; R fills up column block by column block
+    KS_CHECK(!V->matrix, KS_ERR_SUP, "Orthogonalization method not available for non-standard inner product");
+    int rc = KS_SUCCESS;
+    for (int s = l; s < k && !rc; s += 64) { V->l = s; V->k = std::min(s + 64, k); rc = ks_bv_orthogonalize(V, R, ldr); }
+    V->l = l; V->k = k;
+    return rc;
+  }
   const int ldb = k;
   std::vector<double> Rb((size_t)ldb * k, 0.0), S((size_t)ldb * k, 0.0);     // Rb plays V->Abuffer, S the inverse
   double *R22 = Rb.data() + (size_t)l * ldb + l, *S22 = S.data() + (size_t)l * ldb + l;
