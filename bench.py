@@ -436,6 +436,7 @@ def main():
             idt.copy_(torch.frombuffer(bytearray(ks.Context.get_unique_id()), dtype=torch.uint8))
         dist.broadcast(idt, 0)
         ctx.init_rccl(rank, world, bytes(idt.cpu().numpy().tobytes()))
+        ctx.comm_check()                  # allreduce / allgather / neighbour exchange against known answers before anything is timed
 
     side = args.side
     if world == 1 and not force_dist:

@@ -121,6 +121,11 @@ typedef struct ks_comm_ops {
 } ks_comm_ops;
 int ks_comm_set_ops(ks_ctx ctx, int rank, int size, const ks_comm_ops *ops, void *user);
 int ks_comm_rank_size(ks_ctx ctx, int *rank, int *size);
+/* Known-answer run of the installed communicator: an allreduce with a closed-form sum, two allgathers of one int per rank and
+ * a ring exchange with ranks rank+1 / rank-1. Collective; returns KS_ERR_LIB with a message naming the first mismatch. A no-op
+ * on a single rank without forced collectives. (The reference leans on MPI's own correctness here; a communicator handed in
+ * through ks_comm_set_ops is foreign code, so the library offers the check an integrator runs once after installing it.) */
+int ks_comm_check(ks_ctx ctx);
 /* device<->host copy on the context's stream (synchronous); kind: 0 = host->device, 1 = device->host */
 int ks_ctx_memcpy(ks_ctx ctx, void *dst, const void *src, size_t bytes, int kind);
 /* the same on a given stream (the `stream` argument a ks_comm_ops callback receives; NULL = the context's): what a provider that

@@ -143,6 +143,10 @@ class Context:
         _lib.check(self.L.ks_comm_set_ops(self.h, rank, size, C.byref(self._ops), None))
         self.rank, self.size = rank, size
 
+    def comm_check(self):
+        """Known-answer run of the installed communicator (collective): allreduce, allgather, ring exchange."""
+        _lib.check(self.L.ks_comm_check(self.h))
+
     def memcpy_h2d(self, dev_ptr, host_array, stream=None):
         """stream: the `stream` argument a communicator callback received (None: the context's own)."""
         _lib.check(self.L.ks_ctx_memcpy_stream(self.h, C.c_void_p(dev_ptr), host_array.ctypes.data_as(C.c_void_p), host_array.nbytes, 0, C.c_void_p(stream)))

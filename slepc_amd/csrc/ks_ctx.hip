@@ -305,7 +305,6 @@ static int rccl_allgather_host(void *user, const void *send, int bytes, void *re
   if (!rc) rc = g_rccl.allgather(d + (size_t)bytes * ctx->comm.size, d, (size_t)bytes, NCCL_INT8, ctx->comm.nccl_comm, ctx->stream);
   if (!rc && hipMemcpyAsync(recv, d, (size_t)bytes * ctx->comm.size, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = 3;
   if (ks_sync(ctx) != hipSuccess && !rc) rc = 4;
-  hipFree(d);
   return rc;
 }
 static int rccl_exchange(void *user, int npeers, const int *peers, const void *dev_send, const int *send_off, const int *send_cnt,
@@ -401,7 +400,7 @@ int ks_allreduce_sum(ks_ctx ctx, double *dev_buf, int count)
 
 int ks_comm_allgather_host(ks_ctx ctx, const void *send, int bytes, void *recv)
 {
-  if (ctx->comm.size == 1) { memcpy(recv, send, bytes); return KS_SUCCESS; }
+  if (ctx->comm.size == 1 && !(ctx->comm.force_collectives && ctx->comm.ops.allgather_host)) { memcpy(recv, send, bytes); return KS_SUCCESS; }
   KS_CHECK(ctx->comm.ops.allgather_host, KS_ERR_ORDER, "no communicator");
   int rc = ctx->comm.ops.allgather_host(ctx->comm.user, send, bytes, recv);
   KS_CHECK(rc == 0, KS_ERR_LIB, "allgather failed (%d)", rc);
@@ -410,7 +409,7 @@ int ks_comm_allgather_host(ks_ctx ctx, const void *send, int bytes, void *recv)
 
 int ks_comm_bcast0_host(ks_ctx ctx, void *buf, int bytes)
 {
-  if (ctx->comm.size == 1 || bytes <= 0) return KS_SUCCESS;
+  if ((ctx->comm.size == 1 && !ctx->comm.force_collectives) || bytes <= 0) return KS_SUCCESS;
   std::vector<char> all((size_t)bytes * ctx->comm.size);
   KS_CALL(ks_comm_allgather_host(ctx, buf, bytes, all.data()));
   if (ctx->comm.rank) memcpy(buf, all.data(), (size_t)bytes);
@@ -425,4 +424,50 @@ int ks_comm_exchange(ks_ctx ctx, int npeers, const int *peers, const void *dev_s
   int rc = ctx->comm.ops.exchange(ctx->comm.user, npeers, peers, dev_send, send_off, send_cnt, dev_recv, recv_off, recv_cnt, elem_bytes, (void *)(stream ? stream : ctx->stream));
   KS_CHECK(rc == 0, KS_ERR_LIB, "neighbour exchange failed (%d)", rc);
   return KS_SUCCESS;
+}
+
+// Known-answer run of the three provider operations (what an integrator calls once after installing a communicator, and
+// what bench.py calls before the timed region): an allreduce whose sum is known in closed form, an allgather of one int per
+// rank, and a ring exchange with the neighbours rank+1 and rank-1 (with itself at size 1 under KSGPU_FORCE_MULTI).
+extern "C" int ks_comm_check(ks_ctx ctx)
+{
+  KS_CHECK(ctx, KS_ERR_ARG_NULL, "ctx is NULL");
+  KS_HIP(hipSetDevice(ctx->device));
+  const int size = ctx->comm.size, rank = ctx->comm.rank;
+  if (!ks_is_multi(ctx)) return KS_SUCCESS;
+  double *d = nullptr;
+  KS_HIP(hipMalloc(&d, 16 * sizeof(double)));
+  int rc = KS_SUCCESS;
+  do {
+    double h[16];
+    for (int i = 0; i < 4; i++) h[i] = (double)(rank + 1) * (i + 1);
+    if (hipMemcpyAsync(d, h, 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = KS_ERR_LIB; break; }
+    if ((rc = ks_allreduce_sum(ctx, d, 4))) break;
+    if (hipMemcpyAsync(h, d, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || ks_sync(ctx) != hipSuccess) { rc = KS_ERR_LIB; break; }
+    for (int i = 0; i < 4; i++)
+      if (h[i] != 0.5 * size * (size + 1) * (i + 1)) { ks_set_error("communicator check: allreduce gave %g for entry %d, expected %g", h[i], i, 0.5 * size * (size + 1) * (i + 1)); rc = KS_ERR_LIB; }
+    if (rc) break;
+    std::vector<int> all(size, -1);
+    const int mine = 7 * rank + 1;
+    if ((rc = ks_comm_allgather_host(ctx, &mine, (int)sizeof(int), all.data()))) break;
+    if ((rc = ks_comm_allgather_host(ctx, &mine, (int)sizeof(int), all.data()))) break;       // twice: the staging buffer is reused
+    for (int r = 0; r < size; r++)
+      if (all[r] != 7 * r + 1) { ks_set_error("communicator check: allgather slot %d holds %d, expected %d", r, all[r], 7 * r + 1); rc = KS_ERR_LIB; }
+    if (rc) break;
+    if (size == 1 && !ctx->comm.nccl_comm) break;                  // a caller-supplied provider need not know how to exchange with itself
+    int peers[2] = { (rank + 1) % size, (rank + size - 1) % size };
+    const int np = peers[0] == peers[1] ? 1 : 2;
+    int soff[2] = { 0, 2 }, roff[2] = { 0, 2 }, cnt[2] = { 2, 2 };
+    for (int i = 0; i < np; i++) { h[2 * i] = 100.0 * rank + peers[i]; h[2 * i + 1] = -h[2 * i]; }
+    for (int i = 4; i < 8; i++) h[i] = 0.0;
+    if (hipMemcpyAsync(d, h, 8 * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = KS_ERR_LIB; break; }
+    if ((rc = ks_comm_exchange(ctx, np, peers, d, soff, cnt, d + 4, roff, cnt, (int)sizeof(double), ctx->stream))) break;
+    if (hipMemcpyAsync(h, d, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || ks_sync(ctx) != hipSuccess) { rc = KS_ERR_LIB; break; }
+    for (int i = 0; i < np; i++) {
+      const double want = 100.0 * peers[i] + rank;
+      if (h[4 + 2 * i] != want || h[4 + 2 * i + 1] != -want) { ks_set_error("communicator check: exchange with rank %d delivered %g %g, expected %g %g", peers[i], h[4 + 2 * i], h[4 + 2 * i + 1], want, -want); rc = KS_ERR_LIB; }
+    }
+  } while (0);
+  hipFree(d);
+  return rc;
 }

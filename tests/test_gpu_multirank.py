@@ -71,6 +71,7 @@ def _worker(rank, world, port, q):
         from oracle import oracle as O
         ctx = ks.Context(0)
         _install_gloo_ops(ks, ctx, dist, torch, rank, world)
+        ctx.comm_check()
         nx, ny, nz = 12, 10, 9
         plane = nx * ny
         z0, z1 = P.split_ownership(nz, world)[rank]
@@ -249,6 +250,8 @@ def _rccl_worker(q):
         from oracle import oracle as O
         ctx = ks.Context(0)
         ctx.init_rccl(0, 1, ks.Context.get_unique_id())
+        ctx.comm_check()                  # ncclAllReduce, ncclAllGather (staging buffer reused by a second call), ncclSend/ncclRecv with itself
+        ctx.comm_check()
         Ao = O.laplacian2d(40)
         A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
         eps = ks.EPS(ctx); eps.SetOperators(A); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(4, 20); eps.Solve()

@@ -70,6 +70,7 @@ def _rank(rank, world, comm, geom, x, m, out):
         plane = nx * ny
         ctx = ks.Context(0)
         comm.install(ctx, rank)
+        ctx.comm_check()
         A = ks.Mat.laplacian3d(ctx, nx, ny, p * world, rank * p, p)
         r0, r1 = rank * p * plane, (rank + 1) * p * plane
         res = {"n": A.n, "layout": A.layout()}
