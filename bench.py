@@ -390,6 +390,26 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def oneshot_child(args, limit=180.0):
+    """The N>1 measurement once more with the one-shot allreduce, in a child process per rank (same launcher environment, another
+    rendezvous port): whatever happens to that path - mailboxes that cannot be mapped, a check that fails, a hang - stays in the
+    children, which are stopped at `limit` seconds; the headline number has been taken before and is reported regardless."""
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(20000 + (int(env.get("MASTER_PORT", "29511")) + 1789) % 20000)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--min-steps", str(args.min_steps), "--side", str(args.side), "--no-configs", "--no-cpu-baseline", "--no-prof", "--oneshot-leg"]
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=None if env.get("RANK", "0") == "0" else subprocess.DEVNULL, timeout=limit)
+        lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if lines:
+            return json.loads(lines[-1])
+        return {"active": "unknown", "reason": "the child left no report (exit code %d)" % p.returncode}
+    except subprocess.TimeoutExpired:
+        return {"active": "unknown", "reason": "the child was stopped after %.0f s" % limit}
+    except Exception as e:       # noqa: BLE001 - the side leg must not take the headline down with it
+        return {"active": "unknown", "reason": "%r" % (e,)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -402,6 +422,8 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the side legs (configs C2 / C5, SpMV layouts)")
     ap.add_argument("--no-c5", action="store_true")
     ap.add_argument("--c5-n", type=int, default=5000000)
+    ap.add_argument("--no-oneshot", action="store_true", help="N>1: skip the side leg that repeats the measurement with the one-shot allreduce")
+    ap.add_argument("--oneshot-leg", action="store_true", help=argparse.SUPPRESS)     # the side leg itself (a child process of every rank)
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -423,6 +445,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     force_dist = os.environ.get("BENCH_FORCE_DIST") == "1"     # rehearse the N>1 code path (RCCL comm, slab grid) on one GPU
+    if force_dist:
+        os.environ.setdefault("KSGPU_FORCE_MULTI", "1")        # ... with the collectives really issued (allreduce per pass, broadcast per restart)
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -437,6 +461,25 @@ def main():
         dist.broadcast(idt, 0)
         ctx.init_rccl(rank, world, bytes(idt.cpu().numpy().tobytes()))
         ctx.comm_check()                  # allreduce / allgather / neighbour exchange against known answers before anything is timed
+    oneshot = None
+    if args.oneshot_leg and dist is None:
+        raise SystemExit("--oneshot-leg is the N>1 side leg")
+    if args.oneshot_leg:
+        # every rank's verdict is the same at each of these exits (set_allreduce and comm_check agree among the ranks)
+        oneshot = {"active": ctx.set_allreduce("oneshot")}
+        if oneshot["active"] == "oneshot":
+            try:
+                ctx.comm_check()
+            except RuntimeError as e:
+                oneshot = {"active": "provider", "reason": "known-answer check failed with the one-shot path: %s" % e}
+                ctx.set_allreduce("provider")
+        else:
+            oneshot["reason"] = "some rank could not map the other ranks' mailboxes"
+        if oneshot["active"] != "oneshot":
+            if rank == 0:
+                os.dup2(real_stdout, 1); print(json.dumps(oneshot), flush=True); os.dup2(2, 1)
+            dist.barrier(); dist.destroy_process_group()
+            return
 
     side = args.side
     if world == 1 and not force_dist:
@@ -464,9 +507,19 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     steps = t["steps"]
+    if args.oneshot_leg:
+        if rank == 0:
+            oneshot.update({"value": world * steps / dt, "unit": "steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "gs_passes_per_step": t["gs_passes"] / steps})
+            os.dup2(real_stdout, 1); print(json.dumps(oneshot), flush=True); os.dup2(2, 1)
+        del eps
+        dist.barrier(); dist.destroy_process_group()
+        return
     prof_timed, prof = ph.prof_timed, ph.prof_tail
     tail_steps = (ph.marks["t2"][0] - ph.marks["t1"][0]) if "t2" in ph.marks else 0
 
+    leg = None
+    if dist is not None and not args.no_oneshot:
+        leg = oneshot_child(args)         # every rank starts its own child; rank 0's child reports
     if rank == 0:
         n_local = A.n
         out = {
@@ -539,6 +592,12 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(side)
             except Exception as e:       # noqa: BLE001 - the baseline must not take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+        if leg is not None:
+            if leg.get("value"):
+                leg["vs_provider_allreduce"] = round(leg["value"] / out["value"], 4)
+            leg["note"] = ("the same measurement in a child process of every rank with ks_comm_set_allreduce(ONESHOT): the Gram-Schmidt sums go through "
+                           "peer-mapped mailboxes, one kernel per rank, instead of ncclAllReduce; `value` above is the RCCL path")
+            out["oneshot_allreduce"] = leg
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

@@ -126,6 +126,20 @@ int ks_comm_rank_size(ks_ctx ctx, int *rank, int *size);
  * on a single rank without forced collectives. (The reference leans on MPI's own correctness here; a communicator handed in
  * through ks_comm_set_ops is foreign code, so the library offers the check an integrator runs once after installing it.) */
 int ks_comm_check(ks_ctx ctx);
+/* Which allreduce the Gram-Schmidt passes use. KS_ALLREDUCE_PROVIDER: the communicator's own (ncclAllReduce with the
+ * RCCL provider; what bvblas.c:255 MPIU_Allreduce is to the reference). KS_ALLREDUCE_ONESHOT: one kernel per rank writes the k+1
+ * values into a mailbox of every rank (peer-mapped uncached device memory: hipIpc between processes, xGMI between GPUs) and adds
+ * what arrived in rank order - identical bits on all ranks, no library call on the critical path; reductions longer than 128
+ * doubles keep going through the provider. Collective; *active returns what was installed: the one-shot path is taken only if
+ * every rank could map every mailbox, else all ranks stay on the provider. A rank that receives no packet within
+ * KSGPU_ONESHOT_TIMEOUT_MS (default 2000) returns NaN and the next host wait fails with KS_ERR_LIB - never a hang. */
+#define KS_ALLREDUCE_PROVIDER 0
+#define KS_ALLREDUCE_ONESHOT 1
+int ks_comm_set_allreduce(ks_ctx ctx, int kind, int *active);
+int ks_comm_get_allreduce(ks_ctx ctx, int *active);
+/* in-place SUM over the ranks of `count` doubles in device memory, ordered on the context's stream (bvblas.c:255 MPIU_Allreduce): the
+ * reduction every library kernel uses, for callers that keep their own replicated device scalars (an adapter's VecDot) */
+int ks_comm_allreduce_sum(ks_ctx ctx, double *dev_buf, int count);
 /* device<->host copy on the context's stream (synchronous); kind: 0 = host->device, 1 = device->host */
 int ks_ctx_memcpy(ks_ctx ctx, void *dst, const void *src, size_t bytes, int kind);
 /* the same on a given stream (the `stream` argument a ks_comm_ops callback receives; NULL = the context's): what a provider that

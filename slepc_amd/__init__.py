@@ -143,6 +143,17 @@ class Context:
         _lib.check(self.L.ks_comm_set_ops(self.h, rank, size, C.byref(self._ops), None))
         self.rank, self.size = rank, size
 
+    def set_allreduce(self, kind):
+        """kind: "oneshot" (peer-mapped mailboxes, one kernel per rank) or "provider" (the communicator's allreduce).
+        Collective; returns what is active afterwards - "provider" if any rank could not map the mailboxes."""
+        act = C.c_int()
+        _lib.check(self.L.ks_comm_set_allreduce(self.h, {"provider": 0, "oneshot": 1}[kind], C.byref(act)))
+        return "oneshot" if act.value == 1 else "provider"
+
+    def allreduce_sum_dev(self, dev_ptr, count):
+        """In-place sum over the ranks of `count` doubles at a device address, ordered on the context's stream."""
+        _lib.check(self.L.ks_comm_allreduce_sum(self.h, C.c_void_p(dev_ptr), count))
+
     def comm_check(self):
         """Known-answer run of the installed communicator (collective): allreduce, allgather, ring exchange."""
         _lib.check(self.L.ks_comm_check(self.h))

@@ -42,6 +42,9 @@ _SIG = {
     "ks_ctx_memcpy_stream": [vp, vp, vp, C.c_size_t, C.c_int, vp],
     "ks_comm_rank_size": [vp, ip, ip],
     "ks_comm_check": [vp],
+    "ks_comm_set_allreduce": [vp, C.c_int, ip],
+    "ks_comm_get_allreduce": [vp, ip],
+    "ks_comm_allreduce_sum": [vp, vp, C.c_int],
     # mat
     "ks_mat_create_csr": [vp, C.c_int, C.c_int, C.c_int, ip, ip, dp, C.POINTER(vp)],
     "ks_mat_create_laplacian3d": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],

@@ -1,7 +1,10 @@
 // Context, error reporting, HIP-event profiling and the allreduce providers (RCCL / callback).
 #include "ksgpu_internal.h"
+#include "ks_oneshot.cuh"
 #include <cstdarg>
 #include <dlfcn.h>
+#include <unistd.h>
+#include <cstdint>
 
 static thread_local char g_errmsg[512] = "";
 
@@ -82,6 +85,7 @@ extern "C" int ks_ctx_destroy(ks_ctx ctx)
   ks_sync(ctx);
   for (auto &p : ctx->pending) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
   for (auto &e : ctx->event_pool) hipEventDestroy(e);
+  ks_oneshot_release(ctx);
   if (ctx->comm.nccl_comm && ctx->comm.rccl_lib) {
     typedef int (*destroy_t)(void *);
     destroy_t f = (destroy_t)dlsym(ctx->comm.rccl_lib, "ncclCommDestroy");
@@ -387,12 +391,160 @@ extern "C" int ks_ctx_memcpy(ks_ctx ctx, void *dst, const void *src, size_t byte
   return KS_SUCCESS;
 }
 
+// ---- one-shot allreduce -------------------------------------------------------------------------
+// the k+1 <= 61 doubles of a Gram-Schmidt pass are summed by ONE kernel per rank and no library call: every rank
+// writes its values into a mailbox of every rank (its own included) and then adds what arrived in its own mailbox in rank
+// order, so all ranks hold the same bits. A double travels as two 8-byte packets {sequence number, 32 data bits}: an
+// 8-byte store is indivisible on the fabric, so a packet whose sequence number matches carries its data and no fence or
+// separate flag is needed. Mailboxes live in uncached device memory (remote stores land in memory, local polls read memory).
+// Two parities of slots: a rank can be at most one call ahead of another (it needs that rank's packets of call s+1 to get
+// past s+1, and those are sent after the rank has consumed call s), so packets of call s+2 never overwrite unread ones of s.
+// Every wait is bounded: a rank that sees no packet for timeout_ticks gives up, poisons its result with NaN and raises the
+// error word the host finds at its next wait.
+__global__ __launch_bounds__(512) void k_allreduce_oneshot(double *__restrict__ buf, int count, KsOneShotArgs o)
+{
+  __shared__ unsigned sh[KS_ONESHOT_MAX_RANKS][2 * KS_ONESHOT_MAX_COUNT];
+  __shared__ int failed;
+  ks_oneshot_sum(buf, buf, count, o, sh, &failed);
+}
+
+static int oneshot_allreduce(ks_ctx ctx, double *dev_buf, int count)
+{
+  auto &os = ctx->comm.oneshot;
+  KsOneShotArgs o;
+  KS_CHECK(ks_oneshot_next(ctx, count, &o), KS_ERR_PLIB, "one-shot allreduce is not active");
+  (void)os;
+  hipLaunchKernelGGL(k_allreduce_oneshot, dim3(1), dim3(512), 0, ctx->stream, dev_buf, count, o);
+  KS_HIP(hipGetLastError());
+  return KS_SUCCESS;
+}
+
+// the arguments of the next one-shot call (its sequence number is consumed); false: not active, or too long a message
+bool ks_oneshot_next(ks_ctx ctx, int count, KsOneShotArgs *o)
+{
+  auto &os = ctx->comm.oneshot;
+  if (!os.enabled || count > KS_ONESHOT_MAX_COUNT || count <= 0) return false;
+  if (++os.seq == 0) ++os.seq;                       // 0 is what an untouched mailbox holds
+  for (int r = 0; r < KS_ONESHOT_MAX_RANKS; r++) o->peer[r] = os.peer[r];
+  o->mine = os.mine; o->err = os.err_dev; o->err_local = os.err_local; o->timeout_ticks = os.timeout_ticks; o->seq = os.seq; o->me = ctx->comm.rank; o->size = ctx->comm.size;
+  return true;
+}
+
+int ks_oneshot_error(ks_ctx ctx)
+{
+  const volatile int *e = ctx->comm.oneshot.err_host;
+  if (e && *e) KS_FAIL(KS_ERR_LIB, "one-shot allreduce number %d saw no packet from some rank within its time limit (results since then are NaN)", *e);
+  return KS_SUCCESS;
+}
+
+void ks_oneshot_release(ks_ctx ctx)
+{
+  auto &os = ctx->comm.oneshot;
+  os.enabled = false;
+  for (int r = 0; r < KS_ONESHOT_MAX_RANKS; r++) {
+    if (os.opened[r] && os.peer[r]) hipIpcCloseMemHandle(os.peer[r]);
+    os.peer[r] = nullptr; os.opened[r] = false;
+  }
+  if (os.mine) hipFree(os.mine);
+  os.mine = nullptr;
+  if (os.err_host) hipHostFree(os.err_host);
+  os.err_host = os.err_dev = nullptr;
+  if (os.err_local) hipFree(os.err_local);
+  os.err_local = nullptr;
+  (void)hipGetLastError();
+}
+
+struct OneShotHello { int ok, pid, device, pad; unsigned long long ptr; hipIpcMemHandle_t handle; };
+
+// Collective. kind KS_ALLREDUCE_ONESHOT: map every rank's mailbox; the one-shot path is switched on only if EVERY rank managed
+// (the ranks agree through a second allgather), otherwise everything is released again and the provider's allreduce stays.
+extern "C" int ks_comm_set_allreduce(ks_ctx ctx, int kind, int *active)
+{
+  KS_CHECK(ctx, KS_ERR_ARG_NULL, "ctx is NULL");
+  KS_CHECK(kind == KS_ALLREDUCE_PROVIDER || kind == KS_ALLREDUCE_ONESHOT, KS_ERR_ARG_OUTOFRANGE, "unknown allreduce kind %d", kind);
+  KS_HIP(hipSetDevice(ctx->device));
+  KS_HIP(hipStreamSynchronize(ctx->stream));
+  auto &os = ctx->comm.oneshot;
+  if (active) *active = KS_ALLREDUCE_PROVIDER;
+  ks_oneshot_release(ctx);
+  if (kind == KS_ALLREDUCE_PROVIDER || !ks_is_multi(ctx)) return KS_SUCCESS;
+  const int size = ctx->comm.size, rank = ctx->comm.rank;
+  KS_CHECK(ctx->comm.ops.allgather_host, KS_ERR_ORDER, "no communicator installed");
+  const size_t bytes = (size_t)2 * KS_ONESHOT_MAX_RANKS * 2 * KS_ONESHOT_MAX_COUNT * sizeof(unsigned long long);
+  OneShotHello me; memset(&me, 0, sizeof(me));
+  me.pid = (int)getpid(); me.device = ctx->device;
+  bool ok = size <= KS_ONESHOT_MAX_RANKS;
+  if (ok) {
+    void *p = nullptr;
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+    if (!p && hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+    os.mine = (unsigned long long *)p;
+    ok = p && hipMemset(p, 0, bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    if (ok) ok = hipHostMalloc((void **)&os.err_host, sizeof(int), hipHostMallocMapped) == hipSuccess;
+    if (ok) { *os.err_host = 0; ok = hipHostGetDevicePointer((void **)&os.err_dev, os.err_host, 0) == hipSuccess; }
+    if (ok) ok = hipMalloc((void **)&os.err_local, sizeof(int)) == hipSuccess && hipMemset(os.err_local, 0, sizeof(int)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    if (ok) {
+      me.ptr = (unsigned long long)(uintptr_t)p;
+      if (hipIpcGetMemHandle(&me.handle, p) != hipSuccess) { (void)hipGetLastError(); me.pad = 1; }     // pad = 1: no handle; ranks of this process can still use the pointer
+    }
+  }
+  me.ok = ok ? 1 : 0;
+  std::vector<OneShotHello> all(size);
+  KS_CALL(ks_comm_allgather_host(ctx, &me, (int)sizeof(me), all.data()));
+  for (int r = 0; r < size && ok; r++) {
+    if (!all[r].ok) { ok = false; break; }
+    if (r == rank) { os.peer[r] = os.mine; continue; }
+    if (all[r].pid == me.pid) {
+      if (all[r].device != ctx->device) {
+        hipError_t e = hipDeviceEnablePeerAccess(all[r].device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = false;
+        (void)hipGetLastError();
+      }
+      os.peer[r] = (unsigned long long *)(uintptr_t)all[r].ptr;
+    } else {
+      void *q = nullptr;
+      if (all[r].pad || hipIpcOpenMemHandle(&q, all[r].handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+      else { os.peer[r] = (unsigned long long *)q; os.opened[r] = true; }
+    }
+  }
+  int mine_ok = ok ? 1 : 0;
+  std::vector<int> oks(size, 0);
+  KS_CALL(ks_comm_allgather_host(ctx, &mine_ok, (int)sizeof(int), oks.data()));
+  for (int r = 0; r < size; r++) if (!oks[r]) ok = false;
+  if (!ok) { ks_oneshot_release(ctx); return KS_SUCCESS; }
+  int khz = 100000;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
+  const char *tm = getenv("KSGPU_ONESHOT_TIMEOUT_MS");
+  const long long ms = tm && atoll(tm) > 0 ? atoll(tm) : 2000;
+  os.timeout_ticks = ms * khz;
+  os.seq = 0;
+  os.enabled = true;
+  if (active) *active = KS_ALLREDUCE_ONESHOT;
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_comm_allreduce_sum(ks_ctx ctx, double *dev_buf, int count)
+{
+  KS_CHECK(ctx && dev_buf, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(count >= 0, KS_ERR_ARG_OUTOFRANGE, "negative count");
+  KS_HIP(hipSetDevice(ctx->device));
+  return ks_allreduce_sum(ctx, dev_buf, count);
+}
+
+extern "C" int ks_comm_get_allreduce(ks_ctx ctx, int *active)
+{
+  KS_CHECK(ctx && active, KS_ERR_ARG_NULL, "NULL argument");
+  *active = ctx->comm.oneshot.enabled ? KS_ALLREDUCE_ONESHOT : KS_ALLREDUCE_PROVIDER;
+  return KS_SUCCESS;
+}
+
 // In-place SUM allreduce of `count` doubles in device memory, stream-ordered (bvblas.c:255 MPIU_Allreduce).
 int ks_allreduce_sum(ks_ctx ctx, double *dev_buf, int count)
 {
   if (!ks_is_multi(ctx) || count <= 0) return KS_SUCCESS;
   KS_CHECK(ctx->comm.ops.allreduce_sum, KS_ERR_ORDER, "size>1 but no communicator: call ks_comm_init_rccl or ks_comm_set_ops");
   KsProfScope ps(ctx, KS_K_ALLREDUCE, 8.0 * count);
+  if (ctx->comm.oneshot.enabled && count <= KS_ONESHOT_MAX_COUNT) return oneshot_allreduce(ctx, dev_buf, count);
   int rc = ctx->comm.ops.allreduce_sum(ctx->comm.user, dev_buf, count, (void *)ctx->stream);
   KS_CHECK(rc == 0, KS_ERR_LIB, "allreduce failed (%d)", rc);
   return KS_SUCCESS;
@@ -427,47 +579,67 @@ int ks_comm_exchange(ks_ctx ctx, int npeers, const int *peers, const void *dev_s
 }
 
 // Known-answer run of the three provider operations (what an integrator calls once after installing a communicator, and
-// what bench.py calls before the timed region): an allreduce whose sum is known in closed form, an allgather of one int per
+// what bench.py calls before the timed region): allreduces whose sums are known in closed form (64 of them enqueued back to
+// back, so that a one-shot path goes through its slot parities without a host wait in between), allgathers of one int per
 // rank, and a ring exchange with the neighbours rank+1 and rank-1 (with itself at size 1 under KSGPU_FORCE_MULTI).
+// Every rank runs every stage whatever it has seen so far, and the verdict is agreed through a last allgather: the call
+// returns the same on all ranks and leaves no rank waiting in a collective the others skipped.
 extern "C" int ks_comm_check(ks_ctx ctx)
 {
   KS_CHECK(ctx, KS_ERR_ARG_NULL, "ctx is NULL");
   KS_HIP(hipSetDevice(ctx->device));
   const int size = ctx->comm.size, rank = ctx->comm.rank;
   if (!ks_is_multi(ctx)) return KS_SUCCESS;
+  KS_CHECK(ctx->comm.ops.allreduce_sum && ctx->comm.ops.allgather_host && ctx->comm.ops.exchange, KS_ERR_ORDER, "no communicator installed");
+  constexpr int NCALL = 64, LEN = 8;
   double *d = nullptr;
-  KS_HIP(hipMalloc(&d, 16 * sizeof(double)));
-  int rc = KS_SUCCESS;
-  do {
-    double h[16];
-    for (int i = 0; i < 4; i++) h[i] = (double)(rank + 1) * (i + 1);
-    if (hipMemcpyAsync(d, h, 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = KS_ERR_LIB; break; }
-    if ((rc = ks_allreduce_sum(ctx, d, 4))) break;
-    if (hipMemcpyAsync(h, d, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || ks_sync(ctx) != hipSuccess) { rc = KS_ERR_LIB; break; }
-    for (int i = 0; i < 4; i++)
-      if (h[i] != 0.5 * size * (size + 1) * (i + 1)) { ks_set_error("communicator check: allreduce gave %g for entry %d, expected %g", h[i], i, 0.5 * size * (size + 1) * (i + 1)); rc = KS_ERR_LIB; }
-    if (rc) break;
+  KS_HIP(hipMalloc(&d, (NCALL * LEN + 16) * sizeof(double)));
+  std::vector<double> h(NCALL * LEN + 16);
+  bool bad = false;
+  char msg[400] = "";
+  auto fail = [&](const char *fmt, auto... a) { if (!bad) snprintf(msg, sizeof(msg), fmt, a...); bad = true; };
+  // (1) allreduce
+  for (int i = 0; i < NCALL; i++) for (int j = 0; j < LEN; j++) h[i * LEN + j] = (rank + 1) * (i + 1) * (j + 1) / 16.0;
+  if (hipMemcpyAsync(d, h.data(), NCALL * LEN * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) fail("communicator check: upload failed");
+  for (int i = 0; i < NCALL; i++)
+    if (ks_allreduce_sum(ctx, d + i * LEN, LEN) != KS_SUCCESS) fail("communicator check: allreduce call %d failed: %s", i, ks_last_error_message());
+  if (hipMemcpyAsync(h.data(), d, NCALL * LEN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || ks_sync(ctx) != hipSuccess) {
+    if (ks_oneshot_error(ctx)) fail("communicator check: %s", ks_last_error_message());        // the one-shot path gave up waiting
+    else fail("communicator check: waiting for the allreduces failed");
+  }
+  for (int i = 0; i < NCALL && !bad; i++) for (int j = 0; j < LEN; j++) {
+    const double want = 0.5 * size * (size + 1) * (i + 1) * (j + 1) / 16.0;
+    if (h[i * LEN + j] != want) { fail("communicator check: allreduce %d gave %g for entry %d, expected %g", i, h[i * LEN + j], j, want); break; }
+  }
+  // (2) allgather, twice: the staging buffer is reused
+  for (int rep = 0; rep < 2; rep++) {
     std::vector<int> all(size, -1);
-    const int mine = 7 * rank + 1;
-    if ((rc = ks_comm_allgather_host(ctx, &mine, (int)sizeof(int), all.data()))) break;
-    if ((rc = ks_comm_allgather_host(ctx, &mine, (int)sizeof(int), all.data()))) break;       // twice: the staging buffer is reused
-    for (int r = 0; r < size; r++)
-      if (all[r] != 7 * r + 1) { ks_set_error("communicator check: allgather slot %d holds %d, expected %d", r, all[r], 7 * r + 1); rc = KS_ERR_LIB; }
-    if (rc) break;
-    if (size == 1 && !ctx->comm.nccl_comm) break;                  // a caller-supplied provider need not know how to exchange with itself
+    const int mine = 7 * rank + 1 + rep;
+    if (ctx->comm.ops.allgather_host(ctx->comm.user, &mine, (int)sizeof(int), all.data()) != 0 && !ctx->comm.oneshot.err_host) fail("communicator check: allgather failed");
+    for (int r = 0; r < size; r++) if (all[r] != 7 * r + 1 + rep) fail("communicator check: allgather slot %d holds %d, expected %d", r, all[r], 7 * r + 1 + rep);
+  }
+  // (3) ring exchange
+  if (size > 1 || ctx->comm.nccl_comm) {                  // a caller-supplied provider need not know how to exchange with itself
     int peers[2] = { (rank + 1) % size, (rank + size - 1) % size };
     const int np = peers[0] == peers[1] ? 1 : 2;
     int soff[2] = { 0, 2 }, roff[2] = { 0, 2 }, cnt[2] = { 2, 2 };
     for (int i = 0; i < np; i++) { h[2 * i] = 100.0 * rank + peers[i]; h[2 * i + 1] = -h[2 * i]; }
     for (int i = 4; i < 8; i++) h[i] = 0.0;
-    if (hipMemcpyAsync(d, h, 8 * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = KS_ERR_LIB; break; }
-    if ((rc = ks_comm_exchange(ctx, np, peers, d, soff, cnt, d + 4, roff, cnt, (int)sizeof(double), ctx->stream))) break;
-    if (hipMemcpyAsync(h, d, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || ks_sync(ctx) != hipSuccess) { rc = KS_ERR_LIB; break; }
+    if (hipMemcpyAsync(d, h.data(), 8 * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) fail("communicator check: upload failed");
+    if (ctx->comm.ops.exchange(ctx->comm.user, np, peers, d, soff, cnt, d + 4, roff, cnt, (int)sizeof(double), (void *)ctx->stream) != 0) fail("communicator check: neighbour exchange failed");
+    if (hipMemcpyAsync(h.data(), d, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) fail("communicator check: waiting for the exchange failed");
     for (int i = 0; i < np; i++) {
       const double want = 100.0 * peers[i] + rank;
-      if (h[4 + 2 * i] != want || h[4 + 2 * i + 1] != -want) { ks_set_error("communicator check: exchange with rank %d delivered %g %g, expected %g %g", peers[i], h[4 + 2 * i], h[4 + 2 * i + 1], want, -want); rc = KS_ERR_LIB; }
+      if (h[4 + 2 * i] != want || h[4 + 2 * i + 1] != -want) fail("communicator check: exchange with rank %d delivered %g %g, expected %g %g", peers[i], h[4 + 2 * i], h[4 + 2 * i + 1], want, -want);
     }
-  } while (0);
+  }
+  // (4) the verdict, agreed
+  std::vector<int> verdict(size, 1);
+  const int mine = bad ? 1 : 0;
+  (void)ctx->comm.ops.allgather_host(ctx->comm.user, &mine, (int)sizeof(int), verdict.data());
   hipFree(d);
-  return rc;
+  (void)hipGetLastError();
+  if (bad) KS_FAIL(KS_ERR_LIB, "%s", msg);
+  for (int r = 0; r < size; r++) if (verdict[r]) KS_FAIL(KS_ERR_LIB, "communicator check: rank %d reported a failure", r);
+  return KS_SUCCESS;
 }

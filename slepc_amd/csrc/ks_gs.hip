@@ -21,6 +21,7 @@
 // Multi-rank: the reduce and bookkeeping halves are split around an allreduce of k+1 doubles
 // (bvblas.c:255 MPIU_Allreduce) on the same stream.
 #include "ks_sweeps.cuh"
+#include "ks_oneshot.cuh"
 #include <algorithm>
 
 using namespace ksk;
@@ -179,6 +180,17 @@ __global__ __launch_bounds__(GF_BLOCK) void k_reduce_state(const double *__restr
   __shared__ double c_lds[KS_MAX_COLS + 8];
   reduce_partials_to_lds(partials, st->pgrid, ncols, c_lds);
   if ((int)threadIdx.x < ncols) out[threadIdx.x] = c_lds[threadIdx.x];
+}
+
+// the same with the one-shot allreduce behind it: the block sums go from LDS into every rank's mailbox, out receives the global sums
+__global__ __launch_bounds__(GF_BLOCK) void k_reduce_oneshot(const double *__restrict__ partials, const KsGsState *__restrict__ st, int ncols, double *__restrict__ out, KsOneShotArgs o)
+{
+  __shared__ double c_lds[KS_MAX_COLS + 8];
+  __shared__ unsigned sh[KS_ONESHOT_MAX_RANKS][2 * KS_ONESHOT_MAX_COUNT];
+  __shared__ int failed;
+  reduce_partials_to_lds(partials, st->pgrid, ncols, c_lds);
+  __syncthreads();
+  ks_oneshot_sum(c_lds, out, ncols, o, sh, &failed);
 }
 
 // the global-memory side of a plan: H(:,col) (entries nc+i, bvbasic.c:784-786), the pending coefficients, BV_SetValue; all lanes
@@ -468,6 +480,13 @@ int launch_reduce_allreduce(ks_bv bv, const GsArgs &a)
   ks_ctx ctx = bv->ctx;
   KsProfScope ps(ctx, KS_K_GSFIN, 8.0 * bv->last_grid * (a.k + 1));
   ps.tag(a.col, a.slot, a.k, bv->n);
+  KsOneShotArgs o;
+  if (ks_oneshot_next(ctx, a.k + 1, &o)) {       // reduction and exchange in one launch
+    KS_CALL(ks_oneshot_error(ctx));
+    hipLaunchKernelGGL(k_reduce_oneshot, dim3(1), dim3(GF_BLOCK), 0, ctx->stream, bv->partials, bv->gs, a.k + 1, bv->cred, o);
+    KS_HIP(hipGetLastError());
+    return KS_SUCCESS;
+  }
   hipLaunchKernelGGL(k_reduce_state, dim3(1), dim3(GF_BLOCK), 0, ctx->stream, bv->partials, bv->gs, a.k + 1, bv->cred);
   KS_HIP(hipGetLastError());
   return ks_allreduce_sum(ctx, bv->cred, a.k + 1);

@@ -22,6 +22,8 @@ struct KsProfSlot { long long launches = 0; double ms = 0.0; double bytes = 0.0;
 struct KsProfPending { hipEvent_t e0, e1; int kclass; int variant; double bytes; double hbm; int tag_col; int tag_slot; int tag_k; long long tag_n; bool done; };
 
 // ---- communicator -------------------------------------------------------------------------------
+#define KS_ONESHOT_MAX_RANKS 16
+#define KS_ONESHOT_MAX_COUNT 128
 struct KsComm {
   int rank = 0, size = 1;
   bool force_collectives = false;   // KSGPU_FORCE_MULTI=1: take the multi-rank code path even with one rank (tests)
@@ -32,6 +34,18 @@ struct KsComm {
   // active provider (RCCL fills these with its own implementations)
   ks_comm_ops ops = {nullptr, nullptr, nullptr};
   void *user = nullptr;
+  // one-shot allreduce over peer-mapped mailboxes (ks_comm_set_allreduce): every rank owns a mailbox in uncached device
+  // memory, mapped by all the others (hipIpc between processes, the plain pointer inside one process)
+  struct {
+    bool enabled = false;
+    unsigned seq = 0;                                    // call counter, the same on every rank; travels inside every packet
+    unsigned long long *mine = nullptr;                  // [2 parities][KS_ONESHOT_MAX_RANKS][2 * KS_ONESHOT_MAX_COUNT] packets
+    unsigned long long *peer[KS_ONESHOT_MAX_RANKS] = {}; // every rank's mailbox as mapped here (peer[rank] == mine)
+    bool opened[KS_ONESHOT_MAX_RANKS] = {};              // mapped with hipIpcOpenMemHandle
+    int *err_host = nullptr, *err_dev = nullptr;         // pinned: the sequence number of the first call that timed out, 0 = none
+    int *err_local = nullptr;                            // the same word in device memory (what later kernels of this rank look at)
+    long long timeout_ticks = 0;                         // wall_clock64 ticks (100 MHz) a rank waits for a packet before it gives up
+  } oneshot;
 };
 
 struct ks_ctx_s {
@@ -64,7 +78,14 @@ struct ks_ctx_s {
 };
 
 // every host wait on the context's stream goes through here, so that tests can assert that a call enqueues without waiting
-static inline hipError_t ks_sync(ks_ctx ctx) { ctx->nsync++; return hipStreamSynchronize(ctx->stream); }
+// (a one-shot allreduce that gave up waiting shows here as a launch time-out, at the first wait after it)
+static inline hipError_t ks_sync(ks_ctx ctx)
+{
+  ctx->nsync++;
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  const volatile int *os = ctx->comm.oneshot.err_host;
+  return (e == hipSuccess && os && *os) ? hipErrorLaunchTimeOut : e;
+}
 
 int ks_prof_begin(ks_ctx ctx, int kclass, int variant, double alg_bytes, double hbm_bytes);   // records start event when profiling
 int ks_prof_end(ks_ctx ctx, size_t index);
@@ -82,6 +103,10 @@ struct KsStepRec;
 void ks_prof_resolve_gs(ks_ctx ctx, const KsStepRec *recs, int col0, int col1);   // re-file tagged records of columns [col0,col1]
 
 int ks_allreduce_sum(ks_ctx ctx, double *dev_buf, int count);   // no-op when size==1
+struct KsOneShotArgs { unsigned long long *peer[KS_ONESHOT_MAX_RANKS]; const unsigned long long *mine; int *err; int *err_local; long long timeout_ticks; unsigned seq; int me, size; };
+bool ks_oneshot_next(ks_ctx ctx, int count, KsOneShotArgs *o);  // arguments of the next one-shot call, or false when the provider has to do it
+int ks_oneshot_error(ks_ctx ctx);                               // KS_ERR_LIB once a one-shot allreduce has timed out (checked wherever the host has just waited)
+void ks_oneshot_release(ks_ctx ctx);
 int ks_comm_allgather_host(ks_ctx ctx, const void *send, int bytes, void *recv);
 int ks_comm_exchange(ks_ctx ctx, int npeers, const int *peers, const void *dev_send, const int *send_off, const int *send_cnt,
                      void *dev_recv, const int *recv_off, const int *recv_cnt, int elem_bytes, hipStream_t stream = nullptr);   // nullptr: the context's stream

@@ -279,3 +279,129 @@ def test_native_rccl_provider_single_rank_forced_collectives():
     assert "error" not in out, out.get("error")
     assert out["ok"]
     assert out["allreduces"] >= 2 * out["steps"]          # one ncclAllReduce per executed Gram-Schmidt pass went through RCCL
+
+
+def _oneshot_worker(rank, world, port, q, absent_rank):
+    """absent_rank >= 0: that rank skips one allreduce - the others must come back with an error, not hang."""
+    sys.path.insert(0, ROOT)
+    if absent_rank >= 0:
+        os.environ["KSGPU_ONESHOT_TIMEOUT_MS"] = "300"
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import slepc_amd as ks
+        from slepc_amd import partition as P
+        ctx = ks.Context(0)
+        _install_gloo_ops(ks, ctx, dist, torch, rank, world)
+        res = {"active": ctx.set_allreduce("oneshot")}
+        if absent_rank >= 0:
+            import time
+            if rank == absent_rank:
+                time.sleep(1.5)
+            t0 = time.perf_counter()
+            try:
+                ctx.comm_check()
+                res["raised"] = False
+            except RuntimeError as e:
+                res["raised"] = str(e)
+            res["seconds"] = time.perf_counter() - t0
+            res["back"] = ctx.set_allreduce("provider")
+            ctx.comm_check()                      # the provider is unharmed
+            dist.barrier()
+            q.put((rank, res))
+            return
+        ctx.comm_check()
+        # the values every rank ends up with are the same bits: sums of rank-dependent irrational numbers, 1..128 long (128 = the
+        # longest one-shot message; longer ones go through the provider)
+        X = ks.BV(ctx, 64, 12, N=64 * world)             # its coefficient buffer (12 x 12 doubles) is the device scratch
+        bits = []
+        for count in (1, 2, 31, 61, 128, 129):
+            h = np.sqrt(np.arange(1, count + 1) * (rank + 2.0)) * (-1.0) ** np.arange(count)
+            d = X.buffer_ptr()
+            ctx.memcpy_h2d(d, h)
+            ctx.allreduce_sum_dev(d, count)
+            out = np.empty(count); ctx.memcpy_d2h(out, d)
+            want = sum(np.sqrt(np.arange(1, count + 1) * (r + 2.0)) * (-1.0) ** np.arange(count) for r in range(world))
+            assert np.allclose(out, want, rtol=1e-14, atol=0), (count, out, want)
+            bits.append(out.tobytes())
+        res["bits"] = bits
+        nx, ny, nz = 12, 10, 9
+        z0, z1 = P.split_ownership(nz, world)[rank]
+        A = ks.Mat.laplacian3d(ctx, nx, ny, nz, z0, z1 - z0)
+        m = 12
+        V = ks.BV(ctx, A.n, m + 1, N=A.N, row_start=z0 * nx * ny)
+        V.SetRandomColumn(0)
+        _, nrm, _ = V.OrthogonalizeColumn(0); V.ScaleColumn(0, 1.0 / nrm)
+        T = np.zeros((m + 1, 3), order="F")
+        mm, beta, brk = V.MatLanczos(A, T, 0, m)
+        res["T"] = T[:m, :2].copy(); res["beta"] = beta; res["mm"] = mm; res["passes"] = V.gs_passes()[0]
+        M = np.zeros((m + 1, m + 1), order="F"); V.SetActiveColumns(0, m + 1); V.Dot(V, M)
+        res["orth"] = float(np.abs(M - np.eye(m + 1)).max())
+        eps = ks.EPS(ctx); eps.SetOperators(A); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(3, 12); eps.Solve()
+        res["eig"] = [eps.GetEigenvalue(i)[0] for i in range(3)]
+        res["its"] = eps.GetIterationNumber(); res["nconv"] = eps.GetConverged()
+        res["err"] = [eps.ComputeError(i) for i in range(3)]
+        res["back"] = ctx.set_allreduce("provider")
+        ctx.comm_check()
+        dist.barrier()
+        q.put((rank, res))
+    except Exception:      # noqa: BLE001
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_oneshot(world, absent_rank=-1):
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = 31300 + (os.getpid() % 1500) + 11 * world + (3 if absent_rank >= 0 else 0)
+    procs = [mpc.Process(target=_oneshot_worker, args=(r, world, port, q, absent_rank)) for r in range(world)]
+    for p in procs: p.start()
+    out = dict(q.get(timeout=400) for _ in range(world))
+    for p in procs: p.join(120)
+    for r in range(world):
+        assert "error" not in out[r], out[r].get("error")
+    return out
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4])
+def test_oneshot_allreduce_between_processes_sharing_one_gpu(world):
+    """SURVEY 8e's one-shot allreduce: every process maps the others' mailboxes through hipIpc (the route the ranks of an 8-GPU node
+    take over xGMI; here the mailboxes sit on one card) and one kernel per rank does the sum. Same Lanczos coefficients, pass
+    counts and eigenvalues as the single-rank oracle, identical bits on every rank."""
+    from oracle import oracle as O
+    out = _run_oneshot(world)
+    A = O.laplacian3d(12, 10, 9); m = 12
+    V = O.BV(A.n, m + 1); V.SetRandomColumn(0)
+    _, nrm, _ = V.OrthogonalizeColumn(0); V.ScaleColumn(0, 1 / nrm)
+    p0 = V.passes_total()
+    T = np.zeros((m + 1, 3), order="F")
+    mm, beta, brk = V.MatLanczos(A, T, 0, m)
+    r = O.eps_krylovschur_hep(A, 3, ncv=12)
+    for rk in range(world):
+        o = out[rk]
+        assert o["active"] == "oneshot" and o["back"] == "provider"
+        assert o["mm"] == mm and abs(o["beta"] - beta) < 1e-12 and np.abs(o["T"] - T[:m, :2]).max() < 1e-12
+        assert o["passes"] - 1 == V.passes_total() - p0
+        assert o["orth"] < 1e-13
+        assert o["its"] == r.its and o["nconv"] == r.nconv and max(o["err"]) < 1e-8
+        assert np.allclose(o["eig"], r.eigr[r.perm][:3], rtol=1e-10)
+        assert o["bits"] == out[0]["bits"] and o["eig"] == out[0]["eig"] and o["beta"] == out[0]["beta"]
+
+
+@pytest.mark.timeout(600)
+def test_oneshot_allreduce_gives_up_when_a_rank_never_arrives():
+    """Rank 1 arrives 1.5 s late, the time limit is 0.3 s: rank 0 gives up (its 64 enqueued calls do not wait 64 times), rank 1 then
+    finds rank 0's packets overwritten and gives up as well; both run the rest of the check, agree on the verdict, and go back to
+    the provider's allreduce, which still works."""
+    out = _run_oneshot(2, absent_rank=1)
+    for rk in (0, 1):
+        assert out[rk]["active"] == "oneshot" and out[rk]["back"] == "provider"
+        assert out[rk]["raised"] and "communicator check" in out[rk]["raised"], out[rk]
+    assert "one-shot" in out[0]["raised"]
+    assert out[0]["seconds"] < 6.0
