@@ -396,6 +396,7 @@ def oneshot_child(args, limit=180.0):
     children, which are stopped at `limit` seconds; the headline number has been taken before and is reported regardless."""
     env = dict(os.environ)
     env["MASTER_PORT"] = str(20000 + (int(env.get("MASTER_PORT", "29511")) + 1789) % 20000)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # under torchrun the ranks would look for the agent's store on the old port: rank 0's child opens its own
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--min-steps", str(args.min_steps), "--side", str(args.side), "--no-configs", "--no-cpu-baseline", "--no-prof", "--oneshot-leg"]
     try:
