@@ -374,18 +374,23 @@ def side_configs(ks, ctx, barrier, args):
             sp = ph.prof_tail
             spmv_ms = sum(v["ms"] for (nm, _), v in sp.items() if nm == "spmv_csr"); spmv_n = sum(v["launches"] for (nm, _), v in sp.items() if nm == "spmv_csr")
             spmv_alg = sum(v["alg_bytes"] for (nm, _), v in sp.items() if nm == "spmv_csr")
+            spmv_hbm = sum(v["hbm_bytes"] for (nm, _), v in sp.items() if nm == "spmv_csr")
             its_per_solve = kst["iterations"] / max(1, kst["solves"])
             out["C5"] = {"workload": "random nonsymmetric CSR n=%d nnz=%d (+ tridiagonal B, nnz=%d), GNHEP shift-and-invert target 0, nev=20 m=60, GMRES(30)+Jacobi inner solves"
                                      % (n5, nnz, nnzb),
                          "value": t["steps"] / t["seconds"], "unit": "steps/s", "steps": t["steps"], "ms_per_step": 1e3 * t["seconds"] / t["steps"],
                          "mean_k": round(t["mean_k"], 2), "cycles": t["cycles"], "inner_iterations_per_step": round(its_per_solve, 2),
                          "spmv_layout": A.layout(), "setup_seconds": round(tgen, 1),
-                         "roofline": {"bound": "hbm", "kernel": "k_spmv_sliced (+ k_sum_parts) and the small SpMV of B, all MatMult launches of a step",
+                         "roofline": {"bound": "hbm", "kernel": ("k_binned_gather + k_binned_reduce" if A.layout() == "binned" else "k_spmv_sliced (+ k_sum_parts)")
+                                      + " and the small SpMV of B, all MatMult launches of a step",
                                       "achieved": round(spmv_alg / spmv_ms / 1e6, 1) if spmv_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": round(spmv_alg / spmv_ms / 1e6 / HBM_PEAK_GBS, 4) if spmv_ms else None,
+                                      "own_bytes_GBps": round(spmv_hbm / spmv_ms / 1e6, 1) if spmv_ms else None,
+                                      "own_bytes_frac": round(spmv_hbm / spmv_ms / 1e6 / HBM_PEAK_GBS, 4) if spmv_ms else None,
                                       "avg_launch_us": round(1e3 * spmv_ms / max(1, spmv_n), 1), "launches_per_step": round(spmv_n / tail_steps, 2),
-                                      "bytes": "SURVEY 8d: 12 nnz + 4(n+1) + 16 n per MatMult; the x gather of a uniformly random matrix is a cache-line "
-                                               "rate, not an HBM rate (DESIGN.md section 4)"},
+                                      "bytes": "achieved / frac: SURVEY 8d's CSR bytes, 12 nnz + 4(n+1) + 16 n per MatMult. own_bytes_*: what the layout itself streams - "
+                                               "the binned layout moves 28 bytes per nonzero in two passes (16-bit column -> gathered x out; gathered x, value and 16-bit "
+                                               "row -> y) so that no random access leaves the CU (DESIGN.md section 6)"},
                          "kernel_classes": tab}
             del eps
             A.destroy(); B.destroy()

@@ -171,7 +171,7 @@ int ks_mat_shell_set_enqueue_only(ks_mat A, int flag);   /* the callback only en
 int ks_mat_destroy(ks_mat A);
 int ks_mat_get_sizes(ks_mat A, int *n_local, int *n_global, long long *nnz_local);
 /* device layout chosen at assembly for the local diagonal block (KSGPU_SPMV=csr|sell|sliced overrides the choice) */
-enum { KS_MAT_LAYOUT_CSR = 0, KS_MAT_LAYOUT_SELL = 1, KS_MAT_LAYOUT_SLICED = 2, KS_MAT_LAYOUT_SHELL = 3, KS_MAT_LAYOUT_DICT = 4, KS_MAT_LAYOUT_ODICT = 5 };
+enum { KS_MAT_LAYOUT_CSR = 0, KS_MAT_LAYOUT_SELL = 1, KS_MAT_LAYOUT_SLICED = 2, KS_MAT_LAYOUT_SHELL = 3, KS_MAT_LAYOUT_DICT = 4, KS_MAT_LAYOUT_ODICT = 5, KS_MAT_LAYOUT_BINNED = 6 };
 int ks_mat_get_layout(ks_mat A, int *layout);
 /* MatMult: y = A x on device pointers (x, y: n_local doubles owned by this rank).
    Multi-rank: performs the halo exchange of x (PETSc VecScatter inside MatMult_MPIAIJ).        */

@@ -43,7 +43,7 @@ KCLASSES = ["spmv_csr", "bv_dot_sweep", "gs_bookkeeping", "gs_update_fused_dot",
 # kernel symbol behind each (class, variant) as rocprofv3 --kernel-trace names it (16-byte-load forms)
 def kernel_symbol(name, var):
     if name == "spmv_csr":
-        return "k_spmv_dict<W>" if var == 16 else "k_spmv_odict<W>" if var == 17 else ("k_spmv_sell<8>" if var == 8 else "k_spmv_csr<G, 4, false, false>")
+        return "k_spmv_dict<W>" if var == 16 else "k_spmv_odict<W>" if var == 17 else "k_binned_gather + k_binned_reduce" if var == 18 else ("k_spmv_sell<8>" if var == 8 else "k_spmv_csr<G, 4, false, false>")
     if name == "bv_dot_sweep":
         return "k_dot_sweep<%d, 2>" % var
     if name in ("gs_update_fused_dot", "gs_update") or (name == "gated_noop" and var > 0):
@@ -252,7 +252,7 @@ class Mat:
 
     def layout(self):
         v = C.c_int(); _lib.check(self.ctx.L.ks_mat_get_layout(self.h, C.byref(v)))
-        return ["csr", "sell", "sliced", "shell", "dict", "odict"][v.value]
+        return ["csr", "sell", "sliced", "shell", "dict", "odict", "binned"][v.value]
 
     def norm_inf(self):
         v = C.c_double(); _lib.check(self.ctx.L.ks_mat_norm_inf(self.h, C.byref(v))); return v.value

@@ -20,6 +20,8 @@
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <numeric>
+#include <thread>
+#include <type_traits>
 
 namespace {
 
@@ -603,8 +605,200 @@ __global__ void k_sum_parts(int n, const double *__restrict__ ypart, double *__r
   }
 }
 
+
+// ---- binned product (ksgpu_internal.h: use_binned) ---------------------------------------------------------------------------------
+// Why: the product of a uniformly random matrix in a row-ordered layout pulls a 128-byte line of x through L2 -> L1 for every nonzero and
+// runs at that line rate (1.3 ms for config 5), however x is cut for the L2s. Here no random access leaves the CU: phase 1
+// gathers from a piece of x in LDS and streams the gathered values out in the order phase 2 wants them; phase 2 streams them back in with
+// the values and adds into rows of y in LDS. 28 bytes per nonzero of pure streams instead of 12 bytes + a line (profiles/r02_micro_binned_spmv*).
+constexpr int BN_MAXSEG = 12;            // segments a 1024-entry window may touch on the fast path
+constexpr int BN_CS_MAX = 9984;          // columns of a slice: 78 KB of LDS next to the two offset rows
+// phase 1: grid = slices, 1024 threads; LDS: x piece [cs], off1 row [wb + 1], off2t row [wb]
+__global__ __launch_bounds__(1024) void k_binned_gather(int n, int cs, int wb, int nwin, const long long *__restrict__ sbase, const unsigned short *__restrict__ col16,
+                                                        const int *__restrict__ off1, const int *__restrict__ off2t, const int *__restrict__ wseg,
+                                                        const double *__restrict__ x, double *__restrict__ G)
+{
+  extern __shared__ double bn_lds[];
+  double *xs = bn_lds;
+  int *o1 = (int *)(bn_lds + cs);
+  int *o2 = o1 + wb + 1;
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+  const long long c0 = (long long)s * cs;
+  for (int i = tid; i < cs; i += blockDim.x) xs[i] = (c0 + i < n) ? x[c0 + i] : 0.0;
+  for (int i = tid; i <= wb; i += blockDim.x) o1[i] = off1[(size_t)s * (wb + 1) + i];
+  for (int i = tid; i < wb; i += blockDim.x) o2[i] = off2t[(size_t)s * wb + i];
+  __syncthreads();
+  const unsigned *cp = reinterpret_cast<const unsigned *>(col16 + sbase[s]);     // slices start at even positions: 4-byte aligned
+  const int total = o1[wb];                                                       // even
+  for (int win = w; win * 1024 < total; win += nw) {
+    const int base = win * 1024;
+    unsigned c[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int e = base + k * 128 + 2 * lane; c[k] = e < total ? __builtin_nontemporal_load(cp + (e >> 1)) : 0u; }
+    const int lo = wseg[(size_t)s * nwin + win];
+    int bnd[BN_MAXSEG], dlt[BN_MAXSEG];
+#pragma unroll
+    for (int j = 0; j < BN_MAXSEG; j++) { const int sg = min(lo + j, wb - 1); bnd[j] = o1[sg + 1]; dlt[j] = o2[sg] - o1[sg]; }
+    const bool fits = bnd[BN_MAXSEG - 1] >= min(base + 1024, total);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int e = base + k * 128 + 2 * lane;
+      if (e < total) {
+        int d;
+        if (fits) {
+          d = dlt[0];
+#pragma unroll
+          for (int j = 1; j < BN_MAXSEG; j++) d = (e >= bnd[j - 1]) ? dlt[j] : d;
+        } else { int sg = lo; while (e >= o1[sg + 1]) sg++; d = o2[sg] - o1[sg]; }      // many short segments: look each pair up
+        const ksk::ks_d2v g = {xs[c[k] & 0xffffu], xs[c[k] >> 16]};
+        __builtin_nontemporal_store(g, reinterpret_cast<ksk::ks_d2v *>(G + ((long long)e + d)));   // pairs never straddle a segment: both orders keep segments even
+      }
+    }
+  }
+}
+// phase 2: grid = wave-bins / 4, 256 threads: a wave per wave-bin; LDS: 4 x (wr + 1) accumulators (the last one takes the padding entries)
+__global__ __launch_bounds__(256) void k_binned_reduce(int n, int wr, const long long *__restrict__ bstart, const double *__restrict__ G, const double *__restrict__ val,
+                                                       const unsigned short *__restrict__ row16, double *__restrict__ y)
+{
+  extern __shared__ double bn_lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + w;
+  double *acc = bn_lds + (size_t)w * (wr + 1);
+  for (int i = lane; i <= wr; i += 64) acc[i] = 0.0;
+  const long long e0 = bstart[b], e1 = bstart[b + 1];
+  for (long long q = e0; q < e1; q += 512) {
+    double g[8], a[8]; unsigned short r[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const long long e = q + k * 64 + lane; const bool ok = e < e1;
+      g[k] = ok ? __builtin_nontemporal_load(G + e) : 0.0; a[k] = ok ? __builtin_nontemporal_load(val + e) : 0.0; r[k] = ok ? __builtin_nontemporal_load(row16 + e) : (unsigned short)wr;
+    }
+    // the adds of one instruction go lane by lane, instructions in program order: a fixed order per row, run after run
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (q + k * 64 + lane < e1) __hip_atomic_fetch_add(acc + r[k], a[k] * g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  for (int i = lane; i < wr; i += 64) { const long long row = (long long)b * wr + i; if (row < n) y[row] = acc[i]; }
+}
+
+
+// Host-side build of the binned layout from the device CSR of the diagonal block (copied back once; the counting sort per wave-bin is cache
+// friendly and runs on a few threads).
+static int build_binned(ks_mat A)
+{
+  ks_ctx ctx = A->ctx;
+  const char *force = getenv("KSGPU_SPMV");
+  if (force && strcmp(force, "binned")) return KS_SUCCESS;
+  const int n = A->n;
+  if (n < 4096 || A->nnz_d == 0) return KS_SUCCESS;
+  if (!force) {
+    // the same matrices the XCD-sliced layout was built for: x well beyond an L2 and most entries far from the diagonal
+    if ((double)n * 8.0 < 6.0 * 1048576.0 || A->nnz_d < 8LL * n) return KS_SUCCESS;
+    unsigned long long *cnt = nullptr, h = 0;
+    KS_HIP(hipMalloc(&cnt, sizeof(unsigned long long))); KS_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k_far_entries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, n / 16, A->d_rowptr, A->d_col, cnt);
+    KS_HIP(hipMemcpyAsync(&h, cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream)); KS_HIP(ks_sync(ctx)); hipFree(cnt);
+    if ((double)h < 0.5 * (double)A->nnz_d) return KS_SUCCESS;
+  }
+  // slices: a multiple of the CU count (a workgroup per slice, one resident per CU), each at most BN_CS_MAX columns
+  const int ncu = std::max(ctx->num_cu, 1);
+  const long long per_round = (long long)ncu * BN_CS_MAX;
+  const int ns = (int)(ncu * ((n + per_round - 1) / per_round));
+  const int cs = (n + ns - 1) / ns;
+  const int wb = 4 * ns, wr = (n + wb - 1) / wb;
+  if (cs > 65535 || wr + 1 > 65535) return KS_SUCCESS;
+  if (A->nnz_d + (long long)ns * wb >= 2147483647LL) return KS_SUCCESS;          // bin-major positions are 32-bit
+  const long long nnz = A->nnz_d;
+  std::vector<int> rp(n + 1), col(nnz); std::vector<double> val(nnz);
+  KS_HIP(hipMemcpyAsync(rp.data(), A->d_rowptr, sizeof(int) * (n + 1), hipMemcpyDeviceToHost, ctx->stream));
+  KS_HIP(hipMemcpyAsync(col.data(), A->d_col, sizeof(int) * nnz, hipMemcpyDeviceToHost, ctx->stream));
+  KS_HIP(hipMemcpyAsync(val.data(), A->d_val, sizeof(double) * nnz, hipMemcpyDeviceToHost, ctx->stream));
+  KS_HIP(ks_sync(ctx));
+  const unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  auto parallel_bins = [&](auto fn) {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nthr; t++) th.emplace_back([&, t] { for (int b = (int)t; b < wb; b += (int)nthr) fn(b); });
+    for (auto &x : th) x.join();
+  };
+  // segment lengths (padded to even), bin-major [wb][ns]
+  std::vector<int> len((size_t)wb * ns, 0);
+  parallel_bins([&](int b) {
+    int *L = len.data() + (size_t)b * ns;
+    const int r0 = std::min((long long)b * wr, (long long)n), r1 = std::min((long long)(b + 1) * wr, (long long)n);
+    for (int p = rp[r0]; p < rp[r1]; p++) L[col[p] / cs]++;
+    for (int s = 0; s < ns; s++) L[s] = (L[s] + 1) & ~1;
+  });
+  std::vector<int> off2((size_t)wb * ns);                 // bin-major start of (wb, s)
+  std::vector<long long> bstart(wb + 1);
+  long long run = 0;
+  for (int b = 0; b < wb; b++) { bstart[b] = run; for (int s = 0; s < ns; s++) { off2[(size_t)b * ns + s] = (int)run; run += len[(size_t)b * ns + s]; } }
+  bstart[wb] = run;
+  const long long entries = run;
+  std::vector<int> off1((size_t)ns * (wb + 1)), off2t((size_t)ns * wb);
+  std::vector<long long> sbase(ns + 1);
+  long long srun = 0; int nwin = 1;
+  for (int s = 0; s < ns; s++) {
+    sbase[s] = srun;
+    int lrun = 0;
+    for (int b = 0; b < wb; b++) { off1[(size_t)s * (wb + 1) + b] = lrun; off2t[(size_t)s * wb + b] = off2[(size_t)b * ns + s]; lrun += len[(size_t)b * ns + s]; }
+    off1[(size_t)s * (wb + 1) + wb] = lrun;
+    srun += lrun;
+    nwin = std::max(nwin, (lrun + 1023) / 1024);
+  }
+  sbase[ns] = srun;
+  KS_CHECK(srun == entries, KS_ERR_PLIB, "binned layout: the two orders disagree (%lld vs %lld entries)", srun, entries);
+  std::vector<int> wseg((size_t)ns * nwin, 0);
+  for (int s = 0; s < ns; s++) {
+    const int *o1 = off1.data() + (size_t)s * (wb + 1);
+    int sg = 0;
+    for (int wdw = 0; wdw < nwin; wdw++) {
+      const int base = wdw * 1024;
+      while (sg < wb - 1 && o1[sg + 1] <= base) sg++;
+      wseg[(size_t)s * nwin + wdw] = sg;
+    }
+  }
+  std::vector<double> val2(entries, 0.0);
+  std::vector<unsigned short> row16(entries, (unsigned short)wr), col16(entries, 0);      // padding: value 0 into the spare accumulator, column 0 of its slice
+  parallel_bins([&](int b) {
+    std::vector<int> cur(ns, 0);
+    const int r0 = std::min((long long)b * wr, (long long)n), r1 = std::min((long long)(b + 1) * wr, (long long)n);
+    for (int r = r0; r < r1; r++)
+      for (int p = rp[r]; p < rp[r + 1]; p++) {
+        const int s = col[p] / cs, i = cur[s]++;
+        const long long p2 = (long long)off2[(size_t)b * ns + s] + i;
+        val2[p2] = val[p]; row16[p2] = (unsigned short)(r - r0);
+        col16[sbase[s] + off1[(size_t)s * (wb + 1) + b] + i] = (unsigned short)(col[p] - s * cs);
+      }
+  });
+  std::vector<int>().swap(col); std::vector<double>().swap(val);
+  auto up = [&](auto **dev, const auto &host) -> int {
+    using T = typename std::remove_reference<decltype(host)>::type::value_type;
+    KS_HIP(hipMalloc((void **)dev, sizeof(T) * std::max<size_t>(host.size(), 1)));
+    KS_HIP(hipMemcpy(*dev, host.data(), sizeof(T) * host.size(), hipMemcpyHostToDevice));
+    return KS_SUCCESS;
+  };
+  KS_CALL(up(&A->bn_col16, col16)); KS_CALL(up(&A->bn_row16, row16)); KS_CALL(up(&A->bn_val, val2));
+  KS_CALL(up(&A->bn_off1, off1)); KS_CALL(up(&A->bn_off2t, off2t)); KS_CALL(up(&A->bn_wseg, wseg));
+  KS_CALL(up(&A->bn_sbase, sbase)); KS_CALL(up(&A->bn_bstart, bstart));
+  KS_HIP(hipMalloc(&A->bn_g, sizeof(double) * std::max<long long>(entries, 1)));
+  KS_HIP(hipMemset(A->bn_g, 0, sizeof(double) * std::max<long long>(entries, 1)));
+  const int lds1 = cs * 8 + (2 * wb + 1) * 4, lds2 = 4 * (wr + 1) * 8;
+  KS_HIP(hipFuncSetAttribute((const void *)k_binned_gather, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+  KS_HIP(hipFuncSetAttribute((const void *)k_binned_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+  // diagonal and infinity norm are taken from the CSR arrays before they are released
+  KS_HIP(hipMalloc(&A->diag_cache, sizeof(double) * n));
+  KS_CALL(ks_mat_get_diagonal_internal(A, A->diag_cache));
+  KS_HIP(ks_sync(ctx));
+  double nrm = 0.0;
+  KS_CALL(ks_mat_norm_inf_local(A, &nrm));
+  A->norm_inf_cache = nrm;
+  A->use_binned = true; A->bn_ns = ns; A->bn_cs = cs; A->bn_wb = wb; A->bn_wr = wr; A->bn_nwin = nwin; A->bn_entries = entries;
+  hipFree(A->d_col); hipFree(A->d_val); A->d_col = nullptr; A->d_val = nullptr;
+  return KS_SUCCESS;
+}
+
 int build_sliced(ks_mat A)
 {
+  if (A->use_binned) return KS_SUCCESS;
   ks_ctx ctx = A->ctx;
   const char *force = getenv("KSGPU_SPMV");
   if (force && strcmp(force, "sliced")) return KS_SUCCESS;
@@ -734,7 +928,7 @@ int build_dict(ks_mat A)
 
 int build_sell(ks_mat A)
 {
-  if (A->use_sliced) return KS_SUCCESS;
+  if (A->use_sliced || A->use_binned) return KS_SUCCESS;
   ks_ctx ctx = A->ctx;
   const char *force = getenv("KSGPU_SPMV");
   if (force && !strcmp(force, "csrvec")) { A->force_csr_vector = true; return KS_SUCCESS; }     // the CSR-vector kernel at any size (A/B against the row-block kernel)
@@ -822,6 +1016,7 @@ extern "C" int ks_mat_create_csr(ks_ctx ctx, int n_local, int row_start, int n_g
   }
   int rc = build_halo_plan(A, garray);
   if (!rc) rc = compact_offdiag_rows(A);
+  if (!rc) rc = build_binned(A);
   if (!rc) rc = build_sliced(A);
   if (!rc) rc = build_sell(A);
   if (rc) { ks_mat_destroy(A); return rc; }
@@ -906,6 +1101,7 @@ extern "C" int ks_mat_destroy(ks_mat A)
   hipFree(A->s_ptr); hipFree(A->s_len); hipFree(A->s_col); hipFree(A->s_val);
   hipFree(A->dc_codes); hipFree(A->dc_val); hipFree(A->dc_off); hipFree(A->dc_codes8); hipFree(A->dc_vals);
   hipFree(A->sl_rowptr); hipFree(A->sl_col); hipFree(A->sl_val); hipFree(A->sl_base); hipFree(A->ypart); hipFree(A->diag_cache);
+  hipFree(A->bn_col16); hipFree(A->bn_row16); hipFree(A->bn_val); hipFree(A->bn_g); hipFree(A->bn_off1); hipFree(A->bn_off2t); hipFree(A->bn_wseg); hipFree(A->bn_sbase); hipFree(A->bn_bstart);
   delete A;
   return KS_SUCCESS;
 }
@@ -922,7 +1118,7 @@ extern "C" int ks_mat_shell_set_enqueue_only(ks_mat A, int flag)
 extern "C" int ks_mat_get_layout(ks_mat A, int *layout)     // storage of the diagonal block: KS_MAT_LAYOUT_*
 {
   KS_CHECK(A && layout, KS_ERR_ARG_NULL, "NULL argument");
-  *layout = A->shell_mult ? KS_MAT_LAYOUT_SHELL : (A->use_sliced ? KS_MAT_LAYOUT_SLICED : (A->use_dict ? KS_MAT_LAYOUT_DICT : (A->use_odict ? KS_MAT_LAYOUT_ODICT : (A->use_sell ? KS_MAT_LAYOUT_SELL : KS_MAT_LAYOUT_CSR))));
+  *layout = A->shell_mult ? KS_MAT_LAYOUT_SHELL : A->use_binned ? KS_MAT_LAYOUT_BINNED : (A->use_sliced ? KS_MAT_LAYOUT_SLICED : (A->use_dict ? KS_MAT_LAYOUT_DICT : (A->use_odict ? KS_MAT_LAYOUT_ODICT : (A->use_sell ? KS_MAT_LAYOUT_SELL : KS_MAT_LAYOUT_CSR))));
   return KS_SUCCESS;
 }
 extern "C" int ks_mat_get_sizes(ks_mat A, int *n_local, int *n_global, long long *nnz_local)
@@ -962,10 +1158,15 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
   }
   {
     const double csr_bytes = 12.0 * A->nnz + 4.0 * (A->n + 1) + 16.0 * A->n;                    // what the CSR algorithm moves
-    KsProfScope ps(ctx, KS_K_SPMV, csr_bytes, A->use_dict ? 16 : (A->use_odict ? 17 : (A->use_sell ? 8 : 0)),   // variant 16: k_spmv_dict, 17: k_spmv_odict, 8: k_spmv_sell<8>, 0: k_spmv_csr
-                   A->use_dict ? (2.0 * A->dict_w + 16.0) * A->n + 12.0 * A->nnz_o
+    KsProfScope ps(ctx, KS_K_SPMV, csr_bytes, A->use_binned ? 18 : A->use_dict ? 16 : (A->use_odict ? 17 : (A->use_sell ? 8 : 0)),   // variant 16: k_spmv_dict, 17: k_spmv_odict, 8: k_spmv_sell<8>, 0: k_spmv_csr
+                   A->use_binned ? 28.0 * A->bn_entries + 16.0 * A->n + 12.0 * A->nnz_o
+                   : A->use_dict ? (2.0 * A->dict_w + 16.0) * A->n + 12.0 * A->nnz_o
                    : (A->use_odict ? 8.0 * A->nnz_d + (A->dict_w + 16.0) * A->n + 12.0 * A->nnz_o : -1.0));   // the dictionary layouts' own compulsory bytes
-    if (A->use_sliced) {
+    if (A->use_binned) {
+      hipLaunchKernelGGL(k_binned_gather, dim3((unsigned)A->bn_ns), dim3(1024), (size_t)A->bn_cs * 8 + (size_t)(2 * A->bn_wb + 1) * 4, ctx->stream, A->n, A->bn_cs, A->bn_wb, A->bn_nwin,
+                         A->bn_sbase, A->bn_col16, A->bn_off1, A->bn_off2t, A->bn_wseg, x, A->bn_g);
+      hipLaunchKernelGGL(k_binned_reduce, dim3((unsigned)(A->bn_wb / 4)), dim3(256), (size_t)4 * (A->bn_wr + 1) * 8, ctx->stream, A->n, A->bn_wr, A->bn_bstart, A->bn_g, A->bn_val, A->bn_row16, y);
+    } else if (A->use_sliced) {
       const int per_xcd = std::max(1, std::min((A->n + 255) / 256, (ctx->num_cu / 8) * 8));       // 8 resident workgroups per CU of the XCD
       hipLaunchKernelGGL(k_spmv_sliced, dim3((unsigned)(8 * per_xcd)), dim3(256), 0, ctx->stream, A->n, A->nslice, A->sl_rowptr, A->sl_base, A->sl_col, A->sl_val, x, A->ypart);
       hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)std::min((A->n + 255) / 256, ctx->num_cu * 8)), dim3(256), 0, ctx->stream, A->n, A->ypart, y);
@@ -1033,7 +1234,7 @@ int ks_mat_get_diagonal_internal(ks_mat A, double *d)
   ks_ctx ctx = A->ctx;
   KS_CHECK(!A->shell_mult, KS_ERR_SUP, "a matrix-free operator has no stored diagonal");
   if (A->n == 0) return KS_SUCCESS;
-  if (A->use_sliced || A->have_cache) { KS_HIP(hipMemcpyAsync(d, A->diag_cache, sizeof(double) * A->n, hipMemcpyDeviceToDevice, ctx->stream)); return KS_SUCCESS; }
+  if (A->use_sliced || A->use_binned || A->have_cache) { KS_HIP(hipMemcpyAsync(d, A->diag_cache, sizeof(double) * A->n, hipMemcpyDeviceToDevice, ctx->stream)); return KS_SUCCESS; }
   const unsigned nb = (unsigned)((A->n + 255) / 256);
   if (A->use_sell) hipLaunchKernelGGL(k_diag_sell, dim3(nb), dim3(256), 0, ctx->stream, A->n, A->s_ptr, A->s_len, A->s_col, A->s_val, d);
   else hipLaunchKernelGGL(k_diag_csr, dim3(nb), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, d);
@@ -1069,7 +1270,7 @@ __global__ void k_rowabs_rows(int nrows, const int *__restrict__ rows, const int
 int ks_mat_norm_inf_local(ks_mat A, double *val)          // this rank's rows only
 {
   ks_ctx ctx = A->ctx;
-  if (A->use_sliced || A->have_cache) { *val = A->norm_inf_cache; return KS_SUCCESS; }     // taken before the CSR arrays were released
+  if (A->use_sliced || A->use_binned || A->have_cache) { *val = A->norm_inf_cache; return KS_SUCCESS; }     // taken before the CSR arrays were released
   double local = 0.0;
   if (A->n > 0) {
     double *w = nullptr;

@@ -144,6 +144,22 @@ struct ks_mat_s {
   int *sl_rowptr = nullptr; int *sl_col = nullptr; double *sl_val = nullptr; long long *sl_base = nullptr;   // [nslice][n+1], entries, device offsets [nslice+1]
   double *ypart = nullptr;                    // [8][n]
   double *diag_cache = nullptr; double norm_inf_cache = -1.0;   // kept because the CSR arrays are released after slicing
+  // Binned ("propagation blocking") copy of the diagonal block for wide-scatter matrices, the successor of the XCD-sliced one: the product
+  // runs in two streaming phases with every random access in LDS. Columns are cut into bn_ns slices of bn_cs, rows into bn_wb wave-bins of
+  // bn_wr. Entries are stored twice over: the 16-bit slice-local column in SLICE-major order (slice, wave-bin, row), the value and the 16-bit
+  // bin-local row in BIN-major order (wave-bin, slice, row); a (slice, wave-bin) segment is contiguous in both and starts at an even position
+  // (one padding entry with value 0 where needed). Phase 1 (a workgroup per slice, its piece of x in LDS) writes G = x[col] in bin-major
+  // order; phase 2 (a wave per wave-bin, its rows of y in LDS) streams G, val and row and adds val * G into its rows.
+  bool use_binned = false;
+  int bn_ns = 0, bn_cs = 0, bn_wb = 0, bn_wr = 0, bn_nwin = 0;
+  long long bn_entries = 0;                   // entries incl. padding
+  unsigned short *bn_col16 = nullptr, *bn_row16 = nullptr;
+  double *bn_val = nullptr, *bn_g = nullptr;
+  int *bn_off1 = nullptr;                     // [ns][wb + 1] start of segment (s, wb) inside slice s's stream
+  int *bn_off2t = nullptr;                    // [ns][wb]     start of that segment in bin-major order
+  int *bn_wseg = nullptr;                     // [ns][nwin]   segment in which the 1024-entry window of slice s begins
+  long long *bn_sbase = nullptr;              // [ns + 1]     start of slice s in bn_col16
+  long long *bn_bstart = nullptr;             // [wb + 1]     start of wave-bin wb in bin-major order
   // off-diagonal block (columns owned by other ranks), compressed to ghost indices [0,nghost)
   int *o_rowptr = nullptr; int *o_col = nullptr; double *o_val = nullptr; long long nnz_o = 0;
   int nghost = 0;

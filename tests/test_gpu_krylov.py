@@ -244,10 +244,46 @@ def test_spmv_xcd_sliced_layout(ctx, monkeypatch):
         assert np.allclose(A.get_diagonal(), S.diagonal(), rtol=0, atol=1e-15)
         assert abs(A.norm_inf() - abs(S).sum(axis=1).max()) < 1e-12
         assert np.array_equal(A.mult(x), y)                              # fixed-order partial sums: run-to-run identical
+    Ao, _ = nc.config5_pencil_fast(1_500_000, mean_nnz=12)               # x = 12 MB > 6 MB, entries far from the diagonal
+    A = _mat(ctx, Ao)
+    assert A.layout() == "sliced"                                          # (forced here; the automatic choice for such a matrix is the binned layout, below)
+    x = rng.standard_normal(Ao.n)
+    assert np.allclose(A.mult(x), Ao.mult(x), rtol=0, atol=1e-11)
+    assert abs(A.get_diagonal()[12345] - Ao.to_scipy().diagonal()[12345]) < 1e-13
+
+
+def test_spmv_binned_layout(ctx, monkeypatch):
+    """The binned (two-phase) layout: gather from a piece of x in LDS into bin-major order, then a wave per bin of rows adds val * G into its
+    rows in LDS. Forced on small and ragged matrices incl. empty rows, unsorted columns and duplicate entries (many short segments: the
+    per-pair lookup path), and chosen automatically for a wide-scatter matrix with a 12 MB vector (long segments: the window path);
+    run-to-run identical; diagonal and infinity norm stay available after the CSR arrays are released."""
+    import slepc_amd as ks
+    import nhep_cases as nc
+    rng = np.random.default_rng(18)
+    monkeypatch.setenv("KSGPU_SPMV", "binned")
+    for n, mean in [(5000, 3), (20000, 20), (70001, 7), (300007, 40)]:
+        lens = np.clip(rng.poisson(mean, n), 0, n); lens[rng.integers(0, n, n // 20)] = 0
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        col = rng.integers(0, n, rowptr[-1]).astype(np.int32)          # unsorted, duplicates allowed
+        val = rng.uniform(-1, 1, rowptr[-1])
+        Ao = O.CSR(n, rowptr, col, val)
+        A = _mat(ctx, Ao)
+        assert A.layout() == "binned"
+        x = rng.standard_normal(n)
+        y, y0 = A.mult(x), Ao.mult(x)
+        assert np.allclose(y, y0, rtol=0, atol=1e-13 * max(1, mean)) and np.all(y[lens == 0] == 0.0)
+        assert np.array_equal(A.mult(x), y)                              # a fixed order of additions per row: run-to-run identical
+        xi = x.copy(); xi[::97] = np.inf                                  # an infinite entry of x reaches exactly the rows that use it (padding entries do not spread it)
+        yi = A.mult(xi)
+        touched = np.zeros(n, bool); rows = np.repeat(np.arange(n), lens); touched[rows[col % 97 == 0]] = True
+        assert np.all(np.isfinite(yi[~touched])) and not np.any(np.isfinite(yi[touched]))
+        S = Ao.to_scipy()                                                 # (scipy sorts and merges the shared index arrays in place: last)
+        assert np.allclose(A.get_diagonal(), S.diagonal(), rtol=0, atol=1e-15)
+        assert abs(A.norm_inf() - abs(S).sum(axis=1).max()) < 1e-12
     monkeypatch.delenv("KSGPU_SPMV")
     Ao, _ = nc.config5_pencil_fast(1_500_000, mean_nnz=12)               # x = 12 MB > 6 MB, entries far from the diagonal
     A = _mat(ctx, Ao)
-    assert A.layout() == "sliced"
+    assert A.layout() == "binned"
     assert ks.Mat.laplacian3d(ctx, 160, 160, 160).layout() == "dict"       # banded: stays with the row-ordered layouts
     x = rng.standard_normal(Ao.n)
     assert np.allclose(A.mult(x), Ao.mult(x), rtol=0, atol=1e-11)

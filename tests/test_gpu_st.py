@@ -293,13 +293,13 @@ def test_config5_large_properties(ctx):
     print("config5 n=%d: %d steps, %d restarts, %.1f GMRES its/solve, %.2f s -> %.1f steps/s" % (n, steps, eps.GetIterationNumber(), s["iterations"] / s["solves"], dt, steps / dt))
 
 
-def test_st_apply_on_xcd_sliced_matrix(ctx):
-    """The inner GMRES running on the XCD-sliced SpMV layout (chosen automatically for this 12 MB wide-scatter matrix):
+def test_st_apply_on_binned_matrix(ctx):
+    """The inner GMRES running on the binned SpMV layout (chosen automatically for this 12 MB wide-scatter matrix):
     the solve satisfies (A - sigma B) y = B x to the KSP tolerance, checked with host arithmetic."""
     import slepc_amd as ks
     Ao, Bo = nc.config5_pencil_fast(1_500_000, mean_nnz=12)
     A = _mat(ctx, Ao); B = _mat(ctx, Bo)
-    assert A.layout() == "sliced"
+    assert A.layout() == "binned"
     st = ks.ST(ctx)
     st.SetType("sinvert"); st.SetShift(1.5); st.SetMatrices(A, B); st.SetKSP(rtol=1e-11)
     x = np.random.default_rng(6).standard_normal(Ao.n)
@@ -436,7 +436,7 @@ def test_config5_with_bicgstab(ctx):
 
 
 def test_config5_at_its_stated_size_step_capped(ctx):
-    """BASELINE config 5 at its real n = 5 * 10^6 (1.65e8 nonzeros, XCD-sliced layout, generalized shift-and-invert at the
+    """BASELINE config 5 at its real n = 5 * 10^6 (1.65e8 nonzeros, binned layout, generalized shift-and-invert at the
     config's target 0, nev 20, m 60), capped at one full cycle plus a restart cycle. Too large for the LU oracle and, at
     target 0, far from converged after 90 steps, so the checks are size-independent properties: STApply satisfies
     (A - sigma B) y = B x to the inner tolerance on a random vector (host arithmetic), one linear solve per Arnoldi step at
@@ -447,7 +447,7 @@ def test_config5_at_its_stated_size_step_capped(ctx):
     n = 5_000_000
     (ar, ac, av), (br, bc, bv) = config5_pencil_arrays(n)
     A = ks.Mat.from_csr(ctx, ar, ac, av); B = ks.Mat.from_csr(ctx, br, bc, bv)
-    assert A.layout() == "sliced" and A.nnz == int(ar[-1])
+    assert A.layout() == "binned" and A.nnz == int(ar[-1])
     Sa = sp.csr_matrix((av, ac, ar), shape=(n, n)); Sb = sp.csr_matrix((bv, bc, br), shape=(n, n))
     st = ks.ST(ctx); st.SetType("sinvert"); st.SetShift(0.0); st.SetMatrices(A, B)
     x = np.random.default_rng(11).standard_normal(n)
