@@ -133,5 +133,10 @@ int main()
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); printf("phase 1, %-44s %7.1f us\n", name, ms / 4 * 1e3);
   };
   diag(k_phase1<0>, "as it is"); diag(k_phase1<1>, "no store");
+  for (int nt : {256, 512, 768, 1024}) {
+    for (int r = 0; r < 2; r++) hipLaunchKernelGGL(k_phase1<0>, dim3(NS), dim3(nt), lds1, 0, col16, off1, off2t, wseg, nwin, x, G, per_slice);
+    CK(hipEventRecord(e0)); for (int r = 0; r < 4; r++) hipLaunchKernelGGL(k_phase1<0>, dim3(NS), dim3(nt), lds1, 0, col16, off1, off2t, wseg, nwin, x, G, per_slice);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); printf("phase 1 with %4d threads per workgroup: %7.1f us\n", nt, ms / 4 * 1e3);
+  }
   return 0;
 }
