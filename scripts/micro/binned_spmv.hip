@@ -20,7 +20,7 @@ constexpr int MAXSEG = 12;
 typedef double d2v __attribute__((ext_vector_type(2)));
 template <int DIAG>
 __global__ __launch_bounds__(1024) void k_phase1(const unsigned short *__restrict__ col16, const int *__restrict__ off1, const int *__restrict__ off2t, const int *__restrict__ wseg, int nwin,
-                                                 const double *__restrict__ x, double *__restrict__ G, long long per_slice)
+                                                 const double *__restrict__ x, double *__restrict__ G, long long per_slice, const double *__restrict__ val1)
 {
   extern __shared__ double lds[];
   double *xs = lds;                       // CS doubles
@@ -36,9 +36,10 @@ __global__ __launch_bounds__(1024) void k_phase1(const unsigned short *__restric
   double sink = 0.0;
   for (int win = w; win * 1024 < total; win += nw) {
     const int base = win * 1024;
-    unsigned c[8];
+    unsigned c[8]; d2v a[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { const int e = base + k * 128 + 2 * lane; c[k] = e < total ? __builtin_nontemporal_load(cs + (e >> 1)) : 0u; }
+    for (int k = 0; k < 8; k++) { const int e = base + k * 128 + 2 * lane; c[k] = e < total ? __builtin_nontemporal_load(cs + (e >> 1)) : 0u;
+      if (DIAG == 5) a[k] = e < total ? __builtin_nontemporal_load((const d2v *)(val1 + (long long)s * per_slice + e)) : d2v{0.0, 0.0}; }
     const int lo = wseg[(long long)s * nwin + win];
     int bnd[MAXSEG], dlt[MAXSEG];
 #pragma unroll
@@ -54,7 +55,8 @@ __global__ __launch_bounds__(1024) void k_phase1(const unsigned short *__restric
 #pragma unroll
           for (int j = 1; j < MAXSEG; j++) d = (e >= bnd[j - 1]) ? dlt[j] : d;
         } else { int sg = lo; while (e >= o1[sg + 1]) sg++; d = o2[sg] - o1[sg]; }
-        const d2v g = {xs[c[k] & 0xffffu], xs[c[k] >> 16]};
+        d2v g = {xs[c[k] & 0xffffu], xs[c[k] >> 16]};
+        if (DIAG == 5) { g.x *= a[k].x; g.y *= a[k].y; }
         if (DIAG == 1) sink += g.x + g.y + d; else __builtin_nontemporal_store(g, (d2v *)(G + (e + d)));
       }
     }
@@ -63,6 +65,7 @@ __global__ __launch_bounds__(1024) void k_phase1(const unsigned short *__restric
 }
 
 // phase 2: grid WB / 4, 256 threads, one wave per wave-bin
+template <bool VALS>
 __global__ __launch_bounds__(256) void k_phase2(const double *__restrict__ G, const double *__restrict__ val, const unsigned short *__restrict__ row16,
                                                 const long long *__restrict__ binstart, double *__restrict__ y, int n)
 {
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void k_phase2(const double *__restrict__ G, co
   for (long long b = e0; b < e1; b += 512) {
     double g[8], a[8]; unsigned short r[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { const long long e = b + k * 64 + lane; const bool ok = e < e1; g[k] = ok ? __builtin_nontemporal_load(G + e) : 0.0; a[k] = ok ? __builtin_nontemporal_load(val + e) : 0.0; r[k] = ok ? __builtin_nontemporal_load(row16 + e) : 0; }
+    for (int k = 0; k < 8; k++) { const long long e = b + k * 64 + lane; const bool ok = e < e1; g[k] = ok ? __builtin_nontemporal_load(G + e) : 0.0; a[k] = VALS ? (ok ? __builtin_nontemporal_load(val + e) : 0.0) : 1.0; r[k] = ok ? __builtin_nontemporal_load(row16 + e) : 0; }
 #pragma unroll
     for (int k = 0; k < 8; k++) { const long long e = b + k * 64 + lane; if (e < e1) __hip_atomic_fetch_add(acc + r[k], a[k] * g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   }
@@ -115,27 +118,36 @@ int main()
   CK(hipFuncSetAttribute((const void *)k_phase1<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
   CK(hipFuncSetAttribute((const void *)k_phase1<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
 
-  CK(hipFuncSetAttribute((const void *)k_phase2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+  CK(hipFuncSetAttribute((const void *)k_phase2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); CK(hipFuncSetAttribute((const void *)k_phase2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); CK(hipFuncSetAttribute((const void *)k_phase1<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
   hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
   for (int rep = 0; rep < 6; rep++) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k_phase1<0>, dim3(NS), dim3(1024), lds1, 0, col16, off1, off2t, wseg, nwin, x, G, per_slice);
+    hipLaunchKernelGGL(k_phase1<0>, dim3(NS), dim3(1024), lds1, 0, col16, off1, off2t, wseg, nwin, x, G, per_slice, (const double *)nullptr);
     CK(hipEventRecord(e1));
-    hipLaunchKernelGGL(k_phase2, dim3(WB / 4), dim3(256), lds2, 0, G, val, row16, binstart, y, n);
+    hipLaunchKernelGGL(k_phase2<true>, dim3(WB / 4), dim3(256), lds2, 0, G, val, row16, binstart, y, n);
     CK(hipEventRecord(e2)); CK(hipEventSynchronize(e2));
     CK(hipGetLastError());
     float m1, m2; CK(hipEventElapsedTime(&m1, e0, e1)); CK(hipEventElapsedTime(&m2, e1, e2));
     if (rep >= 2) printf("phase 1 %7.1f us (%6.1f GB/s of 10 B/entry)   phase 2 %7.1f us (%6.1f GB/s of 18 B/entry)   total %7.1f us\n", m1 * 1e3, nnz * 10.0 / m1 / 1e6, m2 * 1e3, nnz * 18.0 / m2 / 1e6, (m1 + m2) * 1e3);
   }
   auto diag = [&](auto kern, const char *name) {
-    for (int r = 0; r < 2; r++) hipLaunchKernelGGL(kern, dim3(NS), dim3(1024), lds1, 0, col16, off1, off2t, wseg, nwin, x, G, per_slice);
-    CK(hipEventRecord(e0)); for (int r = 0; r < 4; r++) hipLaunchKernelGGL(kern, dim3(NS), dim3(1024), lds1, 0, col16, off1, off2t, wseg, nwin, x, G, per_slice);
+    for (int r = 0; r < 2; r++) hipLaunchKernelGGL(kern, dim3(NS), dim3(1024), lds1, 0, col16, off1, off2t, wseg, nwin, x, G, per_slice, (const double *)nullptr);
+    CK(hipEventRecord(e0)); for (int r = 0; r < 4; r++) hipLaunchKernelGGL(kern, dim3(NS), dim3(1024), lds1, 0, col16, off1, off2t, wseg, nwin, x, G, per_slice, (const double *)nullptr);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); printf("phase 1, %-44s %7.1f us\n", name, ms / 4 * 1e3);
   };
   diag(k_phase1<0>, "as it is"); diag(k_phase1<1>, "no store");
+  for (int rep = 0; rep < 4; rep++) {     // the values on phase 1's side: P = val * x[col] out, phase 2 reads P and the row only
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_phase1<5>, dim3(NS), dim3(1024), lds1, 0, col16, off1, off2t, wseg, nwin, x, G, per_slice, val);
+    CK(hipEventRecord(e1));
+    hipLaunchKernelGGL(k_phase2<false>, dim3(WB / 4), dim3(256), lds2, 0, G, val, row16, binstart, y, n);
+    CK(hipEventRecord(e2)); CK(hipEventSynchronize(e2));
+    float m1, m2; CK(hipEventElapsedTime(&m1, e0, e1)); CK(hipEventElapsedTime(&m2, e1, e2));
+    if (rep >= 1) printf("values in phase 1: phase 1 %7.1f us (18 B/entry)   phase 2 %7.1f us (10 B/entry)   total %7.1f us\n", m1 * 1e3, m2 * 1e3, (m1 + m2) * 1e3);
+  }
   for (int nt : {256, 512, 768, 1024}) {
-    for (int r = 0; r < 2; r++) hipLaunchKernelGGL(k_phase1<0>, dim3(NS), dim3(nt), lds1, 0, col16, off1, off2t, wseg, nwin, x, G, per_slice);
-    CK(hipEventRecord(e0)); for (int r = 0; r < 4; r++) hipLaunchKernelGGL(k_phase1<0>, dim3(NS), dim3(nt), lds1, 0, col16, off1, off2t, wseg, nwin, x, G, per_slice);
+    for (int r = 0; r < 2; r++) hipLaunchKernelGGL(k_phase1<0>, dim3(NS), dim3(nt), lds1, 0, col16, off1, off2t, wseg, nwin, x, G, per_slice, (const double *)nullptr);
+    CK(hipEventRecord(e0)); for (int r = 0; r < 4; r++) hipLaunchKernelGGL(k_phase1<0>, dim3(NS), dim3(nt), lds1, 0, col16, off1, off2t, wseg, nwin, x, G, per_slice, (const double *)nullptr);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); printf("phase 1 with %4d threads per workgroup: %7.1f us\n", nt, ms / 4 * 1e3);
   }
   return 0;
