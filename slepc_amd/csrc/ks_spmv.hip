@@ -706,6 +706,7 @@ static int build_binned(ks_mat A)
   const int cs = (n + ns - 1) / ns;
   const int wb = 4 * ns, wr = (n + wb - 1) / wb;
   if (cs > 65535 || wr + 1 > 65535) return KS_SUCCESS;
+  if ((size_t)cs * 8 + (size_t)(2 * wb + 1) * 4 > 156 * 1024 || (size_t)4 * (wr + 1) * 8 > 156 * 1024) return KS_SUCCESS;   // the offset rows of more than ~20 M local rows no longer fit LDS next to the piece of x: the XCD-sliced layout takes those
   if (A->nnz_d + (long long)ns * wb >= 2147483647LL) return KS_SUCCESS;          // bin-major positions are 32-bit
   const long long nnz = A->nnz_d;
   std::vector<int> rp(n + 1), col(nnz); std::vector<double> val(nnz);
