@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <numeric>
 #include <thread>
+#include <new>
 #include <type_traits>
 
 namespace {
@@ -709,6 +710,7 @@ static int build_binned(ks_mat A)
   if ((size_t)cs * 8 + (size_t)(2 * wb + 1) * 4 > 156 * 1024 || (size_t)4 * (wr + 1) * 8 > 156 * 1024) return KS_SUCCESS;   // the offset rows of more than ~20 M local rows no longer fit LDS next to the piece of x: the XCD-sliced layout takes those
   if (A->nnz_d + (long long)ns * wb >= 2147483647LL) return KS_SUCCESS;          // bin-major positions are 32-bit
   const long long nnz = A->nnz_d;
+  try {                                               // the build holds about 25 bytes per nonzero in host memory: without it the sliced layout takes the matrix
   std::vector<int> rp(n + 1), col(nnz); std::vector<double> val(nnz);
   KS_HIP(hipMemcpyAsync(rp.data(), A->d_rowptr, sizeof(int) * (n + 1), hipMemcpyDeviceToHost, ctx->stream));
   KS_HIP(hipMemcpyAsync(col.data(), A->d_col, sizeof(int) * nnz, hipMemcpyDeviceToHost, ctx->stream));
@@ -794,6 +796,12 @@ static int build_binned(ks_mat A)
   A->norm_inf_cache = nrm;
   A->use_binned = true; A->bn_ns = ns; A->bn_cs = cs; A->bn_wb = wb; A->bn_wr = wr; A->bn_nwin = nwin; A->bn_entries = entries;
   hipFree(A->d_col); hipFree(A->d_val); A->d_col = nullptr; A->d_val = nullptr;
+  } catch (const std::bad_alloc &) {
+    hipFree(A->bn_col16); hipFree(A->bn_row16); hipFree(A->bn_val); hipFree(A->bn_g); hipFree(A->bn_off1); hipFree(A->bn_off2t); hipFree(A->bn_wseg); hipFree(A->bn_sbase); hipFree(A->bn_bstart);
+    A->bn_col16 = A->bn_row16 = nullptr; A->bn_val = A->bn_g = nullptr; A->bn_off1 = A->bn_off2t = A->bn_wseg = nullptr; A->bn_sbase = A->bn_bstart = nullptr;
+    hipFree(A->diag_cache); A->diag_cache = nullptr;
+    (void)hipGetLastError();
+  }
   return KS_SUCCESS;
 }
 
