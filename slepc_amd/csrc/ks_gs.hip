@@ -419,12 +419,14 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long lo
   double acc[KT + 1];
 #pragma unroll
   for (int i = 0; i <= KT; i++) acc[i] = 0.0;
-  if (VEC == 2 && plain) {                // basis resident in the Infinity Cache: plain loads (ks_sweeps.cuh)
-    if (fuse && npend == 1 && !scal) upd_tiles<KT, VEC, 1, 1, true>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
-    else if (!fuse && npend == 2) upd_tiles<KT, VEC, 2, 0, true>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
-    else upd_tiles<KT, VEC, 0, -1, false>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
-  } else if (VEC == 2 && fuse && npend == 1 && !scal) upd_tiles<KT, VEC, 1, 1, false>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
-  else if (VEC == 2 && !fuse && npend == 2) upd_tiles<KT, VEC, 2, 0, false>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
+  // Wide row panels (4 KT registers) leave no room for preloaded coefficients: past a width the specialised forms spill (k_gs_update<64,2> ran its final
+  // pass at 2.2 TB/s, <56,2> at 3.0) and the generic form, which reads the coefficients from where the prologue put them (LDS) as it uses them, is the
+  // faster one. Measured per width (profiles/r02_wide_probe*.txt): final pass specialised up to 48 columns, fused pass up to 40.
+  constexpr bool SPEC_FUSED = KT <= 40, SPEC_FINAL = KT <= 48;
+  if (VEC == 2 && plain && SPEC_FUSED && fuse && npend == 1 && !scal) upd_tiles<KT, VEC, 1, 1, true>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);     // basis resident in the Infinity Cache: plain loads (ks_sweeps.cuh)
+  else if (VEC == 2 && plain && SPEC_FINAL && !fuse && npend == 2) upd_tiles<KT, VEC, 2, 0, true>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
+  else if (VEC == 2 && !plain && SPEC_FUSED && fuse && npend == 1 && !scal) upd_tiles<KT, VEC, 1, 1, false>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
+  else if (VEC == 2 && !plain && SPEC_FINAL && !fuse && npend == 2) upd_tiles<KT, VEC, 2, 0, false>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
   else upd_tiles<KT, VEC, 0, -1, false>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
   if (!fuse) return;
   if (!folded && blockIdx.x == 0 && threadIdx.x == 0) *pgrid = gridDim.x;        // (folded: already part of the state workgroup 0 wrote)
