@@ -827,19 +827,28 @@ int orthogonalize_column(ks_bv bv, int j, int normalize, double *H, double *norm
     KS_CALL(begin_run(bv));
     KS_CALL(enqueue_fused_gs(bv, j, normalize, 0));
     KsGsState st; KsStepRec rec;
-    KS_CALL(fetch_state(bv, &st, &rec, j, j));
+    // the coefficients the caller asks for travel with the state (one host wait): the buffer up to and including column j
+    const size_t ldb = (size_t)(bv->nc + bv->m), want = (H && j > bv->l) ? (size_t)(j + 1) * ldb : 0;
+    const bool batched = want && want * sizeof(double) + 4096 <= KS_PINNED_D2H_BYTES;
+    std::vector<double> cb(batched ? want : 0);
+    KS_CALL(fetch_state(bv, &st, &rec, j, j, batched ? cb.data() : nullptr, batched ? want : 0));
+    bool fresh = batched;
     if (st.halt_col == j) {                       // rare: third pass and/or explicit norm needed
       if (ctx->prof_on) { KsStepRec tmp = rec; tmp.passes = st.pass + 1; tmp.expl = 0; ks_prof_resolve_gs(ctx, &tmp, j, j); }
       KS_CALL(enqueue_gs_completion(bv, j, normalize, 0));
       KS_CALL(fetch_state(bv, &st, &rec, j, j));
+      fresh = false;
     }
     ks_prof_resolve_gs(ctx, &rec, j, j);
     bv->passes_last_host = rec.passes; bv->passes_total_host += rec.passes;
     if (norm) *norm = rec.nrm;
     if (lindep) *lindep = rec.lindep;
     if (H && j > bv->l) {   // BV_StoreCoefficients bvimpl.h:403-415: entries l..j-1
-      KS_HIP(hipMemcpyAsync(H, bv->buffer + (size_t)j * (bv->nc + bv->m) + bv->nc + bv->l, sizeof(double) * (j - bv->l), hipMemcpyDeviceToHost, ctx->stream));
-      KS_HIP(ks_sync(ctx));
+      if (fresh) memcpy(H, cb.data() + (size_t)j * ldb + bv->nc + bv->l, sizeof(double) * (j - bv->l));
+      else {
+        KS_HIP(hipMemcpyAsync(H, bv->buffer + (size_t)j * ldb + bv->nc + bv->l, sizeof(double) * (j - bv->l), hipMemcpyDeviceToHost, ctx->stream));
+        KS_HIP(ks_sync(ctx));
+      }
     }
     return KS_SUCCESS;
   }
@@ -868,6 +877,13 @@ extern "C" int ks_bv_orthogonalizecolumn(ks_bv bv, int j, double *H, double *nor
   KS_CHECK(j >= 0, KS_ERR_ARG_OUTOFRANGE, "Index j must be non-negative");
   KS_CHECK(j < bv->m, KS_ERR_ARG_OUTOFRANGE, "Index j=%d but BV only has %d columns", j, bv->m);
   return orthogonalize_column(bv, j, 0, H, norm, lindep);
+}
+
+// BVOrthonormalizeColumn that also hands back the coefficients (what a GMRES over a BV needs for its Hessenberg column): the scaling rides in the
+// final update, coefficients, norm and flag come back in one host wait
+int ks_bv_orthonormalize_coefs(ks_bv bv, int j, double *H, double *norm, int *lindep)
+{
+  return orthogonalize_column(bv, j, 1, H, norm, lindep);
 }
 
 extern "C" int ks_bv_orthonormalizecolumn(ks_bv bv, int j, int replace, double *norm, int *lindep)   // bvorthog.c:380-427

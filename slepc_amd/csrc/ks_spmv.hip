@@ -659,7 +659,7 @@ __global__ __launch_bounds__(1024) void k_binned_gather(int n, int cs, int wb, i
 }
 // phase 2: grid = wave-bins / 4, 256 threads: a wave per wave-bin; LDS: 4 x (wr + 1) accumulators (the last one takes the padding entries)
 __global__ __launch_bounds__(256) void k_binned_reduce(int n, int wr, const long long *__restrict__ bstart, const double *__restrict__ G, const double *__restrict__ val,
-                                                       const unsigned short *__restrict__ row16, double *__restrict__ y)
+                                                       const unsigned short *__restrict__ row16, double *__restrict__ y, const double *__restrict__ rowscale)
 {
   extern __shared__ double bn_lds[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256) void k_binned_reduce(int n, int wr, const long
 #pragma unroll
     for (int k = 0; k < 8; k++) if (q + k * 64 + lane < e1) __hip_atomic_fetch_add(acc + r[k], a[k] * g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
-  for (int i = lane; i < wr; i += 64) { const long long row = (long long)b * wr + i; if (row < n) y[row] = acc[i]; }
+  for (int i = lane; i < wr; i += 64) { const long long row = (long long)b * wr + i; if (row < n) y[row] = rowscale ? rowscale[row] * acc[i] : acc[i]; }
 }
 
 
@@ -1141,9 +1141,13 @@ extern "C" int ks_mat_get_sizes(ks_mat A, int *n_local, int *n_global, long long
 
 // y = A x.  Multi-rank: pack boundary entries, exchange with the neighbours (RCCL send/recv over xGMI),
 // diagonal block product, then the off-diagonal rows add their ghost contributions.
-int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
+// a row scaling can ride in the product's last pass: the binned layout on a rank without off-diagonal rows (their contribution is added afterwards)
+bool ks_mat_can_rowscale(ks_mat A) { return A && !A->shell_mult && A->use_binned && A->n_orows == 0; }
+
+int ks_mat_mult_internal(ks_mat A, const double *x, double *y, const double *rowscale)
 {
   ks_ctx ctx = A->ctx;
+  if (rowscale && !ks_mat_can_rowscale(A)) KS_FAIL(KS_ERR_PLIB, "row scaling asked of a product that cannot fold it in");
   if (A->shell_mult) return A->shell_mult(A->shell_user, x, y);
   const bool multi = ctx->comm.size > 1 && (A->nsend > 0 || A->nghost > 0);
   // Halo under the diagonal-block product (PETSc: VecScatterBegin / local product / VecScatterEnd in MatMult_MPIAIJ): pack and
@@ -1174,7 +1178,7 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y)
     if (A->use_binned) {
       hipLaunchKernelGGL(k_binned_gather, dim3((unsigned)A->bn_ns), dim3(1024), (size_t)A->bn_cs * 8 + (size_t)(2 * A->bn_wb + 1) * 4, ctx->stream, A->n, A->bn_cs, A->bn_wb, A->bn_nwin,
                          A->bn_sbase, A->bn_col16, A->bn_off1, A->bn_off2t, A->bn_wseg, x, A->bn_g);
-      hipLaunchKernelGGL(k_binned_reduce, dim3((unsigned)(A->bn_wb / 4)), dim3(256), (size_t)4 * (A->bn_wr + 1) * 8, ctx->stream, A->n, A->bn_wr, A->bn_bstart, A->bn_g, A->bn_val, A->bn_row16, y);
+      hipLaunchKernelGGL(k_binned_reduce, dim3((unsigned)(A->bn_wb / 4)), dim3(256), (size_t)4 * (A->bn_wr + 1) * 8, ctx->stream, A->n, A->bn_wr, A->bn_bstart, A->bn_g, A->bn_val, A->bn_row16, y, rowscale);
     } else if (A->use_sliced) {
       const int per_xcd = std::max(1, std::min((A->n + 255) / 256, (ctx->num_cu / 8) * 8));       // 8 resident workgroups per CU of the XCD
       hipLaunchKernelGGL(k_spmv_sliced, dim3((unsigned)(8 * per_xcd)), dim3(256), 0, ctx->stream, A->n, A->nslice, A->sl_rowptr, A->sl_base, A->sl_col, A->sl_val, x, A->ypart);

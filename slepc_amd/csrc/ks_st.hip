@@ -53,6 +53,7 @@ int linop_apply(ks_st st, double a, ks_mat A, double b, ks_mat B, bool identity_
   ks_ctx ctx = st->ctx;
   const long long n = st->n;
   if (A) {
+    if (s && a == 1.0 && (b == 0.0 || (!B && !identity_term)) && ks_mat_can_rowscale(A)) return ks_mat_mult_internal(A, x, out, s);   // out = s .* (A x) in the product's own launches
     KS_CALL(ks_mat_mult_internal(A, x, out));
     if (b != 0.0) {                                         // a zero shift leaves A alone (MatMult_Shell, stshellmat.c:52: "if (ctx->alpha!=0.0)")
       if (B) { KS_CALL(ks_mat_mult_internal(B, x, tmp)); return lincomb(ctx, n, s, a, out, b, tmp, out); }
@@ -96,7 +97,7 @@ int gmres_solve(ks_st st, const double *rhs, double *y)
     for (int j = 0; j < m; j++) {
       KS_CALL(apply_P(st, st->dinv, ks_bv_col(K, j), ks_bv_col(K, j + 1), t1));
       double hn = 0.0; int lindep = 0;
-      KS_CALL(ks_bv_orthogonalizecolumn(K, j + 1, h.data(), &hn, &lindep));
+      KS_CALL(ks_bv_orthonormalize_coefs(K, j + 1, h.data(), &hn, &lindep));       // the 1/hn scaling rides in the final update; h, hn and the flag arrive in one host wait
       its++; st->its++;
       h[j + 1] = hn;
       for (int i = 0; i < j; i++) { const double t = cs[i] * h[i] + sn[i] * h[i + 1]; h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1]; h[i] = t; }
@@ -107,7 +108,6 @@ int gmres_solve(ks_st st, const double *rhs, double *y)
       for (int i = 0; i <= j; i++) H[(size_t)i + (size_t)j * (m + 1)] = h[i];
       res = fabs(g[j + 1]); jj = j + 1;
       if (res <= tol || its >= st->max_it || lindep || hn == 0.0) break;
-      KS_CALL(ks_bv_scalecolumn(K, j + 1, 1.0 / hn));
     }
     for (int i = jj - 1; i >= 0; i--) {                     // back substitution R yc = g
       double t = g[i];

@@ -274,7 +274,9 @@ int ksk_multvec(ks_bv bv, const double *A, int lda, int ncols, double alpha, dou
 int ksk_scale(ks_ctx ctx, double *x, size_t n, double alpha);
 int ksk_copy(ks_ctx ctx, const double *src, double *dst, size_t n);
 
-int ks_mat_mult_internal(ks_mat A, const double *x, double *y);
+int ks_mat_mult_internal(ks_mat A, const double *x, double *y, const double *rowscale = nullptr);   // rowscale: y = rowscale .* (A x) where the layout can fold it into its last pass (else the caller scales)
+bool ks_mat_can_rowscale(ks_mat A);                                 // the product can take a row scaling in the same launches
+int ks_bv_orthonormalize_coefs(ks_bv bv, int j, double *H, double *norm, int *lindep);
 int ksb_ipmatmult(ks_bv bv, const double *x, const double **z);   // z = x, or B*x (in bv->Bx) when a matrix is set
 int ksb_norm_b(ks_bv bv, const double *x, double *val);            // sqrt(x' B x) with the BV_SafeSqrt check (BVNorm_Private)
 int ksb_dot_range(ks_bv X, int xs, int xe, ks_bv Y, int ys, int ye, double *M, int ldm);          // M(ys:ye,xs:xe) = Y(:,ys:ye)^T X(:,xs:xe)
