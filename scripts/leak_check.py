@@ -37,6 +37,15 @@ def cycle(i):
     V.Orthogonalize(None)
     for o in (eps, e2, e3):
         assert o.GetConverged() >= 1
+    # the binned and the XCD-sliced SpMV layouts (forced on a small random matrix), and the communicator's one-shot mailboxes
+    os.environ["KSGPU_SPMV"] = ["binned", "sliced"][i % 2]
+    rng = np.random.default_rng(i)
+    nb = 6000; rp = np.arange(0, 8 * nb + 1, 8, dtype=np.int32)
+    M = ks.Mat.from_csr(ctx, rp, rng.integers(0, nb, 8 * nb).astype(np.int32), rng.uniform(-1, 1, 8 * nb))
+    del os.environ["KSGPU_SPMV"]
+    assert M.layout() == ["binned", "sliced"][i % 2]
+    M.mult(np.ones(nb))
+    M.destroy()
     del eps, e2, e3, V, A, An, L, B, st
 
 
