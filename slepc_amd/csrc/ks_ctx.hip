@@ -597,7 +597,10 @@ extern "C" int ks_comm_check(ks_ctx ctx)
   std::vector<double> h(NCALL * LEN + 16);
   bool bad = false;
   char msg[400] = "";
-  auto fail = [&](const char *fmt, auto... a) { if (!bad) snprintf(msg, sizeof(msg), fmt, a...); bad = true; };
+  auto fail = [&](const char *fmt, auto... a) {
+    if (!bad) { if constexpr (sizeof...(a) == 0) snprintf(msg, sizeof(msg), "%s", fmt); else snprintf(msg, sizeof(msg), fmt, a...); }
+    bad = true;
+  };
   // (1) allreduce
   for (int i = 0; i < NCALL; i++) for (int j = 0; j < LEN; j++) h[i * LEN + j] = (rank + 1) * (i + 1) * (j + 1) / 16.0;
   if (hipMemcpyAsync(d, h.data(), NCALL * LEN * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) fail("communicator check: upload failed");
