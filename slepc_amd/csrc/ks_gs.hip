@@ -314,7 +314,12 @@ __device__ __forceinline__ void upd_tiles(const double *V, long long ld, int n, 
         }
       }
       if (scal) { s.x *= alpha; s.y *= alpha; }
-      if (store) *reinterpret_cast<double2 *>(v + r) = s;
+      if (store) {
+        // written through (sc1): beside the k read streams a write-through store costs 20 us less per sweep than a write-back one on the boxes where the
+        // stored column is expensive (profiles/r02_micro_update_write5.txt); the vector is next read by another kernel in any case
+        const ks_d2v sv = {s.x, s.y};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(reinterpret_cast<ks_d2v *>(v + r)), "v"(sv) : "memory");
+      }
       if (fuse) {
 #pragma unroll
         for (int i = 0; i < KT; i++) { acc[i] = fma(xv[i].x, s.x, acc[i]); acc[i] = fma(xv[i].y, s.y, acc[i]); }
