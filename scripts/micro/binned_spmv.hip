@@ -57,7 +57,11 @@ __global__ __launch_bounds__(1024) void k_phase1(const unsigned short *__restric
         } else { int sg = lo; while (e >= o1[sg + 1]) sg++; d = o2[sg] - o1[sg]; }
         d2v g = {xs[c[k] & 0xffffu], xs[c[k] >> 16]};
         if (DIAG == 5) { g.x *= a[k].x; g.y *= a[k].y; }
-        if (DIAG == 1) sink += g.x + g.y + d; else __builtin_nontemporal_store(g, (d2v *)(G + (e + d)));
+        if (DIAG == 1) sink += g.x + g.y + d;
+        else if (DIAG == 6) *(d2v *)(G + (e + d)) = g;
+        else if (DIAG == 7) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"((d2v *)(G + (e + d))), "v"(g) : "memory");
+        else if (DIAG == 8) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"((d2v *)(G + (e + d))), "v"(g) : "memory");
+        else __builtin_nontemporal_store(g, (d2v *)(G + (e + d)));
       }
     }
   }
@@ -118,7 +122,7 @@ int main()
   CK(hipFuncSetAttribute((const void *)k_phase1<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
   CK(hipFuncSetAttribute((const void *)k_phase1<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
 
-  CK(hipFuncSetAttribute((const void *)k_phase2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); CK(hipFuncSetAttribute((const void *)k_phase2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); CK(hipFuncSetAttribute((const void *)k_phase1<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+  CK(hipFuncSetAttribute((const void *)k_phase2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); CK(hipFuncSetAttribute((const void *)k_phase2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); CK(hipFuncSetAttribute((const void *)k_phase1<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1)); CK(hipFuncSetAttribute((const void *)k_phase1<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1)); CK(hipFuncSetAttribute((const void *)k_phase1<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1)); CK(hipFuncSetAttribute((const void *)k_phase1<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
   hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
   for (int rep = 0; rep < 6; rep++) {
     CK(hipEventRecord(e0));
@@ -135,7 +139,7 @@ int main()
     CK(hipEventRecord(e0)); for (int r = 0; r < 4; r++) hipLaunchKernelGGL(kern, dim3(NS), dim3(1024), lds1, 0, col16, off1, off2t, wseg, nwin, x, G, per_slice, (const double *)nullptr);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); printf("phase 1, %-44s %7.1f us\n", name, ms / 4 * 1e3);
   };
-  diag(k_phase1<0>, "as it is"); diag(k_phase1<1>, "no store");
+  diag(k_phase1<0>, "as it is (nt store)"); diag(k_phase1<1>, "no store"); diag(k_phase1<6>, "plain store"); diag(k_phase1<7>, "sc1 store"); diag(k_phase1<8>, "sc0 sc1 nt store"); diag(k_phase1<0>, "as it is (nt store)");
   for (int rep = 0; rep < 4; rep++) {     // the values on phase 1's side: P = val * x[col] out, phase 2 reads P and the row only
     CK(hipEventRecord(e0));
     hipLaunchKernelGGL(k_phase1<5>, dim3(NS), dim3(1024), lds1, 0, col16, off1, off2t, wseg, nwin, x, G, per_slice, val);
