@@ -343,6 +343,10 @@ def _oneshot_worker(rank, world, port, q, absent_rank):
         res["eig"] = [eps.GetEigenvalue(i)[0] for i in range(3)]
         res["its"] = eps.GetIterationNumber(); res["nconv"] = eps.GetConverged()
         res["err"] = [eps.ComputeError(i) for i in range(3)]
+        # a basis wider than the fused kernels: the chunked dots reduce 65..71 coefficients per pass, still one-shot (<= 128)
+        e3 = ks.EPS(ctx); e3.SetOperators(A); e3.SetProblemType(ks.EPS_HEP); e3.SetDimensions(20, 70); e3.Solve()
+        res["wide_eig"] = [e3.GetEigenvalue(i)[0] for i in range(20)]; res["wide_its"] = e3.GetIterationNumber(); res["wide_nconv"] = e3.GetConverged()
+        del e3
         res["back"] = ctx.set_allreduce("provider")
         ctx.comm_check()
         dist.barrier()
@@ -392,6 +396,9 @@ def test_oneshot_allreduce_between_processes_sharing_one_gpu(world):
         assert o["its"] == r.its and o["nconv"] == r.nconv and max(o["err"]) < 1e-8
         assert np.allclose(o["eig"], r.eigr[r.perm][:3], rtol=1e-10)
         assert o["bits"] == out[0]["bits"] and o["eig"] == out[0]["eig"] and o["beta"] == out[0]["beta"]
+        assert o["wide_eig"] == out[0]["wide_eig"] and o["wide_its"] == out[0]["wide_its"] and o["wide_nconv"] >= 20
+    rw = O.eps_krylovschur_hep(A, 20, ncv=70)
+    assert out[0]["wide_its"] == rw.its and np.allclose(out[0]["wide_eig"], rw.eigr[rw.perm][:20], rtol=1e-10)
 
 
 @pytest.mark.timeout(600)
