@@ -93,6 +93,7 @@ extern "C" int ks_ctx_destroy(ks_ctx ctx)
   }
   if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
   for (int i = 0; i < 2; i++) if (ctx->ev_h2d[i]) hipEventDestroy(ctx->ev_h2d[i]);
+  if (ctx->ev_fetch) hipEventDestroy(ctx->ev_fetch);
   if (ctx->comm.ag_dev) hipFree(ctx->comm.ag_dev);
   if (ctx->split.dev) hipFree(ctx->split.dev);
   if (ctx->halo_stream) { hipStreamSynchronize(ctx->halo_stream); hipStreamDestroy(ctx->halo_stream); }

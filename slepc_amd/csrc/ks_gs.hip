@@ -688,6 +688,40 @@ int fetch_state(ks_bv bv, KsGsState *st, KsStepRec *recs, int j0, int j1, double
   return KS_SUCCESS;
 }
 
+// The same in two halves, for a caller that enqueues more work between them: _begin puts the three copies into the pinned area and marks their end
+// with an event, _end waits for that event only - the work enqueued after _begin keeps the device busy while the host reads the results. Returns
+// false (nothing enqueued) when the results do not fit the pinned area: the caller then uses fetch_state.
+bool fetch_state_begin(ks_bv bv, int j0, int j1, size_t coef_len, int *rc)
+{
+  ks_ctx ctx = bv->ctx;
+  *rc = KS_SUCCESS;
+  const size_t nrec = (j1 >= j0) ? (size_t)(j1 - j0 + 1) : 0;
+  const size_t off_rec = (sizeof(KsGsState) + 63) / 64 * 64, off_coef = (off_rec + nrec * sizeof(KsStepRec) + 63) / 64 * 64;
+  if (off_coef + coef_len * sizeof(double) > KS_PINNED_D2H_BYTES) return false;
+  char *pin = (char *)ctx->h_pinned;
+  auto chk = [&](hipError_t e) { if (e != hipSuccess && *rc == KS_SUCCESS) { ks_set_error("fetch_state_begin: %s", hipGetErrorString(e)); *rc = KS_ERR_LIB; } };
+  if (!ctx->ev_fetch) chk(hipEventCreateWithFlags(&ctx->ev_fetch, hipEventDisableTiming));
+  chk(hipMemcpyAsync(pin, bv->gs, sizeof(KsGsState), hipMemcpyDeviceToHost, ctx->stream));
+  if (nrec) chk(hipMemcpyAsync(pin + off_rec, bv->recs + j0, sizeof(KsStepRec) * nrec, hipMemcpyDeviceToHost, ctx->stream));
+  if (coef_len) chk(hipMemcpyAsync(pin + off_coef, bv->buffer, sizeof(double) * coef_len, hipMemcpyDeviceToHost, ctx->stream));
+  if (*rc == KS_SUCCESS) chk(hipEventRecord(ctx->ev_fetch, ctx->stream));
+  return true;
+}
+int fetch_state_end(ks_bv bv, KsGsState *st, KsStepRec *recs, int j0, int j1, double *coef_out, size_t coef_len)
+{
+  ks_ctx ctx = bv->ctx;
+  const size_t nrec = (recs && j1 >= j0) ? (size_t)(j1 - j0 + 1) : 0;
+  const size_t off_rec = (sizeof(KsGsState) + 63) / 64 * 64, off_coef = (off_rec + nrec * sizeof(KsStepRec) + 63) / 64 * 64;
+  const char *pin = (const char *)ctx->h_pinned;
+  ctx->nsync++;
+  KS_HIP(hipEventSynchronize(ctx->ev_fetch));
+  memcpy(st, pin, sizeof(KsGsState));
+  if (nrec) memcpy(recs, pin + off_rec, sizeof(KsStepRec) * nrec);
+  if (coef_len) memcpy(coef_out, pin + off_coef, sizeof(double) * coef_len);
+  if (st->err) KS_FAIL(st->err, "Invalid inner product (BV_SafeSqrt): negative v^H v");
+  return KS_SUCCESS;
+}
+
 // ---- host-driven generic Gram-Schmidt (MGS, vector argument, `which` selection) -----------------
 // Literal restatement of bvorthog.c on top of the primitive ops; every step synchronises, as the
 // reference's GPU backend does.  h/c are host arrays of nc+m entries when v is given, else the buffer.
@@ -823,39 +857,68 @@ int store_buffer_column(ks_bv bv, int j, const double *hh, int len)
 
 bool use_fused(ks_bv bv) { return bv->orthog_type == KS_BV_ORTHOG_CGS && bv->nc + bv->m <= 8000 && !getenv("KSGPU_NO_FUSED_GS"); }
 
+// The two halves of the fused orthogonalisation of column j: the enqueue (no host wait) and the collection of its results (one host wait; a
+// column the device flagged is completed here, *late_completion says so: whatever was enqueued behind the first half saw an unfinished column).
+// early_copies: the result copies are enqueued right behind the program (with the coefficient buffer when want_coefs), so that work the caller enqueues
+// next does not stand between the program and its results; gs_collect_column then only waits for those copies
+int gs_enqueue_column(ks_bv bv, int j, int normalize, bool early_copies = false, bool want_coefs = false)
+{
+  KS_CALL(begin_run(bv));
+  KS_CALL(enqueue_fused_gs(bv, j, normalize, 0));
+  bv->fetch_pending = false;
+  if (early_copies) {
+    const size_t ldb = (size_t)(bv->nc + bv->m), want = (want_coefs && j > bv->l) ? (size_t)(j + 1) * ldb : 0;
+    int rc = KS_SUCCESS;
+    if (fetch_state_begin(bv, j, j, want, &rc)) { bv->fetch_pending = true; bv->fetch_coefs = want; }
+    KS_CALL(rc);
+  }
+  return KS_SUCCESS;
+}
+int gs_collect_column(ks_bv bv, int j, int normalize, double *H, double *norm, int *lindep, int *late_completion)
+{
+  ks_ctx ctx = bv->ctx;
+  KsGsState st; KsStepRec rec;
+  // the coefficients the caller asks for travel with the state (one host wait): the buffer up to and including column j
+  const size_t ldb = (size_t)(bv->nc + bv->m), want = (H && j > bv->l) ? (size_t)(j + 1) * ldb : 0;
+  bool batched = want && want * sizeof(double) + 4096 <= KS_PINNED_D2H_BYTES;
+  std::vector<double> cb(batched ? want : 0);
+  if (bv->fetch_pending) {
+    bv->fetch_pending = false;
+    batched = want && bv->fetch_coefs == want;
+    cb.resize(batched ? want : 0);
+    KS_CALL(fetch_state_end(bv, &st, &rec, j, j, batched ? cb.data() : nullptr, batched ? want : 0));
+  } else KS_CALL(fetch_state(bv, &st, &rec, j, j, batched ? cb.data() : nullptr, batched ? want : 0));
+  bool fresh = batched;
+  if (late_completion) *late_completion = 0;
+  if (st.halt_col == j) {                       // rare: third pass and/or explicit norm needed
+    if (ctx->prof_on) { KsStepRec tmp = rec; tmp.passes = st.pass + 1; tmp.expl = 0; ks_prof_resolve_gs(ctx, &tmp, j, j); }
+    KS_CALL(enqueue_gs_completion(bv, j, normalize, 0));
+    KS_CALL(fetch_state(bv, &st, &rec, j, j));
+    fresh = false;
+    if (late_completion) *late_completion = 1;
+  }
+  ks_prof_resolve_gs(ctx, &rec, j, j);
+  bv->passes_last_host = rec.passes; bv->passes_total_host += rec.passes;
+  if (norm) *norm = rec.nrm;
+  if (lindep) *lindep = rec.lindep;
+  if (H && j > bv->l) {   // BV_StoreCoefficients bvimpl.h:403-415: entries l..j-1
+    if (fresh) memcpy(H, cb.data() + (size_t)j * ldb + bv->nc + bv->l, sizeof(double) * (j - bv->l));
+    else {
+      KS_HIP(hipMemcpyAsync(H, bv->buffer + (size_t)j * ldb + bv->nc + bv->l, sizeof(double) * (j - bv->l), hipMemcpyDeviceToHost, ctx->stream));
+      KS_HIP(ks_sync(ctx));
+    }
+  }
+  return KS_SUCCESS;
+}
+
 // Orthogonalize column j; fused or generic. Returns norm/lindep on the host (synchronises).
 int orthogonalize_column(ks_bv bv, int j, int normalize, double *H, double *norm, int *lindep)
 {
   ks_ctx ctx = bv->ctx;
   KS_HIP(hipSetDevice(ctx->device));
   if (use_fused(bv)) {
-    KS_CALL(begin_run(bv));
-    KS_CALL(enqueue_fused_gs(bv, j, normalize, 0));
-    KsGsState st; KsStepRec rec;
-    // the coefficients the caller asks for travel with the state (one host wait): the buffer up to and including column j
-    const size_t ldb = (size_t)(bv->nc + bv->m), want = (H && j > bv->l) ? (size_t)(j + 1) * ldb : 0;
-    const bool batched = want && want * sizeof(double) + 4096 <= KS_PINNED_D2H_BYTES;
-    std::vector<double> cb(batched ? want : 0);
-    KS_CALL(fetch_state(bv, &st, &rec, j, j, batched ? cb.data() : nullptr, batched ? want : 0));
-    bool fresh = batched;
-    if (st.halt_col == j) {                       // rare: third pass and/or explicit norm needed
-      if (ctx->prof_on) { KsStepRec tmp = rec; tmp.passes = st.pass + 1; tmp.expl = 0; ks_prof_resolve_gs(ctx, &tmp, j, j); }
-      KS_CALL(enqueue_gs_completion(bv, j, normalize, 0));
-      KS_CALL(fetch_state(bv, &st, &rec, j, j));
-      fresh = false;
-    }
-    ks_prof_resolve_gs(ctx, &rec, j, j);
-    bv->passes_last_host = rec.passes; bv->passes_total_host += rec.passes;
-    if (norm) *norm = rec.nrm;
-    if (lindep) *lindep = rec.lindep;
-    if (H && j > bv->l) {   // BV_StoreCoefficients bvimpl.h:403-415: entries l..j-1
-      if (fresh) memcpy(H, cb.data() + (size_t)j * ldb + bv->nc + bv->l, sizeof(double) * (j - bv->l));
-      else {
-        KS_HIP(hipMemcpyAsync(H, bv->buffer + (size_t)j * ldb + bv->nc + bv->l, sizeof(double) * (j - bv->l), hipMemcpyDeviceToHost, ctx->stream));
-        KS_HIP(ks_sync(ctx));
-      }
-    }
-    return KS_SUCCESS;
+    KS_CALL(gs_enqueue_column(bv, j, normalize));
+    return gs_collect_column(bv, j, normalize, H, norm, lindep, nullptr);
   }
   std::vector<double> hh(bv->nc + bv->m + 1, 0.0);
   double nrm = 0.0; int lin = 0, np = 0;
@@ -890,6 +953,11 @@ int ks_bv_orthonormalize_coefs(ks_bv bv, int j, double *H, double *norm, int *li
 {
   return orthogonalize_column(bv, j, 1, H, norm, lindep);
 }
+// the same in two halves, for a caller that has work to enqueue behind the orthogonalisation before it looks at the result (the next operator
+// application of a GMRES): available when the fused program runs (classical Gram-Schmidt)
+bool ks_bv_orthonormalize_can_split(ks_bv bv) { return use_fused(bv); }
+int ks_bv_orthonormalize_enqueue(ks_bv bv, int j) { KS_HIP(hipSetDevice(bv->ctx->device)); return gs_enqueue_column(bv, j, 1, true, true); }
+int ks_bv_orthonormalize_collect(ks_bv bv, int j, double *H, double *norm, int *lindep, int *late_completion) { return gs_collect_column(bv, j, 1, H, norm, lindep, late_completion); }
 
 extern "C" int ks_bv_orthonormalizecolumn(ks_bv bv, int j, int replace, double *norm, int *lindep)   // bvorthog.c:380-427
 {

@@ -93,11 +93,25 @@ int gmres_solve(ks_st st, const double *rhs, double *y)
   for (;;) {
     KS_CALL(ks_bv_scalecolumn(K, 0, 1.0 / beta));
     std::fill(g.begin(), g.end(), 0.0); g[0] = beta;
-    int jj = 0; double res = beta;
+    int jj = 0; double res = beta, res_before = beta;
+    const bool split = ks_bv_orthonormalize_can_split(K);
+    bool applied = false;                           // K(:, j+1) = P K(:, j) already enqueued (speculatively, during the previous iteration)
     for (int j = 0; j < m; j++) {
-      KS_CALL(apply_P(st, st->dinv, ks_bv_col(K, j), ks_bv_col(K, j + 1), t1));
+      if (!applied) KS_CALL(apply_P(st, st->dinv, ks_bv_col(K, j), ks_bv_col(K, j + 1), t1));
+      applied = false;
       double hn = 0.0; int lindep = 0;
-      KS_CALL(ks_bv_orthonormalize_coefs(K, j + 1, h.data(), &hn, &lindep));       // the 1/hn scaling rides in the final update; h, hn and the flag arrive in one host wait
+      if (split) {
+        // The next operator application goes in behind the orthogonalisation BEFORE the host waits for this column's coefficients, so the device
+        // is not idle while the host rotates and tests (30 us per iteration in the trace, profiles/r02_config5_kernel_trace_gaps.txt) - but only
+        // when the residual history says another iteration is coming: a product wasted on the last iteration costs more than the gaps of a solve.
+        const double predicted = (j == 0) ? res : res * std::min(1.0, res / res_before);
+        const bool spec = (j + 1 < m) && (its + 1 < st->max_it) && predicted > 3.0 * tol;
+        int late = 0;
+        KS_CALL(ks_bv_orthonormalize_enqueue(K, j + 1));
+        if (spec) KS_CALL(apply_P(st, st->dinv, ks_bv_col(K, j + 1), ks_bv_col(K, j + 2), t1));
+        KS_CALL(ks_bv_orthonormalize_collect(K, j + 1, h.data(), &hn, &lindep, &late));
+        applied = spec && !late;                    // a column completed late was multiplied unfinished: apply again
+      } else KS_CALL(ks_bv_orthonormalize_coefs(K, j + 1, h.data(), &hn, &lindep));       // the 1/hn scaling rides in the final update; h, hn and the flag arrive in one host wait
       its++; st->its++;
       h[j + 1] = hn;
       for (int i = 0; i < j; i++) { const double t = cs[i] * h[i] + sn[i] * h[i + 1]; h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1]; h[i] = t; }
@@ -106,7 +120,7 @@ int gmres_solve(ks_st st, const double *rhs, double *y)
       h[j] = r; h[j + 1] = 0.0;
       g[j + 1] = -sn[j] * g[j]; g[j] = cs[j] * g[j];
       for (int i = 0; i <= j; i++) H[(size_t)i + (size_t)j * (m + 1)] = h[i];
-      res = fabs(g[j + 1]); jj = j + 1;
+      res_before = res; res = fabs(g[j + 1]); jj = j + 1;
       if (res <= tol || its >= st->max_it || lindep || hn == 0.0) break;
     }
     for (int i = jj - 1; i >= 0; i--) {                     // back substitution R yc = g

@@ -75,6 +75,7 @@ struct ks_ctx_s {
   // KS_PINNED_H2D_DOUBLES doubles for coefficient uploads (alternating; an event per half says when its last upload has left)
   double *h_pinned = nullptr; size_t h_pinned_len = 0;
   hipEvent_t ev_h2d[2] = {nullptr, nullptr}; int h2d_next = 0;
+  hipEvent_t ev_fetch = nullptr;        // marks the end of a batch of result copies that was enqueued ahead of further work (ks_gs.hip: fetch_state_begin / _end)
 };
 
 // every host wait on the context's stream goes through here, so that tests can assert that a call enqueues without waiting
@@ -232,6 +233,7 @@ struct ks_bv_s {
   int orthog_type = KS_BV_ORTHOG_CGS, orthog_ref = KS_BV_ORTHOG_REFINE_IFNEEDED, orthog_block = KS_BV_ORTHOG_BLOCK_GS;
   ks_mat matrix = nullptr;   // inner-product matrix B of BVSetMatrix (positive definite), borrowed; nullptr = standard
   double *Bx = nullptr;      // B*x of the vector an inner product is being taken with (BV_IPMatMult bvimpl.h:147-158)
+  bool fetch_pending = false; size_t fetch_coefs = 0;     // result copies of the last enqueued column are on their way (gs_enqueue_column with early copies)
   double *pend = nullptr;    // [3][KS_PSTRIDE] coefficients of the passes since the vector was last written back (what the next update applies, pass by pass)
   double orthog_eta = 0.7071;
   double deftol = 10 * 2.220446049250313e-16;
@@ -277,6 +279,9 @@ int ksk_copy(ks_ctx ctx, const double *src, double *dst, size_t n);
 int ks_mat_mult_internal(ks_mat A, const double *x, double *y, const double *rowscale = nullptr);   // rowscale: y = rowscale .* (A x) where the layout can fold it into its last pass (else the caller scales)
 bool ks_mat_can_rowscale(ks_mat A);                                 // the product can take a row scaling in the same launches
 int ks_bv_orthonormalize_coefs(ks_bv bv, int j, double *H, double *norm, int *lindep);
+bool ks_bv_orthonormalize_can_split(ks_bv bv);
+int ks_bv_orthonormalize_enqueue(ks_bv bv, int j);
+int ks_bv_orthonormalize_collect(ks_bv bv, int j, double *H, double *norm, int *lindep, int *late_completion);
 int ksb_ipmatmult(ks_bv bv, const double *x, const double **z);   // z = x, or B*x (in bv->Bx) when a matrix is set
 int ksb_norm_b(ks_bv bv, const double *x, double *val);            // sqrt(x' B x) with the BV_SafeSqrt check (BVNorm_Private)
 int ksb_dot_range(ks_bv X, int xs, int xe, ks_bv Y, int ys, int ye, double *M, int ldm);          // M(ys:ye,xs:xe) = Y(:,ys:ye)^T X(:,xs:xe)
