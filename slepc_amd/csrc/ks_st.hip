@@ -85,17 +85,28 @@ int gmres_solve(ks_st st, const double *rhs, double *y)
   KS_HIP(hipMemsetAsync(y, 0, sizeof(double) * std::max<long long>(n, 1), ctx->stream));
   KS_CALL(lincomb(ctx, n, st->dinv, 1.0, rhs, 0.0, nullptr, ks_bv_col(K, 0)));
   double beta = 0.0;
-  KS_CALL(ks_bv_normcolumn(K, 0, KS_NORM_2, &beta));
+  const bool split = ks_bv_orthonormalize_can_split(K);
+  bool k0_normalised = false, applied0 = false;
+  if (split) {
+    // norm and scaling of the first basis vector as one enqueued program (BVOrthonormalizeColumn of column 0), the first operator application behind it:
+    // the host learns beta while the product runs
+    int lin0 = 0, late0 = 0;
+    KS_CALL(ks_bv_orthonormalize_enqueue(K, 0));
+    KS_CALL(apply_P(st, st->dinv, ks_bv_col(K, 0), ks_bv_col(K, 1), t1));
+    KS_CALL(ks_bv_orthonormalize_collect(K, 0, nullptr, &beta, &lin0, &late0));
+    k0_normalised = true; applied0 = !late0;
+  } else KS_CALL(ks_bv_normcolumn(K, 0, KS_NORM_2, &beta));
   st->last_rnorm = beta;
   if (beta == 0.0) return KS_SUCCESS;
   const double tol = std::max(st->rtol * beta, 1e-50);
   int its = 0;
   for (;;) {
-    KS_CALL(ks_bv_scalecolumn(K, 0, 1.0 / beta));
+    if (!k0_normalised) KS_CALL(ks_bv_scalecolumn(K, 0, 1.0 / beta));
+    k0_normalised = false;
     std::fill(g.begin(), g.end(), 0.0); g[0] = beta;
     int jj = 0; double res = beta, res_before = beta;
-    const bool split = ks_bv_orthonormalize_can_split(K);
-    bool applied = false;                           // K(:, j+1) = P K(:, j) already enqueued (speculatively, during the previous iteration)
+    bool applied = applied0;                        // K(:, j+1) = P K(:, j) already enqueued (speculatively, during the previous iteration)
+    applied0 = false;
     for (int j = 0; j < m; j++) {
       if (!applied) KS_CALL(apply_P(st, st->dinv, ks_bv_col(K, j), ks_bv_col(K, j + 1), t1));
       applied = false;
