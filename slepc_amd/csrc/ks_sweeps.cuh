@@ -37,11 +37,24 @@ static inline int ks_basis_is_cache_resident(size_t columns, size_t ld) { return
 constexpr int SW_BLOCK = 256;
 constexpr int SW_WAVES = SW_BLOCK / 64;
 
+// Sum over the 64 lanes with DPP moves (VALU cross-lane reads: quad permutes, row rotations, the two row broadcasts) instead of __shfl_down, which
+// goes through the LDS crossbar (ds_bpermute, two per double and step): a sweep ends with KT + 1 of these per wave, 4 waves sharing one LDS pipe.
+// The total forms in lane 63 and is handed to every lane.
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v)
+{
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
+  v += dpp_mov<0xb1>(v);       // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4e>(v);       // quad_perm [2,3,0,1]
+  v += dpp_mov<0x124>(v);      // row_ror 4
+  v += dpp_mov<0x128>(v);      // row_ror 8: every lane of a 16-lane row holds the row's sum
+  v += dpp_mov<0x142>(v);      // row_bcast 15: rows 1..3 add the sum of the row before
+  v += dpp_mov<0x143>(v);      // row_bcast 31: rows 2, 3 add lane 31 (rows 0 + 1); lane 63 = all four rows
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 // Block-combine KT per-thread accumulators and write them to partials[i*gridDim.x + blockIdx.x], i<ncols.

