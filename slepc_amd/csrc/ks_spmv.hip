@@ -70,7 +70,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_csr(int nrows, const int *_
       long long r = wb + u * GPW + gi;
       if (lane_g == 0 && r < nrows) {
         long long out = ROWLIST ? rowlist[r] : r;
-        if (ACCUM) y[out] += t; else y[out] = t;
+        if (ACCUM) y[out] += t; else __builtin_nontemporal_store(t, y + out);
       }
     }
   }
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_spmv_csr_stream(int n, const int *__res
       for (int p = lo; p < hi; p++) { const int sl = cs_slot(p - e0); acc = fma(sa[sl], sx[sl], acc); }
       __syncthreads();
     }
-    if (has) y[r] = acc;
+    if (has) __builtin_nontemporal_store(acc, y + r);
     __syncthreads();                       // erange is rewritten by the next row block
   }
 }
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_sell(int nrows, int nslices
 #pragma unroll
       for (int u = 0; u < UNR; u++) acc = fma(a[u], xv[u], acc);
     }
-    if (r < nrows) y[r] = acc;
+    if (r < nrows) __builtin_nontemporal_store(acc, y + r);
   }
 }
 
@@ -207,7 +207,9 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_dict(int nrows, const uint4
     double acc = 0.0;
 #pragma unroll
     for (int e = 0; e < W; e++) acc = fma(a[e], xv[e], acc);
-    y[r] = acc;
+    // Nontemporal, as in every product kernel below: a plain store leaves the 80 MB of y dirty in the L2s, and their write-back then mixes into the
+    // read streams of the dot sweep that follows (15 us of its 303 on the 216^3 workload: profiles/r02_ab_spmv_store_nt.txt)
+    __builtin_nontemporal_store(acc, y + r);
   }
 }
 
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_odict(int nrows, const unsi
     double acc = 0.0;
 #pragma unroll
     for (int e = 0; e < W; e++) acc = fma(a[e], xv[e], acc);
-    y[r] = acc;
+    __builtin_nontemporal_store(acc, y + r);
   }
 }
 
@@ -602,7 +604,7 @@ __global__ void k_sum_parts(int n, const double *__restrict__ ypart, double *__r
     double s = ypart[r];
 #pragma unroll
     for (int x = 1; x < 8; x++) s += ypart[(size_t)x * n + r];
-    y[r] = s;
+    __builtin_nontemporal_store(s, y + r);
   }
 }
 
@@ -678,7 +680,7 @@ __global__ __launch_bounds__(256) void k_binned_reduce(int n, int wr, const long
 #pragma unroll
     for (int k = 0; k < 8; k++) if (q + k * 64 + lane < e1) __hip_atomic_fetch_add(acc + r[k], a[k] * g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
-  for (int i = lane; i < wr; i += 64) { const long long row = (long long)b * wr + i; if (row < n) y[row] = rowscale ? rowscale[row] * acc[i] : acc[i]; }
+  for (int i = lane; i < wr; i += 64) { const long long row = (long long)b * wr + i; if (row < n) __builtin_nontemporal_store(rowscale ? rowscale[row] * acc[i] : acc[i], y + row); }
 }
 
 
