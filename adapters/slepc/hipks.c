@@ -14,10 +14,10 @@
    BV-level slots exactly as the functions below do); every PETSc / SLEPc call below is used with the argument lists the
    reference's own svec / svechip implementation uses.
 
-   Storage. The library owns the (nc+m)*ld column-major device block (BVSVEC layout). ctx->v is a HIP Vec created WITH that
+   Storage. The library owns the (nc+m)*ld column-major device block (BVSVEC layout). ctx->svec.v is a HIP Vec created WITH that
    block (VecCreate{Seq,MPI}HIPWithArray), so BVGetArray(Read), BVGetColumn, BVGetMat and PETSc's host<->device coherence
    work as they do for BVSVEC on HIP vectors; every compute slot brackets its ks_* call with VecHIPGetArray/Restore on
-   ctx->v, which tells PETSc that the device copy is the valid one.
+   ctx->svec.v, which tells PETSc that the device copy is the valid one.
    Coefficient buffer. bv->buffer (BVGetBufferVec, bvbasic.c:775-791) is a VECSEQHIP; its device array is handed to the
    library with ks_bv_set_buffer, so BV_CleanCoefficients / BV_SetValue / BV_StoreCoefficients of the interface layer
    (their _HIP forms: bv->hip is set) and the library's kernels work on the same memory.
@@ -26,15 +26,20 @@
 */
 #include <slepc/private/bvimpl.h>
 #include <petscdevice_hip.h>
+#include "../src/sys/classes/bv/impls/svec/svec.h"
 #include <ksgpu.h>
 
 #define BVHIPKS "hipks"
 
+/* The slots that only move views around - getcolumn / restorecolumn, getmat / restoremat, matmult (a MatMult per column on Vec
+   views) - need no kernel of ours: they are BVSVEC's own HIP functions, which svec.h declares SLEPC_INTERN for use inside
+   libslepc and which look at nothing but the two members of BV_SVEC. The private data therefore BEGINS with a BV_SVEC, so that
+   (BV_SVEC*)bv->data is valid, and BVCreate_HIPKS installs BVGetColumn_Svec_HIP, BVRestoreColumn_Svec_HIP, BVGetMat_Svec_HIP,
+   BVRestoreMat_Svec_HIP and BVMatMult_Svec_HIP (svechip.hip.cpp:269,363,375,458,488) as they are. */
 typedef struct {
+  BV_SVEC     svec;         /* v: HIP Vec over the library's column block; mpi. MUST stay the first member */
   ks_ctx      kctx;
   ks_bv       kbv;
-  Vec         v;            /* HIP Vec over the library's column block */
-  PetscBool   mpi;
   PetscScalar *bufptr;      /* device array of bv->buffer currently adopted by the library (NULL: the library's own) */
   MPI_Comm    comm;
 } BV_HIPKS;
@@ -104,10 +109,16 @@ static const ks_comm_ops SlepcKsMpiOps = {HipksAllreduceSum,HipksAllgatherHost,H
    them. The buffer Vec is re-created lazily after BVResize (bvbasic.c:356,783): adopt its device array when it changes. */
 static PetscErrorCode HipksSync(BV bv)
 {
-  BV_HIPKS    *ctx = (BV_HIPKS*)bv->data;
-  PetscScalar *d_buf = NULL,*p;
+  BV_HIPKS         *ctx = (BV_HIPKS*)bv->data;
+  PetscScalar      *d_buf = NULL,*p;
+  PetscObjectState state;
 
   PetscFunctionBegin;
+  /* the object state moves whenever the contents may have changed (BVRestoreColumn of a written Vec bvbasic.c:1176, BVScaleColumn
+     bvops.c:356, ...) and stays put between the passes BVOrthogonalizeGS makes on one column (bvorthog.c:176-202): the token under
+     which ks_bv_gramschmidt_pass chains a pass to the dot products its predecessor left (3 reads of the basis per CGS2 step, not 4) */
+  PetscCall(PetscObjectStateGet((PetscObject)bv,&state));
+  KS(ks_bv_set_state(ctx->kbv,(uint64_t)state));
   KS(ks_bv_set_layout(ctx->kbv,(int)bv->nc,(int)bv->m));
   KS(ks_bv_set_active_columns(ctx->kbv,(int)bv->l,(int)bv->k));
   KS(ks_bv_set_orthogonalization(ctx->kbv,(int)bv->orthog_type,(int)bv->orthog_ref,(double)bv->orthog_eta));
@@ -132,13 +143,13 @@ static PetscErrorCode BVMult_HIPKS(BV Y,PetscScalar alpha,PetscScalar beta,BV X,
   PetscFunctionBegin;
   if (!Y->n) PetscFunctionReturn(PETSC_SUCCESS);
   PetscCall(HipksSync(Y)); PetscCall(HipksSync(X));
-  PetscCall(VecHIPGetArrayRead(x->v,&d_px));
-  PetscCall(VecHIPGetArray(y->v,&d_py));
+  PetscCall(VecHIPGetArrayRead(x->svec.v,&d_px));
+  PetscCall(VecHIPGetArray(y->svec.v,&d_py));
   if (Q) { PetscCall(MatDenseGetLDA(Q,&ldq)); PetscCall(MatDenseGetArrayRead(Q,&q)); }      /* host seqdense, replicated (bvops.c:33-36) */
   KS(ks_bv_mult(y->kbv,alpha,beta,x->kbv,q,(int)ldq));
   if (Q) PetscCall(MatDenseRestoreArrayRead(Q,&q));
-  PetscCall(VecHIPRestoreArrayRead(x->v,&d_px));
-  PetscCall(VecHIPRestoreArray(y->v,&d_py));
+  PetscCall(VecHIPRestoreArrayRead(x->svec.v,&d_px));
+  PetscCall(VecHIPRestoreArray(y->svec.v,&d_py));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -150,13 +161,13 @@ static PetscErrorCode BVMultVec_HIPKS(BV X,PetscScalar alpha,PetscScalar beta,Ve
 
   PetscFunctionBegin;
   PetscCall(HipksSync(X));
-  PetscCall(VecHIPGetArrayRead(x->v,&d_px));
+  PetscCall(VecHIPGetArrayRead(x->svec.v,&d_px));
   if (beta==(PetscScalar)0.0) PetscCall(VecHIPGetArrayWrite(y,&d_py));
   else PetscCall(VecHIPGetArray(y,&d_py));
   if (!q) PetscCall(VecHIPGetArray(X->buffer,&d_q));            /* coefficients in the buffer's scratch column (svec.c:46) */
   KS(ks_bv_multvec(x->kbv,alpha,beta,d_py,q));
   if (!q) PetscCall(VecHIPRestoreArray(X->buffer,&d_q));
-  PetscCall(VecHIPRestoreArrayRead(x->v,&d_px));
+  PetscCall(VecHIPRestoreArrayRead(x->svec.v,&d_px));
   if (beta==(PetscScalar)0.0) PetscCall(VecHIPRestoreArrayWrite(y,&d_py));
   else PetscCall(VecHIPRestoreArray(y,&d_py));
   PetscFunctionReturn(PETSC_SUCCESS);
@@ -173,11 +184,11 @@ static PetscErrorCode BVMultInPlace_HIPKS(BV V,Mat Q,PetscInt s,PetscInt e)
   if (s>=e || !V->n) PetscFunctionReturn(PETSC_SUCCESS);
   PetscCall(HipksSync(V));
   PetscCall(MatDenseGetLDA(Q,&ldq));
-  PetscCall(VecHIPGetArray(ctx->v,&d_pv));
+  PetscCall(VecHIPGetArray(ctx->svec.v,&d_pv));
   PetscCall(MatDenseGetArrayRead(Q,&q));
   KS(ks_bv_multinplace(ctx->kbv,q,(int)ldq,(int)s,(int)e));
   PetscCall(MatDenseRestoreArrayRead(Q,&q));
-  PetscCall(VecHIPRestoreArray(ctx->v,&d_pv));
+  PetscCall(VecHIPRestoreArray(ctx->svec.v,&d_pv));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -192,11 +203,11 @@ static PetscErrorCode BVMultInPlaceHermitianTranspose_HIPKS(BV V,Mat Q,PetscInt 
   if (s>=e || !V->n) PetscFunctionReturn(PETSC_SUCCESS);
   PetscCall(HipksSync(V));
   PetscCall(MatDenseGetLDA(Q,&ldq));
-  PetscCall(VecHIPGetArray(ctx->v,&d_pv));
+  PetscCall(VecHIPGetArray(ctx->svec.v,&d_pv));
   PetscCall(MatDenseGetArrayRead(Q,&q));
   KS(ks_bv_multinplace_trans(ctx->kbv,q,(int)ldq,(int)s,(int)e));
   PetscCall(MatDenseRestoreArrayRead(Q,&q));
-  PetscCall(VecHIPRestoreArray(ctx->v,&d_pv));
+  PetscCall(VecHIPRestoreArray(ctx->svec.v,&d_pv));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -210,13 +221,13 @@ static PetscErrorCode BVDot_HIPKS(BV X,BV Y,Mat M)
   PetscFunctionBegin;
   PetscCall(HipksSync(X)); PetscCall(HipksSync(Y));
   PetscCall(MatDenseGetLDA(M,&ldm));
-  PetscCall(VecHIPGetArrayRead(x->v,&d_px));
-  PetscCall(VecHIPGetArrayRead(y->v,&d_py));
+  PetscCall(VecHIPGetArrayRead(x->svec.v,&d_px));
+  PetscCall(VecHIPGetArrayRead(y->svec.v,&d_py));
   PetscCall(MatDenseGetArray(M,&m));
   KS(ks_bv_dot(x->kbv,y->kbv,m,(int)ldm));                    /* includes the reduction over ranks (bvblas.c:218) */
   PetscCall(MatDenseRestoreArray(M,&m));
-  PetscCall(VecHIPRestoreArrayRead(x->v,&d_px));
-  PetscCall(VecHIPRestoreArrayRead(y->v,&d_py));
+  PetscCall(VecHIPRestoreArrayRead(x->svec.v,&d_px));
+  PetscCall(VecHIPRestoreArrayRead(y->svec.v,&d_py));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -233,14 +244,14 @@ static PetscErrorCode HipksDotVec(BV X,Vec y,PetscScalar *q,PetscBool reduce)
     PetscCall(BV_IPMatMult(X,y));
     z = X->Bx;
   }
-  PetscCall(VecHIPGetArrayRead(x->v,&d_px));
+  PetscCall(VecHIPGetArrayRead(x->svec.v,&d_px));
   PetscCall(VecHIPGetArrayRead(z,&d_py));
   if (!q) PetscCall(VecHIPGetArray(X->buffer,&d_q));             /* result to the buffer's scratch column (svec.c:123) */
   if (reduce) KS(ks_bv_dotvec(x->kbv,d_py,q));
   else KS(ks_bv_dotvec_local(x->kbv,d_py,q));
   if (!q) PetscCall(VecHIPRestoreArray(X->buffer,&d_q));
   PetscCall(VecHIPRestoreArrayRead(z,&d_py));
-  PetscCall(VecHIPRestoreArrayRead(x->v,&d_px));
+  PetscCall(VecHIPRestoreArrayRead(x->svec.v,&d_px));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 static PetscErrorCode BVDotVec_HIPKS(BV X,Vec y,PetscScalar *q) { return HipksDotVec(X,y,q,PETSC_TRUE); }
@@ -254,10 +265,10 @@ static PetscErrorCode BVScale_HIPKS(BV bv,PetscInt j,PetscScalar alpha)
   PetscFunctionBegin;
   if (!bv->n) PetscFunctionReturn(PETSC_SUCCESS);
   PetscCall(HipksSync(bv));
-  PetscCall(VecHIPGetArray(ctx->v,&d_pv));
+  PetscCall(VecHIPGetArray(ctx->svec.v,&d_pv));
   if (PetscUnlikely(j<0)) KS(ks_bv_scale(ctx->kbv,alpha));
   else KS(ks_bv_scalecolumn(ctx->kbv,(int)j,alpha));
-  PetscCall(VecHIPRestoreArray(ctx->v,&d_pv));
+  PetscCall(VecHIPRestoreArray(ctx->svec.v,&d_pv));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -269,11 +280,11 @@ static PetscErrorCode HipksNorm(BV bv,PetscInt j,NormType type,PetscReal *val,Pe
 
   PetscFunctionBegin;
   PetscCall(HipksSync(bv));
-  PetscCall(VecHIPGetArrayRead(ctx->v,&d_pv));
+  PetscCall(VecHIPGetArrayRead(ctx->svec.v,&d_pv));
   if (!reduce) KS(ks_bv_norm_local(ctx->kbv,(int)j,kt,val));
   else if (PetscUnlikely(j<0)) KS(ks_bv_norm(ctx->kbv,kt,val));
   else KS(ks_bv_normcolumn(ctx->kbv,(int)j,kt,val));
-  PetscCall(VecHIPRestoreArrayRead(ctx->v,&d_pv));
+  PetscCall(VecHIPRestoreArrayRead(ctx->svec.v,&d_pv));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 static PetscErrorCode BVNorm_HIPKS(BV bv,PetscInt j,NormType type,PetscReal *val) { return HipksNorm(bv,j,type,val,PETSC_TRUE); }
@@ -286,33 +297,9 @@ static PetscErrorCode BVNormalize_HIPKS(BV bv,PetscScalar *eigi)
 
   PetscFunctionBegin;
   PetscCall(HipksSync(bv));
-  PetscCall(VecHIPGetArray(ctx->v,&d_pv));
+  PetscCall(VecHIPGetArray(ctx->svec.v,&d_pv));
   KS(ks_bv_normalize(ctx->kbv,eigi? eigi+bv->l: NULL));        /* entry 0 belongs to column l, as BVNormalize_Svec passes it (svec.c:196) */
-  PetscCall(VecHIPRestoreArray(ctx->v,&d_pv));
-  PetscFunctionReturn(PETSC_SUCCESS);
-}
-
-/* ops->matmult: any Mat type (the user's AIJ/HIPSPARSE matrix or the MATSHELL below), column by column through the
-   BV's own Vec wrappers, as BVMatMult_Svec_HIP does when the single-product path is off */
-static PetscErrorCode BVMatMult_HIPKS(BV V,Mat A,BV W)
-{
-  BV_HIPKS          *v = (BV_HIPKS*)V->data,*w = (BV_HIPKS*)W->data;
-  const PetscScalar *d_pv;
-  PetscScalar       *d_pw;
-  PetscInt          j;
-
-  PetscFunctionBegin;
-  PetscCall(VecHIPGetArrayRead(v->v,&d_pv));
-  PetscCall(VecHIPGetArrayWrite(w->v,&d_pw));
-  for (j=0;j<V->k-V->l;j++) {
-    PetscCall(VecHIPPlaceArray(V->cv[1],(PetscScalar*)d_pv+(V->nc+V->l+j)*V->ld));
-    PetscCall(VecHIPPlaceArray(W->cv[1],d_pw+(W->nc+W->l+j)*W->ld));
-    PetscCall(MatMult(A,V->cv[1],W->cv[1]));
-    PetscCall(VecHIPResetArray(V->cv[1]));
-    PetscCall(VecHIPResetArray(W->cv[1]));
-  }
-  PetscCall(VecHIPRestoreArrayRead(v->v,&d_pv));
-  PetscCall(VecHIPRestoreArrayWrite(w->v,&d_pw));
+  PetscCall(VecHIPRestoreArray(ctx->svec.v,&d_pv));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -324,11 +311,11 @@ static PetscErrorCode BVCopy_HIPKS(BV V,BV W)
 
   PetscFunctionBegin;
   PetscCall(HipksSync(V)); PetscCall(HipksSync(W));
-  PetscCall(VecHIPGetArrayRead(v->v,&d_pv));
-  PetscCall(VecHIPGetArray(w->v,&d_pw));
+  PetscCall(VecHIPGetArrayRead(v->svec.v,&d_pv));
+  PetscCall(VecHIPGetArray(w->svec.v,&d_pw));
   KS(ks_bv_copy(v->kbv,w->kbv));
-  PetscCall(VecHIPRestoreArrayRead(v->v,&d_pv));
-  PetscCall(VecHIPRestoreArray(w->v,&d_pw));
+  PetscCall(VecHIPRestoreArrayRead(v->svec.v,&d_pv));
+  PetscCall(VecHIPRestoreArray(w->svec.v,&d_pw));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -339,9 +326,9 @@ static PetscErrorCode BVCopyColumn_HIPKS(BV V,PetscInt j,PetscInt i)
 
   PetscFunctionBegin;
   PetscCall(HipksSync(V));
-  PetscCall(VecHIPGetArray(ctx->v,&d_pv));
+  PetscCall(VecHIPGetArray(ctx->svec.v,&d_pv));
   KS(ks_bv_copycolumn(ctx->kbv,(int)j,(int)i));
-  PetscCall(VecHIPRestoreArray(ctx->v,&d_pv));
+  PetscCall(VecHIPRestoreArray(ctx->svec.v,&d_pv));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -354,14 +341,14 @@ static PetscErrorCode HipksWrapStorage(BV bv,PetscInt m)
   char        str[50];
 
   PetscFunctionBegin;
-  PetscCall(VecDestroy(&ctx->v));
+  PetscCall(VecDestroy(&ctx->svec.v));
   KS(ks_bv_get_array(ctx->kbv,&d_array));
   PetscCall(PetscLayoutGetBlockSize(bv->map,&bs));
-  if (ctx->mpi) PetscCall(VecCreateMPIHIPWithArray(PetscObjectComm((PetscObject)bv),bs,m*bv->ld,PETSC_DECIDE,d_array,&ctx->v));
-  else PetscCall(VecCreateSeqHIPWithArray(PetscObjectComm((PetscObject)bv),bs,m*bv->ld,d_array,&ctx->v));
+  if (ctx->svec.mpi) PetscCall(VecCreateMPIHIPWithArray(PetscObjectComm((PetscObject)bv),bs,m*bv->ld,PETSC_DECIDE,d_array,&ctx->svec.v));
+  else PetscCall(VecCreateSeqHIPWithArray(PetscObjectComm((PetscObject)bv),bs,m*bv->ld,d_array,&ctx->svec.v));
   if (((PetscObject)bv)->name) {
     PetscCall(PetscSNPrintf(str,sizeof(str),"%s_0",((PetscObject)bv)->name));
-    PetscCall(PetscObjectSetName((PetscObject)ctx->v,str));
+    PetscCall(PetscObjectSetName((PetscObject)ctx->svec.v,str));
   }
   PetscFunctionReturn(PETSC_SUCCESS);
 }
@@ -380,85 +367,21 @@ static PetscErrorCode BVResize_HIPKS(BV bv,PetscInt m,PetscBool copy)
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
-static PetscErrorCode BVGetColumn_HIPKS(BV bv,PetscInt j,Vec *v)
-{
-  BV_HIPKS    *ctx = (BV_HIPKS*)bv->data;
-  PetscScalar *d_pv;
-  PetscInt    l;
-
-  PetscFunctionBegin;
-  (void)v;
-  l = BVAvailableVec;
-  PetscCall(VecHIPGetArray(ctx->v,&d_pv));
-  PetscCall(VecHIPPlaceArray(bv->cv[l],d_pv+(bv->nc+j)*bv->ld));
-  PetscFunctionReturn(PETSC_SUCCESS);
-}
-
-static PetscErrorCode BVRestoreColumn_HIPKS(BV bv,PetscInt j,Vec *v)
-{
-  BV_HIPKS *ctx = (BV_HIPKS*)bv->data;
-  PetscInt l;
-
-  PetscFunctionBegin;
-  (void)v;
-  l = (j==bv->ci[0])? 0: 1;
-  PetscCall(VecHIPResetArray(bv->cv[l]));
-  PetscCall(VecHIPRestoreArray(ctx->v,NULL));
-  PetscFunctionReturn(PETSC_SUCCESS);
-}
-
-static PetscErrorCode BVGetArray_HIPKS(BV bv,PetscScalar **a) { PetscFunctionBegin; PetscCall(VecGetArray(((BV_HIPKS*)bv->data)->v,a)); PetscFunctionReturn(PETSC_SUCCESS); }
-static PetscErrorCode BVRestoreArray_HIPKS(BV bv,PetscScalar **a) { PetscFunctionBegin; PetscCall(VecRestoreArray(((BV_HIPKS*)bv->data)->v,a)); PetscFunctionReturn(PETSC_SUCCESS); }
-static PetscErrorCode BVGetArrayRead_HIPKS(BV bv,const PetscScalar **a) { PetscFunctionBegin; PetscCall(VecGetArrayRead(((BV_HIPKS*)bv->data)->v,a)); PetscFunctionReturn(PETSC_SUCCESS); }
-static PetscErrorCode BVRestoreArrayRead_HIPKS(BV bv,const PetscScalar **a) { PetscFunctionBegin; PetscCall(VecRestoreArrayRead(((BV_HIPKS*)bv->data)->v,a)); PetscFunctionReturn(PETSC_SUCCESS); }
-
-/* ops->getmat / restoremat: a dense HIP Mat over the active columns, as BVGetMat_Svec_HIP (svechip.hip.cpp:458-500) */
-static PetscErrorCode BVGetMat_HIPKS(BV bv,Mat *A)
-{
-  BV_HIPKS    *ctx = (BV_HIPKS*)bv->data;
-  PetscScalar *vv,*aa;
-  PetscBool   create=PETSC_FALSE;
-  PetscInt    m,cols;
-
-  PetscFunctionBegin;
-  m = bv->k-bv->l;
-  if (!bv->Aget) create=PETSC_TRUE;
-  else {
-    PetscCall(MatDenseHIPGetArray(bv->Aget,&aa));
-    PetscCheck(!aa,PetscObjectComm((PetscObject)bv),PETSC_ERR_ARG_WRONGSTATE,"BVGetMat already called on this BV");
-    PetscCall(MatGetSize(bv->Aget,NULL,&cols));
-    if (cols!=m) { PetscCall(MatDestroy(&bv->Aget)); create=PETSC_TRUE; }
-  }
-  PetscCall(VecHIPGetArray(ctx->v,&vv));
-  if (create) {
-    PetscCall(MatCreateDenseFromVecType(PetscObjectComm((PetscObject)bv),bv->vtype,bv->n,PETSC_DECIDE,bv->N,m,bv->ld,vv,&bv->Aget));
-    PetscCall(MatDenseHIPReplaceArray(bv->Aget,NULL));
-  }
-  PetscCall(MatDenseHIPPlaceArray(bv->Aget,vv+(bv->nc+bv->l)*bv->ld));
-  *A = bv->Aget;
-  PetscFunctionReturn(PETSC_SUCCESS);
-}
-
-static PetscErrorCode BVRestoreMat_HIPKS(BV bv,Mat *A)
-{
-  BV_HIPKS    *ctx = (BV_HIPKS*)bv->data;
-  PetscScalar *vv,*aa;
-
-  PetscFunctionBegin;
-  PetscCall(MatDenseHIPGetArray(bv->Aget,&aa));
-  vv = aa-(bv->nc+bv->l)*bv->ld;
-  PetscCall(MatDenseHIPResetArray(bv->Aget));
-  PetscCall(VecHIPRestoreArray(ctx->v,&vv));
-  *A = NULL;
-  PetscFunctionReturn(PETSC_SUCCESS);
-}
+/* BVGetArray_Svec and its three companions are static in svec.c (:297-326): the same one-line forwards to the Vec */
+static PetscErrorCode BVGetArray_HIPKS(BV bv,PetscScalar **a) { PetscFunctionBegin; PetscCall(VecGetArray(((BV_HIPKS*)bv->data)->svec.v,a)); PetscFunctionReturn(PETSC_SUCCESS); }
+static PetscErrorCode BVRestoreArray_HIPKS(BV bv,PetscScalar **a) { PetscFunctionBegin; PetscCall(VecRestoreArray(((BV_HIPKS*)bv->data)->svec.v,a)); PetscFunctionReturn(PETSC_SUCCESS); }
+static PetscErrorCode BVGetArrayRead_HIPKS(BV bv,const PetscScalar **a) { PetscFunctionBegin; PetscCall(VecGetArrayRead(((BV_HIPKS*)bv->data)->svec.v,a)); PetscFunctionReturn(PETSC_SUCCESS); }
+static PetscErrorCode BVRestoreArrayRead_HIPKS(BV bv,const PetscScalar **a) { PetscFunctionBegin; PetscCall(VecRestoreArrayRead(((BV_HIPKS*)bv->data)->svec.v,a)); PetscFunctionReturn(PETSC_SUCCESS); }
 
 /* ops->gramschmidt (bvimpl.h:53): ONE Gram-Schmidt pass; BVOrthogonalizeGS (bvorthog.c:145-217) keeps the refinement loop,
    lindep and the coefficient clean-up. onrm / nrm are NULL when the caller passes NULL (REFINE_NEVER, first call of
    REFINE_ALWAYS). Column form on the standard inner product with CGS: the fused kernels (one dot sweep, device-side
    bookkeeping, one update; coefficients added into column j of bv->buffer, which the library has adopted).
    Everything else - a Vec argument, MGS with `which`, a B-inner product, an indefinite one - is one pass written on this
-   BV's primitive operations through the public interface, which handle B and the signature themselves. */
+   BV's primitive operations through the public interface, which handle B and the signature themselves. That pass IS the
+   reference's BVOrthogonalizeMGS1 / BVOrthogonalizeCGS1 (bvorthog.c:52-85, 91-132) step for step: those two are `static` in
+   bvorthog.c and the BVOrthogonalizeGS1 macro (:134) reaches them only when ops->gramschmidt is NULL, so a type that fills
+   the slot has to bring the non-fused cases along; nothing here is new arithmetic. */
 static PetscErrorCode HipksGramSchmidtGeneric(BV bv,PetscInt j,Vec v,PetscBool *which,PetscScalar *h,PetscScalar *c,PetscReal *onrm,PetscReal *nrm)
 {
   PetscBool   mgs = (bv->orthog_type==BV_ORTHOG_MGS)? PETSC_TRUE: PETSC_FALSE;
@@ -531,11 +454,11 @@ static PetscErrorCode BVGramSchmidt_HIPKS(BV bv,PetscInt j,Vec v,PetscBool *whic
     PetscFunctionReturn(PETSC_SUCCESS);
   }
   PetscCall(HipksSync(bv));                                     /* adopts bv->buffer (created by the caller, bvorthog.c:331) */
-  PetscCall(VecHIPGetArray(ctx->v,&d_pv));
+  PetscCall(VecHIPGetArray(ctx->svec.v,&d_pv));
   PetscCall(VecHIPGetArray(bv->buffer,&d_buf));
   KS(ks_bv_gramschmidt_pass(ctx->kbv,(int)j,NULL,NULL,NULL,NULL,onrm,nrm));
   PetscCall(VecHIPRestoreArray(bv->buffer,&d_buf));
-  PetscCall(VecHIPRestoreArray(ctx->v,&d_pv));
+  PetscCall(VecHIPRestoreArray(ctx->svec.v,&d_pv));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -544,7 +467,7 @@ static PetscErrorCode BVDestroy_HIPKS(BV bv)
   BV_HIPKS *ctx = (BV_HIPKS*)bv->data;
 
   PetscFunctionBegin;
-  PetscCall(VecDestroy(&ctx->v));
+  PetscCall(VecDestroy(&ctx->svec.v));
   PetscCall(VecDestroy(&bv->cv[0]));
   PetscCall(VecDestroy(&bv->cv[1]));
   KS(ks_bv_destroy(ctx->kbv));
@@ -575,7 +498,7 @@ SLEPC_EXTERN PetscErrorCode BVCreate_HIPKS(BV bv)
   SETERRQ(PetscObjectComm((PetscObject)bv),PETSC_ERR_SUP,"BVHIPKS is built for real double scalars and 32-bit indices");
 #endif
   bv->hip = PETSC_TRUE;                                         /* the _HIP forms of the coefficient helpers (bvimpl.h:618-631) */
-  PetscCall(PetscStrcmp(bv->vtype,VECMPIHIP,&ctx->mpi));
+  PetscCall(PetscStrcmp(bv->vtype,VECMPIHIP,&ctx->svec.mpi));
   ctx->comm = PetscObjectComm((PetscObject)bv);
 
   PetscCall(PetscLayoutGetLocalSize(bv->map,&nloc));
@@ -598,9 +521,9 @@ SLEPC_EXTERN PetscErrorCode BVCreate_HIPKS(BV bv)
     PetscCheck(isdense,PetscObjectComm((PetscObject)bv->Acreate),PETSC_ERR_SUP,"BVHIPKS requires a dense matrix in BVCreateFromMat()");
     PetscCall(MatDenseGetArrayRead(bv->Acreate,&aa));
     PetscCall(MatDenseGetLDA(bv->Acreate,&lda));
-    PetscCall(VecGetArray(ctx->v,&vv));
+    PetscCall(VecGetArray(ctx->svec.v,&vv));
     for (j=0;j<bv->m;j++) PetscCall(PetscArraycpy(vv+j*bv->ld,aa+j*lda,bv->n));
-    PetscCall(VecRestoreArray(ctx->v,&vv));
+    PetscCall(VecRestoreArray(ctx->svec.v,&vv));
     PetscCall(MatDenseRestoreArrayRead(bv->Acreate,&aa));
     PetscCall(MatDestroy(&bv->Acreate));
   }
@@ -619,18 +542,18 @@ SLEPC_EXTERN PetscErrorCode BVCreate_HIPKS(BV bv)
   bv->ops->norm             = BVNorm_HIPKS;
   bv->ops->norm_local       = BVNorm_Local_HIPKS;
   bv->ops->normalize        = BVNormalize_HIPKS;
-  bv->ops->matmult          = BVMatMult_HIPKS;
+  bv->ops->matmult          = BVMatMult_Svec_HIP;       /* BVSVEC's own: a MatMult per column on Vec views (svechip.hip.cpp:269) */
   bv->ops->copy             = BVCopy_HIPKS;
   bv->ops->copycolumn       = BVCopyColumn_HIPKS;
   bv->ops->resize           = BVResize_HIPKS;
-  bv->ops->getcolumn        = BVGetColumn_HIPKS;
-  bv->ops->restorecolumn    = BVRestoreColumn_HIPKS;
+  bv->ops->getcolumn        = BVGetColumn_Svec_HIP;     /* BVSVEC's own (svechip.hip.cpp:363,375) */
+  bv->ops->restorecolumn    = BVRestoreColumn_Svec_HIP;
   bv->ops->getarray         = BVGetArray_HIPKS;
   bv->ops->restorearray     = BVRestoreArray_HIPKS;
   bv->ops->getarrayread     = BVGetArrayRead_HIPKS;
   bv->ops->restorearrayread = BVRestoreArrayRead_HIPKS;
-  bv->ops->getmat           = BVGetMat_HIPKS;
-  bv->ops->restoremat       = BVRestoreMat_HIPKS;
+  bv->ops->getmat           = BVGetMat_Svec_HIP;        /* BVSVEC's own (svechip.hip.cpp:458,488) */
+  bv->ops->restoremat       = BVRestoreMat_Svec_HIP;
   bv->ops->gramschmidt      = BVGramSchmidt_HIPKS;
   bv->ops->destroy          = BVDestroy_HIPKS;
   /* left NULL on purpose, as BVSVEC does: dotvec_begin/_end and norm_begin/_end (the interface's PetscSplitReduction path

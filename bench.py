@@ -204,17 +204,18 @@ def update_kernel_roofline(ks, prof_timed):
         return None
     kt, d = max(sym.items(), key=lambda kv: kv[1]["ms_exec"])
     achieved = d["hbm"] / d["ms_exec"] / 1e6          # bytes this kernel must move per launch / its time
-    kname = "k_gs_update<%d, 2>" % kt
+    kname = "k_gs_update<%d, 2, false>" % kt
     traffic, tsrc = None, None
     if os.path.exists(TRAFFIC_FILE):
         try:
             tj = json.load(open(TRAFFIC_FILE))
-            traffic = tj.get(kname, {}).get("hbm_bytes_per_executed_launch")
+            traffic = (tj.get(kname) or tj.get(kname.replace(", false>", ">")) or {}).get("hbm_bytes_per_executed_launch")
             tsrc = tj.get("_source")
         except Exception:      # noqa: BLE001
             traffic = None
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_kind": "lookup" if traffic is not None else None,      # not measured by this run: read from the committed PMC summary of the same command
             "traffic_source": tsrc if traffic is not None else None,
             "kernel": kname, "launches_executed": d["n_exec"], "launches_gated_off": d["n_noop"],
             "avg_launch_us_executed": round(1e3 * d["ms_exec"] / d["n_exec"], 2),
@@ -303,29 +304,40 @@ def dropin_slot_leg(ks, ctx, A, ncv, cycles=3):
     V.MatLanczos(A, T, 0, ncv)                                  # a valid orthonormal basis to expand against (native path)
     ld = ncv + 1
     buf = V.buffer_ptr()
-    zero = np.zeros(ld)
     k0 = ncv // 2
     ctx.synchronize()
     steps, passes = 0, 0
+    state = 1                                                   # the BV's PetscObjectState, bumped where the reference bumps it
+    s0 = ctx.sync_count()
     t0 = time.perf_counter()
     for _ in range(cycles):
         for j in range(k0, ncv):
-            A.mult_dev(V.column_ptr(j), V.column_ptr(j + 1))    # BVMatMultColumn
+            A.mult_dev(V.column_ptr(j), V.column_ptr(j + 1))    # BVMatMultColumn (MatMult into the column Vec)
+            state += 1                                          #   BVRestoreColumn of a written Vec (bvbasic.c:1176)
             col = j + 1
-            ctx.memcpy_h2d(buf + 8 * col * ld, zero[:col])      # BV_CleanCoefficients(bv,col,NULL)
+            ctx.memset(buf + 8 * col * ld, 0, 8 * col)          # BV_CleanCoefficients_HIP: hipMemset on the stream (bvhip.hip.cpp:345-360)
+            V.SetState(state)                                   # HipksSync at the head of the slot
             onrm, nrm = V.GramSchmidtPass(col); passes += 1
             l = 1
             while l < 3 and nrm != 0.0 and abs(nrm) < 0.7071 * abs(onrm):
                 l += 1
+                V.SetState(state)
                 onrm, nrm = V.GramSchmidtPass(col); passes += 1
-            ctx.memcpy_h2d(buf + 8 * (col * ld + col), np.array([nrm]))   # BV_SetValue(bv,col,col,NULL,nrm)
-            V.ScaleColumn(col, 1.0 / nrm)
+            ctx.memcpy_h2d(buf + 8 * (col * ld + col), np.array([nrm]))   # BV_SetValue_HIP: synchronous hipMemcpy of one scalar (bvhip.hip.cpp:397-413)
+            state += 1                                          #   end of BVOrthogonalizeColumn (bvorthog.c:338)
+            V.ScaleColumn(col, 1.0 / nrm)                       # BVScaleColumn
+            state += 1                                          #   (bvops.c:356)
             steps += 1
     ctx.synchronize()
     dt = time.perf_counter() - t0
+    ch = V.GsChainStats()
     return {"value": steps / dt, "unit": "steps/s", "steps": steps, "gs_passes_per_step": passes / steps,
-            "note": "one ops->gramschmidt call per pass through the C ABI (4 reads of V per CGS2 step, a host wait per pass, a separate scale), "
-                    "driven from Python here as the reference's BVMatLanczos would from C; the headline is the library's own enqueued run"}
+            "passes_chained": ch["chained"], "passes_with_own_dot_sweep": ch["fresh"], "host_waits_per_step": (ctx.sync_count() - s0) / steps,
+            "note": "one ops->gramschmidt call per pass through the C ABI, driven from Python here as the reference's BVMatLanczos / "
+                    "BVOrthogonalizeGS would from C (clean coefficients, pass, refinement test on the host, pass, set value, scale), the "
+                    "object state announced as adapters/slepc/hipks.c does. A pass is one dot sweep (first pass only) and one update "
+                    "launch whose prologue hands onrm / nrm to the host; the second pass is chained to the dots the first one left: 3 "
+                    "reads of V per CGS2 step, one extra 8n write and a separate scale against the library's own enqueued run (the headline)"}
 
 
 def side_configs(ks, ctx, barrier, args):

@@ -145,6 +145,9 @@ int ks_ctx_memcpy(ks_ctx ctx, void *dst, const void *src, size_t bytes, int kind
 /* the same on a given stream (the `stream` argument a ks_comm_ops callback receives; NULL = the context's): what a provider that
    stages through the host uses to order itself after the work already enqueued there */
 int ks_ctx_memcpy_stream(ks_ctx ctx, void *dst, const void *src, size_t bytes, int kind, void *stream);
+/* fill device memory on the context's stream; enqueues only (what BV_CleanCoefficients_HIP's hipMemset, bvhip.hip.cpp:345-360, is on the
+   stream PETSc works on) */
+int ks_ctx_memset(ks_ctx ctx, void *dev, int value, size_t bytes);
 
 /* ---- Mat: the MatMult(AIJ) slot ------------------------------------------------------------- */
 /* CSR arrays as in PETSc SeqAIJ (i,j,a): rowptr[n_local+1], col[nnz] (GLOBAL column indices),
@@ -241,8 +244,21 @@ int ks_bv_matmultcolumn(ks_bv V, ks_mat A, int j);                              
      h, c       : HOST arrays of nc+m entries (bv->h, bv->c), or both NULL = column j and the scratch column of the BV's buffer;
                   the pass ADDS its coefficients to h (BV_AddCoefficients), c holds this pass's coefficients
      onrm, nrm  : norm before the pass / estimated norm after it (explicit when the estimate breaks down); either may be NULL
-   Returns KS_ERR_USER_INPUT for an invalid inner product (BV_SafeSqrt). Synchronises (the outputs are host scalars).   */
+   Returns KS_ERR_USER_INPUT for an invalid inner product (BV_SafeSqrt).
+   Column form, CGS, standard inner product: the pass is ONE dot sweep and ONE update launch; onrm / nrm reach the host while the update
+   still runs (the call waits for the pass's bookkeeping, not for the stream). The other forms synchronise.                          */
 int ks_bv_gramschmidt_pass(ks_bv bv, int j, double *v_dev, const int *which, double *h, double *c, double *onrm, double *nrm);
+/* Pass chaining for the slot above. `state` is the caller's modification counter of the BV - PetscObjectStateGet((PetscObject)bv,&state):
+   PETSc bumps it in BVRestoreColumn (when the Vec was written), BVScaleColumn, BVMultInPlace ... (bvbasic.c:1176, bvops.c:356,243), i.e. whenever the contents may have
+   changed, and NOT between the passes BVOrthogonalizeGS makes on one column (bvorthog.c:176-202). Once a state has been announced, a pass whose
+   bookkeeping predicts that the caller's refinement loop comes back (same policy, same eta: ks_bv_set_orthogonalization) leaves the dot
+   products of the next pass behind, and the next ks_bv_gramschmidt_pass on the same column under the SAME state uses them instead of a dot
+   sweep: 3 reads of the basis per CGS2 step instead of 4. Any other state, column or intervening sweep of this BV: the pass takes its own
+   dots, as before. A caller that never calls this gets the unchained behaviour. The caller promises that the state changes whenever BV storage
+   or the coefficient buffer is written by anyone but ks_bv_gramschmidt_pass itself. */
+int ks_bv_set_state(ks_bv bv, uint64_t state);
+/* instrumentation: passes of the slot that were chained to their predecessor's dots / that ran their own dot sweep */
+int ks_bv_gs_chain_stats(ks_bv bv, long long *chained, long long *fresh);
 /* The whole of BVOrthogonalizeColumn / BVOrthonormalizeColumn (not ops slots: the entry points a caller uses that drives this
    library directly): fused, device-resident classical Gram-Schmidt of column j against columns [0,j) with the reference's
    refinement policy; coefficients accumulate in the buffer column j.                              */

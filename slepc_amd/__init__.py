@@ -43,17 +43,18 @@ KCLASSES = ["spmv_csr", "bv_dot_sweep", "gs_bookkeeping", "gs_update_fused_dot",
 # kernel symbol behind each (class, variant) as rocprofv3 --kernel-trace names it (16-byte-load forms)
 def kernel_symbol(name, var):
     if name == "spmv_csr":
-        return "k_spmv_dict<W>" if var == 16 else "k_spmv_odict<W>" if var == 17 else "k_binned_gather + k_binned_reduce" if var == 18 else ("k_spmv_sell<8>" if var == 8 else "k_spmv_csr<G, 4, false, false>")
+        return ("k_spmv_dict<W>" if var == 16 else "k_spmv_odict<W>" if var == 17 else "k_binned_gather + k_binned_reduce" if var == 18
+                else "k_spmv_sell<8>" if var == 8 else "k_spmv_csr_stream | k_spmv_csr<G, 4, false, false>")
     if name == "bv_dot_sweep":
         return "k_dot_sweep<%d, 2>" % var
     if name in ("gs_update_fused_dot", "gs_update") or (name == "gated_noop" and var > 0):
-        return "k_gs_update<%d, 2>" % var
+        return "k_gs_update<%d, 2, false>" % var        # (the ops->gramschmidt slot's passes run k_gs_update<KT, 2, true>)
     if name == "gs_bookkeeping":
         return "k_gs_finish<true, true>"
     if name in ("bv_multinplace", "bv_mult"):
-        return "k_panel_mult_mfma<%d, NT>" % (var // 4) if var else "k_panel_mult<KT, false>"
+        return "k_panel_mult_direct<%d, NT, U>" % (var // 4) if var else "k_multvec<2>"       # variant = 4 * KS4 (ks_panel.hip ksp_mult_mfma)
     if name == "bv_dot_panel":
-        return "k_panel_dot_mfma<MT, NT>"
+        return "k_panel_dot_direct<MT, NT, SAME, U>"
     return name
 
 
@@ -161,6 +162,10 @@ class Context:
     def memcpy_h2d(self, dev_ptr, host_array, stream=None):
         """stream: the `stream` argument a communicator callback received (None: the context's own)."""
         _lib.check(self.L.ks_ctx_memcpy_stream(self.h, C.c_void_p(dev_ptr), host_array.ctypes.data_as(C.c_void_p), host_array.nbytes, 0, C.c_void_p(stream)))
+
+    def memset(self, dev_ptr, value, nbytes):
+        """hipMemsetAsync on the context's stream: enqueues only."""
+        _lib.check(self.L.ks_ctx_memset(self.h, C.c_void_p(dev_ptr), value, nbytes))
 
     def memcpy_d2h(self, host_array, dev_ptr, stream=None):
         _lib.check(self.L.ks_ctx_memcpy_stream(self.h, host_array.ctypes.data_as(C.c_void_p), C.c_void_p(dev_ptr), host_array.nbytes, 1, C.c_void_p(stream)))
@@ -507,6 +512,15 @@ class BV:
         o = C.c_double(); nr = C.c_double()
         _lib.check(self.ctx.L.ks_bv_gramschmidt_pass(self.h, j, None, None, None, None, C.byref(o) if want_onrm else None, C.byref(nr) if want_nrm else None))
         return (o.value if want_onrm else None), (nr.value if want_nrm else None)
+
+    def SetState(self, state):
+        """The caller's modification counter (PetscObjectStateGet on the BV): arms the pass chaining of the ops->gramschmidt slot."""
+        _lib.check(self.ctx.L.ks_bv_set_state(self.h, state))
+
+    def GsChainStats(self):
+        a = C.c_longlong(); b = C.c_longlong()
+        _lib.check(self.ctx.L.ks_bv_gs_chain_stats(self.h, C.byref(a), C.byref(b)))
+        return {"chained": a.value, "fresh": b.value}
 
     def buffer_ptr(self):
         p = C.c_void_p(); _lib.check(self.ctx.L.ks_bv_get_buffer(self.h, C.byref(p))); return p.value

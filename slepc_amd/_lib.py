@@ -40,6 +40,7 @@ _SIG = {
     "ks_comm_set_ops": [vp, C.c_int, C.c_int, C.POINTER(CommOps), vp],
     "ks_ctx_memcpy": [vp, vp, vp, C.c_size_t, C.c_int],
     "ks_ctx_memcpy_stream": [vp, vp, vp, C.c_size_t, C.c_int, vp],
+    "ks_ctx_memset": [vp, vp, C.c_int, C.c_size_t],
     "ks_comm_rank_size": [vp, ip, ip],
     "ks_comm_check": [vp],
     "ks_comm_set_allreduce": [vp, C.c_int, ip],
@@ -106,6 +107,8 @@ _SIG = {
     "ks_bv_orthogonalizevec": [vp, vp, dp, dp, ip],
     "ks_bv_orthogonalizesomecolumn": [vp, C.c_int, ip, dp, dp, ip],
     "ks_bv_gs_passes": [vp, llp, ip],
+    "ks_bv_set_state": [vp, C.c_uint64],
+    "ks_bv_gs_chain_stats": [vp, llp, llp],
     "ks_bv_resize": [vp, C.c_int, C.c_int],
     "ks_bv_set_random": [vp, C.c_uint64],
     "ks_bv_insert_vec": [vp, C.c_int, vp],

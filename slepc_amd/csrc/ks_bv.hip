@@ -151,6 +151,7 @@ int ksk_dot(ks_bv bv, const double *A, int lda, int ncols, const double *y, bool
   // narrow sweeps.
   const int dot_per_cu = std::max(1, std::min(4, (30 + ncols - 1) / ncols));
   const KsGsState *g = gate ? bv->gs : nullptr;
+  bv->spec.valid = false;                                       // the partials a chained Gram-Schmidt pass would have read are rewritten
   const int plain = ks_basis_is_cache_resident((size_t)(bv->nc + bv->m), (size_t)bv->ld);
   const int rev = bv->sweep_dir; bv->sweep_dir ^= 1;            // snake over the basis with the sweeps before and after (ks_gs.hip launch_update)
   KsProfScope ps(ctx, KS_K_DOT, 8.0 * bv->n * (ncols + (y >= A && y < A + (size_t)ncols * lda ? 0 : 1)), ks_kt_for(ncols));
@@ -180,6 +181,7 @@ int ksk_multvec(ks_bv bv, const double *A, int lda, int ncols, double alpha, dou
   ks_ctx ctx = bv->ctx;
   const bool v2 = (lda % 2 == 0) && aligned16(A) && aligned16(y);
   const int grid = sweep_grid(ctx, bv->n, v2 ? 2 : 1);
+  bv->spec.valid = false;                                       // y may be a column of this BV
   KsProfScope ps(ctx, KS_K_UPD, 8.0 * bv->n * (ncols + 2));
   if (v2) hipLaunchKernelGGL((k_multvec<2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, alpha, beta, q_dev, y, gate);
   else hipLaunchKernelGGL((k_multvec<1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, A, (long long)lda, bv->n, ncols, alpha, beta, q_dev, y, gate);
@@ -242,6 +244,7 @@ extern "C" int ks_bv_create(ks_ctx ctx, int n_local, int n_global, int m, int ld
   KS_HIP(hipSetDevice(ctx->device));
   ks_bv bv = new ks_bv_s();
   bv->ctx = ctx; bv->n = n_local; bv->N = n_global; bv->m = m; bv->l = 0; bv->k = m; bv->nc = 0;
+  bv->fused_gs = !getenv("KSGPU_NO_FUSED_GS");
   if (ld) {   // BV_SetDefaultLD bvimpl.h:471-484: a user value must be >= n
     if (ld < n_local) { delete bv; KS_FAIL(KS_ERR_USER_INPUT, "The leading dimension %d should be larger or equal to the local number of rows %d", ld, n_local); }
     bv->ld = ld;
@@ -436,12 +439,13 @@ extern "C" int ks_bv_set_orthogonalization(ks_bv bv, int type, int refine, doubl
   KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
   KS_CHECK(type == KS_BV_ORTHOG_CGS || type == KS_BV_ORTHOG_MGS, KS_ERR_ARG_WRONG, "Unknown orthogonalization type");
   KS_CHECK(refine >= 0 && refine <= 2, KS_ERR_ARG_WRONG, "Unknown refinement type");
-  if (eta > 0.0) { KS_CHECK(eta <= 1.0, KS_ERR_ARG_OUTOFRANGE, "Invalid eta value"); bv->orthog_eta = eta; }
+  if (eta > 0.0) { KS_CHECK(eta <= 1.0, KS_ERR_ARG_OUTOFRANGE, "Invalid eta value"); if (eta != bv->orthog_eta) bv->spec.valid = false; bv->orthog_eta = eta; }
+  if (type != bv->orthog_type || refine != bv->orthog_ref) bv->spec.valid = false;      // a chained Gram-Schmidt pass was predicted under the old policy
   bv->orthog_type = type; bv->orthog_ref = refine;
   return KS_SUCCESS;
 }
 
-extern "C" int ks_bv_get_array(ks_bv bv, double **dev) { KS_CHECK(bv && dev, KS_ERR_ARG_NULL, "NULL argument"); *dev = bv->array; return KS_SUCCESS; }
+extern "C" int ks_bv_get_array(ks_bv bv, double **dev) { KS_CHECK(bv && dev, KS_ERR_ARG_NULL, "NULL argument"); *dev = bv->array; bv->spec.valid = false; return KS_SUCCESS; }   // a writable view: whatever a Gram-Schmidt pass left for its successor no longer counts
 extern "C" int ks_bv_get_buffer(ks_bv bv, double **dev) { KS_CHECK(bv && dev, KS_ERR_ARG_NULL, "NULL argument"); *dev = bv->buffer; return KS_SUCCESS; }
 // BVSetBufferVec bvbasic.c:720 on a raw device array of (nc+m)*m doubles: the adapter hands over the array of the reference's
 // bv->buffer Vec, so that BV_CleanCoefficients / BV_SetValue / BV_StoreCoefficients of the caller and the kernels of this library
@@ -449,6 +453,7 @@ extern "C" int ks_bv_get_buffer(ks_bv bv, double **dev) { KS_CHECK(bv && dev, KS
 extern "C" int ks_bv_set_buffer(ks_bv bv, double *dev)
 {
   KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  if (dev != bv->buffer) bv->spec.valid = false;
   if (dev) { if (bv->own_buffer) { bv->buffer_own = bv->buffer; bv->own_buffer = false; } bv->buffer = dev; }
   else if (!bv->own_buffer) { bv->buffer = bv->buffer_own; bv->buffer_own = nullptr; bv->own_buffer = true; }
   return KS_SUCCESS;
@@ -459,6 +464,7 @@ extern "C" int ks_bv_set_layout(ks_bv bv, int nc, int m)
 {
   KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
   KS_CHECK(nc >= 0 && m > 0 && nc + m == bv->nc + bv->m, KS_ERR_ARG_OUTOFRANGE, "nc=%d, m=%d do not add up to the %d allocated columns", nc, m, bv->nc + bv->m);
+  if (nc != bv->nc) bv->spec.valid = false;
   bv->nc = nc; bv->m = m;
   bv->l = std::min(bv->l, bv->m); bv->k = std::min(bv->k, bv->m);
   return KS_SUCCESS;
@@ -469,6 +475,7 @@ extern "C" int ks_bv_get_column(ks_bv bv, int j, double **dev)
   KS_CHECK(j < bv->m, KS_ERR_ARG_OUTOFRANGE, "You requested column %d but only columns 0 to %d are available", j, bv->m - 1);
   KS_CHECK(j >= -bv->nc, KS_ERR_ARG_OUTOFRANGE, "You requested constraint %d but only %d are available", -j, bv->nc);       // bvbasic.c BVGetColumn: negative = constraint
   *dev = ks_bv_col(bv, j);
+  bv->spec.valid = false;
   return KS_SUCCESS;
 }
 
@@ -476,6 +483,7 @@ extern "C" int ks_bv_set_column_host(ks_bv bv, int j, const double *host)
 {
   KS_CHECK(bv && host, KS_ERR_ARG_NULL, "NULL argument");
   KS_CHECK(j >= 0 && j < bv->m, KS_ERR_ARG_OUTOFRANGE, "column %d out of range", j);
+  bv->spec.valid = false;
   KS_HIP(hipSetDevice(bv->ctx->device));
   KS_HIP(hipMemcpyAsync(ks_bv_col(bv, j), host, sizeof(double) * bv->n, hipMemcpyHostToDevice, bv->ctx->stream));
   KS_HIP(ks_sync(bv->ctx));
@@ -631,6 +639,7 @@ static int multinplace(ks_bv V, const double *Q, int ldq, int s, int e, bool tra
   KS_CHECK(V && Q, KS_ERR_ARG_NULL, "NULL argument");
   KS_CHECK(s >= V->l && s <= V->m, KS_ERR_ARG_OUTOFRANGE, "Argument s has wrong value %d, should be between %d and %d", s, V->l, V->m);
   KS_CHECK(e >= V->l && e <= V->m, KS_ERR_ARG_OUTOFRANGE, "Argument e has wrong value %d, should be between %d and %d", e, V->l, V->m);
+  V->spec.valid = false;
   KS_CHECK(ldq >= (trans ? e : V->k), KS_ERR_ARG_SIZ, "Mat argument has %d rows, should have at least %d", ldq, trans ? e : V->k);
   if (s >= e || !V->n) return KS_SUCCESS;
   ks_ctx ctx = V->ctx;
@@ -802,6 +811,7 @@ extern "C" int ks_bv_scale(ks_bv bv, double alpha)   // bvops.c:311, svec.c:150-
 {
   KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
   if (alpha == 1.0 || !bv->n || bv->k <= bv->l) return KS_SUCCESS;
+  bv->spec.valid = false;
   KS_HIP(hipSetDevice(bv->ctx->device));
   return ksk_scale(bv->ctx, bv->array + (size_t)(bv->nc + bv->l) * bv->ld, (size_t)(bv->k - bv->l) * bv->ld, alpha);
 }
@@ -811,6 +821,7 @@ extern "C" int ks_bv_scalecolumn(ks_bv bv, int j, double alpha)   // bvops.c:341
   KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
   KS_CHECK(j >= 0 && j < bv->m, KS_ERR_ARG_OUTOFRANGE, "Argument j has wrong value %d, the number of columns is %d", j, bv->m);
   if (alpha == 1.0 || !bv->n) return KS_SUCCESS;
+  bv->spec.valid = false;
   KS_HIP(hipSetDevice(bv->ctx->device));
   return ksk_scale(bv->ctx, ks_bv_col(bv, j), bv->n, alpha);
 }
@@ -831,6 +842,7 @@ static int norm_core(ks_bv bv, const double *A, int ncols, int j, int type, doub
   ks_ctx ctx = bv->ctx;
   if (ncols <= 0) { *val = 0.0; return KS_SUCCESS; }
   KS_CHECK(ncols <= KS_PSTRIDE - 8, KS_ERR_SUP, "norm over more than %d columns", KS_PSTRIDE - 8);
+  bv->spec.valid = false;                                       // the column sums go through the partials array
   const int grid = std::max(1, std::min((bv->n + SW_BLOCK - 1) / SW_BLOCK, std::min(ctx->num_cu * 4, KS_MAX_BLOCKS)));
   KsProfScope ps(ctx, KS_K_NORM, 8.0 * bv->n * ncols);
   std::vector<double> h;
@@ -1051,6 +1063,7 @@ extern "C" int ks_bv_copycolumn(ks_bv V, int j, int i)   // svec.c:249-259
   KS_CHECK(V, KS_ERR_ARG_NULL, "BV is NULL");
   KS_CHECK(j >= 0 && j < V->m && i >= 0 && i < V->m, KS_ERR_ARG_OUTOFRANGE, "column index out of range (%d -> %d, m=%d)", j, i, V->m);
   if (j == i) return KS_SUCCESS;
+  V->spec.valid = false;
   KS_HIP(hipSetDevice(V->ctx->device));
   return ksk_copy(V->ctx, ks_bv_col(V, j), ks_bv_col(V, i), V->n);
 }

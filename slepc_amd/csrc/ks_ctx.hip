@@ -94,6 +94,8 @@ extern "C" int ks_ctx_destroy(ks_ctx ctx)
   if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
   for (int i = 0; i < 2; i++) if (ctx->ev_h2d[i]) hipEventDestroy(ctx->ev_h2d[i]);
   if (ctx->ev_fetch) hipEventDestroy(ctx->ev_fetch);
+  if (ctx->ev_mail) hipEventDestroy(ctx->ev_mail);
+  if (ctx->gs_mail) hipHostFree(ctx->gs_mail);
   if (ctx->comm.ag_dev) hipFree(ctx->comm.ag_dev);
   if (ctx->split.dev) hipFree(ctx->split.dev);
   if (ctx->halo_stream) { hipStreamSynchronize(ctx->halo_stream); hipStreamDestroy(ctx->halo_stream); }
@@ -389,6 +391,14 @@ extern "C" int ks_ctx_memcpy(ks_ctx ctx, void *dst, const void *src, size_t byte
   KS_HIP(hipSetDevice(ctx->device));
   if (bytes) KS_HIP(hipMemcpyAsync(dst, src, bytes, kind == 0 ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, ctx->stream));
   KS_HIP(ks_sync(ctx));
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_ctx_memset(ks_ctx ctx, void *dev, int value, size_t bytes)
+{
+  KS_CHECK(ctx && (bytes == 0 || dev), KS_ERR_ARG_NULL, "NULL argument");
+  KS_HIP(hipSetDevice(ctx->device));
+  if (bytes) KS_HIP(hipMemsetAsync(dev, value, bytes, ctx->stream));
   return KS_SUCCESS;
 }
 

@@ -43,6 +43,11 @@ struct GsArgs {
                    // update never carries dots and the 1/nrm scaling is a kernel of its own
   int gs1;         // 0: slot of the device-resident program; 1 / 2: ONE pass with the semantics of the ops->gramschmidt slot
                    // (BVOrthogonalizeCGS1), without (1) / with (2) the self dot product in c[k]
+  int ncols_in;    // gs1: dots waiting in the partials (k, or k + 1 with the self dot; a chained pass always finds k + 1)
+  int pass_idx;    // gs1: 1 for a pass that took its own dots, 2, 3 for passes chained to the one before (the caller's refinement loop)
+  int spec_ok;     // gs1: the update may carry the dots of the pass the caller is expected to ask for next
+  unsigned long long mail_seq;   // gs1: stamp of this call in the host mailbox
+  KsGsMail *mail;  // gs1: pinned host record the bookkeeping's scalars go to (the host polls it while the update sweep runs)
   double eta, deftol;
 };
 
@@ -82,6 +87,15 @@ __device__ void gs1_bookkeep(const GsArgs a, const double *c, KsGsState *st, Boo
   st->pending_scale = 0; st->more_ = 0; st->expl = 0;
   KsStepRec r; r.onrm = beta; r.nrm = beta * beta - sum; r.passes = 1; r.lindep = 0; r.expl = 0; r.col = a.col;
   plan->rec = r; plan->set_rec = 1;
+  // Will the caller's refinement loop (BVOrthogonalizeGS bvorthog.c:176-202, same policy and eta: mirrored by the adapter) ask for another
+  // pass? Then this update also leaves the dots of that pass behind (they are row-local, ks_gs.hip header). A wrong guess costs nothing
+  // but the unused partial sums: the host only chains the next call to them when nothing touched the BV in between.
+  if (a.spec_ok && k > 0) {
+    if (a.refine == KS_BV_ORTHOG_REFINE_IFNEEDED && a.gs1 == 2 && r.nrm > 0.0) {
+      const double nrm = sqrt(r.nrm);
+      if (a.pass_idx < 3 && nrm != 0.0 && fabs(nrm) < a.eta * fabs(beta)) st->fuse_dot = 1;        // bvorthog.c:179
+    } else if (a.refine == KS_BV_ORTHOG_REFINE_ALWAYS && a.gs1 == 1 && a.pass_idx == 1) st->fuse_dot = 1;   // bvorthog.c:198-199
+  }
 }
 
 // Bookkeeping for one slot.  Thread 0 only.  c[0..k] are the (globally reduced) dots of the current
@@ -365,7 +379,8 @@ struct FoldArgs {
   KsStepRec *recs;
 };
 
-template <int KT, int VEC>
+// GS1: the launch is one pass of the ops->gramschmidt slot (its own instantiation, so that the device-resident program's kernel carries none of it)
+template <int KT, int VEC, bool GS1>
 __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long long ld, int n, int k, double *v, const double *__restrict__ cg_global,
                                                         double *__restrict__ partials, const KsGsState *__restrict__ st, int *__restrict__ pgrid, int rev, int plain,
                                                         int folded, FoldArgs fa)
@@ -383,7 +398,7 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long lo
     if (threadIdx.x == 0) {
       KsGsState s = *fa.st_in;
       int go = 1;
-      if (!s.active || (a.slot > 1 && !s.expl && !s.more_)) { go = 0; s.do_update = 0; }     // halted run / column already final
+      if (!GS1 && (!s.active || (a.slot > 1 && !s.expl && !s.more_))) { go = 0; s.do_update = 0; }     // halted run / column already final
       s_sh = s; go_sh = go;
     }
     __syncthreads();
@@ -391,12 +406,12 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long lo
       if (blockIdx.x == 0 && threadIdx.x == 0) *fa.st_out = s_sh;                             // the chain of states goes on through a launch that does nothing
       return;
     }
-    const int ncols = a.k + 1;
+    const int ncols = GS1 ? a.ncols_in : a.k + 1;
     if (fa.cred) { if ((int)threadIdx.x < ncols) c_lds[threadIdx.x] = fa.cred[threadIdx.x]; __syncthreads(); }
     else reduce_partials_to_lds(fa.partials_in, s_sh.pgrid, ncols, c_lds);
     if (threadIdx.x == 0) {
       KsGsState s = s_sh;
-      gs_bookkeep(a, c_lds, &s, &plan_sh);
+      if (GS1) gs1_bookkeep(a, c_lds, &s, &plan_sh); else gs_bookkeep(a, c_lds, &s, &plan_sh);
       if (s.do_update && s.fuse_dot) s.pgrid = gridDim.x;                                     // the grid of the partials this launch is about to write
       s_sh = s;
     }
@@ -407,7 +422,21 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long lo
     if (blockIdx.x == 0) {
       apply_plan(a, plan_sh, c_lds, fa.buffer, fa.pend);
       if ((int)threadIdx.x < ncols && !(a.col == 0 && (int)threadIdx.x <= a.k)) fa.buffer[threadIdx.x] = c_lds[threadIdx.x];   // scratch c = buffer column 0 (column 0's own coefficients live there: apply_plan has just written them)
-      if (threadIdx.x == 0) { *fa.st_out = s_sh; if (plan_sh.set_rec) fa.recs[a.col] = plan_sh.rec; }
+      if (threadIdx.x == 0) {
+        *fa.st_out = s_sh; if (plan_sh.set_rec) fa.recs[a.col] = plan_sh.rec;
+        if (GS1 && a.mail) {
+          // the scalars the slot returns go straight to pinned host memory: the host has them when this sweep STARTS, not when it ends, and
+          // enqueues the caller's next pass behind it. Payload, system-scope fence, then the stamp the host polls for.
+          KsGsMail *m = a.mail;
+          __hip_atomic_store(&m->onrm, plan_sh.rec.onrm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&m->nrm, plan_sh.rec.nrm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&m->fused, s_sh.do_update && s_sh.fuse_dot ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&m->err, s_sh.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __threadfence_system();
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(&m->seq, a.mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
     }
     __syncthreads();
     if (!s_sh.do_update) return;
@@ -428,11 +457,20 @@ __global__ __launch_bounds__(SW_BLOCK) void k_gs_update(const double *V, long lo
   // pass at 2.2 TB/s, <56,2> at 3.0) and the generic form, which reads the coefficients from where the prologue put them (LDS) as it uses them, is the
   // faster one. Measured per width (profiles/r02_wide_probe*.txt): final pass specialised up to 48 columns, fused pass up to 40.
   constexpr bool SPEC_FUSED = KT <= 40, SPEC_FINAL = KT <= 48;
+  if (GS1) {
+    // a pass of the slot applies its own coefficients only and always stores; it carries the next pass's dots or it does not
+    if (VEC == 2 && plain && SPEC_FUSED && fuse && npend == 1 && !scal) upd_tiles<KT, VEC, 1, 1, true>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
+    else if (VEC == 2 && !plain && SPEC_FUSED && fuse && npend == 1 && !scal) upd_tiles<KT, VEC, 1, 1, false>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
+    else if (VEC == 2 && plain && SPEC_FINAL && !fuse && npend == 1) upd_tiles<KT, VEC, 1, 0, true>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
+    else if (VEC == 2 && !plain && SPEC_FINAL && !fuse && npend == 1) upd_tiles<KT, VEC, 1, 0, false>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
+    else upd_tiles<KT, VEC, 0, -1, false>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
+  } else {
   if (VEC == 2 && plain && SPEC_FUSED && fuse && npend == 1 && !scal) upd_tiles<KT, VEC, 1, 1, true>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);     // basis resident in the Infinity Cache: plain loads (ks_sweeps.cuh)
   else if (VEC == 2 && plain && SPEC_FINAL && !fuse && npend == 2) upd_tiles<KT, VEC, 2, 0, true>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
   else if (VEC == 2 && !plain && SPEC_FUSED && fuse && npend == 1 && !scal) upd_tiles<KT, VEC, 1, 1, false>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
   else if (VEC == 2 && !plain && SPEC_FINAL && !fuse && npend == 2) upd_tiles<KT, VEC, 2, 0, false>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
   else upd_tiles<KT, VEC, 0, -1, false>(V, ld, n, k, v, cg, npend, fuse, scal, store, alpha, rev, acc);
+  }
   if (!fuse) return;
   if (!folded && blockIdx.x == 0 && threadIdx.x == 0) *pgrid = gridDim.x;        // (folded: already part of the state workgroup 0 wrote)
   // block combine: partial index i<k <- acc[i]; index k <- acc[KT] (the self dot)
@@ -485,18 +523,19 @@ int launch_finish(ks_bv bv, const GsArgs &a)
 int launch_reduce_allreduce(ks_bv bv, const GsArgs &a)
 {
   ks_ctx ctx = bv->ctx;
-  KsProfScope ps(ctx, KS_K_GSFIN, 8.0 * bv->last_grid * (a.k + 1));
+  const int ncols = a.gs1 ? a.ncols_in : a.k + 1;
+  KsProfScope ps(ctx, KS_K_GSFIN, 8.0 * bv->last_grid * ncols);
   ps.tag(a.col, a.slot, a.k, bv->n);
   KsOneShotArgs o;
-  if (ks_oneshot_next(ctx, a.k + 1, &o)) {       // reduction and exchange in one launch
-    KS_CALL(ks_oneshot_error(ctx));
-    hipLaunchKernelGGL(k_reduce_oneshot, dim3(1), dim3(GF_BLOCK), 0, ctx->stream, bv->partials, bv->gs, a.k + 1, bv->cred, o);
+  KS_CALL(ks_oneshot_error(ctx));                // before a sequence number is taken: a call that does not send must not consume one
+  if (ks_oneshot_next(ctx, ncols, &o)) {         // reduction and exchange in one launch
+    hipLaunchKernelGGL(k_reduce_oneshot, dim3(1), dim3(GF_BLOCK), 0, ctx->stream, bv->partials, bv->gs, ncols, bv->cred, o);
     KS_HIP(hipGetLastError());
     return KS_SUCCESS;
   }
-  hipLaunchKernelGGL(k_reduce_state, dim3(1), dim3(GF_BLOCK), 0, ctx->stream, bv->partials, bv->gs, a.k + 1, bv->cred);
+  hipLaunchKernelGGL(k_reduce_state, dim3(1), dim3(GF_BLOCK), 0, ctx->stream, bv->partials, bv->gs, ncols, bv->cred);
   KS_HIP(hipGetLastError());
-  return ks_allreduce_sum(ctx, bv->cred, a.k + 1);
+  return ks_allreduce_sum(ctx, bv->cred, ncols);
 }
 
 // fold: the slot's GsArgs when the kernel carries its own bookkeeping, nullptr after a k_gs_finish launch
@@ -520,16 +559,22 @@ int launch_update(ks_bv bv, int col, double *v, int slot, const GsArgs *fold = n
   ps.tag(col, slot, k, bv->n);
   FoldArgs fa; memset(&fa, 0, sizeof(fa));
   const int folded = fold ? 1 : 0;
+  bv->spec.valid = false;                          // whatever dots an earlier pass of the ops->gramschmidt slot left are about to be replaced
   double *pout = bv->partials;                     // where fused dots go
   if (folded) { fa.a = *fold; fa.cred = ks_is_multi(ctx) ? bv->cred : nullptr; fa.partials_in = bv->partials; fa.st_in = bv->gs; fa.st_out = bv->gs_alt; fa.buffer = bv->buffer; fa.pend = bv->pend; fa.recs = bv->recs; pout = bv->partials_alt; }
-#define LAUNCH_UPD(KT)                                                                                                                                 \
+#define LAUNCH_UPD_G(KT, G)                                                                                                                            \
   do {                                                                                                                                                 \
-    if (v2) { grid = ks_sweep_grid_for(ctx, bv->n, 2, (const void *)k_gs_update<KT, 2>, upd_per_cu); bv->last_grid = grid;                                                        \
-      hipLaunchKernelGGL((k_gs_update<KT, 2>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->pend, pout, bv->gs, &bv->gs->pgrid, rev, plain, folded, fa); } \
-    else { grid = ks_sweep_grid_for(ctx, bv->n, 1, (const void *)k_gs_update<KT, 1>, upd_per_cu); bv->last_grid = grid;                                                           \
-      hipLaunchKernelGGL((k_gs_update<KT, 1>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->pend, pout, bv->gs, &bv->gs->pgrid, rev, plain, folded, fa); }   \
+    if (v2) { grid = ks_sweep_grid_for(ctx, bv->n, 2, (const void *)k_gs_update<KT, 2, G>, upd_per_cu); bv->last_grid = grid;                                                        \
+      hipLaunchKernelGGL((k_gs_update<KT, 2, G>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->pend, pout, bv->gs, &bv->gs->pgrid, rev, plain, folded, fa); } \
+    else { grid = ks_sweep_grid_for(ctx, bv->n, 1, (const void *)k_gs_update<KT, 1, G>, upd_per_cu); bv->last_grid = grid;                                                           \
+      hipLaunchKernelGGL((k_gs_update<KT, 1, G>), dim3(grid), dim3(SW_BLOCK), 0, ctx->stream, V, (long long)bv->ld, bv->n, k, v, bv->pend, pout, bv->gs, &bv->gs->pgrid, rev, plain, folded, fa); }   \
   } while (0)
-  KS_KT_DISPATCH(kk, LAUNCH_UPD);
+#define LAUNCH_UPD(KT) LAUNCH_UPD_G(KT, false)
+#define LAUNCH_UPD1(KT) LAUNCH_UPD_G(KT, true)
+  if (fold && fold->gs1) KS_KT_DISPATCH(kk, LAUNCH_UPD1);
+  else KS_KT_DISPATCH(kk, LAUNCH_UPD);
+#undef LAUNCH_UPD1
+#undef LAUNCH_UPD_G
 #undef LAUNCH_UPD
   KS_HIP(hipGetLastError());
   if (folded) { std::swap(bv->gs, bv->gs_alt); std::swap(bv->partials, bv->partials_alt); }      // what the next launch reads
@@ -715,6 +760,7 @@ int fetch_state_end(ks_bv bv, KsGsState *st, KsStepRec *recs, int j0, int j1, do
   const char *pin = (const char *)ctx->h_pinned;
   ctx->nsync++;
   KS_HIP(hipEventSynchronize(ctx->ev_fetch));
+  KS_CALL(ks_oneshot_error(ctx));                  // a one-shot allreduce that gave up shows at every host wait, this one included (ksgpu.h)
   memcpy(st, pin, sizeof(KsGsState));
   if (nrec) memcpy(recs, pin + off_rec, sizeof(KsStepRec) * nrec);
   if (coef_len) memcpy(coef_out, pin + off_coef, sizeof(double) * coef_len);
@@ -855,7 +901,7 @@ int store_buffer_column(ks_bv bv, int j, const double *hh, int len)
   return KS_SUCCESS;
 }
 
-bool use_fused(ks_bv bv) { return bv->orthog_type == KS_BV_ORTHOG_CGS && bv->nc + bv->m <= 8000 && !getenv("KSGPU_NO_FUSED_GS"); }
+bool use_fused(ks_bv bv) { return bv->orthog_type == KS_BV_ORTHOG_CGS && bv->nc + bv->m <= 8000 && bv->fused_gs; }
 
 // The two halves of the fused orthogonalisation of column j: the enqueue (no host wait) and the collection of its results (one host wait; a
 // column the device flagged is completed here, *late_completion says so: whatever was enqueued behind the first half saw an unfinished column).
@@ -1022,20 +1068,23 @@ extern "C" int ks_bv_orthogonalizesomecolumn(ks_bv bv, int j, const int *which, 
 // owns the refinement loop: it cleans the coefficients, calls the slot once per pass (onrm / nrm may be NULL: REFINE_NEVER and the
 // first REFINE_ALWAYS call), compares |nrm| with eta |onrm|, computes lindep and stores the norm next to the coefficients.
 namespace {
-int gs1_fused_column(ks_bv bv, int j, double *onrm, double *nrm)
+// The pass as three dependent launches and a stream wait: dot sweep, 1-block bookkeeping, update. Kept for what the chained form below does not
+// cover: column 0 without constraints (nothing to update), a B-inner product (the dots of every pass are taken with B v).
+int gs1_plain_column(ks_bv bv, int j, double *onrm, double *nrm)
 {
   ks_ctx ctx = bv->ctx;
   const bool need = onrm || nrm;
   const int k = bv->nc + j;
   if (k == 0 && !need) return KS_SUCCESS;
-  GsArgs a; a.wide = 0; a.bmat = bv->matrix ? 1 : 0; a.gs1 = need ? 2 : 1; a.k = k; a.col = j; a.slot = 1; a.refine = bv->orthog_ref; a.normalize = 0; a.krylov = 0; a.ldb = bv->nc + bv->m;
-  a.spec_last = 0; a.eta = bv->orthog_eta; a.deftol = bv->deftol;
+  GsArgs a; memset(&a, 0, sizeof(a));
+  a.wide = 0; a.bmat = bv->matrix ? 1 : 0; a.gs1 = need ? 2 : 1; a.k = k; a.col = j; a.slot = 1; a.refine = bv->orthog_ref; a.normalize = 0; a.krylov = 0; a.ldb = bv->nc + bv->m;
+  a.spec_last = 0; a.eta = bv->orthog_eta; a.deftol = bv->deftol; a.ncols_in = k + (need ? 1 : 0); a.pass_idx = 1;
   double *v = ks_bv_col(bv, j);
   const double *z = v;
   KS_CALL(ksb_ipmatmult(bv, v, &z));                                                             // B v for a B-inner product
   KS_CALL(ksk_dot(bv, ks_bv_col(bv, -bv->nc), bv->ld, k + (need ? 1 : 0), z, false));          // BVDotColumnInc / BVDotColumn
   KS_CALL(launch_finish(bv, a));
-  if (k > 0) KS_CALL(launch_update(bv, j, v, 2));                                              // BVMultColumn(bv,-1,1,j,c)
+  if (k > 0) KS_CALL(launch_update(bv, j, v, 1));                                              // BVMultColumn(bv,-1,1,j,c)
   KsGsState st; KsStepRec rec;
   KS_CALL(fetch_state(bv, &st, &rec, j, j));
   ks_prof_resolve_gs(ctx, &rec, j, j);
@@ -1044,6 +1093,77 @@ int gs1_fused_column(ks_bv bv, int j, double *onrm, double *nrm)
   if (nrm) {
     if (rec.nrm <= 0.0) KS_CALL(ks_bv_normcolumn(bv, j, KS_NORM_2, nrm));                      // BV_NormVecOrColumn bvorthog.c:126
     else *nrm = sqrt(rec.nrm);
+  }
+  return KS_SUCCESS;
+}
+
+int gs_mailbox(ks_ctx ctx)
+{
+  if (ctx->gs_mail) return KS_SUCCESS;
+  KS_HIP(hipHostMalloc((void **)&ctx->gs_mail, 256, hipHostMallocMapped | hipHostMallocCoherent));
+  memset(ctx->gs_mail, 0, 256);
+  KS_HIP(hipHostGetDevicePointer((void **)&ctx->gs_mail_dev, ctx->gs_mail, 0));
+  KS_HIP(hipEventCreateWithFlags(&ctx->ev_mail, hipEventDisableTiming));
+  return KS_SUCCESS;
+}
+
+// Wait for the stamp `seq` in the mailbox. The stamp is written by the update kernel's prologue, i.e. when that launch STARTS; the event behind
+// the launch is the fallback that cannot fail to arrive (everything a finished launch wrote to host memory is visible).
+int gs_mail_wait(ks_ctx ctx, unsigned long long seq, KsGsMail *out)
+{
+  volatile KsGsMail *m = ctx->gs_mail;
+  ctx->nsync++; ctx->nmailwait++;
+  bool got = false;
+  for (unsigned spins = 1; !got; spins++) {
+    if (__atomic_load_n(&ctx->gs_mail->seq, __ATOMIC_ACQUIRE) == seq) { got = true; break; }
+    if ((spins & 255u) == 0) {
+      const hipError_t q = hipEventQuery(ctx->ev_mail);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) { ks_set_error("waiting for a Gram-Schmidt pass: %s", hipGetErrorString(q)); return KS_ERR_LIB; }
+    }
+    __builtin_ia32_pause();
+  }
+  if (!got && __atomic_load_n(&ctx->gs_mail->seq, __ATOMIC_ACQUIRE) != seq) KS_FAIL(KS_ERR_LIB, "the Gram-Schmidt pass finished without reporting (stamp %llu expected)", seq);
+  out->onrm = m->onrm; out->nrm = m->nrm; out->fused = m->fused; out->err = m->err; out->seq = seq;
+  return ks_oneshot_error(ctx);
+}
+
+// The pass as the caller's refinement loop sees it, at the cost of the device-resident program: ONE launch per pass after the first dot sweep
+// and no stream wait. The update kernel runs the pass's bookkeeping in its prologue, hands onrm / nrm to the host through the mailbox as it
+// starts, applies and STORES the pass (the slot's contract: the column in memory is v - V c when the call returns... is enqueued) and, when the
+// mirrored refinement policy says the caller will come back, also accumulates the dots of the next pass from the row panel it holds. A next
+// call on the same column with the caller's state token unchanged (ks_bv_set_state) is chained to those dots: no dot sweep, 3 reads of the
+// basis per CGS2 step instead of 4.
+int gs1_fused_column(ks_bv bv, int j, double *onrm, double *nrm)
+{
+  ks_ctx ctx = bv->ctx;
+  const bool need = onrm || nrm;
+  const int k = bv->nc + j;
+  if (k == 0 || bv->matrix) return gs1_plain_column(bv, j, onrm, nrm);
+  KS_CALL(gs_mailbox(ctx));
+  const bool chained = bv->spec.armed && bv->spec.valid && bv->spec.col == j && bv->spec.token_at == bv->spec.token;
+  GsArgs a; memset(&a, 0, sizeof(a));
+  a.gs1 = need ? 2 : 1; a.k = k; a.col = j; a.slot = 1; a.refine = bv->orthog_ref; a.ldb = bv->nc + bv->m; a.eta = bv->orthog_eta; a.deftol = bv->deftol;
+  a.ncols_in = chained ? k + 1 : k + (need ? 1 : 0);
+  a.pass_idx = chained ? bv->spec.pass_idx + 1 : 1;
+  a.spec_ok = bv->spec.armed ? 1 : 0;
+  a.mail = ctx->gs_mail_dev; a.mail_seq = ++ctx->gs_mail_seq;
+  double *v = ks_bv_col(bv, j);
+  if (!chained) KS_CALL(ksk_dot(bv, ks_bv_col(bv, -bv->nc), bv->ld, a.ncols_in, v, false));    // BVDotColumnInc / BVDotColumn
+  if (ks_is_multi(ctx)) KS_CALL(launch_reduce_allreduce(bv, a));                               // bvblas.c:255
+  KS_CALL(launch_update(bv, j, v, 1, &a));                                                     // bookkeeping + BVMultColumn(bv,-1,1,j,c) [+ next dots]
+  KS_HIP(hipEventRecord(ctx->ev_mail, ctx->stream));
+  KsGsMail r;
+  KS_CALL(gs_mail_wait(ctx, a.mail_seq, &r));
+  if (chained) bv->spec.chained++; else bv->spec.fresh++;
+  if (r.err) KS_FAIL(r.err, "Invalid inner product (BV_SafeSqrt): negative v^H v");
+  bv->spec.valid = bv->spec.armed && r.fused; bv->spec.col = j; bv->spec.token_at = bv->spec.token; bv->spec.pass_idx = a.pass_idx;
+  if (ctx->prof_on) { KsStepRec rec; rec.nrm = r.nrm; rec.onrm = r.onrm; rec.passes = 1; rec.lindep = 0; rec.expl = 0; rec.col = j; ks_prof_resolve_gs(ctx, &rec, j, j); }
+  bv->passes_last_host = 1; bv->passes_total_host += 1;
+  if (onrm) *onrm = r.onrm;
+  if (nrm) {
+    if (r.nrm <= 0.0) KS_CALL(ks_bv_normcolumn(bv, j, KS_NORM_2, nrm));                        // BV_NormVecOrColumn bvorthog.c:126 (its sweep drops the chain)
+    else *nrm = sqrt(r.nrm);
   }
   return KS_SUCCESS;
 }
@@ -1081,6 +1201,20 @@ extern "C" int ks_bv_gramschmidt_pass(ks_bv bv, int j, double *v_dev, const int 
     KS_HIP(hipMemcpyAsync(bv->buffer, cp, sizeof(double) * len, hipMemcpyHostToDevice, ctx->stream));      // scratch column "s" (bvbasic.c:757-769)
     KS_HIP(ks_sync(ctx));
   }
+  return KS_SUCCESS;
+}
+
+extern "C" int ks_bv_set_state(ks_bv bv, uint64_t state)
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  bv->spec.armed = true; bv->spec.token = state;
+  return KS_SUCCESS;
+}
+extern "C" int ks_bv_gs_chain_stats(ks_bv bv, long long *chained, long long *fresh)
+{
+  KS_CHECK(bv, KS_ERR_ARG_NULL, "BV is NULL");
+  if (chained) *chained = bv->spec.chained;
+  if (fresh) *fresh = bv->spec.fresh;
   return KS_SUCCESS;
 }
 

@@ -21,6 +21,10 @@ void ks_set_error(const char *fmt, ...);
 struct KsProfSlot { long long launches = 0; double ms = 0.0; double bytes = 0.0; double hbm = 0.0; };
 struct KsProfPending { hipEvent_t e0, e1; int kclass; int variant; double bytes; double hbm; int tag_col; int tag_slot; int tag_k; long long tag_n; bool done; };
 
+// Host mailbox of the ops->gramschmidt slot (one per context, pinned coherent host memory): the update kernel's bookkeeping writes the scalars
+// the slot returns here and stamps them with the call's sequence number; the host polls the stamp instead of waiting for the stream.
+struct KsGsMail { double onrm, nrm; int fused, err; unsigned long long seq; };
+
 // ---- communicator -------------------------------------------------------------------------------
 #define KS_ONESHOT_MAX_RANKS 16
 #define KS_ONESHOT_MAX_COUNT 128
@@ -76,6 +80,10 @@ struct ks_ctx_s {
   double *h_pinned = nullptr; size_t h_pinned_len = 0;
   hipEvent_t ev_h2d[2] = {nullptr, nullptr}; int h2d_next = 0;
   hipEvent_t ev_fetch = nullptr;        // marks the end of a batch of result copies that was enqueued ahead of further work (ks_gs.hip: fetch_state_begin / _end)
+  KsGsMail *gs_mail = nullptr, *gs_mail_dev = nullptr;   // ops->gramschmidt slot: host mailbox and its device address (allocated on first use)
+  unsigned long long gs_mail_seq = 0;
+  hipEvent_t ev_mail = nullptr;         // behind the launch that writes the mailbox: what the host falls back on if the stamp does not show up
+  long long nmailwait = 0;              // waits on the mailbox (instrumentation; they also count in nsync)
 };
 
 // every host wait on the context's stream goes through here, so that tests can assert that a call enqueues without waiting
@@ -234,8 +242,12 @@ struct ks_bv_s {
   ks_mat matrix = nullptr;   // inner-product matrix B of BVSetMatrix (positive definite), borrowed; nullptr = standard
   double *Bx = nullptr;      // B*x of the vector an inner product is being taken with (BV_IPMatMult bvimpl.h:147-158)
   bool fetch_pending = false; size_t fetch_coefs = 0;     // result copies of the last enqueued column are on their way (gs_enqueue_column with early copies)
+  // ops->gramschmidt slot, pass chaining (ks_bv_set_state): the last pass on column `col` left the next pass's dots in `partials`; they are used
+  // only if the caller's state token is still `token_at` and no sweep of this BV has rewritten the partials since
+  struct { bool armed = false, valid = false; unsigned long long token = 0, token_at = 0; int col = -1, pass_idx = 0; long long chained = 0, fresh = 0; } spec;
   double *pend = nullptr;    // [3][KS_PSTRIDE] coefficients of the passes since the vector was last written back (what the next update applies, pass by pass)
   double orthog_eta = 0.7071;
+  bool fused_gs = true;      // the device-resident Gram-Schmidt program may be used (KSGPU_NO_FUSED_GS, a test switch, is read when the BV is created)
   double deftol = 10 * 2.220446049250313e-16;
   double *array = nullptr;      // m*ld
   double *buffer = nullptr;     // (nc+m)*m ; column 0 = scratch c

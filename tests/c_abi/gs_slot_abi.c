@@ -18,7 +18,11 @@ enum { N = 2000, M = 9 };
 
 static double entry(int i, int j) { return (double)(((i * 37 + j * 101 + ((i * i) % 13) * 7) % 17) - 8) * 0.0625; }
 
-typedef struct { ks_ctx ctx; ks_bv bv; double *buffer; int nc, m; int refine, mgs; double eta; int passes; } Caller;
+typedef struct { ks_ctx ctx; ks_bv bv; double *buffer; int nc, m; int refine, mgs; double eta; int passes; uint64_t state; } Caller;
+
+/* what the adapter's HipksSync does at the head of every slot: mirror the caller's fields, among them the object state
+   (PetscObjectStateGet): it stays put between the passes BVOrthogonalizeGS makes on a column and moves whenever a column changes */
+#define PASS(c, j, onrm, nrm) (ks_bv_set_state((c)->bv, (c)->state) || ks_bv_gramschmidt_pass((c)->bv, (j), NULL, NULL, NULL, NULL, (onrm), (nrm)))
 
 /* BV_CleanCoefficients(bv,j,NULL) bvimpl.h:289-301: zero column j of the buffer, entries 0..nc+j-1 */
 static int clean_coefficients(Caller *c, int j)
@@ -41,28 +45,71 @@ static int caller_orthogonalize_column(Caller *c, int j, double *norm, int *lind
   if (clean_coefficients(c, j)) return 1;
   switch (c->refine) {
   case KS_BV_ORTHOG_REFINE_IFNEEDED:
-    CHK(ks_bv_gramschmidt_pass(c->bv, j, NULL, NULL, NULL, NULL, &onrm, &nrm)); c->passes++;
+    CHK(PASS(c, j, &onrm, &nrm)); c->passes++;
     l = 1;
     while (l < 3 && nrm != 0.0 && fabs(nrm) < c->eta * fabs(onrm)) {
       l++;
       if (c->mgs) onrm = nrm;                                                              /* bvorthog.c:181-182 */
-      CHK(ks_bv_gramschmidt_pass(c->bv, j, NULL, NULL, NULL, NULL, c->mgs ? NULL : &onrm, &nrm)); c->passes++;
+      CHK(PASS(c, j, c->mgs ? NULL : &onrm, &nrm)); c->passes++;
     }
     *lindep = !(nrm != 0.0 && fabs(nrm) >= c->eta * fabs(onrm));
     break;
   case KS_BV_ORTHOG_REFINE_NEVER:
-    CHK(ks_bv_gramschmidt_pass(c->bv, j, NULL, NULL, NULL, NULL, NULL, NULL)); c->passes++;
+    CHK(PASS(c, j, NULL, NULL)); c->passes++;
     CHK(ks_bv_normcolumn(c->bv, j, KS_NORM_2, &nrm));
     *lindep = !(nrm != 0.0);
     break;
   default:
-    CHK(ks_bv_gramschmidt_pass(c->bv, j, NULL, NULL, NULL, NULL, NULL, NULL)); c->passes++;
-    CHK(ks_bv_gramschmidt_pass(c->bv, j, NULL, NULL, NULL, NULL, &onrm, &nrm)); c->passes++;
+    CHK(PASS(c, j, NULL, NULL)); c->passes++;
+    CHK(PASS(c, j, &onrm, &nrm)); c->passes++;
     *lindep = !(nrm != 0.0 && fabs(nrm) >= c->eta * fabs(onrm));
     break;
   }
   *norm = nrm;
   if (set_value(c, j, j, *lindep ? 0.0 : nrm)) return 1;
+  c->state++;                                                  /* PetscObjectStateIncrease at the end of BVOrthogonalizeColumn (bvorthog.c:338) */
+  return 0;
+}
+
+/* Pass chaining (ks_bv_set_state): column 3 = column 0 + a 2^-12 perturbation needs two passes. Three runs of the same two passes
+   on fresh copies of the same four columns: with the state announced and unchanged (the second pass is chained to the dots the
+   first one left), without any state (both passes take their own dots), and with the column rewritten between the passes behind
+   the library's back - a copy through a pointer lent earlier - and the state bumped as PETSc would (the second pass must take
+   its own dots of the NEW content). */
+static int chain_case(ks_ctx ctx, int mode, double *col)
+{
+  enum { MC = 4 };
+  ks_bv W; double *wbuf, *c3, zero[MC] = {0}, onrm1 = 0, nrm1 = 0, onrm2 = 0, nrm2 = 0, expect = 0, h[MC * MC];
+  long long chained = 0, fresh = 0;
+  uint64_t state = 100;
+  int i, j;
+  CHK(ks_bv_create(ctx, N, N, MC, 0, &W));
+  CHK(ks_bv_set_orthogonalization(W, KS_BV_ORTHOG_CGS, KS_BV_ORTHOG_REFINE_IFNEEDED, 0.0));
+  for (j = 0; j < MC; j++) {
+    for (i = 0; i < N; i++) col[i] = j == 3 ? entry(i, 0) + ldexp(entry(i, 4), -12) : entry(i, j);
+    CHK(ks_bv_set_column_host(W, j, col));
+  }
+  CHK(ks_bv_get_buffer(W, &wbuf));
+  CHK(ks_bv_get_column(W, 3, &c3));                 /* lent before the passes, as a Vec obtained with BVGetColumn would be */
+  for (j = 0; j < 3; j++) { double nr; int ld; CHK(ks_bv_orthonormalizecolumn(W, j, 0, &nr, &ld)); }
+  CHK(ks_ctx_memcpy(ctx, wbuf + 3 * MC, zero, sizeof(double) * 3, 0));
+  if (mode != 1) CHK(ks_bv_set_state(W, state));
+  CHK(ks_bv_gramschmidt_pass(W, 3, NULL, NULL, NULL, NULL, &onrm1, &nrm1));
+  if (mode == 2) {
+    for (i = 0; i < N; i++) col[i] = entry(i, 7);
+    CHK(ks_ctx_memcpy(ctx, c3, col, sizeof(double) * N, 0));
+    state++;
+    { double s = 0; for (i = 0; i < N; i++) s += col[i] * col[i]; expect = sqrt(s); }
+  }
+  if (mode != 1) CHK(ks_bv_set_state(W, state));
+  CHK(ks_bv_gramschmidt_pass(W, 3, NULL, NULL, NULL, NULL, &onrm2, &nrm2));
+  CHK(ks_bv_gs_chain_stats(W, &chained, &fresh));
+  CHK(ks_bv_get_buffer_host(W, h));
+  printf("chain mode %d onrm1 %.17g nrm1 %.17g onrm2 %.17g nrm2 %.17g chained %lld fresh %lld expect %.17g h %.17g %.17g %.17g\n", mode, onrm1, nrm1, onrm2, nrm2, chained, fresh, expect,
+         h[3 * MC], h[3 * MC + 1], h[3 * MC + 2]);
+  CHK(ks_bv_get_column_host(W, 3, col));
+  { double s = 0; for (i = 0; i < N; i++) s += col[i] * col[i]; printf("chain mode %d column_norm %.17g\n", mode, sqrt(s)); }
+  CHK(ks_bv_destroy(W));
   return 0;
 }
 
@@ -82,7 +129,7 @@ int main(int argc, char **argv)
   CHK(ks_bv_get_column(bufbv, 0, &c.buffer));
   CHK(ks_bv_set_buffer(c.bv, c.buffer));
   { double *chk = NULL; CHK(ks_bv_get_buffer(c.bv, &chk)); if (chk != c.buffer) { fprintf(stderr, "the adopted buffer is not in use\n"); return 3; } }
-  c.nc = 0; c.m = M; c.refine = refine; c.mgs = mgs; c.eta = 0.7071; c.passes = 0;
+  c.nc = 0; c.m = M; c.refine = refine; c.mgs = mgs; c.eta = 0.7071; c.passes = 0; c.state = 1;
 
   col = (double *)malloc(sizeof(double) * N); x0 = (double *)malloc(sizeof(double) * N);
   x1 = (double *)malloc(sizeof(double) * N); x2 = (double *)malloc(sizeof(double) * N);
@@ -106,8 +153,10 @@ int main(int argc, char **argv)
        rounding noise that is left of it - is zeroed so that both sides go on with the same basis */
     if (lindep || norm == 0.0 || j == 6) CHK(ks_bv_scalecolumn(c.bv, j, 0.0));
     else CHK(ks_bv_scalecolumn(c.bv, j, 1.0 / norm));
+    c.state++;                                                 /* BVScaleColumn: PetscObjectStateIncrease (bvops.c:356) */
     printf("column %d passes %d lindep %d norm %.17g\n", j, c.passes - before, lindep, norm);
   }
+  { long long chained = 0, fresh = 0; CHK(ks_bv_gs_chain_stats(c.bv, &chained, &fresh)); printf("chainstats chained %lld fresh %lld\n", chained, fresh); }
   CHK(ks_bv_get_buffer_host(c.bv, H));
   for (j = 0; j < M; j++) {
     printf("H[:,%d]", j);
@@ -164,6 +213,7 @@ int main(int argc, char **argv)
     printf("constraints onrm %.17g nrm %.17g h %.17g %.17g %.17g residual_dots %.3e %.3e %.3e\n", onrm, nrm, hc0[0], hc0[1], hc0[2], dots[0], dots[1], dots[2]);
     CHK(ks_bv_destroy(W));
   }
+  if (!mgs && refine == 0) { for (i = 0; i < 3; i++) if (chain_case(c.ctx, i, col)) return 1; }
   free(col); free(x0); free(x1); free(x2);
   CHK(ks_bv_destroy(c.bv)); CHK(ks_bv_destroy(bufbv)); CHK(ks_ctx_destroy(c.ctx));
   return 0;

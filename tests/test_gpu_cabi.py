@@ -110,3 +110,28 @@ def test_gramschmidt_slot_replayed_from_c_matches_the_oracle(tmp_path, refine, m
     assert np.allclose([float(con[6]), float(con[7]), float(con[8])], h, rtol=0, atol=1e-11)
     assert abs(float(con[4]) - np.linalg.norm(w6 - h[0] * c0 - h[1] * c1 - h[2] * q0)) < 1e-9
     assert max(abs(float(con[10])), abs(float(con[11])), abs(float(con[12]))) < 1e-12
+    # pass chaining (ks_bv_set_state): the caller announced its object state at every call, as the adapter's HipksSync does
+    stats = [ln.split() for ln in out.splitlines() if ln.startswith("chainstats")][0]
+    chained, fresh = int(stats[2]), int(stats[4])
+    if mgs:
+        assert chained == 0 and fresh == 0            # MGS goes through the primitive ops
+    elif refine == 1:
+        assert chained == 0                           # REFINE_NEVER: one pass per column, nothing to chain to
+    else:
+        assert chained >= 3, stats                    # every second pass of a column under an unchanged state
+        assert chained + fresh == sum(int(c[3]) for c in cols[1:])       # column 0 has nothing to orthogonalize against (k = 0: plain path)
+    if refine == 0 and not mgs:
+        ch = {int(t[2]): t for t in (ln.split() for ln in out.splitlines() if ln.startswith("chain mode") and " onrm1 " in ln)}
+        cn = {int(t[2]): float(t[4]) for t in (ln.split() for ln in out.splitlines() if ln.startswith("chain mode") and " column_norm " in ln)}
+        f = lambda t, i: float(t[i])                  # noqa: E731
+        a, b, c2 = ch[0], ch[1], ch[2]
+        assert (int(a[12]), int(a[14])) == (1, 1)     # announced, unchanged state: second pass chained to the first one's dots
+        assert (int(b[12]), int(b[14])) == (0, 2)     # no state announced: both passes take their own dots
+        assert (int(c2[12]), int(c2[14])) == (0, 2)   # column rewritten + state bumped between the passes: own dots of the new content
+        assert f(a, 4) == f(b, 4) and f(a, 6) == f(b, 6)                   # first passes are the same launches
+        assert f(a, 6) < 0.7071 * f(a, 4)                                  # the case does need its second pass
+        for i in (8, 10):
+            assert abs(f(a, i) - f(b, i)) <= 1e-12 * abs(f(b, i)), (i, a, b)
+        assert np.allclose([f(a, 18), f(a, 19), f(a, 20)], [f(b, 18), f(b, 19), f(b, 20)], rtol=1e-14, atol=1e-15)
+        assert abs(cn[0] - cn[1]) <= 1e-13 * cn[1]
+        assert abs(f(c2, 8) - f(c2, 16)) <= 1e-13 * f(c2, 16), c2           # onrm of the second pass = norm of what the column NOW holds
