@@ -182,6 +182,17 @@ int ks_mat_get_layout(ks_mat A, int *layout);
    Multi-rank: performs the halo exchange of x (PETSc VecScatter inside MatMult_MPIAIJ).        */
 int ks_mat_mult(ks_mat A, const double *x_dev, double *y_dev);
 int ks_mat_mult_host(ks_mat A, const double *x_host, double *y_host);  /* convenience for tests (single rank) */
+/* How MatMult moves the boundary entries of x between ranks. KS_HALO_PROVIDER: packed into a send buffer and handed to the
+ * communicator's exchange (grouped ncclSend / ncclRecv with the RCCL provider; PETSc's VecScatter is the reference's). KS_HALO_PEER: the pack
+ * kernel stores every boundary entry straight into the ghost mailbox of the rank that needs it (device memory of that rank mapped here:
+ * hipIpc between processes, xGMI between GPUs), stamped and acknowledged per product, and the receiver copies its mailbox into its ghost
+ * array - no library call per product. Collective; *active returns what was installed: the peer path only if every rank could map all
+ * its neighbours' mailboxes (at most 16 neighbours per rank). A rank that waits longer than KSGPU_ONESHOT_TIMEOUT_MS (default 2000) for a
+ * neighbour fills its ghosts with NaN and the next host wait fails with KS_ERR_LIB - never a hang. */
+#define KS_HALO_PROVIDER 0
+#define KS_HALO_PEER 1
+int ks_mat_set_halo(ks_mat A, int kind, int *active);
+int ks_mat_get_halo(ks_mat A, int *active);
 
 /* ---- BV: the _BVOps slots ------------------------------------------------------------------- */
 int ks_bv_create(ks_ctx ctx, int n_local, int n_global, int m, int ld /*0: default*/, ks_bv *bv); /* ops->create, BV_SetDefaultLD bvimpl.h:471 */
@@ -307,7 +318,9 @@ int ks_eps_set_deflation_space(ks_eps eps, int n, const double *const *v_dev); /
 /* DSSetParallel on the solver's DS (dsbasic.c; krylovschur.c:281 DSSynchronize): with KS_DS_PARALLEL_SYNCHRONIZED, after every projected
    solve rank 0's projected matrix, vectors, eigenvalues and the outcome of the expansion (beta, length, breakdown) are broadcast, so the
    replicated control flow cannot diverge when a caller-supplied allreduce does not return identical bits on every rank. Default:
-   synchronized (the reference's default is redundant; the broadcast is a few KB per restart). */
+   synchronized (the reference's default is redundant). Cost per restart: 2 ld^2 + 2 ncv + 3 doubles from rank 0 - 16 KB at ncv = 30,
+   66 KB at ncv = 64 - as one ncclBroadcast and one host wait with the RCCL provider; a caller-supplied provider has no broadcast
+   slot and pays an allgather of that many bytes per rank. */
 enum { KS_DS_PARALLEL_REDUNDANT = 0, KS_DS_PARALLEL_SYNCHRONIZED = 1 };
 int ks_eps_set_ds_parallel(ks_eps eps, int pmode);
 int ks_eps_get_ds_parallel(ks_eps eps, int *pmode);

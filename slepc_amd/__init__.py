@@ -255,6 +255,13 @@ class Mat:
     def set_enqueue_only(self, flag=True):
         _lib.check(self.ctx.L.ks_mat_shell_set_enqueue_only(self.h, int(bool(flag))))
 
+    def set_halo(self, kind):
+        """kind: "peer" (boundary entries stored straight into the neighbours' ghost mailboxes) or "provider" (the communicator's
+        exchange). Collective; returns what is active afterwards - "provider" if any rank could not map its neighbours."""
+        act = C.c_int()
+        _lib.check(self.ctx.L.ks_mat_set_halo(self.h, {"provider": 0, "peer": 1}[kind], C.byref(act)))
+        return "peer" if act.value == 1 else "provider"
+
     def layout(self):
         v = C.c_int(); _lib.check(self.ctx.L.ks_mat_get_layout(self.h, C.byref(v)))
         return ["csr", "sell", "sliced", "shell", "dict", "odict", "binned"][v.value]

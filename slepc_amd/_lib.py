@@ -48,6 +48,8 @@ _SIG = {
     "ks_comm_allreduce_sum": [vp, vp, C.c_int],
     # mat
     "ks_mat_create_csr": [vp, C.c_int, C.c_int, C.c_int, ip, ip, dp, C.POINTER(vp)],
+    "ks_mat_set_halo": [vp, C.c_int, ip],
+    "ks_mat_get_halo": [vp, ip],
     "ks_mat_create_laplacian3d": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
     "ks_mat_create_laplacian2d": [vp, C.c_int, C.c_int, C.POINTER(vp)],
     "ks_mat_destroy": [vp],

@@ -86,6 +86,8 @@ extern "C" int ks_ctx_destroy(ks_ctx ctx)
   for (auto &p : ctx->pending) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
   for (auto &e : ctx->event_pool) hipEventDestroy(e);
   ks_oneshot_release(ctx);
+  if (ctx->comm.halo_err_host) hipHostFree(ctx->comm.halo_err_host);
+  if (ctx->comm.halo_err_local) hipFree(ctx->comm.halo_err_local);
   if (ctx->comm.nccl_comm && ctx->comm.rccl_lib) {
     typedef int (*destroy_t)(void *);
     destroy_t f = (destroy_t)dlsym(ctx->comm.rccl_lib, "ncclCommDestroy");
@@ -118,7 +120,9 @@ int ks_ctx_halo_stream(ks_ctx ctx)
 extern "C" int ks_ctx_synchronize(ks_ctx ctx)
 {
   KS_CHECK(ctx, KS_ERR_ARG_NULL, "ctx is NULL");
-  KS_HIP(ks_sync(ctx));
+  const hipError_t e = ks_sync(ctx);
+  if (e != hipSuccess) KS_CALL(ks_oneshot_error(ctx));        // a one-shot allreduce or a peer-mapped halo exchange that gave up: say which
+  KS_HIP(e);
   return KS_SUCCESS;
 }
 
@@ -262,9 +266,10 @@ typedef int (*nccl_allgather_t)(const void *, void *, size_t, int, void *, hipSt
 typedef int (*nccl_send_t)(const void *, size_t, int, int, void *, hipStream_t);
 typedef int (*nccl_recv_t)(void *, size_t, int, int, void *, hipStream_t);
 typedef int (*nccl_group_t)();
+typedef int (*nccl_bcast_t)(const void *, void *, size_t, int, int, void *, hipStream_t);
 enum { NCCL_INT8 = 0, NCCL_INT32 = 2, NCCL_FLOAT64 = 8, NCCL_SUM = 0 };
 
-struct RcclFns { nccl_allreduce_t allreduce; nccl_allgather_t allgather; nccl_send_t send; nccl_recv_t recv; nccl_group_t gstart, gend; };
+struct RcclFns { nccl_allreduce_t allreduce; nccl_allgather_t allgather; nccl_send_t send; nccl_recv_t recv; nccl_group_t gstart, gend; nccl_bcast_t bcast; };
 static RcclFns g_rccl;
 
 static void *open_rccl()
@@ -343,6 +348,7 @@ extern "C" int ks_comm_init_rccl(ks_ctx ctx, int rank, int size, const unsigned 
   g_rccl.recv = (nccl_recv_t)dlsym(h, "ncclRecv");
   g_rccl.gstart = (nccl_group_t)dlsym(h, "ncclGroupStart");
   g_rccl.gend = (nccl_group_t)dlsym(h, "ncclGroupEnd");
+  g_rccl.bcast = (nccl_bcast_t)dlsym(h, "ncclBroadcast");        // optional: without it the broadcast of the projected problem goes through the allgather
   KS_CHECK(f && g_rccl.allreduce && g_rccl.allgather && g_rccl.send && g_rccl.recv && g_rccl.gstart && g_rccl.gend, KS_ERR_LIB, "RCCL symbols not found");
   NcclUniqueIdRaw raw; memcpy(raw.internal, id, KS_UNIQUE_ID_BYTES);
   void *comm = nullptr;
@@ -435,9 +441,10 @@ bool ks_oneshot_next(ks_ctx ctx, int count, KsOneShotArgs *o)
 {
   auto &os = ctx->comm.oneshot;
   if (!os.enabled || count > KS_ONESHOT_MAX_COUNT || count <= 0) return false;
+  os.par ^= 1u;                                      // the two-parity argument above needs a flip on every call, also across the stamp's wrap
   if (++os.seq == 0) ++os.seq;                       // 0 is what an untouched mailbox holds
   for (int r = 0; r < KS_ONESHOT_MAX_RANKS; r++) o->peer[r] = os.peer[r];
-  o->mine = os.mine; o->err = os.err_dev; o->err_local = os.err_local; o->timeout_ticks = os.timeout_ticks; o->seq = os.seq; o->me = ctx->comm.rank; o->size = ctx->comm.size;
+  o->mine = os.mine; o->err = os.err_dev; o->err_local = os.err_local; o->timeout_ticks = os.timeout_ticks; o->seq = os.seq; o->par = os.par; o->me = ctx->comm.rank; o->size = ctx->comm.size;
   return true;
 }
 
@@ -445,6 +452,8 @@ int ks_oneshot_error(ks_ctx ctx)
 {
   const volatile int *e = ctx->comm.oneshot.err_host;
   if (e && *e) KS_FAIL(KS_ERR_LIB, "one-shot allreduce number %d saw no packet from some rank within its time limit (results since then are NaN)", *e);
+  const volatile int *hh = ctx->comm.halo_err_host;
+  if (hh && *hh) KS_FAIL(KS_ERR_LIB, "a peer-mapped halo exchange gave up waiting for a neighbour (ghost values since then are NaN)");
   return KS_SUCCESS;
 }
 
@@ -528,7 +537,8 @@ extern "C" int ks_comm_set_allreduce(ks_ctx ctx, int kind, int *active)
   const char *tm = getenv("KSGPU_ONESHOT_TIMEOUT_MS");
   const long long ms = tm && atoll(tm) > 0 ? atoll(tm) : 2000;
   os.timeout_ticks = ms * khz;
-  os.seq = 0;
+  { const char *s0 = getenv("KSGPU_ONESHOT_SEQ0"); os.seq = s0 ? (unsigned)strtoul(s0, nullptr, 0) : 0u; }     // test hook: start the stamps near their 32-bit wrap
+  os.par = 0;
   os.enabled = true;
   if (active) *active = KS_ALLREDUCE_ONESHOT;
   return KS_SUCCESS;
@@ -573,6 +583,22 @@ int ks_comm_allgather_host(ks_ctx ctx, const void *send, int bytes, void *recv)
 int ks_comm_bcast0_host(ks_ctx ctx, void *buf, int bytes)
 {
   if ((ctx->comm.size == 1 && !ctx->comm.force_collectives) || bytes <= 0) return KS_SUCCESS;
+  if (ctx->comm.nccl_comm && g_rccl.bcast && ctx->comm.ops.allgather_host == rccl_allgather_host) {
+    // native provider: ONE ncclBroadcast of rank 0's bytes through the device staging area and one host wait (the allgather form below
+    // ships size x bytes and is what a caller-supplied provider, which has no broadcast slot, is left with)
+    if (ctx->comm.ag_len < (size_t)bytes) {
+      if (ctx->comm.ag_dev) hipFree(ctx->comm.ag_dev);
+      ctx->comm.ag_dev = nullptr; ctx->comm.ag_len = 0;
+      KS_HIP(hipMalloc(&ctx->comm.ag_dev, (size_t)bytes));
+      ctx->comm.ag_len = (size_t)bytes;
+    }
+    if (ctx->comm.rank == 0) KS_HIP(hipMemcpyAsync(ctx->comm.ag_dev, buf, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    const int rc = g_rccl.bcast(ctx->comm.ag_dev, ctx->comm.ag_dev, (size_t)bytes, NCCL_INT8, 0, ctx->comm.nccl_comm, ctx->stream);
+    KS_CHECK(rc == 0, KS_ERR_LIB, "ncclBroadcast failed (%d)", rc);
+    if (ctx->comm.rank != 0) KS_HIP(hipMemcpyAsync(buf, ctx->comm.ag_dev, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    KS_HIP(ks_sync(ctx));
+    return KS_SUCCESS;
+  }
   std::vector<char> all((size_t)bytes * ctx->comm.size);
   KS_CALL(ks_comm_allgather_host(ctx, buf, bytes, all.data()));
   if (ctx->comm.rank) memcpy(buf, all.data(), (size_t)bytes);
@@ -604,7 +630,6 @@ extern "C" int ks_comm_check(ks_ctx ctx)
   KS_CHECK(ctx->comm.ops.allreduce_sum && ctx->comm.ops.allgather_host && ctx->comm.ops.exchange, KS_ERR_ORDER, "no communicator installed");
   constexpr int NCALL = 64, LEN = 8;
   double *d = nullptr;
-  KS_HIP(hipMalloc(&d, (NCALL * LEN + 16) * sizeof(double)));
   std::vector<double> h(NCALL * LEN + 16);
   bool bad = false;
   char msg[400] = "";
@@ -612,6 +637,14 @@ extern "C" int ks_comm_check(ks_ctx ctx)
     if (!bad) { if constexpr (sizeof...(a) == 0) snprintf(msg, sizeof(msg), "%s", fmt); else snprintf(msg, sizeof(msg), fmt, a...); }
     bad = true;
   };
+  // (0) a rank whose own set-up fails must not leave the others waiting in the stages below: agree on the set-up first
+  {
+    if (hipMalloc(&d, (NCALL * LEN + 16) * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); d = nullptr; }
+    std::vector<int> oks(size, 0);
+    const int mine_ok = d ? 1 : 0;
+    if (ctx->comm.ops.allgather_host(ctx->comm.user, &mine_ok, (int)sizeof(int), oks.data()) != 0) { if (d) hipFree(d); KS_FAIL(KS_ERR_LIB, "communicator check: allgather failed"); }
+    for (int r = 0; r < size; r++) if (!oks[r]) { if (d) hipFree(d); KS_FAIL(KS_ERR_MEM, "communicator check: rank %d could not allocate its test buffer", r); }
+  }
   // (1) allreduce
   for (int i = 0; i < NCALL; i++) for (int j = 0; j < LEN; j++) h[i * LEN + j] = (rank + 1) * (i + 1) * (j + 1) / 16.0;
   if (hipMemcpyAsync(d, h.data(), NCALL * LEN * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) fail("communicator check: upload failed");
@@ -629,7 +662,7 @@ extern "C" int ks_comm_check(ks_ctx ctx)
   for (int rep = 0; rep < 2; rep++) {
     std::vector<int> all(size, -1);
     const int mine = 7 * rank + 1 + rep;
-    if (ctx->comm.ops.allgather_host(ctx->comm.user, &mine, (int)sizeof(int), all.data()) != 0 && !ctx->comm.oneshot.err_host) fail("communicator check: allgather failed");
+    if (ctx->comm.ops.allgather_host(ctx->comm.user, &mine, (int)sizeof(int), all.data()) != 0) fail("communicator check: allgather failed");
     for (int r = 0; r < size; r++) if (all[r] != 7 * r + 1 + rep) fail("communicator check: allgather slot %d holds %d, expected %d", r, all[r], 7 * r + 1 + rep);
   }
   // (3) ring exchange

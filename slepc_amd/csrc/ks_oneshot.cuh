@@ -8,7 +8,7 @@ __device__ __forceinline__ void ks_oneshot_sum(const double *in, double *out, in
                                                unsigned (*sh)[2 * KS_ONESHOT_MAX_COUNT], int *failed)
 {
   const int tid = threadIdx.x, nw = 2 * count, total = o.size * nw;
-  const size_t par = (size_t)(o.seq & 1u) * KS_ONESHOT_MAX_RANKS;
+  const size_t par = (size_t)(o.par & 1u) * KS_ONESHOT_MAX_RANKS;
   const unsigned seq = o.seq;
   if (tid == 0) *failed = *(volatile int *)o.err_local;      // an earlier call of this rank gave up: send (the peers may still be fine), do not wait again
   for (int idx = tid; idx < total; idx += blockDim.x) {

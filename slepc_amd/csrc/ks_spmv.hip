@@ -21,6 +21,8 @@
 #include <algorithm>
 #include <numeric>
 #include <thread>
+#include <system_error>
+#include <sched.h>
 #include <new>
 #include <type_traits>
 
@@ -115,6 +117,124 @@ __global__ __launch_bounds__(256) void k_spmv_csr_stream(int n, const int *__res
     }
     if (has) __builtin_nontemporal_store(acc, y + r);
     __syncthreads();                       // erange is rewritten by the next row block
+  }
+}
+
+// ---- CSR, row blocks streamed through LDS, one wave per 64 rows (no workgroup barrier) -------------------------------------------
+// The same idea with the wave as the unit. A wave takes 64 consecutive rows; their entries are ONE contiguous run of col / val, which it
+// streams in chunks of 512 with fully coalesced nontemporal loads (lane l of step u loads entry 64 u + l) and parks in a wave-private piece
+// of LDS; then lane = row: every lane runs the reference's loop over its own row's segment, acc = fma(val, x, acc) in entry order - the
+// bits of the SELL / dictionary kernels. Nothing waits for another wave: LDS operations of one wave execute in order, so the hand-over
+// from the loading lanes to the row lanes needs no barrier (the workgroup form above spends four fifths of its wave cycles parked at
+// barriers and s_waitcnt, profiles/r03_pmc_csr_kernels.txt), and the col / val loads of the next chunk - of the same rows or of the
+// wave's next 64, whose row pointers were loaded one group ahead - are issued before the row sums of this one. Workgroups on one XCD
+// (blockIdx % 8) take one contiguous eighth of the rows, so an XCD's L2 holds the part of x its rows gather from.
+// ROWSIDE: where x is gathered. false: by the loading lanes (lane = entry), (value, x) pairs go through LDS - every lane has work whatever
+// the row lengths. true: by the row lanes (lane = row) - (value, column) go through LDS and the 64 lanes of a gather instruction ask for the
+// same entry position of 64 consecutive rows, which for a banded or stencil-like matrix is a few cache lines where the entry-side gather
+// touches two to three times as many (216^3 Laplacian: the entry-side gathers cost 35 of 211 us, profiles/r03_csr_wave_variants.txt);
+// pays only while a chunk spans most of the wave's rows, i.e. for short rows: chosen at assembly from the mean row length.
+// (16-byte loads of four consecutive entries per lane were tried for the streams: fewer instructions, no faster, and the gathers of such a
+// lane assignment touch still more lines.)
+constexpr int CW_PAD = 8;                                  // col / val allocations are this much longer than nnz
+constexpr int CW_STEPS = 8, CW_CHUNK = 64 * CW_STEPS;      // entries per wave and chunk
+constexpr int CW_U = 8;                                    // row side: gathers in flight per lane
+__device__ __forceinline__ int cw_slot(int e) { return e + (e >> 5); }     // one slot of skew per 32 entries (rows whose length is a multiple of 32)
+struct CwRegs { int c[CW_STEPS]; double a[CW_STEPS]; };
+__device__ __forceinline__ void cw_load(CwRegs &r, const int *__restrict__ col, const double *__restrict__ val, int e0, int E1, int lane)
+{
+#pragma unroll
+  for (int u = 0; u < CW_STEPS; u++) {
+    const int e = e0 + u * 64 + lane;
+    const bool ok = e < E1;
+    r.c[u] = ok ? ksk::ldstream(col + e) : -1;
+    r.a[u] = ok ? ksk::ldstream(val + e) : 0.0;
+  }
+}
+struct CwRows { int p0, p1, E0, E1; long long r; bool has; };
+__device__ __forceinline__ CwRows cw_rows(int n, const int *__restrict__ rp, int g, int w, int lane)
+{
+  CwRows q; q.p0 = q.p1 = q.E0 = q.E1 = 0; q.has = false;
+  const long long r0 = (long long)g * 256 + (long long)w * 64;
+  q.r = r0 + lane;
+  if (r0 >= n) return q;
+  q.has = q.r < n;
+  if (q.has) { q.p0 = ksk::ldstream(rp + q.r); q.p1 = ksk::ldstream(rp + q.r + 1); }
+  q.E0 = rp[r0]; q.E1 = rp[r0 + 64 < n ? r0 + 64 : n];                 // the wave's run of entries (uniform: scalar loads)
+  return q;
+}
+template <bool ROWSIDE>
+__global__ __launch_bounds__(256) void k_spmv_csr_wave(int n, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
+                                                       const double *__restrict__ x, double *__restrict__ y, int xcd_remap)
+{
+  __shared__ double sa_all[4][CW_CHUNK + CW_CHUNK / 32];
+  __shared__ double sb_all[4][ROWSIDE ? (CW_CHUNK + CW_CHUNK / 32) / 2 : CW_CHUNK + CW_CHUNK / 32];       // x values, or the columns (4 bytes each)
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double *sa = sa_all[w], *sx = sb_all[w];
+  int *sc = reinterpret_cast<int *>(sb_all[w]);
+  const int NG = (n + 255) / 256;                          // groups of 256 rows: one per workgroup and iteration, 64 rows per wave
+  int g, gend, gstep;
+  if (xcd_remap) {
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3, lc = gridDim.x >> 3;
+    g = (int)((long long)NG * xcd / 8) + li; gend = (int)((long long)NG * (xcd + 1) / 8); gstep = lc;
+  } else { g = blockIdx.x; gend = NG; gstep = gridDim.x; }
+  if (g >= gend) return;
+  // Software pipeline over (row group, chunk): while the rows of one chunk are summed, the col / val loads of the NEXT chunk are in
+  // flight - the next chunk of the same rows, or the first chunk of the wave's next 64 rows.
+  CwRows cu = cw_rows(n, rp, g, w, lane);
+  CwRows nx = g + gstep < gend ? cw_rows(n, rp, g + gstep, w, lane) : CwRows{0, 0, 0, 0, 0, false};
+  CwRegs cur, nxt;
+  int e0 = cu.E0;
+  if (e0 < cu.E1) cw_load(cur, col, val, e0, cu.E1, lane);
+  bool nxt_loaded = false;                                 // the first chunk of group nx is already in `nxt`
+  double acc = 0.0;
+  for (;;) {
+    if (e0 < cu.E1) {
+      if (ROWSIDE) {
+#pragma unroll
+        for (int u = 0; u < CW_STEPS; u++) { const int sl = cw_slot(u * 64 + lane); sa[sl] = cur.a[u]; sc[sl] = cur.c[u]; }
+      } else {
+        double xg[CW_STEPS];
+#pragma unroll
+        for (int u = 0; u < CW_STEPS; u++) xg[u] = cur.c[u] >= 0 ? x[cur.c[u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < CW_STEPS; u++) { const int sl = cw_slot(u * 64 + lane); sa[sl] = cur.a[u]; sx[sl] = xg[u]; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int en = e0 + CW_CHUNK;
+      if (en < cu.E1) cw_load(nxt, col, val, en, cu.E1, lane);
+      else if (nx.E0 < nx.E1) { cw_load(nxt, col, val, nx.E0, nx.E1, lane); nxt_loaded = true; }
+      const int lo = max(cu.p0, e0), hi = min(cu.p1, en);
+      if (ROWSIDE) {
+        for (int p = lo; __builtin_amdgcn_ballot_w64(p < hi) != 0; p += CW_U) {
+          double av[CW_U], xv[CW_U];
+#pragma unroll
+          for (int j = 0; j < CW_U; j++) {
+            const bool ok = p + j < hi;
+            const int sl = cw_slot(ok ? p + j - e0 : 0);
+            av[j] = sa[sl];
+            xv[j] = ok ? x[sc[sl]] : 0.0;
+          }
+#pragma unroll
+          for (int j = 0; j < CW_U; j++) if (p + j < hi) acc = fma(av[j], xv[j], acc);
+        }
+      } else {
+        for (int p = lo; p < hi; p++) { const int sl = cw_slot(p - e0); acc = fma(sa[sl], sx[sl], acc); }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (en < cu.E1) { cur = nxt; e0 = en; continue; }
+    }
+    // this wave's 64 rows are complete
+    if (cu.has) __builtin_nontemporal_store(acc, y + cu.r);
+    acc = 0.0;
+    g += gstep;
+    if (g >= gend) break;
+    cu = nx;
+    nx = g + gstep < gend ? cw_rows(n, rp, g + gstep, w, lane) : CwRows{0, 0, 0, 0, 0, false};
+    e0 = cu.E0;
+    if (nxt_loaded) cur = nxt;
+    else if (e0 < cu.E1) cw_load(cur, col, val, e0, cu.E1, lane);
+    nxt_loaded = false;
   }
 }
 
@@ -718,10 +838,20 @@ static int build_binned(ks_mat A)
   KS_HIP(hipMemcpyAsync(col.data(), A->d_col, sizeof(int) * nnz, hipMemcpyDeviceToHost, ctx->stream));
   KS_HIP(hipMemcpyAsync(val.data(), A->d_val, sizeof(double) * nnz, hipMemcpyDeviceToHost, ctx->stream));
   KS_HIP(ks_sync(ctx));
-  const unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  // helper threads: the CPUs this process may run on (affinity mask: what a cgroup / taskset leaves), at most 16; a thread that cannot
+  // be started (pids limit) is simply not used - the calling thread takes every stride that has no thread of its own
+  unsigned ncpu = std::thread::hardware_concurrency();
+  { cpu_set_t cs_; CPU_ZERO(&cs_); if (sched_getaffinity(0, sizeof(cs_), &cs_) == 0 && CPU_COUNT(&cs_) > 0) ncpu = (unsigned)CPU_COUNT(&cs_); }
+  const unsigned nthr = std::max(1u, std::min(16u, ncpu));
   auto parallel_bins = [&](auto fn) {
     std::vector<std::thread> th;
-    for (unsigned t = 0; t < nthr; t++) th.emplace_back([&, t] { for (int b = (int)t; b < wb; b += (int)nthr) fn(b); });
+    unsigned started = 1;                                   // stride 0 belongs to the calling thread
+    for (unsigned t = 1; t < nthr; t++) {
+      try { th.emplace_back([&, t] { for (int b = (int)t; b < wb; b += (int)nthr) fn(b); }); started = t + 1; }
+      catch (const std::system_error &) { break; }
+    }
+    for (int b = 0; b < wb; b += (int)nthr) fn(b);
+    for (unsigned t = started; t < nthr; t++) for (int b = (int)t; b < wb; b += (int)nthr) fn(b);      // strides whose thread did not start
     for (auto &x : th) x.join();
   };
   // segment lengths (padded to even), bin-major [wb][ns]
@@ -798,7 +928,7 @@ static int build_binned(ks_mat A)
   A->norm_inf_cache = nrm;
   A->use_binned = true; A->bn_ns = ns; A->bn_cs = cs; A->bn_wb = wb; A->bn_wr = wr; A->bn_nwin = nwin; A->bn_entries = entries;
   hipFree(A->d_col); hipFree(A->d_val); A->d_col = nullptr; A->d_val = nullptr;
-  } catch (const std::bad_alloc &) {
+  } catch (const std::exception &) {                    // out of host memory (or anything else the build throws): the other layouts take the matrix
     hipFree(A->bn_col16); hipFree(A->bn_row16); hipFree(A->bn_val); hipFree(A->bn_g); hipFree(A->bn_off1); hipFree(A->bn_off2t); hipFree(A->bn_wseg); hipFree(A->bn_sbase); hipFree(A->bn_bstart);
     A->bn_col16 = A->bn_row16 = nullptr; A->bn_val = A->bn_g = nullptr; A->bn_off1 = A->bn_off2t = A->bn_wseg = nullptr; A->bn_sbase = A->bn_bstart = nullptr;
     hipFree(A->diag_cache); A->diag_cache = nullptr;
@@ -943,6 +1073,7 @@ int build_sell(ks_mat A)
   ks_ctx ctx = A->ctx;
   const char *force = getenv("KSGPU_SPMV");
   if (force && !strcmp(force, "csrvec")) { A->force_csr_vector = true; return KS_SUCCESS; }     // the CSR-vector kernel at any size (A/B against the row-block kernel)
+  if (force && !strcmp(force, "csrblock")) { A->force_csr_block = true; return KS_SUCCESS; }    // the workgroup-per-256-rows form of the row-block kernel (A/B against the wave form)
   if (force && !strcmp(force, "csr")) return KS_SUCCESS;
   if (A->n == 0 || A->nnz_d == 0) return KS_SUCCESS;
   KS_CALL(build_dict(A));                                   // independent of the SELL decision below; needs the CSR arrays
@@ -1011,8 +1142,8 @@ extern "C" int ks_mat_create_csr(ks_ctx ctx, int n_local, int row_start, int n_g
   for (auto &c : co) c = (int)(std::lower_bound(garray.begin(), garray.end(), c) - garray.begin());
   A->nnz_d = (long long)cd.size(); A->nnz_o = (long long)co.size();
   KS_HIP(hipMalloc(&A->d_rowptr, sizeof(int) * (n_local + 1)));
-  KS_HIP(hipMalloc(&A->d_col, sizeof(int) * std::max<size_t>(cd.size(), 1)));
-  KS_HIP(hipMalloc(&A->d_val, sizeof(double) * std::max<size_t>(vd.size(), 1)));
+  KS_HIP(hipMalloc(&A->d_col, sizeof(int) * (cd.size() + CW_PAD)));
+  KS_HIP(hipMalloc(&A->d_val, sizeof(double) * (vd.size() + CW_PAD)));
   KS_HIP(hipMemcpy(A->d_rowptr, rp_d.data(), sizeof(int) * (n_local + 1), hipMemcpyHostToDevice));
   KS_HIP(hipMemcpy(A->d_col, cd.data(), sizeof(int) * cd.size(), hipMemcpyHostToDevice));
   KS_HIP(hipMemcpy(A->d_val, vd.data(), sizeof(double) * vd.size(), hipMemcpyHostToDevice));
@@ -1056,7 +1187,7 @@ extern "C" int ks_mat_create_laplacian3d(ks_ctx ctx, int nx, int ny, int nz, int
   KS_HIP(hipMemcpy(&nnzo, A->o_rowptr + n, sizeof(int), hipMemcpyDeviceToHost));
   hipFree(cnt_d); hipFree(cnt_o);
   A->nnz_d = nnzd; A->nnz_o = nnzo; A->nnz = (long long)nnzd + nnzo;
-  KS_HIP(hipMalloc(&A->d_col, sizeof(int) * std::max(nnzd, 1))); KS_HIP(hipMalloc(&A->d_val, sizeof(double) * std::max(nnzd, 1)));
+  KS_HIP(hipMalloc(&A->d_col, sizeof(int) * (nnzd + CW_PAD))); KS_HIP(hipMalloc(&A->d_val, sizeof(double) * (nnzd + CW_PAD)));
   KS_HIP(hipMalloc(&A->o_col, sizeof(int) * std::max(nnzo, 1))); KS_HIP(hipMalloc(&A->o_val, sizeof(double) * std::max(nnzo, 1)));
   hipLaunchKernelGGL(k_lap3d_fill, dim3(nb), dim3(256), 0, ctx->stream, nx, ny, nz, z0, nzl, A->d_rowptr, A->d_col, A->d_val, A->o_rowptr, A->o_col, A->o_val);
   KS_HIP(ks_sync(ctx));
@@ -1092,7 +1223,7 @@ extern "C" int ks_mat_create_laplacian2d(ks_ctx ctx, int n, int m, ks_mat *out)
   int nnz = 0; KS_HIP(hipMemcpy(&nnz, A->d_rowptr + N, sizeof(int), hipMemcpyDeviceToHost));
   hipFree(cnt);
   A->nnz = A->nnz_d = nnz;
-  KS_HIP(hipMalloc(&A->d_col, sizeof(int) * nnz)); KS_HIP(hipMalloc(&A->d_val, sizeof(double) * nnz));
+  KS_HIP(hipMalloc(&A->d_col, sizeof(int) * (nnz + CW_PAD))); KS_HIP(hipMalloc(&A->d_val, sizeof(double) * (nnz + CW_PAD)));
   hipLaunchKernelGGL(k_lap2d_fill, dim3(nb), dim3(256), 0, ctx->stream, n, m, A->d_rowptr, A->d_col, A->d_val);
   KS_HIP(ks_sync(ctx));
   A->lanes_per_row = pick_lanes(A->nnz_d, A->n);
@@ -1108,6 +1239,7 @@ extern "C" int ks_mat_destroy(ks_mat A)
   ks_sync(A->ctx);
   hipFree(A->d_rowptr); hipFree(A->d_col); hipFree(A->d_val);
   hipFree(A->o_rowptr); hipFree(A->o_col); hipFree(A->o_val); hipFree(A->o_rows);
+  ks_halo_release(A);
   hipFree(A->ghost); hipFree(A->send_idx); hipFree(A->send_buf);
   hipFree(A->s_ptr); hipFree(A->s_len); hipFree(A->s_col); hipFree(A->s_val);
   hipFree(A->dc_codes); hipFree(A->dc_val); hipFree(A->dc_off); hipFree(A->dc_codes8); hipFree(A->dc_vals);
@@ -1166,9 +1298,12 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y, const double *row
       KS_HIP(hipStreamWaitEvent(hs, ctx->ev_x, 0));
     }
     KsProfScope ps(ctx, KS_K_HALO, 8.0 * (A->nsend + A->nghost));      // (events on the main stream: with the overlap this times the enqueue only)
-    if (A->nsend) hipLaunchKernelGGL(k_pack, dim3((A->nsend + 255) / 256), dim3(256), 0, hs, A->nsend, A->send_idx, x, A->send_buf);
-    KS_CALL(ks_comm_exchange(ctx, (int)A->peers.size(), A->peers.data(), A->send_buf, A->send_off.data(), A->send_cnt.data(),
-                             A->ghost, A->recv_off.data(), A->recv_cnt.data(), (int)sizeof(double), hs));
+    if (A->hp.enabled) KS_CALL(ks_halo_peer_exchange(A, x, hs));      // straight into the neighbours' ghost mailboxes: no library call
+    else {
+      if (A->nsend) hipLaunchKernelGGL(k_pack, dim3((A->nsend + 255) / 256), dim3(256), 0, hs, A->nsend, A->send_idx, x, A->send_buf);
+      KS_CALL(ks_comm_exchange(ctx, (int)A->peers.size(), A->peers.data(), A->send_buf, A->send_off.data(), A->send_cnt.data(),
+                               A->ghost, A->recv_off.data(), A->recv_cnt.data(), (int)sizeof(double), hs));
+    }
     if (overlap) KS_HIP(hipEventRecord(ctx->ev_halo, hs));
   }
   {
@@ -1213,6 +1348,15 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y, const double *row
       const dim3 gr((unsigned)std::max<long long>(blocks, 1));
       const int remap = (remap_env && blocks == groups && blocks >= 64) ? 1 : 0;     // only with one slice group per workgroup (a strided loop would interleave the ranges again)
       hipLaunchKernelGGL((k_spmv_sell<8>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->nslices, A->s_ptr, A->s_len, A->s_col, A->s_val, x, y, remap);
+    } else if (A->n >= 2048 && !A->force_csr_vector && !A->force_csr_block) {
+      // 4 workgroups of 4 waves per CU (registers); a multiple of 8 so that every XCD gets its eighth of the rows
+      const long long NG = ((long long)A->n + 255) / 256;
+      long long nb = std::min<long long>(NG, (long long)ctx->num_cu * 4);
+      const int remap = nb >= 64 ? 1 : 0;
+      if (remap) nb = (nb / 8) * 8;
+      const bool rowside = A->nnz_d <= 12LL * A->n;          // short rows: gather on the row side
+      if (rowside) hipLaunchKernelGGL(k_spmv_csr_wave<true>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, remap);
+      else hipLaunchKernelGGL(k_spmv_csr_wave<false>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, remap);
     } else if (A->n >= 2048 && !A->force_csr_vector) {
       const unsigned nb = (unsigned)std::min<long long>(((long long)A->n + 255) / 256, (long long)ctx->num_cu * 8);
       hipLaunchKernelGGL(k_spmv_csr_stream, dim3(nb), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, x, y);

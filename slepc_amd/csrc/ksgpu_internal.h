@@ -28,6 +28,7 @@ struct KsGsMail { double onrm, nrm; int fused, err; unsigned long long seq; };
 // ---- communicator -------------------------------------------------------------------------------
 #define KS_ONESHOT_MAX_RANKS 16
 #define KS_ONESHOT_MAX_COUNT 128
+#define KS_HALO_MAX_PEERS 16
 struct KsComm {
   int rank = 0, size = 1;
   bool force_collectives = false;   // KSGPU_FORCE_MULTI=1: take the multi-rank code path even with one rank (tests)
@@ -42,7 +43,8 @@ struct KsComm {
   // memory, mapped by all the others (hipIpc between processes, the plain pointer inside one process)
   struct {
     bool enabled = false;
-    unsigned seq = 0;                                    // call counter, the same on every rank; travels inside every packet
+    unsigned seq = 0;                                    // stamp of the call, the same on every rank; travels inside every packet (never 0: what an untouched mailbox holds)
+    unsigned par = 0;                                    // slot parity: flips on EVERY call (not derived from the stamp, which skips 0 when it wraps)
     unsigned long long *mine = nullptr;                  // [2 parities][KS_ONESHOT_MAX_RANKS][2 * KS_ONESHOT_MAX_COUNT] packets
     unsigned long long *peer[KS_ONESHOT_MAX_RANKS] = {}; // every rank's mailbox as mapped here (peer[rank] == mine)
     bool opened[KS_ONESHOT_MAX_RANKS] = {};              // mapped with hipIpcOpenMemHandle
@@ -50,6 +52,9 @@ struct KsComm {
     int *err_local = nullptr;                            // the same word in device memory (what later kernels of this rank look at)
     long long timeout_ticks = 0;                         // wall_clock64 ticks (100 MHz) a rank waits for a packet before it gives up
   } oneshot;
+  // peer-mapped halo exchange (ks_halo.hip): the error word a pack / unpack kernel raises when it gives up waiting (pinned, its device
+  // address, and the copy in device memory later kernels of this rank look at)
+  int *halo_err_host = nullptr, *halo_err_dev = nullptr, *halo_err_local = nullptr;
 };
 
 struct ks_ctx_s {
@@ -92,8 +97,8 @@ static inline hipError_t ks_sync(ks_ctx ctx)
 {
   ctx->nsync++;
   hipError_t e = hipStreamSynchronize(ctx->stream);
-  const volatile int *os = ctx->comm.oneshot.err_host;
-  return (e == hipSuccess && os && *os) ? hipErrorLaunchTimeOut : e;
+  const volatile int *os = ctx->comm.oneshot.err_host, *hh = ctx->comm.halo_err_host;
+  return (e == hipSuccess && ((os && *os) || (hh && *hh))) ? hipErrorLaunchTimeOut : e;
 }
 
 int ks_prof_begin(ks_ctx ctx, int kclass, int variant, double alg_bytes, double hbm_bytes);   // records start event when profiling
@@ -112,7 +117,7 @@ struct KsStepRec;
 void ks_prof_resolve_gs(ks_ctx ctx, const KsStepRec *recs, int col0, int col1);   // re-file tagged records of columns [col0,col1]
 
 int ks_allreduce_sum(ks_ctx ctx, double *dev_buf, int count);   // no-op when size==1
-struct KsOneShotArgs { unsigned long long *peer[KS_ONESHOT_MAX_RANKS]; const unsigned long long *mine; int *err; int *err_local; long long timeout_ticks; unsigned seq; int me, size; };
+struct KsOneShotArgs { unsigned long long *peer[KS_ONESHOT_MAX_RANKS]; const unsigned long long *mine; int *err; int *err_local; long long timeout_ticks; unsigned seq, par; int me, size; };
 bool ks_oneshot_next(ks_ctx ctx, int count, KsOneShotArgs *o);  // arguments of the next one-shot call, or false when the provider has to do it
 int ks_oneshot_error(ks_ctx ctx);                               // KS_ERR_LIB once a one-shot allreduce has timed out (checked wherever the host has just waited)
 void ks_oneshot_release(ks_ctx ctx);
@@ -134,6 +139,7 @@ struct ks_mat_s {
   int *d_rowptr = nullptr; int *d_col = nullptr; double *d_val = nullptr; long long nnz_d = 0;
   int lanes_per_row = 8;
   bool force_csr_vector = false;   // KSGPU_SPMV=csrvec
+  bool force_csr_block = false;    // KSGPU_SPMV=csrblock
   // sliced-ELL copy of the diagonal block (slice = 64 rows = one wavefront), chosen at assembly when the
   // padding it needs is small; val/col stored column-major inside a slice: entry j of row 64s+lane at (sp[s]+j)*64+lane
   bool use_sell = false;
@@ -178,12 +184,19 @@ struct ks_mat_s {
   std::vector<int> peers, send_cnt, recv_cnt, send_off, recv_off;
   int *send_idx = nullptr; int nsend = 0;     // local row indices to pack
   double *send_buf = nullptr;
+  // peer-mapped halo (ks_mat_set_halo, ks_halo.hip): this rank's mailbox - [2 parities][nghost] doubles | flag[2][KS_HALO_MAX_PEERS] | ack[KS_HALO_MAX_PEERS],
+  // uncached device memory - and the neighbours' mailboxes as mapped here; ridx[i] = this rank's index in peer i's own peer list
+  struct { bool enabled = false; unsigned long long seq = 0; char *mine = nullptr; size_t bytes = 0; char *peer_base[KS_HALO_MAX_PEERS] = {}; bool opened[KS_HALO_MAX_PEERS] = {};
+           int ridx[KS_HALO_MAX_PEERS] = {}, remote_off[KS_HALO_MAX_PEERS] = {}, remote_nghost[KS_HALO_MAX_PEERS] = {}; unsigned *tickets = nullptr; long long timeout_ticks = 0; } hp;
   // matrix-free operator (MATSHELL with MATOP_MULT): y = shell_mult(user, x); may synchronise the host
   int (*shell_mult)(void *user, const double *x_dev, double *y_dev) = nullptr;
   bool shell_nosync = false;                  // the callback only enqueues work on the context's stream: a Krylov run may be enqueued ahead through it
   void *shell_user = nullptr;
 };
 int ks_mat_get_diagonal_internal(ks_mat A, double *d_dev);
+void ks_halo_release(ks_mat A);
+int ks_halo_peer_exchange(ks_mat A, const double *x, hipStream_t hs);     // pack into the neighbours' mailboxes, unpack this rank's own (ks_halo.hip)
+
 int ks_mat_norm_inf_local(ks_mat A, double *val);           // max row sum of |a_ij| over this rank's rows
 
 // ---- ST: spectral transformation (ks_st.hip) ----------------------------------------------------

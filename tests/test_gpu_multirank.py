@@ -298,15 +298,23 @@ def _oneshot_worker(rank, world, port, q, absent_rank):
         res = {"active": ctx.set_allreduce("oneshot")}
         if absent_rank >= 0:
             import time
+            X = ks.BV(ctx, 64, 12, N=64 * world)
+            d = X.buffer_ptr()
+            ctx.memcpy_h2d(d, np.arange(1.0, 9.0) * (rank + 1))
+            dist.barrier()
             if rank == absent_rank:
                 time.sleep(1.5)
             t0 = time.perf_counter()
             try:
-                ctx.comm_check()
+                for _ in range(64):                   # 64 enqueued calls must not wait 64 times
+                    ctx.allreduce_sum_dev(d, 8)
+                ctx.synchronize()
                 res["raised"] = False
             except RuntimeError as e:
                 res["raised"] = str(e)
             res["seconds"] = time.perf_counter() - t0
+            out = np.empty(8); ctx.memcpy_d2h(out, d)
+            res["nan"] = bool(np.isnan(out).all())
             res["back"] = ctx.set_allreduce("provider")
             ctx.comm_check()                      # the provider is unharmed
             dist.barrier()
@@ -403,12 +411,187 @@ def test_oneshot_allreduce_between_processes_sharing_one_gpu(world):
 
 @pytest.mark.timeout(600)
 def test_oneshot_allreduce_gives_up_when_a_rank_never_arrives():
-    """Rank 1 arrives 1.5 s late, the time limit is 0.3 s: rank 0 gives up (its 64 enqueued calls do not wait 64 times), rank 1 then
-    finds rank 0's packets overwritten and gives up as well; both run the rest of the check, agree on the verdict, and go back to
-    the provider's allreduce, which still works."""
+    """Rank 1 arrives 1.5 s late at 64 back-to-back allreduces, the time limit is 0.3 s: rank 0 gives up (its 64 enqueued calls do not
+    wait 64 times), rank 1 then finds rank 0's packets overwritten and gives up as well; both get NaN and KS_ERR_LIB at their next host
+    wait, and go back to the provider's allreduce, which still works."""
     out = _run_oneshot(2, absent_rank=1)
     for rk in (0, 1):
         assert out[rk]["active"] == "oneshot" and out[rk]["back"] == "provider"
-        assert out[rk]["raised"] and "communicator check" in out[rk]["raised"], out[rk]
-    assert "one-shot" in out[0]["raised"]
+        assert out[rk]["raised"] and "one-shot" in out[rk]["raised"], out[rk]
+        assert out[rk]["nan"]
     assert out[0]["seconds"] < 6.0
+
+
+# ---- peer-mapped halo exchange (ks_mat_set_halo) and the one-shot stamps across their 32-bit wrap ---------------------------------------
+def _peer_halo_worker(rank, world, port, q, mode):
+    """mode "halo": products through the neighbours' ghost mailboxes against the provider's exchange and the oracle;
+    mode "absent": rank 1 arrives late at a product - the others give up within the time limit, nobody hangs;
+    mode "wrap": the one-shot allreduce with its stamps started just below 2^32."""
+    sys.path.insert(0, ROOT)
+    if mode == "absent":
+        os.environ["KSGPU_ONESHOT_TIMEOUT_MS"] = "300"
+    if mode == "wrap":
+        os.environ["KSGPU_ONESHOT_SEQ0"] = "0xFFFFFFE0"
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import slepc_amd as ks
+        from slepc_amd import partition as P
+        from oracle import oracle as O
+        ctx = ks.Context(0)
+        _install_gloo_ops(ks, ctx, dist, torch, rank, world)
+        res = {}
+        if mode == "wrap":
+            res["active"] = ctx.set_allreduce("oneshot")
+            ctx.comm_check()                                   # 64 back-to-back calls: the stamps run through 0xFFFFFFFF -> 1
+            X = ks.BV(ctx, 64, 12, N=64 * world)
+            d = X.buffer_ptr()
+            for it in range(40):
+                h = np.sqrt(np.arange(1, 32) * (rank + 2.0 + it))
+                ctx.memcpy_h2d(d, h); ctx.allreduce_sum_dev(d, 31)
+                out = np.empty(31); ctx.memcpy_d2h(out, d)
+                want = sum(np.sqrt(np.arange(1, 32) * (r + 2.0 + it)) for r in range(world))
+                assert np.allclose(out, want, rtol=1e-14, atol=0), (it, out, want)
+            ctx.comm_check()
+            res["back"] = ctx.set_allreduce("provider")
+            dist.barrier(); q.put((rank, res)); return
+        nx, ny, nz = 12, 10, 9
+        plane = nx * ny
+        z0, z1 = P.split_ownership(nz, world)[rank]
+        r0, r1 = z0 * plane, z1 * plane
+        Aglob = O.laplacian3d(nx, ny, nz)
+        rng = np.random.default_rng(1)
+        A = ks.Mat.laplacian3d(ctx, nx, ny, nz, z0, z1 - z0)
+        X = ks.BV(ctx, r1 - r0, 3, N=Aglob.n)
+        xs = [rng.standard_normal(Aglob.n) for _ in range(6)]
+        # the provider's exchange first (reference bits), then the same products through the mailboxes
+        prov = []
+        for x in xs:
+            X.set_column(0, x[r0:r1]); A.mult_dev(X.column_ptr(0), X.column_ptr(1)); prov.append(X.column(1))
+        res["active"] = A.set_halo("peer")
+        if mode == "absent":
+            import time
+            if rank == 1:
+                time.sleep(1.5)
+            t0 = time.perf_counter()
+            X.set_column(0, xs[0][r0:r1])
+            try:
+                A.mult_dev(X.column_ptr(0), X.column_ptr(1)); ctx.synchronize(); res["raised"] = False
+            except RuntimeError as e:
+                res["raised"] = str(e)
+            res["seconds"] = time.perf_counter() - t0
+            dist.barrier(); q.put((rank, res)); return
+        peer = []
+        for x in xs:
+            X.set_column(0, x[r0:r1]); A.mult_dev(X.column_ptr(0), X.column_ptr(1)); peer.append(X.column(1))
+        res["bits_equal"] = all(np.array_equal(a, b) for a, b in zip(prov, peer))
+        res["spmv_err"] = float(max(np.abs(p - Aglob.mult(x)[r0:r1]).max() for p, x in zip(peer, xs)))
+        # many products back to back, no reduction in between: y_{k+1} = A y_k / 8 alternating between two columns (the slots' parities
+        # and acknowledgements are all that keeps a fast rank from overwriting what a slow one has not read yet)
+        X.set_column(0, xs[0][r0:r1]); X.ScaleColumn(0, 1.0)
+        yo = xs[0].copy()
+        for k in range(60):
+            a, b = (0, 1) if k % 2 == 0 else (1, 0)
+            A.mult_dev(X.column_ptr(a), X.column_ptr(b)); X.ScaleColumn(b, 0.125)
+            yo = Aglob.mult(yo) * 0.125
+        res["chain_err"] = float(np.abs(X.column(0) - yo[r0:r1]).max() / np.abs(yo).max())
+        # a general CSR matrix with a ONE-WAY pattern: rank r needs entries of rank r+1 only (upper bidiagonal blocks), so a sender gets no
+        # data back from its destination - only acknowledgements
+        n = 64 * world
+        rows = np.arange(n)
+        colsU = np.minimum(rows + 40, n - 1)
+        rp = np.arange(0, 2 * n + 1, 2, dtype=np.int32)
+        col = np.stack([rows, colsU], axis=1).astype(np.int32).ravel()         # rows <= colsU: already in column order
+        val = np.stack([2.0 + rows * 0.01, -1.0 + rows * 0.001], axis=1).ravel()
+        U = O.CSR(n, rp, col, val)
+        q0, q1 = rank * 64, (rank + 1) * 64
+        Ul = ks.Mat.from_csr(ctx, *P.local_block(U.rowptr, U.col, U.val, q0, q1), row_start=q0, n_global=n)
+        res["oneway_active"] = Ul.set_halo("peer")
+        W = ks.BV(ctx, 64, 2, N=n)
+        w = rng.standard_normal(n); wo = w.copy()
+        W.set_column(0, w[q0:q1])
+        for k in range(30):
+            a, b = (0, 1) if k % 2 == 0 else (1, 0)
+            Ul.mult_dev(W.column_ptr(a), W.column_ptr(b)); W.ScaleColumn(b, 0.25)
+            wo = U.mult(wo) * 0.25
+        res["oneway_err"] = float(np.abs(W.column(0) - wo[q0:q1]).max() / max(np.abs(wo).max(), 1e-300))
+        # Lanczos and the full solver on top of the mailbox halo
+        m = 12
+        V = ks.BV(ctx, r1 - r0, m + 1, N=Aglob.n, row_start=r0)
+        V.SetRandomColumn(0)
+        _, nrm, _ = V.OrthogonalizeColumn(0); V.ScaleColumn(0, 1.0 / nrm)
+        T = np.zeros((m + 1, 3), order="F")
+        mm, beta, brk = V.MatLanczos(A, T, 0, m)
+        res["T"] = T[:m, :2].copy(); res["beta"] = beta; res["mm"] = mm
+        eps = ks.EPS(ctx); eps.SetOperators(A); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(3, 12); eps.Solve()
+        res["eig"] = [eps.GetEigenvalue(i)[0] for i in range(3)]; res["its"] = eps.GetIterationNumber(); res["nconv"] = eps.GetConverged()
+        res["err"] = [eps.ComputeError(i) for i in range(3)]
+        res["back"] = A.set_halo("provider")
+        X.set_column(0, xs[1][r0:r1]); A.mult_dev(X.column_ptr(0), X.column_ptr(1))
+        res["back_bits"] = bool(np.array_equal(X.column(1), prov[1]))
+        dist.barrier()
+        q.put((rank, res))
+    except Exception:      # noqa: BLE001
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_peer(world, mode):
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = 33100 + (os.getpid() % 1500) + 13 * world + {"halo": 0, "absent": 5, "wrap": 9}[mode]
+    procs = [mpc.Process(target=_peer_halo_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs: p.start()
+    out = dict(q.get(timeout=400) for _ in range(world))
+    for p in procs: p.join(120)
+    for r in range(world):
+        assert "error" not in out[r], out[r].get("error")
+    return out
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_mapped_halo_between_processes_sharing_one_gpu(world):
+    """SURVEY 8e "neighbour P2P of boundary x entries": every process maps its neighbours' ghost mailboxes through hipIpc (the route the
+    ranks of an 8-GPU node take over xGMI; here on one card), the pack kernel stores straight into them. Same bits as the provider's
+    exchange, the oracle's products, Lanczos coefficients and eigenvalues; 60 products back to back and a one-way communication
+    pattern (acknowledgements only flowing back) stay correct."""
+    from oracle import oracle as O
+    out = _run_peer(world, "halo")
+    A = O.laplacian3d(12, 10, 9); m = 12
+    V = O.BV(A.n, m + 1); V.SetRandomColumn(0)
+    _, nrm, _ = V.OrthogonalizeColumn(0); V.ScaleColumn(0, 1 / nrm)
+    T = np.zeros((m + 1, 3), order="F")
+    mm, beta, brk = V.MatLanczos(A, T, 0, m)
+    r = O.eps_krylovschur_hep(A, 3, ncv=12)
+    for rk in range(world):
+        o = out[rk]
+        assert o["active"] == "peer" and o["oneway_active"] == "peer" and o["back"] == "provider"
+        assert o["bits_equal"] and o["back_bits"] and o["spmv_err"] < 1e-13
+        assert o["chain_err"] < 1e-13 and o["oneway_err"] < 1e-13
+        assert o["mm"] == mm and abs(o["beta"] - beta) < 1e-12 and np.abs(o["T"] - T[:m, :2]).max() < 1e-12
+        assert o["its"] == r.its and o["nconv"] == r.nconv and max(o["err"]) < 1e-8
+        assert np.allclose(o["eig"], r.eigr[r.perm][:3], rtol=1e-10)
+
+
+@pytest.mark.timeout(600)
+def test_peer_mapped_halo_gives_up_when_a_neighbour_never_arrives():
+    """Rank 1 reaches the product 1.5 s late, the time limit is 0.3 s: rank 0 fills its ghosts with NaN, raises the error word and its next
+    host wait fails - it does not hang."""
+    out = _run_peer(2, "absent")
+    assert out[0]["active"] == "peer"
+    assert out[0]["raised"] and "halo" in out[0]["raised"], out[0]
+    assert out[0]["seconds"] < 6.0
+
+
+@pytest.mark.timeout(600)
+def test_oneshot_allreduce_across_the_wrap_of_its_stamps():
+    """The slot parity flips on every call, also where the 32-bit stamp skips 0: more than 100 calls started at 0xFFFFFFE0."""
+    out = _run_peer(2, "wrap")
+    for rk in (0, 1):
+        assert out[rk]["active"] == "oneshot" and out[rk]["back"] == "provider"
