@@ -137,18 +137,27 @@ __global__ __launch_bounds__(256) void k_spmv_csr_stream(int n, const int *__res
 // (16-byte loads of four consecutive entries per lane were tried for the streams: fewer instructions, no faster, and the gathers of such a
 // lane assignment touch still more lines.)
 constexpr int CW_PAD = 8;                                  // col / val allocations are this much longer than nnz
-constexpr int CW_STEPS = 8, CW_CHUNK = 64 * CW_STEPS;      // entries per wave and chunk
-constexpr int CW_U = 8;                                    // row side: gathers in flight per lane
+constexpr int CW_STEPS_MAX = 8;                            // 64 entries per step, chunks of 512 (row side with 256-entry chunks: 62 registers, 8 waves per SIMD, and 237 us instead of 199)
+constexpr int CW_U = 4;                                    // row side: gathers in flight per lane
 __device__ __forceinline__ int cw_slot(int e) { return e + (e >> 5); }     // one slot of skew per 32 entries (rows whose length is a multiple of 32)
-struct CwRegs { int c[CW_STEPS]; double a[CW_STEPS]; };
-__device__ __forceinline__ void cw_load(CwRegs &r, const int *__restrict__ col, const double *__restrict__ val, int e0, int E1, int lane)
+// Load width matters more than instruction count here: 4-byte-per-lane streaming loads top out at 0.7 - 2.5 TB/s on this part, 8- and 16-byte
+// ones at 7 (scripts/micro/load_width.hip, profiles/r03_micro_load_width.txt). So the 4-byte column indices are loaded two per lane (a chunk
+// starts on an even entry: aligned 8-byte loads; lane l of step u holds entries 128 u + 2 l, + 1), the values one per lane (entry 64 u + l),
+// and a row's two row pointers come as one 8-byte load.
+typedef int ks_i2v __attribute__((ext_vector_type(2)));
+template <int CW_STEPS> struct CwRegs { ks_i2v c[CW_STEPS / 2]; double a[CW_STEPS]; };
+template <int CW_STEPS>
+__device__ __forceinline__ void cw_load(CwRegs<CW_STEPS> &r, const int *__restrict__ col, const double *__restrict__ val, int e0, int E1, int lane)
 {
+#pragma unroll
+  for (int u = 0; u < CW_STEPS / 2; u++) {
+    const int e = e0 + u * 128 + 2 * lane;
+    r.c[u] = e < E1 ? __builtin_nontemporal_load(reinterpret_cast<const ks_i2v *>(col + e)) : ks_i2v{-1, -1};      // may take one entry past E1: CW_PAD
+  }
 #pragma unroll
   for (int u = 0; u < CW_STEPS; u++) {
     const int e = e0 + u * 64 + lane;
-    const bool ok = e < E1;
-    r.c[u] = ok ? ksk::ldstream(col + e) : -1;
-    r.a[u] = ok ? ksk::ldstream(val + e) : 0.0;
+    r.a[u] = e < E1 ? ksk::ldstream(val + e) : 0.0;
   }
 }
 struct CwRows { int p0, p1, E0, E1; long long r; bool has; };
@@ -159,14 +168,15 @@ __device__ __forceinline__ CwRows cw_rows(int n, const int *__restrict__ rp, int
   q.r = r0 + lane;
   if (r0 >= n) return q;
   q.has = q.r < n;
-  if (q.has) { q.p0 = ksk::ldstream(rp + q.r); q.p1 = ksk::ldstream(rp + q.r + 1); }
+  if (q.has) { ks_i2v pp; __builtin_memcpy(&pp, rp + q.r, sizeof(pp)); q.p0 = pp.x; q.p1 = pp.y; }       // rp[r], rp[r + 1]: one 8-byte load (4-byte aligned)
   q.E0 = rp[r0]; q.E1 = rp[r0 + 64 < n ? r0 + 64 : n];                 // the wave's run of entries (uniform: scalar loads)
   return q;
 }
-template <bool ROWSIDE>
-__global__ __launch_bounds__(256) void k_spmv_csr_wave(int n, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
+template <bool ROWSIDE, int CW_STEPS>
+__global__ __launch_bounds__(256, ROWSIDE ? 5 : 4) void k_spmv_csr_wave(int n, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
                                                        const double *__restrict__ x, double *__restrict__ y, int xcd_remap)
 {
+  constexpr int CW_CHUNK = 64 * CW_STEPS;
   __shared__ double sa_all[4][CW_CHUNK + CW_CHUNK / 32];
   __shared__ double sb_all[4][ROWSIDE ? (CW_CHUNK + CW_CHUNK / 32) / 2 : CW_CHUNK + CW_CHUNK / 32];       // x values, or the columns (4 bytes each)
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -183,27 +193,32 @@ __global__ __launch_bounds__(256) void k_spmv_csr_wave(int n, const int *__restr
   // flight - the next chunk of the same rows, or the first chunk of the wave's next 64 rows.
   CwRows cu = cw_rows(n, rp, g, w, lane);
   CwRows nx = g + gstep < gend ? cw_rows(n, rp, g + gstep, w, lane) : CwRows{0, 0, 0, 0, 0, false};
-  CwRegs cur, nxt;
-  int e0 = cu.E0;
+  CwRegs<CW_STEPS> cur, nxt;
+  int e0 = cu.E0 & ~1;
   if (e0 < cu.E1) cw_load(cur, col, val, e0, cu.E1, lane);
   bool nxt_loaded = false;                                 // the first chunk of group nx is already in `nxt`
   double acc = 0.0;
   for (;;) {
     if (e0 < cu.E1) {
+#pragma unroll
+      for (int u = 0; u < CW_STEPS; u++) sa[cw_slot(u * 64 + lane)] = cur.a[u];
       if (ROWSIDE) {
 #pragma unroll
-        for (int u = 0; u < CW_STEPS; u++) { const int sl = cw_slot(u * 64 + lane); sa[sl] = cur.a[u]; sc[sl] = cur.c[u]; }
+        for (int u = 0; u < CW_STEPS / 2; u++) { const int sl = cw_slot(u * 128 + 2 * lane); sc[sl] = cur.c[u].x; sc[sl + 1] = cur.c[u].y; }      // 2 l, 2 l + 1 never straddle a skew step
       } else {
         double xg[CW_STEPS];
 #pragma unroll
-        for (int u = 0; u < CW_STEPS; u++) xg[u] = cur.c[u] >= 0 ? x[cur.c[u]] : 0.0;
+        for (int u = 0; u < CW_STEPS / 2; u++) {
+          const int e = e0 + u * 128 + 2 * lane;
+          xg[2 * u] = e < cu.E1 ? x[cur.c[u].x] : 0.0; xg[2 * u + 1] = e + 1 < cu.E1 ? x[cur.c[u].y] : 0.0;
+        }
 #pragma unroll
-        for (int u = 0; u < CW_STEPS; u++) { const int sl = cw_slot(u * 64 + lane); sa[sl] = cur.a[u]; sx[sl] = xg[u]; }
+        for (int u = 0; u < CW_STEPS / 2; u++) { const int sl = cw_slot(u * 128 + 2 * lane); sx[sl] = xg[2 * u]; sx[sl + 1] = xg[2 * u + 1]; }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const int en = e0 + CW_CHUNK;
       if (en < cu.E1) cw_load(nxt, col, val, en, cu.E1, lane);
-      else if (nx.E0 < nx.E1) { cw_load(nxt, col, val, nx.E0, nx.E1, lane); nxt_loaded = true; }
+      else if ((nx.E0 & ~1) < nx.E1) { cw_load(nxt, col, val, nx.E0 & ~1, nx.E1, lane); nxt_loaded = true; }
       const int lo = max(cu.p0, e0), hi = min(cu.p1, en);
       if (ROWSIDE) {
         for (int p = lo; __builtin_amdgcn_ballot_w64(p < hi) != 0; p += CW_U) {
@@ -231,7 +246,7 @@ __global__ __launch_bounds__(256) void k_spmv_csr_wave(int n, const int *__restr
     if (g >= gend) break;
     cu = nx;
     nx = g + gstep < gend ? cw_rows(n, rp, g + gstep, w, lane) : CwRows{0, 0, 0, 0, 0, false};
-    e0 = cu.E0;
+    e0 = cu.E0 & ~1;
     if (nxt_loaded) cur = nxt;
     else if (e0 < cu.E1) cw_load(cur, col, val, e0, cu.E1, lane);
     nxt_loaded = false;
@@ -1349,14 +1364,14 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y, const double *row
       const int remap = (remap_env && blocks == groups && blocks >= 64) ? 1 : 0;     // only with one slice group per workgroup (a strided loop would interleave the ranges again)
       hipLaunchKernelGGL((k_spmv_sell<8>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->nslices, A->s_ptr, A->s_len, A->s_col, A->s_val, x, y, remap);
     } else if (A->n >= 2048 && !A->force_csr_vector && !A->force_csr_block) {
-      // 4 workgroups of 4 waves per CU (registers); a multiple of 8 so that every XCD gets its eighth of the rows
+      // 4 or 5 workgroups of 4 waves per CU (registers; forcing 6 spills: 259 us); a multiple of 8 so that every XCD gets its eighth of the rows
       const long long NG = ((long long)A->n + 255) / 256;
-      long long nb = std::min<long long>(NG, (long long)ctx->num_cu * 4);
+      const bool rowside = A->nnz_d <= 12LL * A->n;          // short rows: gather on the row side
+      long long nb = std::min<long long>(NG, (long long)ctx->num_cu * (rowside ? 5 : 4));
       const int remap = nb >= 64 ? 1 : 0;
       if (remap) nb = (nb / 8) * 8;
-      const bool rowside = A->nnz_d <= 12LL * A->n;          // short rows: gather on the row side
-      if (rowside) hipLaunchKernelGGL(k_spmv_csr_wave<true>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, remap);
-      else hipLaunchKernelGGL(k_spmv_csr_wave<false>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, remap);
+      if (rowside) hipLaunchKernelGGL((k_spmv_csr_wave<true, 8>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, remap);
+      else hipLaunchKernelGGL((k_spmv_csr_wave<false, 8>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, remap);
     } else if (A->n >= 2048 && !A->force_csr_vector) {
       const unsigned nb = (unsigned)std::min<long long>(((long long)A->n + 255) / 256, (long long)ctx->num_cu * 8);
       hipLaunchKernelGGL(k_spmv_csr_stream, dim3(nb), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, x, y);
