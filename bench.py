@@ -141,21 +141,37 @@ def cpu_baseline(n_side, max_seconds=30.0):
         t2 = time.time()
         V.MatLanczos(A, T, m1, NCV)
         dt_first = dt6 + (time.time() - t2)
-        # the steady state the GPU line times: restart-cycle expansions, steps k = 16..30 against the kept half of the
-        # basis, repeated (same vectors every time) until about 12 s of CPU work have been sampled
-        k0, cycles, dt, steps = NCV // 2, 0, 0.0, 0
-        while dt < min(12.0, max_seconds):
-            t2 = time.time()
+        # The steady state the GPU line times: restart cycles = the restart itself (BVMultInPlace of the 30 active columns by an
+        # orthogonal 30 x 15 factor, the host's Q of a projected solve stands in for by a fixed orthogonal matrix; BVCopyColumn of the
+        # residual column) + the expansion, steps k = 16..30 against the kept half of the basis. SURVEY 8d: at least 3 repetitions,
+        # median. A repetition is `per_rep` cycles, sized from one probe cycle so that the three of them take about 12 s.
+        k0 = NCV // 2
+        Qr, _ = np.linalg.qr(np.random.default_rng(7).standard_normal((NCV, NCV)))
+        Qf = np.asfortranarray(Qr)
+
+        def cycle():
+            V.SetActiveColumns(0, NCV)
+            V.MultInPlace(Qf, 0, k0)              # krylovschur.c:326 BVMultInPlace(eps->V,U,eps->nconv,k+l): V(:,0:k0) = V(:,0:ncv) Q(:,0:k0)
+            V.CopyColumn(NCV, k0)                  # krylovschur.c:329
+            V.SetActiveColumns(0, NCV + 1)
             V.MatLanczos(A, T, k0, NCV)
-            dt += time.time() - t2
-            steps += NCV - k0; cycles += 1
-        sample = ("%d restart-cycle expansions (k=%d..%d, CGS2) of the %d^3 workload after its first Lanczos run; no restart GEMM "
-                  "or projected solve in the CPU sample") % (cycles, k0 + 1, NCV, n_side)
+        t2 = time.time(); cycle(); probe = time.time() - t2
+        per_rep = max(1, min(40, int(min(12.0, max_seconds) / 3.0 / max(probe, 1e-3))))
+        reps = []
+        for _ in range(3):
+            t2 = time.time()
+            for _ in range(per_rep):
+                cycle()
+            reps.append(time.time() - t2)
+        dt = sorted(reps)[1]; steps = per_rep * (NCV - k0); cycles = per_rep
+        sample = ("median of 3 repetitions of %d restart cycles each (BVMultInPlace 30 -> 15 columns + BVCopyColumn + expansion k=%d..%d, CGS2) of the %d^3 "
+                  "workload after its first Lanczos run; repetition times %s s; the projected solve (O(m^3) on the host) is not in the CPU sample"
+                  % (cycles, k0 + 1, NCV, n_side, ", ".join("%.2f" % r for r in reps)))
         first = {"value": NCV / dt_first, "unit": "steps/s", "sample": "first Lanczos run, k=1..%d" % NCV}
     else:
         dt, steps, first = dt6, m1, None
         sample = "first %d Lanczos steps (k=1..%d) of the %d^3 workload (full run estimated %.0f s > budget)" % (m1, m1, n_side, est)
-    out = {"value": steps / dt, "unit": "steps/s", "cores": threads, "kind": "port", "sample": sample,
+    out = {"value": steps / dt, "unit": "steps/s", "cores": threads, "kind": "port", "sample": sample, "method": "median of 3 repetitions (SURVEY 8d)",
            "seconds": round(dt, 3), "setup_seconds": round(t1 - t0, 2), "gs_passes": V.passes_total(), "first_cycle": first,
            "same_6_steps_all_cores": {"value": m1 / dt6, "unit": "steps/s", "cores": threads}}
     # one core (the serial build of the oracle), on the first 6 steps only so that it stays within a few seconds
@@ -411,6 +427,41 @@ def side_configs(ks, ctx, barrier, args):
     return out
 
 
+def headline(world, steps, dt, warm_steps, t, args, workload, mat):
+    """The contract part of the JSON line from the measured numbers (rank 0). `dt` is already the maximum over the ranks; weak scaling:
+    the unit is one Arnoldi step on one GPU's 10 077 696-row shard (the N=1 workload), so the whole job processes world*steps of them while
+    the global solver itself advances steps/dt steps per second. mat: n, nnz, N, layout of this rank's matrix."""
+    return {
+        "metric": "Arnoldi steps/sec (and GB/s vs HBM roofline), 3D Laplacian n=10M, m=30, 1/2/4/8 GPU",
+        "value": world * steps / dt, "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": warm_steps,
+        "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": workload, "rows_per_gpu": mat["n"], "nnz_per_gpu": mat["nnz"], "n_global": mat["N"], "nev": NEV, "ncv": NCV,
+                   "orthog": "CGS, refine ifneeded eta=0.7071", "gs_passes_per_step": t["gs_passes"] / steps,
+                   "timed_region": "whole restart cycles of one continuing solve in steady state (after the first cycle and %d warm-up steps)" % warm_steps,
+                   "steps_requested": args.steps, "min_steps": args.min_steps, "cycles": t["cycles"], "restarts": t["cycles"],
+                   "steps_per_cycle": round(steps / t["cycles"], 2), "mean_k": round(t["mean_k"], 2), "timed_seconds": round(dt, 4),
+                   "parallelism": "row-slab x%d" % world,
+                   "spmv_layout": mat["layout"] + (" (2-byte entries: offset code + value code, lossless; y bit-identical to SELL-64; KSGPU_SPMV=sell disables; "
+                                                   "general-matrix layouts: spmv_layouts)" if mat["layout"] == "dict" else ""),
+                   "unit_of_value": "Arnoldi steps on a 10 077 696-row shard, summed over the %d shard(s): value = n_gpus * global_steps_per_s" % world,
+                   "global_steps_per_s": steps / dt},
+    }
+
+
+def attach_oneshot_leg(out, leg):
+    """The N>1 side leg (one-shot allreduce + peer-mapped halo, measured by a child process of every rank) into the line; never fatal."""
+    if leg is None:
+        return out
+    if leg.get("value"):
+        leg["vs_provider_allreduce"] = round(leg["value"] / out["value"], 4)
+    leg["note"] = ("the same measurement in a child process of every rank with ks_comm_set_allreduce(ONESHOT) and ks_mat_set_halo(PEER): the "
+                   "Gram-Schmidt sums go through peer-mapped mailboxes, one kernel per rank, instead of ncclAllReduce, and the boundary entries "
+                   "of x go straight into the neighbours' ghost mailboxes instead of grouped ncclSend / ncclRecv; `value` above is the RCCL path")
+    out["oneshot_allreduce"] = leg
+    return out
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` outside a launcher: start the N ranks as fresh child processes (this process has not
     touched the GPU) and hand their exit code back. Rank 0's JSON line goes straight to our stdout."""
@@ -502,6 +553,7 @@ def main():
     if args.oneshot_leg:
         # every rank's verdict is the same at each of these exits (set_allreduce and comm_check agree among the ranks)
         oneshot = {"active": ctx.set_allreduce("oneshot")}
+        oneshot["halo_requested"] = "peer"                      # applied to the matrix below, once it exists
         if oneshot["active"] == "oneshot":
             try:
                 ctx.comm_check()
@@ -527,6 +579,9 @@ def main():
         nz = planes * world
         A = ks.Mat.laplacian3d(ctx, nx, ny, nz, rank * planes, planes)
         workload = "3-D 7-pt Laplacian %dx%dx%d in %d z-slabs of %d planes (BASELINE config 4 at N=8), Krylov-Schur nev=%d m=%d" % (nx, ny, nz, world, planes, NEV, NCV)
+
+    if args.oneshot_leg and oneshot is not None:
+        oneshot["halo_active"] = A.set_halo("peer")             # collective: boundary entries straight into the neighbours' ghost mailboxes (ks_mat_set_halo)
 
     def barrier():
         ctx.synchronize()                 # the library's own stream
@@ -556,25 +611,8 @@ def main():
     if dist is not None and not args.no_oneshot:
         leg = oneshot_child(args)         # every rank starts its own child; rank 0's child reports
     if rank == 0:
-        n_local = A.n
-        out = {
-            "metric": "Arnoldi steps/sec (and GB/s vs HBM roofline), 3D Laplacian n=10M, m=30, 1/2/4/8 GPU",
-            # weak scaling: the unit is one Arnoldi step on one GPU's 10 077 696-row shard (the N=1 workload), so the
-            # whole job processes world*steps of them; the global solver itself advances steps/dt steps per second
-            "value": world * steps / dt, "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": ph.marks["t0"][0],
-            "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "rows_per_gpu": n_local, "nnz_per_gpu": A.nnz, "n_global": A.N, "nev": NEV, "ncv": NCV,
-                       "orthog": "CGS, refine ifneeded eta=0.7071", "gs_passes_per_step": t["gs_passes"] / steps,
-                       "timed_region": "whole restart cycles of one continuing solve in steady state (after the first cycle and %d warm-up steps)" % ph.marks["t0"][0],
-                       "steps_requested": args.steps, "min_steps": args.min_steps, "cycles": t["cycles"], "restarts": t["cycles"],
-                       "steps_per_cycle": round(steps / t["cycles"], 2), "mean_k": round(t["mean_k"], 2), "timed_seconds": round(dt, 4),
-                       "parallelism": "row-slab x%d" % world,
-                       "spmv_layout": A.layout() + (" (2-byte entries: offset code + value code, lossless; y bit-identical to SELL-64; KSGPU_SPMV=sell disables; "
-                                                    "general-matrix layouts: spmv_layouts)" if A.layout() == "dict" else ""),
-                       "unit_of_value": "Arnoldi steps on a 10 077 696-row shard, summed over the %d shard(s): value = n_gpus * global_steps_per_s" % world,
-                       "global_steps_per_s": steps / dt},
-        }
+        out = headline(world, steps, dt, ph.marks["t0"][0], t, args, workload,
+                       {"n": A.n, "nnz": A.nnz, "N": A.N, "layout": A.layout()})
         if prof_timed:
             rl = update_kernel_roofline(ks, prof_timed)
             if rl:
@@ -620,9 +658,25 @@ def main():
                         os.environ.pop("KSGPU_SPMV", None)
                 out["spmv_layouts"] = {"workload": "MatMult of the %d^3 7-pt Laplacian alone, each device layout (KSGPU_SPMV=...)" % side, "legs": legs,
                                        "note": "dict needs <= 255 distinct values and <= 256 distinct column offsets, odict only the offsets; "
-                                               "sell = SELL-64 for any stencil-like matrix; csr = 256-row blocks of CSR streamed through LDS, for ragged ones; csrvec = the CSR-vector kernel it replaced"}
+                                               "sell = SELL-64 for any stencil-like matrix; csr = CSR row blocks streamed through wave-private LDS (a wave per 64 rows), for ragged ones; csrvec = the CSR-vector kernel it replaced"}
             except Exception as e:      # noqa: BLE001
                 out["spmv_layouts"] = {"error": repr(e)}
+            # the same measurement with the general-matrix SpMV (CSR row blocks; nothing Laplacian-specific in the layout): untimed for the headline
+            try:
+                os.environ["KSGPU_SPMV"] = "csr"
+                try:
+                    Ag = ks.Mat.laplacian3d(ctx, side, side, side)
+                finally:
+                    os.environ.pop("KSGPU_SPMV", None)
+                eg, phg, tg = measure(ks, ctx, Ag, None, barrier, args.warmup, args.steps, args.min_steps, NEV, NCV, ks.EPS_HEP, prof=False)
+                out["value_general_layout"] = {"value": tg["steps"] / tg["seconds"], "unit": "steps/s", "ms_per_step": 1e3 * tg["seconds"] / tg["steps"], "steps": tg["steps"],
+                                               "spmv_layout": Ag.layout(), "spmv_avg_us": out.get("spmv_layouts", {}).get("legs", {}).get("csr", {}).get("avg_us"),
+                                               "note": "the headline's solve with KSGPU_SPMV=csr: MatMult through the CSR row-block kernel (12 B per nonzero, any "
+                                                       "matrix) instead of the 2-byte dictionary layout the assembly picks for this stencil; everything else identical"}
+                del eg
+                Ag.destroy()
+            except Exception as e:      # noqa: BLE001
+                out["value_general_layout"] = {"value": None, "error": repr(e)}
             try:
                 Ad = ks.Mat.laplacian3d(ctx, side, side, side)
                 out["dropin_slot_path"] = dropin_slot_leg(ks, ctx, Ad, NCV)
@@ -635,12 +689,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(side)
             except Exception as e:       # noqa: BLE001 - the baseline must not take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
-        if leg is not None:
-            if leg.get("value"):
-                leg["vs_provider_allreduce"] = round(leg["value"] / out["value"], 4)
-            leg["note"] = ("the same measurement in a child process of every rank with ks_comm_set_allreduce(ONESHOT): the Gram-Schmidt sums go through "
-                           "peer-mapped mailboxes, one kernel per rank, instead of ncclAllReduce; `value` above is the RCCL path")
-            out["oneshot_allreduce"] = leg
+        attach_oneshot_leg(out, leg)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

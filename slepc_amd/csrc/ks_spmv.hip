@@ -17,7 +17,6 @@
 // so that rowptr -> (col,val) -> x[col] dependent chains of different rows overlap.
 // Algorithmic bytes per call: 12*nnz + 4*(n+1) + 16*n.
 #include "ks_sweeps.cuh"
-#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <numeric>
 #include <thread>
@@ -581,15 +580,74 @@ __global__ void k_compact_rows(int n, const int *rp, const int *pos, int *rows, 
   if (r < n && rp[r + 1] > rp[r]) { rows[pos[r]] = r; rp_c[pos[r]] = rp[r]; }
 }
 
+// Exclusive prefix sum of ints (assembly only: row pointers from row counts). Three launches: sums of 2048-item tiles, an exclusive scan
+// of the tile sums by one workgroup, then every tile scans itself (wave shuffles, 8 items per thread) starting from its offset.
+constexpr int SCAN_TILE = 2048;
+__device__ __forceinline__ int scan_wave_incl(int v)
+{
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(v, d, 64); if ((int)(threadIdx.x & 63) >= d) v += t; }
+  return v;
+}
+__global__ __launch_bounds__(256) void k_scan_tile_sums(const int *__restrict__ in, long long n, int *__restrict__ sums)
+{
+  __shared__ int ws[4];
+  const long long base = (long long)blockIdx.x * SCAN_TILE;
+  int s = 0;
+  for (int i = threadIdx.x; i < SCAN_TILE; i += 256) { const long long g = base + i; if (g < n) s += in[g]; }
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ __launch_bounds__(1024) void k_scan_sums(int *__restrict__ sums, int ntiles)
+{
+  __shared__ int ws[16];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < ntiles; b0 += 1024) {
+    const int i = b0 + threadIdx.x;
+    const int v = i < ntiles ? sums[i] : 0;
+    int inc = scan_wave_incl(v);
+    if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) woff += ws[w];
+    const int c = carry;
+    if (i < ntiles) sums[i] = c + woff + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = c + woff + inc;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void k_scan_tiles(const int *__restrict__ in, int *__restrict__ out, long long n, const int *__restrict__ offs)
+{
+  __shared__ int ws[4];
+  const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * 8;
+  int v[8], t = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) { const long long g = base + j; v[j] = g < n ? in[g] : 0; t += v[j]; }
+  const int inc = scan_wave_incl(t);
+  if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  int run = offs[blockIdx.x] + inc - t;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += ws[w];
+#pragma unroll
+  for (int j = 0; j < 8; j++) { const long long g = base + j; if (g < n) out[g] = run; run += v[j]; }
+}
 int exclusive_scan_int(hipStream_t st, const int *in, int *out, long long nitems)
 {
-  size_t tmp_bytes = 0;
-  KS_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, in, out, (int)nitems, st));
-  void *tmp = nullptr;
-  KS_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-  hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, in, out, (int)nitems, st);
+  if (nitems <= 0) return KS_SUCCESS;
+  const int ntiles = (int)((nitems + SCAN_TILE - 1) / SCAN_TILE);
+  int *sums = nullptr;
+  KS_HIP(hipMalloc(&sums, sizeof(int) * (size_t)ntiles));
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(256), 0, st, in, nitems, sums);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, sums, ntiles);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, st, in, out, nitems, sums);
+  hipError_t e = hipGetLastError();
   hipStreamSynchronize(st);
-  hipFree(tmp);
+  hipFree(sums);
   KS_HIP(e);
   return KS_SUCCESS;
 }

@@ -171,6 +171,35 @@ __device__ __forceinline__ void reduce_partials_to_lds(const double *__restrict_
 {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   constexpr int PER_LANE = 16;
+  if (nblocks <= 64 * 8) {
+    // Grids of up to 512 workgroups (every sweep of a basis that is not huge, and all of them at 2 workgroups per CU): a wave takes FOUR of its
+    // columns per round - 32 independent loads in flight per lane, one memory round trip for four columns instead of four. In the update
+    // kernel this runs in EVERY workgroup's prologue, ahead of the sweep: at n = 1e6 (config 2) the column-at-a-time form was a sixth of the
+    // kernel. Same order of additions per column as the general form below: the same bits.
+    constexpr int G = 4, PL = 8;
+    for (int i0 = w; i0 < ncols; i0 += nw * G) {
+      double v[G][PL];
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        const int i = i0 + g * nw;
+        const double *p = partials + (size_t)(i < ncols ? i : i0) * nblocks;
+#pragma unroll
+        for (int u = 0; u < PL; u++) { const int b = lane + 64 * u; v[g][u] = (b < nblocks) ? p[b] : 0.0; }
+      }
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        const int i = i0 + g * nw;
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < PL; u++) s += v[g][u];
+        // (the general form adds 16 values per lane and pass; the upper 8 are zeros here: s + 0.0 == s)
+        s = wave_sum(s);
+        if (lane == 0 && i < ncols) c_lds[i] = s;
+      }
+    }
+    __syncthreads();
+    return;
+  }
   for (int i = w; i < ncols; i += nw) {
     const double *p = partials + (size_t)i * nblocks;
     double s = 0.0;

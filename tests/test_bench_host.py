@@ -77,3 +77,72 @@ def test_self_launch_command(monkeypatch):
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "20"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def _fake_timed(steps=210, cycles=14):
+    return {"steps": steps, "seconds": 0.25, "gs_passes": 2 * steps, "cycles": cycles, "cycle_steps": [15] * cycles, "mean_k": 23.0}
+
+
+def test_n_gt_1_line_assembles_from_a_faked_two_rank_result():
+    """What rank 0 prints at N = 2, built from numbers as the two ranks would have produced them: the contract keys, whole-job value =
+    n_gpus x global steps per second, weak scaling - and it survives json.dumps."""
+    import json
+    args = types.SimpleNamespace(steps=20, min_steps=200, warmup=5)
+    t = _fake_timed()
+    dt = max(0.2500, 0.2531)                         # the maximum over the ranks
+    mat = {"n": 10077696, "nnz": 70263936 - 2 * 186624 // 2, "N": 2 * 10077696, "layout": "dict"}
+    out = bench.headline(2, t["steps"], dt, 45, t, args, "3-D 7-pt Laplacian 432x432x108 in 2 z-slabs of 54 planes", mat)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in out, key
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["vs_baseline"] is None and out["dtype"] == "f64"
+    assert abs(out["value"] - 2 * 210 / dt) < 1e-9 and abs(out["ms_per_step"] - 1e3 * dt / 210) < 1e-12
+    assert out["config"]["global_steps_per_s"] == 210 / dt and out["config"]["parallelism"] == "row-slab x2"
+    assert out["config"]["steps_requested"] == 20 and out["config"]["min_steps"] == 200
+    assert out["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    # the side leg: a child that reported, one that was stopped, none at all
+    leg = {"active": "oneshot", "halo_active": "peer", "value": 1.01 * out["value"], "unit": "steps/s", "ms_per_step": 0.9, "steps": 210, "gs_passes_per_step": 2.0}
+    line = json.loads(json.dumps(bench.attach_oneshot_leg(dict(out), leg)))
+    assert line["oneshot_allreduce"]["vs_provider_allreduce"] == 1.01 and "note" in line["oneshot_allreduce"]
+    line = json.loads(json.dumps(bench.attach_oneshot_leg(dict(out), {"active": "unknown", "reason": "the child was stopped after 180 s"})))
+    assert "vs_provider_allreduce" not in line["oneshot_allreduce"]
+    assert "oneshot_allreduce" not in bench.attach_oneshot_leg(dict(out), None)
+
+
+def test_oneshot_child_command_report_and_time_limit(monkeypatch):
+    """The child leg: its command line (same sizes, no side legs, --oneshot-leg), another rendezvous port, the report parsed from its
+    stdout; a child that prints nothing or is stopped at the limit becomes a reason string, never an exception."""
+    import json
+    import subprocess
+    seen = {}
+
+    def fake_run(cmd, env=None, stdout=None, stderr=None, timeout=None):
+        seen.update(cmd=cmd, env=env, timeout=timeout)
+        return types.SimpleNamespace(returncode=0, stdout=(b"RCCL banner\n" + json.dumps({"active": "oneshot", "halo_active": "peer", "value": 7000.0}).encode() + b"\n"))
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setenv("MASTER_PORT", "29511"); monkeypatch.setenv("RANK", "0")
+    args = types.SimpleNamespace(gpus=8, steps=20, warmup=5, min_steps=200, side=216)
+    leg = bench.oneshot_child(args)
+    assert leg == {"active": "oneshot", "halo_active": "peer", "value": 7000.0}
+    cmd = seen["cmd"]
+    assert cmd[cmd.index("--gpus") + 1] == "8" and "--oneshot-leg" in cmd and "--no-configs" in cmd and "--no-cpu-baseline" in cmd
+    assert seen["env"]["MASTER_PORT"] != "29511" and seen["timeout"] == 180.0
+
+    def silent(cmd, env=None, stdout=None, stderr=None, timeout=None):
+        return types.SimpleNamespace(returncode=3, stdout=b"")
+    monkeypatch.setattr(bench.subprocess, "run", silent)
+    assert "no report" in bench.oneshot_child(args)["reason"]
+
+    def hung(cmd, env=None, stdout=None, stderr=None, timeout=None):
+        raise subprocess.TimeoutExpired(cmd, timeout)
+    monkeypatch.setattr(bench.subprocess, "run", hung)
+    assert "stopped after" in bench.oneshot_child(args)["reason"]
+
+
+def test_wall_time_budget_of_an_n8_run_fits_the_drivers_limit():
+    """--gpus 8 = headline (a 216^3 slab per rank: set-up, 45 + 210 + 210 steps at about 1.2 ms, a few seconds) + at most one child leg of
+    180 s: the worst case must stay well inside the driver's 600 s."""
+    import inspect
+    limit = inspect.signature(bench.oneshot_child).parameters["limit"].default
+    assert limit <= 180.0
+    headline_worst = 120.0            # imports, RCCL bootstrap, matrix build and the three phases, generously
+    assert headline_worst + limit + 30.0 <= 600.0

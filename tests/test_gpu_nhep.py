@@ -522,8 +522,9 @@ def test_eps_ex9_brusselator_golden(ctx, case):
         # "smallest imaginary part" of a real matrix: every real eigenvalue ties at 0, so how many Ritz values have converged by the time the wanted one has
         # - and which of the tied values a restart keeps - hangs on the last bit of the reductions: with the lanes of a wave added in one order the solve ends
         # at restart 39 with 3 converged values (as the oracle's does), in another at restart 36 with 1. The wanted eigenvalue (golden file and oracle) and its
-        # residual are pinned; the count of extra converged values and the exact restart are not.
-        assert eps.GetConverged() >= nev and eps.GetConvergedReason() == r.reason and abs(eps.GetIterationNumber() - r.its) <= 5
+        # residual are pinned, and the solve must land on one of exactly those two outcomes (tests/test_oracle_golden.py: EX9_4_OUTCOMES).
+        from test_oracle_golden import EX9_4_OUTCOMES
+        assert (eps.GetIterationNumber(), eps.GetConverged(), eps.GetConvergedReason()) in EX9_4_OUTCOMES      # exactly the two tie outcomes, nothing in between
         assert eps.ComputeError(0) < 1e-7
         assert abs(complex(*eps.GetEigenvalue(0)) - complex(r.eigr[r.perm[0]], r.eigi[r.perm[0]])) <= 1e-9 * abs(complex(r.eigr[r.perm[0]], r.eigi[r.perm[0]]))
     else:

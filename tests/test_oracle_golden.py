@@ -554,6 +554,10 @@ def test_eps_test1_cayley_golden():
     assert np.allclose(O.ST(A, B, "cayley", 1.0, nu=1.0).backtransform(2.0, 1.0), (2.0, -1.0))
 
 
+# (restarts, converged values, reason) of ex9 suffix 4: the oracle's outcome first, then the one the GPU's reduction order gives
+EX9_4_OUTCOMES = [(39, 3, 1), (36, 1, 1)]
+
+
 def _as_complex(r, k):
     return np.array([complex(r.eigr[j], r.eigi[j]) for j in r.perm[:k]])
 
@@ -570,6 +574,14 @@ def test_eps_ex9_brusselator_golden():
     assert np.allclose(np.round(_as_complex(r, 4), 5), gi.complex_eigenvalue_lines(gi.read("eps/ex9_5.out"))[0], atol=1.5e-5)
     r = O.eps_krylovschur_nhep(nc.brusselator(30), 1, ncv=24, which="smallest_imaginary")
     assert np.allclose(np.round(_as_complex(r, 1), 5), gi.complex_eigenvalue_lines(gi.read("eps/ex9_4.out"))[0], atol=1.5e-5)
+    # Suffix 4 is the one solve of the suite whose integer control flow hangs on the last bit of the reductions: "smallest imaginary part" of a
+    # real matrix ties all real eigenvalues at 0, so which of them a restart keeps - and how many have converged when the wanted one has - is
+    # decided by rounding. The reference's output file pins NEITHER: it prints the one requested value and "All requested eigenvalues computed"
+    # (no iteration count, no nconv), and both outcomes observed print exactly that. The oracle's summation order ends at restart 39 with 3
+    # converged values; the GPU's wave-sum order at restart 36 with 1 (tests/test_gpu_nhep.py accepts exactly these two).
+    assert (r.its, r.nconv, r.reason) == EX9_4_OUTCOMES[0]
+    out = gi.read("eps/ex9_4.out")
+    assert "All requested eigenvalues computed" in out and "iterations" not in out.lower() and "converged" not in out.lower()
 
 
 def test_eps_ex11_fiedler_restart_parameter_golden():
