@@ -235,10 +235,27 @@ int orc_bv_multinplace(orc_bv *V,const double *Q,int ldq,int s,int e,int trans)
     if (trans) orc_gemm_nt(l,n,k,A,lda,pb,ldq,work,l); else orc_gemm_nn(l,n,k,1.0,A,lda,pb,ldq,0.0,work,l);
     for (j=0;j<n;j++) memcpy(A+(size_t)(ss+j)*lda,work+(size_t)j*l,(size_t)l*sizeof(double));
   }
+  /* the 64-row blocks are independent (each reads and writes its own rows): in the OpenMP build they are split over the team, one
+     workspace per thread - the decomposition the reference gets from its MPI ranks, each running this loop on its own rows */
+#ifdef _OPENMP
+#pragma omp parallel private(j)
+  {
+    double *wk=(double*)malloc((size_t)bs*n*sizeof(double)+8);
+    long lb,l0=l;
+#pragma omp for schedule(static)
+    for (lb=0;lb<(m-l0)/bs;lb++) {
+      const int ll=(int)(l0+lb*bs);
+      if (trans) orc_gemm_nt(bs,n,k,A+ll,lda,pb,ldq,wk,bs); else orc_gemm_nn(bs,n,k,1.0,A+ll,lda,pb,ldq,0.0,wk,bs);
+      for (j=0;j<n;j++) memcpy(A+(size_t)(ss+j)*lda+ll,wk+(size_t)j*bs,(size_t)bs*sizeof(double));
+    }
+    free(wk);
+  }
+#else
   for (;l<m;l+=bs) {
     if (trans) orc_gemm_nt(bs,n,k,A+l,lda,pb,ldq,work,bs); else orc_gemm_nn(bs,n,k,1.0,A+l,lda,pb,ldq,0.0,work,bs);
     for (j=0;j<n;j++) memcpy(A+(size_t)(ss+j)*lda+l,work+(size_t)j*bs,(size_t)bs*sizeof(double));
   }
+#endif
   return ORC_OK;
 }
 
