@@ -110,7 +110,9 @@ int main()
     CK(hipMemcpy(row16, h.data(), nnz * 2, hipMemcpyHostToDevice));
     std::vector<int> o1((long long)NS * (WB + 1)), o2((long long)NS * WB);
     const bool contiguous = getenv("CONTIG") != nullptr;      // diagnostic: phase 1 writes G in its own (slice-major) order
-    for (int s = 0; s < NS; s++) { for (int wb = 0; wb <= WB; wb++) o1[(long long)s * (WB + 1) + wb] = wb * SEG; for (int wb = 0; wb < WB; wb++) o2[(long long)s * WB + wb] = contiguous ? (int)(((long long)s * WB + wb) * SEG) : (int)(((long long)wb * NS + s) * SEG); }
+    const int grp = getenv("GROUP") ? atoi(getenv("GROUP")) : 1;   // GROUP=g: the segments of g consecutive wave-bins are adjacent per slice ([wb / g][slice][wb % g]); phase 2's timing is then meaningless
+    printf("group %d\n", grp);
+    for (int s = 0; s < NS; s++) { for (int wb = 0; wb <= WB; wb++) o1[(long long)s * (WB + 1) + wb] = wb * SEG; for (int wb = 0; wb < WB; wb++) o2[(long long)s * WB + wb] = contiguous ? (int)(((long long)s * WB + wb) * SEG) : (int)((((long long)(wb / grp) * NS + s) * grp + wb % grp) * SEG); }
     CK(hipMemcpy(off1, o1.data(), o1.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(off2t, o2.data(), o2.size() * 4, hipMemcpyHostToDevice));
     std::vector<int> ws((long long)NS * nwin); for (int sl = 0; sl < NS; sl++) for (int wi = 0; wi < nwin; wi++) ws[(long long)sl * nwin + wi] = (wi * 1024) / SEG;
     CK(hipMalloc(&wseg, ws.size() * 4)); CK(hipMemcpy(wseg, ws.data(), ws.size() * 4, hipMemcpyHostToDevice));

@@ -4,7 +4,7 @@
 set -o pipefail
 root=$(pwd); out=$root/gpurun_out/pmc_binned; rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-for layout in binned sliced; do
+for layout in ${LAYOUTS:-binned sliced}; do
   export KSGPU_SPMV=$layout
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/${layout}_stats -- python3 $root/scripts/spmv_random.py > $out/${layout}_stats.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${layout}_fetch -- python3 $root/scripts/spmv_random.py > $out/${layout}_fetch.log 2>&1
@@ -16,7 +16,8 @@ import csv, glob, collections, re
 def kname(t):
     m = re.search(r'(k_[a-z_]+)', t)
     return m.group(1) if m else t[:24]
-for layout in ("binned", "sliced"):
+import os
+for layout in os.environ.get("LAYOUTS", "binned sliced").split():
     print("== KSGPU_SPMV=%s" % layout)
     for f in glob.glob("gpurun_out/pmc_binned/%s_stats/*/*kernel_stats.csv" % layout):
         for r in csv.DictReader(open(f)):

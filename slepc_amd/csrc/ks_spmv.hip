@@ -852,26 +852,48 @@ __global__ __launch_bounds__(1024) void k_binned_gather(int n, int cs, int wb, i
     }
   }
 }
-// phase 2: grid = wave-bins / 4, 256 threads: a wave per wave-bin; LDS: 4 x (wr + 1) accumulators (the last one takes the padding entries)
-__global__ __launch_bounds__(256) void k_binned_reduce(int n, int wr, const long long *__restrict__ bstart, const double *__restrict__ G, const double *__restrict__ val,
+// phase 2: grid = wave-bins / 4, 256 threads: a wave per wave-bin; LDS: 4 x (wr + 1) accumulators (the last one takes the padding entries).
+// The wave-bin's entries are ns pieces (one per slice, about 157 entries each, interleaved with the pieces of the workgroup's other three
+// waves); the wave takes them in slice order, THREE pieces at a time, each as up to four 64-entry steps (masked beyond the piece's end), so
+// that 12 steps of (G, value, row) loads are in flight before the first add. Where a piece is and how long comes from the wave-bin's rows
+// of two small tables (wave-uniform: scalar loads) - no per-entry search. (A walk over 512-entry logical windows with a compare chain per
+// entry, the mirror of phase 1, cost 70 us more than the contiguous stream it replaced; this form: profiles/r03_ab_binned.txt.)
+constexpr int BN_P2 = 3;
+__global__ __launch_bounds__(256) void k_binned_reduce(int n, int wr, int ns, const int *__restrict__ log2, const int *__restrict__ off2,
+                                                       const double *__restrict__ G, const double *__restrict__ val,
                                                        const unsigned short *__restrict__ row16, double *__restrict__ y, const double *__restrict__ rowscale)
 {
   extern __shared__ double bn_lds[];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x * 4 + w;
   double *acc = bn_lds + (size_t)w * (wr + 1);
   for (int i = lane; i <= wr; i += 64) acc[i] = 0.0;
-  const long long e0 = bstart[b], e1 = bstart[b + 1];
-  for (long long q = e0; q < e1; q += 512) {
-    double g[8], a[8]; unsigned short r[8];
+  const int *lg = log2 + (size_t)b * (ns + 1), *ph = off2 + (size_t)b * ns;
+  for (int s0 = 0; s0 < ns; s0 += BN_P2) {
+    int pb[BN_P2], pl[BN_P2], maxl = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const long long e = q + k * 64 + lane; const bool ok = e < e1;
-      g[k] = ok ? __builtin_nontemporal_load(G + e) : 0.0; a[k] = ok ? __builtin_nontemporal_load(val + e) : 0.0; r[k] = ok ? __builtin_nontemporal_load(row16 + e) : (unsigned short)wr;
+    for (int j = 0; j < BN_P2; j++) {
+      const int sg = s0 + j < ns ? s0 + j : ns - 1;
+      pb[j] = ph[sg]; pl[j] = s0 + j < ns ? lg[sg + 1] - lg[sg] : 0;
+      maxl = max(maxl, pl[j]);
     }
-    // the adds of one instruction go lane by lane, instructions in program order: a fixed order per row, run after run
+    for (int o = 0; o < maxl; o += 256) {                   // one round unless a piece is longer than 256 entries
+      double g[BN_P2][4], a[BN_P2][4]; unsigned short r[BN_P2][4];
 #pragma unroll
-    for (int k = 0; k < 8; k++) if (q + k * 64 + lane < e1) __hip_atomic_fetch_add(acc + r[k], a[k] * g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      for (int j = 0; j < BN_P2; j++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int e = o + k * 64 + lane; const bool ok = e < pl[j];
+          const long long p = (long long)pb[j] + e;
+          g[j][k] = ok ? __builtin_nontemporal_load(G + p) : 0.0; a[j][k] = ok ? __builtin_nontemporal_load(val + p) : 0.0; r[j][k] = ok ? __builtin_nontemporal_load(row16 + p) : (unsigned short)wr;
+        }
+      // the adds of one instruction go lane by lane, instructions in program order (piece after piece, entry after entry): a fixed order per
+      // row, run after run
+#pragma unroll
+      for (int j = 0; j < BN_P2; j++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (o + k * 64 + lane < pl[j]) __hip_atomic_fetch_add(acc + r[j][k], a[j][k] * g[j][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
   }
   for (int i = lane; i < wr; i += 64) { const long long row = (long long)b * wr + i; if (row < n) __builtin_nontemporal_store(rowscale ? rowscale[row] * acc[i] : acc[i], y + row); }
 }
@@ -935,12 +957,40 @@ static int build_binned(ks_mat A)
     for (int p = rp[r0]; p < rp[r1]; p++) L[col[p] / cs]++;
     for (int s = 0; s < ns; s++) L[s] = (L[s] + 1) & ~1;
   });
-  std::vector<int> off2((size_t)wb * ns);                 // bin-major start of (wb, s)
-  std::vector<long long> bstart(wb + 1);
+  // Bin-major order, GROUPED: `grp` consecutive wave-bins are interleaved slice by slice - [group][slice][wave-bin of the group]
+  // - so that the segments a slice's workgroup writes in phase 1 for `grp` consecutive wave-bins are one contiguous run (80 KB instead of 64
+  // pieces of 1.26 KB, each 0.6 MB from the next; the gather is store-bound: 436 -> 316-331 us in the stand-alone benchmark with uniform
+  // segments, profiles/r03_micro_binned_group.txt).
+  // A wave-bin's own entries are then no longer one stream but ns pieces: phase 2 walks them through a LOGICAL position (piece after piece)
+  // that a per-wave-bin table log2[wb][ns + 1] maps to the physical one (off2), window by window, the way phase 1 finds its destinations.
+  std::vector<int> off2((size_t)wb * ns);                 // physical start of segment (wb, s)
+  std::vector<int> log2((size_t)wb * (ns + 1));           // logical start of segment (wb, s) inside wave-bin wb; [ns]: the wave-bin's entry count
   long long run = 0;
-  for (int b = 0; b < wb; b++) { bstart[b] = run; for (int s = 0; s < ns; s++) { off2[(size_t)b * ns + s] = (int)run; run += len[(size_t)b * ns + s]; } }
-  bstart[wb] = run;
+  // wave-bins whose segments are adjacent per slice. Measured on config 5's matrix, one box (profiles/r03_ab_binned_groups.txt), phase 1 +
+  // phase 2: 1 (the old order): 445 + 488 us; 4: 404 + 507; 16: 390 + 511; 64: 386 + 500; 256: 388 + 511 - the gather gains what its
+  // stores gain from longer runs, the reduce pays a little for reading its pieces further apart.
+  int grp = 64; while (grp > 1 && wb % grp) grp /= 2;
+  for (int g = 0; g < wb / grp; g++)
+    for (int s = 0; s < ns; s++)
+      for (int wl = 0; wl < grp; wl++) { const int b = grp * g + wl; off2[(size_t)b * ns + s] = (int)run; run += len[(size_t)b * ns + s]; }
   const long long entries = run;
+  int nwin2 = 1;
+  for (int b = 0; b < wb; b++) {
+    int lrun = 0;
+    for (int s = 0; s < ns; s++) { log2[(size_t)b * (ns + 1) + s] = lrun; lrun += len[(size_t)b * ns + s]; }
+    log2[(size_t)b * (ns + 1) + ns] = lrun;
+    nwin2 = std::max(nwin2, (lrun + 511) / 512);
+  }
+  std::vector<int> wseg2((size_t)wb * nwin2, 0);          // segment in which the 512-entry window of wave-bin wb begins
+  for (int b = 0; b < wb; b++) {
+    const int *lg = log2.data() + (size_t)b * (ns + 1);
+    int sg = 0;
+    for (int wdw = 0; wdw < nwin2; wdw++) {
+      const int base = wdw * 512;
+      while (sg < ns - 1 && lg[sg + 1] <= base) sg++;
+      wseg2[(size_t)b * nwin2 + wdw] = sg;
+    }
+  }
   std::vector<int> off1((size_t)ns * (wb + 1)), off2t((size_t)ns * wb);
   std::vector<long long> sbase(ns + 1);
   long long srun = 0; int nwin = 1;
@@ -986,7 +1036,7 @@ static int build_binned(ks_mat A)
   };
   KS_CALL(up(&A->bn_col16, col16)); KS_CALL(up(&A->bn_row16, row16)); KS_CALL(up(&A->bn_val, val2));
   KS_CALL(up(&A->bn_off1, off1)); KS_CALL(up(&A->bn_off2t, off2t)); KS_CALL(up(&A->bn_wseg, wseg));
-  KS_CALL(up(&A->bn_sbase, sbase)); KS_CALL(up(&A->bn_bstart, bstart));
+  KS_CALL(up(&A->bn_sbase, sbase)); KS_CALL(up(&A->bn_off2, off2)); KS_CALL(up(&A->bn_log2, log2)); KS_CALL(up(&A->bn_wseg2, wseg2));
   KS_HIP(hipMalloc(&A->bn_g, sizeof(double) * std::max<long long>(entries, 1)));
   KS_HIP(hipMemset(A->bn_g, 0, sizeof(double) * std::max<long long>(entries, 1)));
   const int lds1 = cs * 8 + (2 * wb + 1) * 4, lds2 = 4 * (wr + 1) * 8;
@@ -999,11 +1049,11 @@ static int build_binned(ks_mat A)
   double nrm = 0.0;
   KS_CALL(ks_mat_norm_inf_local(A, &nrm));
   A->norm_inf_cache = nrm;
-  A->use_binned = true; A->bn_ns = ns; A->bn_cs = cs; A->bn_wb = wb; A->bn_wr = wr; A->bn_nwin = nwin; A->bn_entries = entries;
+  A->use_binned = true; A->bn_ns = ns; A->bn_cs = cs; A->bn_wb = wb; A->bn_wr = wr; A->bn_nwin = nwin; A->bn_nwin2 = nwin2; A->bn_entries = entries;
   hipFree(A->d_col); hipFree(A->d_val); A->d_col = nullptr; A->d_val = nullptr;
   } catch (const std::exception &) {                    // out of host memory (or anything else the build throws): the other layouts take the matrix
-    hipFree(A->bn_col16); hipFree(A->bn_row16); hipFree(A->bn_val); hipFree(A->bn_g); hipFree(A->bn_off1); hipFree(A->bn_off2t); hipFree(A->bn_wseg); hipFree(A->bn_sbase); hipFree(A->bn_bstart);
-    A->bn_col16 = A->bn_row16 = nullptr; A->bn_val = A->bn_g = nullptr; A->bn_off1 = A->bn_off2t = A->bn_wseg = nullptr; A->bn_sbase = A->bn_bstart = nullptr;
+    hipFree(A->bn_col16); hipFree(A->bn_row16); hipFree(A->bn_val); hipFree(A->bn_g); hipFree(A->bn_off1); hipFree(A->bn_off2t); hipFree(A->bn_wseg); hipFree(A->bn_sbase); hipFree(A->bn_off2); hipFree(A->bn_log2); hipFree(A->bn_wseg2);
+    A->bn_col16 = A->bn_row16 = nullptr; A->bn_val = A->bn_g = nullptr; A->bn_off1 = A->bn_off2t = A->bn_wseg = nullptr; A->bn_sbase = nullptr; A->bn_off2 = A->bn_log2 = A->bn_wseg2 = nullptr;
     hipFree(A->diag_cache); A->diag_cache = nullptr;
     (void)hipGetLastError();
   }
@@ -1317,7 +1367,7 @@ extern "C" int ks_mat_destroy(ks_mat A)
   hipFree(A->s_ptr); hipFree(A->s_len); hipFree(A->s_col); hipFree(A->s_val);
   hipFree(A->dc_codes); hipFree(A->dc_val); hipFree(A->dc_off); hipFree(A->dc_codes8); hipFree(A->dc_vals);
   hipFree(A->sl_rowptr); hipFree(A->sl_col); hipFree(A->sl_val); hipFree(A->sl_base); hipFree(A->ypart); hipFree(A->diag_cache);
-  hipFree(A->bn_col16); hipFree(A->bn_row16); hipFree(A->bn_val); hipFree(A->bn_g); hipFree(A->bn_off1); hipFree(A->bn_off2t); hipFree(A->bn_wseg); hipFree(A->bn_sbase); hipFree(A->bn_bstart);
+  hipFree(A->bn_col16); hipFree(A->bn_row16); hipFree(A->bn_val); hipFree(A->bn_g); hipFree(A->bn_off1); hipFree(A->bn_off2t); hipFree(A->bn_wseg); hipFree(A->bn_sbase); hipFree(A->bn_off2); hipFree(A->bn_log2); hipFree(A->bn_wseg2);
   delete A;
   return KS_SUCCESS;
 }
@@ -1388,7 +1438,8 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y, const double *row
     if (A->use_binned) {
       hipLaunchKernelGGL(k_binned_gather, dim3((unsigned)A->bn_ns), dim3(1024), (size_t)A->bn_cs * 8 + (size_t)(2 * A->bn_wb + 1) * 4, ctx->stream, A->n, A->bn_cs, A->bn_wb, A->bn_nwin,
                          A->bn_sbase, A->bn_col16, A->bn_off1, A->bn_off2t, A->bn_wseg, x, A->bn_g);
-      hipLaunchKernelGGL(k_binned_reduce, dim3((unsigned)(A->bn_wb / 4)), dim3(256), (size_t)4 * (A->bn_wr + 1) * 8, ctx->stream, A->n, A->bn_wr, A->bn_bstart, A->bn_g, A->bn_val, A->bn_row16, y, rowscale);
+      hipLaunchKernelGGL(k_binned_reduce, dim3((unsigned)(A->bn_wb / 4)), dim3(256), (size_t)4 * (A->bn_wr + 1) * 8, ctx->stream, A->n, A->bn_wr, A->bn_ns, A->bn_log2, A->bn_off2,
+                         A->bn_g, A->bn_val, A->bn_row16, y, rowscale);
     } else if (A->use_sliced) {
       const int per_xcd = std::max(1, std::min((A->n + 255) / 256, (ctx->num_cu / 8) * 8));       // 8 resident workgroups per CU of the XCD
       hipLaunchKernelGGL(k_spmv_sliced, dim3((unsigned)(8 * per_xcd)), dim3(256), 0, ctx->stream, A->n, A->nslice, A->sl_rowptr, A->sl_base, A->sl_col, A->sl_val, x, A->ypart);

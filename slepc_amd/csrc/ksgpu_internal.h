@@ -166,7 +166,7 @@ struct ks_mat_s {
   // (one padding entry with value 0 where needed). Phase 1 (a workgroup per slice, its piece of x in LDS) writes G = x[col] in bin-major
   // order; phase 2 (a wave per wave-bin, its rows of y in LDS) streams G, val and row and adds val * G into its rows.
   bool use_binned = false;
-  int bn_ns = 0, bn_cs = 0, bn_wb = 0, bn_wr = 0, bn_nwin = 0;
+  int bn_ns = 0, bn_cs = 0, bn_wb = 0, bn_wr = 0, bn_nwin = 0, bn_nwin2 = 0;
   long long bn_entries = 0;                   // entries incl. padding
   unsigned short *bn_col16 = nullptr, *bn_row16 = nullptr;
   double *bn_val = nullptr, *bn_g = nullptr;
@@ -174,7 +174,9 @@ struct ks_mat_s {
   int *bn_off2t = nullptr;                    // [ns][wb]     start of that segment in bin-major order
   int *bn_wseg = nullptr;                     // [ns][nwin]   segment in which the 1024-entry window of slice s begins
   long long *bn_sbase = nullptr;              // [ns + 1]     start of slice s in bn_col16
-  long long *bn_bstart = nullptr;             // [wb + 1]     start of wave-bin wb in bin-major order
+  int *bn_off2 = nullptr;                     // [wb][ns]     physical start of segment (wb, s): bin-major order GROUPED by phase-2 workgroup, [wb / 4][ns][wb % 4]
+  int *bn_log2 = nullptr;                     // [wb][ns + 1] logical start of that segment inside its wave-bin (piece after piece); [ns] = entries of the wave-bin
+  int *bn_wseg2 = nullptr;                    // [wb][nwin2]  segment in which the 512-entry logical window of wave-bin wb begins
   // off-diagonal block (columns owned by other ranks), compressed to ghost indices [0,nghost)
   int *o_rowptr = nullptr; int *o_col = nullptr; double *o_val = nullptr; long long nnz_o = 0;
   int nghost = 0;
