@@ -392,7 +392,8 @@ int ks_st_get_ksp_stats(ks_st st, long long *solves, long long *iterations, doub
    Launches of the speculative Gram-Schmidt slots that gated themselves off on the device are
    re-filed under KS_K_NOOP once the host has read back the pass counts.                          */
 enum { KS_K_SPMV = 0, KS_K_DOT, KS_K_GSFIN, KS_K_UPD_FUSED, KS_K_UPD, KS_K_SCALE, KS_K_MULTINPLACE, KS_K_COPY,
-       KS_K_MULT, KS_K_BVDOT, KS_K_NORM, KS_K_HALO, KS_K_ALLREDUCE, KS_K_NOOP, KS_K_OTHER, KS_K_COUNT };
+       KS_K_MULT, KS_K_BVDOT, KS_K_NORM, KS_K_HALO, KS_K_ALLREDUCE, KS_K_NOOP, KS_K_OTHER,
+       KS_K_SPMVDOT /* MatMult fused into the dot sweep that follows it (cache-resident bases, dictionary layout) */, KS_K_COUNT };
 #define KS_PROF_VARIANTS 65      /* variant = KT in 0..64 (every count up to 32 is compiled, then 40, 48, 56, 64) */
 int ks_prof_enable(ks_ctx ctx, int on);   /* 0: off, 1: every class, else a mask with bit (class+1) set per class to time */
 int ks_prof_reset(ks_ctx ctx);

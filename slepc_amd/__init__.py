@@ -39,7 +39,7 @@ EPS_ARBITRARY_FN = C.CFUNCTYPE(C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_
 EPS_MONITOR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_void_p)
 
 KCLASSES = ["spmv_csr", "bv_dot_sweep", "gs_bookkeeping", "gs_update_fused_dot", "gs_update", "bv_scale", "bv_multinplace",
-            "bv_copy", "bv_mult", "bv_dot_panel", "bv_norm", "halo_exchange", "allreduce", "gated_noop", "other"]
+            "bv_copy", "bv_mult", "bv_dot_panel", "bv_norm", "halo_exchange", "allreduce", "gated_noop", "other", "spmv_dot_fused"]
 # kernel symbol behind each (class, variant) as rocprofv3 --kernel-trace names it (16-byte-load forms)
 def kernel_symbol(name, var):
     if name == "spmv_csr":
@@ -47,6 +47,8 @@ def kernel_symbol(name, var):
                 else "k_spmv_sell<8>" if var == 8 else "k_spmv_csr_stream | k_spmv_csr<G, 4, false, false>")
     if name == "bv_dot_sweep":
         return "k_dot_sweep<%d, 2>" % var
+    if name == "spmv_dot_fused":
+        return "k_dot_spmv_dict<%d, W>" % var
     if name in ("gs_update_fused_dot", "gs_update") or (name == "gated_noop" and var > 0):
         return "k_gs_update<%d, 2, false>" % var        # (the ops->gramschmidt slot's passes run k_gs_update<KT, 2, true>)
     if name == "gs_bookkeeping":

@@ -145,7 +145,7 @@ extern "C" int ks_ctx_device_info(ks_ctx ctx, char *arch, int arch_len, int *num
 // ---- profiling ----------------------------------------------------------------------------------
 static const char *g_class_names[KS_K_COUNT] = {
   "spmv_csr", "bv_dot_sweep", "gs_bookkeeping", "gs_update_fused_dot", "gs_update", "bv_scale", "bv_multinplace", "bv_copy",
-  "bv_mult", "bv_dot_panel", "bv_norm", "halo_exchange", "allreduce", "gated_noop", "other" };
+  "bv_mult", "bv_dot_panel", "bv_norm", "halo_exchange", "allreduce", "gated_noop", "other", "spmv_dot_fused" };
 
 extern "C" const char *ks_prof_class_name(int k) { return (k >= 0 && k < KS_K_COUNT) ? g_class_names[k] : "?"; }
 

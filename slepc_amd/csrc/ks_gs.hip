@@ -676,10 +676,10 @@ int enqueue_gs_slots(ks_bv bv, int j, int normalize, int krylov, int first, int 
 }
 
 // Optimistic program of column j (against columns 0..j-1).
-int enqueue_fused_gs(ks_bv bv, int j, int normalize, int krylov)
+int enqueue_fused_gs(ks_bv bv, int j, int normalize, int krylov, bool dots_done = false)
 {
   KS_CHECK(bv->nc + j + 1 <= 8000, KS_ERR_SUP, "device-resident Gram-Schmidt supports at most 8000 columns");
-  if (!bv->matrix && bv->nc + j + 1 <= KS_MAX_COLS) KS_CALL(enqueue_dots(bv, j, krylov));      // with a matrix, or more than 64 coefficients, every slot starts with its own dots
+  if (!dots_done && !bv->matrix && bv->nc + j + 1 <= KS_MAX_COLS) KS_CALL(enqueue_dots(bv, j, krylov));      // with a matrix, or more than 64 coefficients, every slot starts with its own dots
   const int ns = spec_slots(bv), nt = total_slots(bv);
   const bool whole = (ns >= nt) && bv->orthog_ref == KS_BV_ORTHOG_REFINE_NEVER;
   if (whole) return enqueue_gs_slots(bv, j, normalize, krylov, 1, nt, false, true);
@@ -1250,8 +1250,10 @@ static int krylov_run(ks_bv V, ks_mat A, int k, int *m, double *beta, int *break
     while (j0 < m0 && !lin) {
       KS_CALL(begin_run(V));
       for (int j = j0; j < m0; j++) {
-        KS_CALL(ks_mat_mult_internal(A, ks_bv_col(V, j), ks_bv_col(V, j + 1)));    // BVMatMultColumn (not gated: harmless after a halt)
-        KS_CALL(enqueue_fused_gs(V, j + 1, 1, 1));
+        bool dots_done = false;                                                      // the product inside the first dot sweep where that pays (small problems)
+        KS_CALL(ks_mat_mult_dot_fused(A, V, ks_bv_col(V, j), j + 1, true, &dots_done));
+        if (!dots_done) KS_CALL(ks_mat_mult_internal(A, ks_bv_col(V, j), ks_bv_col(V, j + 1)));    // BVMatMultColumn (not gated: harmless after a halt)
+        KS_CALL(enqueue_fused_gs(V, j + 1, 1, 1, dots_done));
       }
       KsGsState st; std::vector<KsStepRec> recs(m0 - j0);
       buf.resize((size_t)V->m * (V->nc + V->m));

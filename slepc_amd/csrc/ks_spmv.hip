@@ -347,6 +347,87 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_dict(int nrows, const uint4
   }
 }
 
+// ---- dictionary product fused into the dot sweep that follows it --------------------------------------------------------------------
+// A Krylov step is y = A x followed by the dot products of y with the basis columns (and itself). While the basis is resident in the
+// Infinity Cache (config 1 and 2: a step is five dependent launches of 5 - 30 us each) the product is worth a launch of its own no longer:
+// the dictionary layout is row-local (lane = row), so the dot sweep's tile loop computes its two rows of y itself - same entry order and fma
+// chain as k_spmv_dict, same bits -, stores them, and uses them from registers as the vector of the dots and as the last "column". One
+// launch, one kernel boundary and one read of y less per step. Not for bases that stream from HBM: the sweep's tiles are interleaved over
+// the XCDs, so the stencil's far neighbours (+-nx*ny) would miss the tile's L2 where k_spmv_dict, which gives every XCD one contiguous
+// range of rows, hits it.
+template <int W>
+__device__ __forceinline__ double dict_row(const uint4 *__restrict__ codes, long long r, const double *sv, const int *so, const double *__restrict__ x)
+{
+  constexpr int Q = W / 8;
+  uint4 c[Q];
+#pragma unroll
+  for (int q = 0; q < Q; q++) c[q] = codes[r * Q + q];
+  double a[W], xv[W];
+#pragma unroll
+  for (int q = 0; q < Q; q++) {
+    const unsigned wds[4] = {c[q].x, c[q].y, c[q].z, c[q].w};
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const unsigned code = (wds[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+      const unsigned oc = code & 0xffu, vc = code >> 8;
+      const bool ok = vc != 255u;
+      a[q * 8 + e] = ok ? sv[vc] : 0.0;
+      xv[q * 8 + e] = ok ? x[r + so[oc]] : 0.0;
+    }
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int e = 0; e < W; e++) acc = fma(a[e], xv[e], acc);
+  return acc;
+}
+template <int KT, int W>
+__global__ __launch_bounds__(ksk::SW_BLOCK) void k_dot_spmv_dict(const double *__restrict__ Vb, long long ld, int n, int ncols, const uint4 *__restrict__ codes,
+                                                                 const double *__restrict__ dval, int nval, const int *__restrict__ doff, int noff,
+                                                                 const double *__restrict__ x, double *__restrict__ y, double *__restrict__ partials,
+                                                                 const KsGsState *__restrict__ gate, int *__restrict__ pgrid, int rev)
+{
+  using namespace ksk;
+  if (gate && !gate->active) return;
+  __shared__ double sv[256];
+  __shared__ int so[256];
+  for (int i = threadIdx.x; i < nval; i += SW_BLOCK) sv[i] = dval[i];
+  for (int i = threadIdx.x; i < noff; i += SW_BLOCK) so[i] = doff[i];
+  __syncthreads();
+  if (pgrid && blockIdx.x == 0 && threadIdx.x == 0) *pgrid = gridDim.x;
+  double acc[KT];
+#pragma unroll
+  for (int i = 0; i < KT; i++) acc[i] = 0.0;
+  const int nprev = ncols - 1;                               // basis columns in memory; the last "column" is y itself
+  const long long tile = (long long)SW_BLOCK * 2, ntiles = ((long long)n + tile - 1) / tile;
+  for (long long t0 = blockIdx.x; t0 < ntiles; t0 += gridDim.x) {
+    const long long t = rev ? ntiles - 1 - t0 : t0;
+    const long long r = t * tile + (long long)threadIdx.x * 2;
+    if (r + 1 < n) {
+      double2 xv[KT];
+#pragma unroll
+      for (int i = 0; i < KT; i++) { const int ii = i < nprev ? i : (nprev > 0 ? nprev - 1 : 0); if (nprev > 0) xv[i] = ldplain2(Vb + (long long)ii * ld + r); else xv[i] = double2{0.0, 0.0}; }
+      double2 yv;
+      yv.x = dict_row<W>(codes, r, sv, so, x); yv.y = dict_row<W>(codes, r + 1, sv, so, x);
+      *reinterpret_cast<double2 *>(y + r) = yv;
+#pragma unroll
+      for (int i = 0; i < KT; i++) {
+        const double2 c = (i == nprev) ? yv : xv[i];
+        acc[i] = fma(c.x, yv.x, acc[i]); acc[i] = fma(c.y, yv.y, acc[i]);
+      }
+    } else if (r < n) {
+      const double yv = dict_row<W>(codes, r, sv, so, x);
+      y[r] = yv;
+#pragma unroll
+      for (int i = 0; i < KT; i++) {
+        const int ii = i < nprev ? i : (nprev > 0 ? nprev - 1 : 0);
+        const double c = (i == nprev) ? yv : (nprev > 0 ? Vb[(long long)ii * ld + r] : 0.0);
+        acc[i] = fma(c, yv, acc[i]);
+      }
+    }
+  }
+  block_write_partials<KT>(acc, ncols, partials);
+}
+
 // Offset-dictionary ELL: the matrix has arbitrary values (variable-coefficient stencils) but still only a few distinct column
 // offsets. The index of an entry shrinks from 4 bytes to 1 (code 255 = padding); the values stay full doubles, stored
 // slice-column-major like SELL-64 so that a wave reads 512 contiguous bytes per entry slot. 7-point stencil: 80 bytes per row
@@ -1237,6 +1318,40 @@ int build_sell(ks_mat A)
 }
 
 } // namespace
+
+// y = A x fused with the dot sweep of y against the ncols - 1 columns in front of it (and itself), where that pays: a single rank, the
+// dictionary layout, no B-inner product, a basis that lives in the Infinity Cache, two-row tiles. *done = false: the caller runs the
+// product and the dots as separate launches. y must be column jy of bv; the dots are those ksk_dot(bv, col(-nc), ld, nc + jy + 1, y) leaves.
+int ks_mat_mult_dot_fused(ks_mat A, ks_bv bv, const double *x, int jy, bool gate, bool *done)
+{
+  *done = false;
+  ks_ctx ctx = A->ctx;
+  const int ncols = bv->nc + jy + 1;
+  const double *Vb = ks_bv_col(bv, -bv->nc);
+  double *y = ks_bv_col(bv, jy);
+  if (!A->use_dict || A->shell_mult || ks_is_multi(ctx) || A->n_orows > 0 || bv->matrix || A->n != bv->n) return KS_SUCCESS;
+  if (ncols < 1 || ncols > KS_MAX_COLS || bv->ld % 2 || (((uintptr_t)Vb) & 15) || (((uintptr_t)y) & 15)) return KS_SUCCESS;
+  if (!ksk::ks_basis_is_cache_resident((size_t)(bv->nc + bv->m), (size_t)bv->ld)) return KS_SUCCESS;
+  if (getenv("KSGPU_NO_SPMV_DOT")) return KS_SUCCESS;        // A/B switch
+  const int dot_per_cu = std::max(1, std::min(4, (30 + ncols - 1) / ncols));          // the grid ksk_dot would use: the partials, and so the bits, are the same
+  const int grid = ks_sweep_grid_for(ctx, bv->n, 2, nullptr, dot_per_cu);
+  const int rev = bv->sweep_dir; bv->sweep_dir ^= 1;
+  bv->spec.valid = false; bv->last_grid = grid;
+  const KsGsState *g = gate ? bv->gs : nullptr;
+  KsProfScope ps(ctx, KS_K_SPMVDOT, 8.0 * bv->n * ncols + 12.0 * A->nnz + 4.0 * (A->n + 1) + 16.0 * A->n, ks_kt_for(ncols), 8.0 * bv->n * ncols + (2.0 * A->dict_w + 8.0) * A->n);
+#define LAUNCH_FD(KT)                                                                                                                                      \
+  do {                                                                                                                                                     \
+    if (A->dict_w == 8) hipLaunchKernelGGL((k_dot_spmv_dict<KT, 8>), dim3(grid), dim3(ksk::SW_BLOCK), 0, ctx->stream, Vb, (long long)bv->ld, bv->n, ncols, (const uint4 *)A->dc_codes, A->dc_val, A->dict_nval, A->dc_off, A->dict_noff, x, y, bv->partials, g, &bv->gs->pgrid, rev); \
+    else if (A->dict_w == 16) hipLaunchKernelGGL((k_dot_spmv_dict<KT, 16>), dim3(grid), dim3(ksk::SW_BLOCK), 0, ctx->stream, Vb, (long long)bv->ld, bv->n, ncols, (const uint4 *)A->dc_codes, A->dc_val, A->dict_nval, A->dc_off, A->dict_noff, x, y, bv->partials, g, &bv->gs->pgrid, rev); \
+    else return KS_SUCCESS;                                                                                                                                \
+  } while (0)
+  if (A->dict_w != 8 && A->dict_w != 16) return KS_SUCCESS;
+  KS_KT_DISPATCH(ncols, LAUNCH_FD);
+#undef LAUNCH_FD
+  KS_HIP(hipGetLastError());
+  *done = true;
+  return KS_SUCCESS;
+}
 
 extern "C" int ks_mat_create_csr(ks_ctx ctx, int n_local, int row_start, int n_global, const int *rowptr, const int *col, const double *val, ks_mat *out)
 {

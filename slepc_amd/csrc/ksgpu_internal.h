@@ -304,7 +304,8 @@ int ksk_scale(ks_ctx ctx, double *x, size_t n, double alpha);
 int ksk_copy(ks_ctx ctx, const double *src, double *dst, size_t n);
 
 int ks_mat_mult_internal(ks_mat A, const double *x, double *y, const double *rowscale = nullptr);   // rowscale: y = rowscale .* (A x) where the layout can fold it into its last pass (else the caller scales)
-bool ks_mat_can_rowscale(ks_mat A);                                 // the product can take a row scaling in the same launches
+bool ks_mat_can_rowscale(ks_mat A);
+int ks_mat_mult_dot_fused(ks_mat A, ks_bv bv, const double *x, int jy, bool gate, bool *done);   // y = A x inside the dot sweep of column jy (ks_spmv.hip); *done = false: not applicable                                 // the product can take a row scaling in the same launches
 int ks_bv_orthonormalize_coefs(ks_bv bv, int j, double *H, double *norm, int *lindep);
 bool ks_bv_orthonormalize_can_split(ks_bv bv);
 int ks_bv_orthonormalize_enqueue(ks_bv bv, int j);

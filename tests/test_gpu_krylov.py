@@ -723,3 +723,40 @@ def test_c_program_against_the_abi(tmp_path):
     lam = gi.eigenvalues_line(r.stdout)
     ref = gi.eigenvalues_line(gi.read("eps/ex2_1.out")); alt = gi.eigenvalues_line(gi.read("eps/ex2_1_alt.out"))
     assert len(lam) == 4 and all(min(abs(l - a), abs(l - b)) < 1.5e-5 for l, a, b in zip(lam, ref, alt))
+
+
+@pytest.mark.parametrize("shape", [("2d", 300), ("3d", 40), ("2d_odd", 301)])
+def test_spmv_fused_into_the_dot_sweep_gives_the_same_bits(ctx, monkeypatch, shape):
+    """Small problems (basis resident in the Infinity Cache, dictionary layout) run y = A x inside the dot sweep that follows it
+    (k_dot_spmv_dict): same entry order and fma chain for y, same tiles and grid for the dots - the Lanczos coefficients and the basis are
+    bit for bit those of the separate launches (KSGPU_NO_SPMV_DOT=1), and both match the oracle."""
+    import slepc_amd as ks
+    kind, N = shape
+    if kind.startswith("2d"):
+        mk = lambda: ks.Mat.laplacian2d(ctx, N); Ao = O.laplacian2d(N)        # noqa: E731
+    else:
+        mk = lambda: ks.Mat.laplacian3d(ctx, N, N, N); Ao = O.laplacian3d(N, N, N)      # noqa: E731
+    m = 14
+    outs = []
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("KSGPU_NO_SPMV_DOT", "1")
+        A = mk(); assert A.layout() == "dict"
+        V = ks.BV(ctx, A.n, m + 1)
+        V.SetRandomColumn(0)
+        _, nrm, _ = V.OrthogonalizeColumn(0); V.ScaleColumn(0, 1.0 / nrm)
+        T = np.zeros((m + 1, 3), order="F")
+        ctx.prof_enable(True); ctx.prof_reset()
+        r = V.MatLanczos(A, T, 0, m)
+        ctx.synchronize()
+        p = ctx.prof_get(); ctx.prof_enable(False)
+        outs.append((T.copy(), V.dense(), r, p))
+    monkeypatch.delenv("KSGPU_NO_SPMV_DOT")
+    assert outs[0][3].get("spmv_dot_fused", {}).get("launches", 0) == m and outs[0][3].get("spmv_csr", {}).get("launches", 0) == 0
+    assert outs[1][3].get("spmv_dot_fused", {}).get("launches", 0) == 0 and outs[1][3].get("spmv_csr", {}).get("launches", 0) == m
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+    Vo = O.BV(Ao.n, m + 1); Vo.SetRandomColumn(0)
+    _, nrm, _ = Vo.OrthogonalizeColumn(0); Vo.ScaleColumn(0, 1.0 / nrm)
+    To = np.zeros((m + 1, 3), order="F")
+    Vo.MatLanczos(Ao, To, 0, m)
+    assert np.allclose(outs[0][0][:m, :2], To[:m, :2], rtol=1e-11, atol=1e-12)
