@@ -39,7 +39,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
 NEV, NCV = 10, 30
 UPD_CLASSES = ["gs_update_fused_dot", "gs_update", "gated_noop"]
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_r02.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this command
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_r03.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this command
 
 
 class Phases:
