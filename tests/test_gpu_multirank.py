@@ -109,6 +109,28 @@ def _worker(rank, world, port, q):
         d = V.DotVecEnd(V.column_ptr(m), a); nrm1 = V.NormColumnEnd(1)
         res["split"] = float(max(np.abs(d - V.DotVec(V.column_ptr(m))).max(), abs(nrm1 - V.NormColumn(1))))
         V.SetActiveColumns(0, m + 1)
+        # (2b) the ops->gramschmidt slot across ranks, with pass chaining (ks_bv_set_state): BVOrthogonalizeGS's loop on the caller's side, every pass
+        # one dot sweep (first pass only) + reduce / allreduce + update launch; the chained pass reduces the partial sums the update kernel left
+        Xg = np.random.default_rng(9).standard_normal((Aglob.n, 6))
+        Xg[:, 3] = Xg[:, 0] + 2.0 ** -10 * Xg[:, 3]; Xg[:, 5] = Xg[:, 1] - 2.0 * Xg[:, 2] + 2.0 ** -12 * Xg[:, 5]
+        W = ks.BV(ctx, r1 - r0, 6, N=Aglob.n, row_start=r0)
+        W.set_dense(Xg[r0:r1])
+        wbuf = W.buffer_ptr(); state = 1; slot = []
+        for j in range(6):
+            if j > 0:
+                ctx.memset(wbuf + 8 * j * 6, 0, 8 * j)
+            W.SetState(state)
+            onrm, nrm = W.GramSchmidtPass(j); passes = 1
+            while passes < 3 and nrm != 0.0 and abs(nrm) < 0.7071 * abs(onrm):
+                passes += 1
+                W.SetState(state)
+                onrm, nrm = W.GramSchmidtPass(j)
+            ctx.memcpy_h2d(wbuf + 8 * (j * 6 + j), np.array([nrm])); state += 1
+            W.ScaleColumn(j, 1.0 / nrm); state += 1
+            slot.append((nrm, passes))
+        res["slot"] = slot; res["slot_H"] = W.buffer(); res["slot_chain"] = W.GsChainStats()
+        M6 = np.zeros((6, 6), order="F"); W.SetActiveColumns(0, 6); W.Dot(W, M6)
+        res["slot_orth"] = float(np.abs(M6 - np.eye(6)).max())
         # (3) full Krylov-Schur solve, replicated control flow
         eps = ks.EPS(ctx); eps.SetOperators(A); eps.SetProblemType(ks.EPS_HEP); eps.SetDimensions(3, 12); eps.Solve()
         res["eig"] = [eps.GetEigenvalue(i)[0] for i in range(3)]
@@ -206,6 +228,27 @@ def test_ranks_sharing_one_gpu_against_oracle(world):
         assert o["nconv"] == r.nconv and o["its"] == r.its
         assert np.allclose(o["eig"], r.eigr[r.perm][:3], rtol=1e-10)
         assert max(o["err"]) < 1e-8
+    # the slot across ranks: identical pass counts and (replicated) scalars on every rank, coefficients as the single-rank oracle's, every
+    # pass after a column's first chained to the dots its predecessor left
+    Xg = np.random.default_rng(9).standard_normal((A.n, 6))
+    Xg[:, 3] = Xg[:, 0] + 2.0 ** -10 * Xg[:, 3]; Xg[:, 5] = Xg[:, 1] - 2.0 * Xg[:, 2] + 2.0 ** -12 * Xg[:, 5]
+    Wo = O.BV(A.n, 6)
+    for j in range(6):
+        Wo.set_column(j, Xg[:, j])
+    oref = []
+    for j in range(6):
+        _, nrm, lin = Wo.OrthogonalizeColumn(j); oref.append((nrm, Wo.passes_last())); Wo.ScaleColumn(j, 1.0 / nrm)
+    Bo = np.array(Wo.buffer)
+    for rk in range(world):
+        o = out[rk]
+        assert [p for _, p in o["slot"]] == [p for _, p in oref], (o["slot"], oref)
+        assert np.allclose([x for x, _ in o["slot"]], [x for x, _ in oref], rtol=1e-7)
+        for j in range(1, 6):
+            assert np.allclose(o["slot_H"][:j, j], Bo[:j, j], rtol=1e-7, atol=1e-9), j
+        assert o["slot_orth"] < 1e-12
+        total = sum(p for _, p in o["slot"][1:])
+        assert o["slot_chain"] == {"chained": total - 5, "fresh": 5} and total - 5 >= 2
+        assert o["slot"] == out[0]["slot"]
     Cg = np.random.default_rng(5).standard_normal((A.n, 2))
     rd = O.eps_krylovschur_hep(A, 3, ncv=12, deflation=Cg)
     rw = O.eps_krylovschur_hep(A, 20, ncv=70)
