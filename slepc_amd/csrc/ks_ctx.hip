@@ -68,12 +68,13 @@ extern "C" int ks_ctx_create(int device, void *stream, ks_ctx *out)
   }
   { const char *ho = getenv("KSGPU_HALO_OVERLAP"); ctx->halo_overlap = !(ho && atoi(ho) == 0); }   // safety switch of a path no multi-GPU box has run yet
   ctx->h_pinned_len = KS_PINNED_D2H_BYTES / sizeof(double) + 2 * KS_PINNED_H2D_DOUBLES;
-  e = hipHostMalloc((void **)&ctx->h_pinned, ctx->h_pinned_len * sizeof(double), hipHostMallocDefault);
+  e = hipHostMalloc((void **)&ctx->h_pinned, ctx->h_pinned_len * sizeof(double), hipHostMallocMapped);
   if (e != hipSuccess) {
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     KS_FAIL(KS_ERR_MEM, "hipHostMalloc of the staging area failed: %s", hipGetErrorString(e));
   }
+  if (getenv("KSGPU_NO_HOST_WRITES") || hipHostGetDevicePointer(&ctx->h_pinned_dev, ctx->h_pinned, 0) != hipSuccess) { (void)hipGetLastError(); ctx->h_pinned_dev = nullptr; }
   *out = ctx;
   return KS_SUCCESS;
 }

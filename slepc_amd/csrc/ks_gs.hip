@@ -704,6 +704,27 @@ int begin_run(ks_bv bv)
 
 struct HostGs { KsGsState st; };
 
+// state, records and coefficient buffer straight into the pinned host area (mapped into the device's address space): one small launch
+// instead of three copy-engine transfers, which sat 16 us apart at the end of every Krylov run (profiles/r03_config2_kernel_trace_gaps.txt)
+__global__ __launch_bounds__(256) void k_results_to_host(const KsGsState *__restrict__ st, const KsStepRec *__restrict__ recs, int nrec, const double *__restrict__ coef, size_t coef_len,
+                                                         char *__restrict__ out, size_t off_rec, size_t off_coef)
+{
+  const unsigned *a = reinterpret_cast<const unsigned *>(st); unsigned *o = reinterpret_cast<unsigned *>(out);
+  for (size_t i = threadIdx.x; i < sizeof(KsGsState) / 4; i += blockDim.x) o[i] = a[i];
+  const unsigned *r = reinterpret_cast<const unsigned *>(recs); unsigned *orr = reinterpret_cast<unsigned *>(out + off_rec);
+  for (size_t i = threadIdx.x; i < (size_t)nrec * sizeof(KsStepRec) / 4; i += blockDim.x) orr[i] = r[i];
+  double *oc = reinterpret_cast<double *>(out + off_coef);
+  for (size_t i = threadIdx.x; i < coef_len; i += blockDim.x) oc[i] = coef[i];
+}
+static_assert(sizeof(KsGsState) % 4 == 0 && sizeof(KsStepRec) % 4 == 0, "word copies");
+bool enqueue_results_to_host(ks_bv bv, int j0, size_t nrec, size_t coef_len, size_t off_rec, size_t off_coef)
+{
+  ks_ctx ctx = bv->ctx;
+  if (!ctx->h_pinned_dev) return false;
+  hipLaunchKernelGGL(k_results_to_host, dim3(1), dim3(256), 0, ctx->stream, bv->gs, nrec ? bv->recs + j0 : bv->recs, (int)nrec, bv->buffer, coef_len, (char *)ctx->h_pinned_dev, off_rec, off_coef);
+  return hipGetLastError() == hipSuccess;
+}
+
 // One host wait for everything the host wants to know after an enqueued run: the device state, the records of columns j0..j1 and
 // (coef_out) the whole coefficient buffer, all copied into the context's pinned area by copies enqueued back to back. Between a
 // Lanczos run and the restart this wait, the host's projected solve and the upload of Q are all the GPU idles for; copies into
@@ -716,9 +737,11 @@ int fetch_state(ks_bv bv, KsGsState *st, KsStepRec *recs, int j0, int j1, double
   const size_t need = off_coef + coef_len * sizeof(double);
   char *pin = (char *)ctx->h_pinned;
   if (need <= KS_PINNED_D2H_BYTES) {
-    KS_HIP(hipMemcpyAsync(pin, bv->gs, sizeof(KsGsState), hipMemcpyDeviceToHost, ctx->stream));
-    if (nrec) KS_HIP(hipMemcpyAsync(pin + off_rec, bv->recs + j0, sizeof(KsStepRec) * nrec, hipMemcpyDeviceToHost, ctx->stream));
-    if (coef_len) KS_HIP(hipMemcpyAsync(pin + off_coef, bv->buffer, sizeof(double) * coef_len, hipMemcpyDeviceToHost, ctx->stream));
+    if (!enqueue_results_to_host(bv, j0, nrec, coef_len, off_rec, off_coef)) {
+      KS_HIP(hipMemcpyAsync(pin, bv->gs, sizeof(KsGsState), hipMemcpyDeviceToHost, ctx->stream));
+      if (nrec) KS_HIP(hipMemcpyAsync(pin + off_rec, bv->recs + j0, sizeof(KsStepRec) * nrec, hipMemcpyDeviceToHost, ctx->stream));
+      if (coef_len) KS_HIP(hipMemcpyAsync(pin + off_coef, bv->buffer, sizeof(double) * coef_len, hipMemcpyDeviceToHost, ctx->stream));
+    }
     KS_HIP(ks_sync(ctx));
     memcpy(st, pin, sizeof(KsGsState));
     if (nrec) memcpy(recs, pin + off_rec, sizeof(KsStepRec) * nrec);
@@ -746,9 +769,11 @@ bool fetch_state_begin(ks_bv bv, int j0, int j1, size_t coef_len, int *rc)
   char *pin = (char *)ctx->h_pinned;
   auto chk = [&](hipError_t e) { if (e != hipSuccess && *rc == KS_SUCCESS) { ks_set_error("fetch_state_begin: %s", hipGetErrorString(e)); *rc = KS_ERR_LIB; } };
   if (!ctx->ev_fetch) chk(hipEventCreateWithFlags(&ctx->ev_fetch, hipEventDisableTiming));
-  chk(hipMemcpyAsync(pin, bv->gs, sizeof(KsGsState), hipMemcpyDeviceToHost, ctx->stream));
-  if (nrec) chk(hipMemcpyAsync(pin + off_rec, bv->recs + j0, sizeof(KsStepRec) * nrec, hipMemcpyDeviceToHost, ctx->stream));
-  if (coef_len) chk(hipMemcpyAsync(pin + off_coef, bv->buffer, sizeof(double) * coef_len, hipMemcpyDeviceToHost, ctx->stream));
+  if (!enqueue_results_to_host(bv, j0, nrec, coef_len, off_rec, off_coef)) {
+    chk(hipMemcpyAsync(pin, bv->gs, sizeof(KsGsState), hipMemcpyDeviceToHost, ctx->stream));
+    if (nrec) chk(hipMemcpyAsync(pin + off_rec, bv->recs + j0, sizeof(KsStepRec) * nrec, hipMemcpyDeviceToHost, ctx->stream));
+    if (coef_len) chk(hipMemcpyAsync(pin + off_coef, bv->buffer, sizeof(double) * coef_len, hipMemcpyDeviceToHost, ctx->stream));
+  }
   if (*rc == KS_SUCCESS) chk(hipEventRecord(ctx->ev_fetch, ctx->stream));
   return true;
 }

@@ -137,7 +137,6 @@ __global__ __launch_bounds__(256) void k_spmv_csr_stream(int n, const int *__res
 // lane assignment touch still more lines.)
 constexpr int CW_PAD = 8;                                  // col / val allocations are this much longer than nnz
 constexpr int CW_STEPS_MAX = 8;                            // 64 entries per step, chunks of 512 (row side with 256-entry chunks: 62 registers, 8 waves per SIMD, and 237 us instead of 199)
-constexpr int CW_U = 4;                                    // row side: gathers in flight per lane
 __device__ __forceinline__ int cw_slot(int e) { return e + (e >> 5); }     // one slot of skew per 32 entries (rows whose length is a multiple of 32)
 // Load width matters more than instruction count here: 4-byte-per-lane streaming loads top out at 0.7 - 2.5 TB/s on this part, 8- and 16-byte
 // ones at 7 (scripts/micro/load_width.hip, profiles/r03_micro_load_width.txt). So the 4-byte column indices are loaded two per lane (a chunk
@@ -171,6 +170,7 @@ __device__ __forceinline__ CwRows cw_rows(int n, const int *__restrict__ rp, int
   q.E0 = rp[r0]; q.E1 = rp[r0 + 64 < n ? r0 + 64 : n];                 // the wave's run of entries (uniform: scalar loads)
   return q;
 }
+constexpr int CW_U = 4;                                    // row side: gathers in flight per lane (8: 110 registers, 4 waves per SIMD, 204 us; 2 or 3 at 6 waves per SIMD still spill)
 template <bool ROWSIDE, int CW_STEPS>
 __global__ __launch_bounds__(256, ROWSIDE ? 5 : 4) void k_spmv_csr_wave(int n, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
                                                        const double *__restrict__ x, double *__restrict__ y, int xcd_remap)

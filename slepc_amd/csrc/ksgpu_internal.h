@@ -83,6 +83,7 @@ struct ks_ctx_s {
   // pinned host staging: [0, KS_PINNED_D2H_BYTES) results coming back (state, records, coefficient buffer), then two halves of
   // KS_PINNED_H2D_DOUBLES doubles for coefficient uploads (alternating; an event per half says when its last upload has left)
   double *h_pinned = nullptr; size_t h_pinned_len = 0;
+  void *h_pinned_dev = nullptr;        // the same area as the device sees it (results written by a kernel instead of the copy engine); nullptr: not mapped
   hipEvent_t ev_h2d[2] = {nullptr, nullptr}; int h2d_next = 0;
   hipEvent_t ev_fetch = nullptr;        // marks the end of a batch of result copies that was enqueued ahead of further work (ks_gs.hip: fetch_state_begin / _end)
   KsGsMail *gs_mail = nullptr, *gs_mail_dev = nullptr;   // ops->gramschmidt slot: host mailbox and its device address (allocated on first use)
