@@ -74,7 +74,7 @@ extern "C" int ks_ctx_create(int device, void *stream, ks_ctx *out)
     delete ctx;
     KS_FAIL(KS_ERR_MEM, "hipHostMalloc of the staging area failed: %s", hipGetErrorString(e));
   }
-  if (getenv("KSGPU_NO_HOST_WRITES") || hipHostGetDevicePointer(&ctx->h_pinned_dev, ctx->h_pinned, 0) != hipSuccess) { (void)hipGetLastError(); ctx->h_pinned_dev = nullptr; }
+  if (hipHostGetDevicePointer(&ctx->h_pinned_dev, ctx->h_pinned, 0) != hipSuccess) { (void)hipGetLastError(); ctx->h_pinned_dev = nullptr; }     // nullptr: results come back through the copy engine
   *out = ctx;
   return KS_SUCCESS;
 }
