@@ -468,3 +468,19 @@ def test_config5_at_its_stated_size_step_capped(ctx):
     V.SetActiveColumns(0, m)
     M = np.zeros((m, m), order="F"); V.Dot(V, M)
     assert np.abs(M - np.eye(m)).max() < 1e-12
+
+
+def test_config5_against_the_independent_dense_fixture(ctx):
+    """The GPU's generalized shift-and-invert solve of the config-5-shaped pencil at n = 900 against the committed LAPACK (dense dggev) eigenvalues
+    of the same pencil (tests/golden/c5/): 1e-9 relative, closest to the target first - a known answer that neither the oracle nor this library produced."""
+    import json
+    import os
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c5", "c5_n900_target36.json")))
+    Ao, Bo = nc.config5_pencil(fx["n"])
+    eps, st = _solve_c5(ctx, Ao, Bo, 6, 24, fx["target"], 1e-14)
+    assert eps.GetConverged() >= 6
+    got = np.array([complex(*eps.GetEigenvalue(i)) for i in range(6)])
+    want = np.array([complex(*z) for z in fx["eigenvalues_by_distance_to_target"]])
+    for k in range(6):
+        assert np.abs(want[:8] - got[k]).min() <= 1e-9 * abs(got[k]), (k, got[k])
+    assert np.all(np.diff(np.abs(got - fx["target"])) >= -1e-9)

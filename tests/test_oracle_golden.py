@@ -1,4 +1,5 @@
 """Pins the CPU oracle against the reference's own golden outputs (CPU only, no GPU needed)."""
+import os
 import numpy as np
 import pytest
 
@@ -644,3 +645,28 @@ def test_eps_test1_nopurify_golden():
     assert np.allclose(np.round(r.eigr[r.perm][:4], 5), gi.eigenvalues_line(gi.read("eps/eps_test1_1.out")), atol=1.5e-5)
     X = np.stack([r.V.column(j) for j in range(r.nconv)], axis=1)
     assert np.abs(X.T @ (B.to_scipy() @ X) - np.eye(r.nconv)).max() < 1e-8
+
+
+def test_config5_oracle_against_the_independent_dense_fixture():
+    """Config 5 has no reference-held fixture (its shift-and-invert tests use PETSc's LU, absent here). The oracle's generalized shift-and-invert
+    Krylov-Schur is pinned instead against LAPACK's dense generalized eigensolver on the same pencil at n = 900 (tests/golden/c5/, generated by
+    the script next to it - a different algorithm in a different library): the generator's arrays by checksum, the eigenvalues nearest the target
+    to 1e-9 relative, in the same order."""
+    import hashlib
+    import json
+    import nhep_cases as nc
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c5", "c5_n900_target36.json")))
+    A, B = nc.config5_pencil(fx["n"])
+    for key, arr in (("A.rowptr", A.rowptr), ("A.col", A.col), ("A.val", A.val), ("B.rowptr", B.rowptr), ("B.col", B.col), ("B.val", B.val)):
+        assert hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest() == fx["sha256"][key], key
+    sigma = fx["target"]
+    r = O.eps_krylovschur_nhep(A, 6, ncv=24, which=O.which_target_magnitude(sigma), st=O.ST(A, B, "sinvert", sigma))
+    assert r.nconv >= 6
+    got = np.array([complex(r.eigr[j], r.eigi[j]) for j in r.perm[:6]])
+    want = np.array([complex(*z) for z in fx["eigenvalues_by_distance_to_target"]])
+    # conjugate pairs are equidistant from a real target: compare as sets of pairs, in order of distance
+    for k in range(6):
+        d = np.abs(want[:8] - got[k]).min()
+        assert d <= 1e-9 * abs(got[k]), (k, got[k], want[:8])
+    assert np.all(np.diff(np.abs(got - sigma)) >= -1e-9)
+    assert abs(np.abs(got[0] - sigma) - np.abs(want[0] - sigma)) <= 1e-9 * abs(want[0])
