@@ -670,3 +670,23 @@ def test_config5_oracle_against_the_independent_dense_fixture():
         assert d <= 1e-9 * abs(got[k]), (k, got[k], want[:8])
     assert np.all(np.diff(np.abs(got - sigma)) >= -1e-9)
     assert abs(np.abs(got[0] - sigma) - np.abs(want[0] - sigma)) <= 1e-9 * abs(want[0])
+
+
+def test_openmp_oracle_multinplace_equals_the_serial_one():
+    """The OpenMP build of the oracle (the CPU baseline leg of bench.py) splits BVMultInPlace's independent 64-row blocks over its team:
+    same bits as the serial build, on a size with a partial first block and several blocks per thread."""
+    n, m = 64 * 37 + 19, 12
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((n, m))
+    Q = np.asfortranarray(rng.standard_normal((m, m)))
+    outs = []
+    for omp in (False, True):
+        V = O.BV(n, m, omp=omp)
+        for j in range(m):
+            V.set_column(j, X[:, j])
+        V.SetActiveColumns(1, m - 1)
+        V.MultInPlace(Q, 2, 9)
+        outs.append(V.dense())
+    assert np.array_equal(outs[0], outs[1])
+    assert np.allclose(outs[0][:, 2:9], X[:, 1:m - 1] @ Q[1:m - 1, 2:9], rtol=1e-13, atol=1e-13)
+    assert np.array_equal(outs[0][:, :2], X[:, :2]) and np.array_equal(outs[0][:, 9:], X[:, 9:])
