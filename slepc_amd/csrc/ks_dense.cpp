@@ -493,6 +493,46 @@ int sym_eig(int n, double *A, int ld, double *w)
   return 0;
 }
 
+void qr_explicit(int M, int n, double *A, int ld, double *R, int ldr, double *Q, int ldq)
+{
+  std::vector<double> tau(n, 0.0);
+  for (int j = 0; j < n; j++) {                                   // dgeqr2: H_j = I - tau v v^T, v(j) = 1, v(j+1:M) stored below the diagonal
+    double *a = A + (size_t)j * ld;
+    double xn2 = 0.0;
+    for (int i = j + 1; i < M; i++) xn2 += a[i] * a[i];
+    const double alpha = a[j];
+    if (xn2 == 0.0) { tau[j] = 0.0; continue; }
+    const double nrm = sqrt(alpha * alpha + xn2);
+    const double beta = alpha >= 0.0 ? -nrm : nrm;
+    tau[j] = (beta - alpha) / beta;
+    const double sc = 1.0 / (alpha - beta);
+    for (int i = j + 1; i < M; i++) a[i] *= sc;
+    a[j] = beta;
+    for (int c = j + 1; c < n; c++) {
+      double *b = A + (size_t)c * ld;
+      double w = b[j];
+      for (int i = j + 1; i < M; i++) w += a[i] * b[i];
+      w *= tau[j];
+      b[j] -= w;
+      for (int i = j + 1; i < M; i++) b[i] -= w * a[i];
+    }
+  }
+  for (int c = 0; c < n; c++) for (int r = 0; r < n; r++) R[(size_t)r + (size_t)c * ldr] = r <= c ? A[(size_t)r + (size_t)c * ld] : 0.0;
+  for (int c = 0; c < n; c++) { double *q = Q + (size_t)c * ldq; for (int i = 0; i < M; i++) q[i] = i == c ? 1.0 : 0.0; }     // dorg2r on [I; 0]
+  for (int j = n - 1; j >= 0; j--) {
+    if (tau[j] == 0.0) continue;
+    const double *a = A + (size_t)j * ld;
+    for (int c = 0; c < n; c++) {
+      double *q = Q + (size_t)c * ldq;
+      double w = q[j];
+      for (int i = j + 1; i < M; i++) w += a[i] * q[i];
+      w *= tau[j];
+      q[j] -= w;
+      for (int i = j + 1; i < M; i++) q[i] -= w * a[i];
+    }
+  }
+}
+
 void tsqr_combine(int n, double *R1, int ld1, double *R2, int ld2)
 {
   // eliminate R2 row by row: row i of R2 is annihilated against rows i..n-1 of R1 (entries left of the diagonal are zero)
@@ -556,6 +596,7 @@ int ksd_potrf_upper(int n, double *A, int ld) { return ksd::potrf_upper(n, A, ld
 int ksd_trtri_upper(int n, double *A, int ld) { return ksd::trtri_upper(n, A, ld); }
 int ksd_sym_eig(int n, double *A, int ld, double *w) { return ksd::sym_eig(n, A, ld, w); }
 void ksd_tsqr_combine(int n, double *R1, int ld1, double *R2, int ld2) { ksd::tsqr_combine(n, R1, ld1, R2, ld2); }
+void ksd_qr_explicit(int M, int n, double *A, int ld, double *R, int ldr, double *Q, int ldq) { ksd::qr_explicit(M, n, A, ld, R, ldr, Q, ldq); }
 int ksd_lu_solve_trans(int n, double *A, int ld, double *b) { return ksd::lu_solve_trans(n, A, ld, b); }
 }
 #endif

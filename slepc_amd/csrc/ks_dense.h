@@ -42,4 +42,9 @@ void tsqr_combine(int n, double *R1, int ld1, double *R2, int ld2);
 // factors, b by x. Returns 0, or the 1-based index of an exactly zero pivot.
 int lu_solve_trans(int n, double *A, int ld, double *b);
 
+// Householder QR of the M x n matrix A (column-major, ld; M >= n) with the orthogonal factor formed explicitly (dgeqr2 + dorg2r):
+// R (n x n, upper triangular, ldr) and Q (M x n, ldq) with A = Q R. The combine step of the tall-skinny QR: A is the stack of the
+// row blocks' triangular factors, block b of Q is what block b's reflectors are applied to when the panel's Q is formed.
+void qr_explicit(int M, int n, double *A, int ld, double *R, int ldr, double *Q, int ldq);
+
 } // namespace ksd

@@ -8,9 +8,11 @@
 //   TSQRCHOL  R by TSQR only, Q = V inv(R)                                             (:646-669, bvlapack.c:483-565)
 // and BVMatProject (bvglobal.c:1014-1160), BVNormalize (bvglobal.c:855-938).
 // The Gram matrices, V*inv(R) and the block Gram-Schmidt against leading columns are the FP64 MFMA panel kernels of
-// ks_panel.hip; the k x k factorisations run on the host (ks_dense.cpp). Deviation from the reference, stated: TSQR
-// does not accumulate the Householder reflectors into an explicit Q (dorgqr); it forms Q = V inv(R) from the TSQR R
-// factor and repeats the step once on Q, which restores orthogonality to working precision for cond(V) < 1/eps.
+// ks_panel.hip; the k x k factorisations run on the host (ks_dense.cpp). TSQR accumulates its Householder reflectors into
+// an explicit Q as the reference does (geqrf / orgqr per block and per tree level, bvlapack.c:380-451): the factor kernel
+// leaves the reflectors in place of the panel, the stack of the blocks' triangular factors is factored on the host with
+// its orthogonal factor formed explicitly, and a second kernel applies every block's reflectors, last tile first, to its
+// block of that factor. TSQRCHOL keeps Q = V inv(R) (bvlapack.c:483-565).
 #include "ksgpu_internal.h"
 #include "ks_dense.h"
 #include <algorithm>
@@ -27,9 +29,15 @@ __device__ __forceinline__ double wsum(double v)
   return v;
 }
 
-// Each block walks its contiguous row range in tiles of 64 rows and keeps a running R (nc x nc, upper triangular) in
-// LDS: QR of [R; tile] by Householder reflectors that touch row j of R and the 64 tile rows only.
-__global__ __launch_bounds__(TS_BLOCK) void k_tsqr_local(const double *__restrict__ V, long long ld, long long n, int nc, long long rows_per_block, double *__restrict__ Rout)
+// Each block walks its contiguous row range in tiles of 64 rows and keeps a running R (nc x nc, upper triangular) in LDS. The block's FIRST
+// tile is factored on its own (dgeqr2: reflector j has its 1 in tile row j and acts on rows j..63), every later tile as [R; tile] by reflectors
+// that touch row j of R and the 64 tile rows only. (Starting the running R at zero instead - [0; tile] - is the same arithmetic for R but
+// not for Q: the orthogonal factor of the augmented matrix has a top block that is zero only in exact arithmetic, eps ||A|| / sigma_min in
+// practice, and the rows that belong to the panel lose that much of their norm.)
+// REFL: leave the reflectors behind - v_j of every tile in place of the panel's entries (the leading 1 is implicit), tau_j in tau[tile][j] -
+// for k_tsqr_formq.
+template <bool REFL>
+__global__ __launch_bounds__(TS_BLOCK) void k_tsqr_local(double *__restrict__ V, long long ld, long long n, int nc, long long rows_per_block, double *__restrict__ Rout, double *__restrict__ tau_out)
 {
   __shared__ double Rr[64 * 64];     // column-major, pitch 64
   __shared__ double Tt[64 * 64];     // tile, column-major: Tt[c*64 + lane]
@@ -39,12 +47,14 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tsqr_local(const double *__restric
   for (long long t0 = r0; t0 < r1; t0 += TS_T) {
     __syncthreads();
     const long long row = t0 + lane;
+    const bool first = t0 == r0;
     for (int c = wave; c < nc; c += TS_BLOCK / 64) Tt[c * 64 + lane] = (row < r1) ? V[(size_t)c * ld + row] : 0.0;
     __syncthreads();
     for (int j = 0; j < nc; j++) {
       // every wave derives the reflector of column j redundantly (same LDS inputs, same arithmetic)
-      const double x = Tt[j * 64 + lane];
-      const double alpha = Rr[j * 64 + j];
+      const double tj = Tt[j * 64 + lane];
+      const double x = first ? (lane > j ? tj : 0.0) : tj;                 // the part of column j the reflector annihilates
+      const double alpha = first ? Tt[j * 64 + j] : Rr[j * 64 + j];       // its pivot: tile row j, or row j of the running R
       const double xn2 = wsum(x * x);
       double tau = 0.0, v = 0.0, beta = alpha;
       if (xn2 != 0.0) {
@@ -56,18 +66,67 @@ __global__ __launch_bounds__(TS_BLOCK) void k_tsqr_local(const double *__restric
       // apply H = I - tau [1; v][1; v]^T to the remaining columns, one column per wave at a time
       for (int c = j + 1 + wave; c < nc; c += TS_BLOCK / 64) {
         const double w = Tt[c * 64 + lane];
-        const double rjc = Rr[c * 64 + j];
-        const double d = tau * (wsum(v * w) + rjc);
-        Tt[c * 64 + lane] = w - d * v;
-        if (lane == 0) Rr[c * 64 + j] = rjc - d;
+        const double pjc = first ? Tt[c * 64 + j] : Rr[c * 64 + j];        // the column's entry in the pivot row
+        const double d = tau * (wsum(v * w) + pjc);
+        if (first) Tt[c * 64 + lane] = (lane == j) ? pjc - d : w - d * v;   // (v = 0 in rows <= j: they keep their values)
+        else { Tt[c * 64 + lane] = w - d * v; if (lane == 0) Rr[c * 64 + j] = pjc - d; }
       }
       __syncthreads();
-      if (threadIdx.x == 0) Rr[j * 64 + j] = beta;
+      if (first) { if (wave == 0 && lane <= j) Rr[j * 64 + lane] = lane == j ? beta : Tt[j * 64 + lane]; }      // column j of R: rows 0..j-1 are final, the pivot becomes beta
+      else if (threadIdx.x == 0) Rr[j * 64 + j] = beta;
       // column j of the tile is spent; the barrier above already separates this step from the next one's reads
+      if (REFL && wave == 0) { Tt[j * 64 + lane] = v; if (lane == 0) tau_out[(size_t)(t0 / TS_T) * nc + j] = tau; }
+    }
+    if (REFL) {
+      __syncthreads();
+      for (int c = wave; c < nc; c += TS_BLOCK / 64) if (row < r1) V[(size_t)c * ld + row] = Tt[c * 64 + lane];
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < nc * nc; i += TS_BLOCK) { const int r = i % nc, c = i / nc; Rout[(size_t)blockIdx.x * nc * nc + i] = (r <= c) ? Rr[c * 64 + r] : 0.0; }
+}
+
+// Q of one block: its reflectors applied, last tile first and within a tile last reflector first, to [C; 0; ...; 0] with C the block's
+// nc x nc piece of the combine step's orthogonal factor. A column of the result depends on the same column of C only: lane = row of the tile,
+// a wave owns its columns from the last tile to the first (the column's part of C in LDS, its 64 tile entries in a register) - no barrier
+// inside a tile. The first tile holds C itself in its first nc rows (its reflectors act inside the tile).
+__global__ __launch_bounds__(TS_BLOCK) void k_tsqr_formq(double *__restrict__ V, long long ld, long long n, int nc, long long rows_per_block, const double *__restrict__ Cin, const double *__restrict__ tau_in)
+{
+  __shared__ double Cc[64 * 64];     // column-major, pitch 64: Cc[c*64 + j]
+  __shared__ double Vt[64 * 64];     // the tile's reflectors
+  __shared__ double ta[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < nc * nc; i += TS_BLOCK) { const int r = i % nc, c = i / nc; Cc[c * 64 + r] = Cin[(size_t)blockIdx.x * nc * nc + i]; }
+  const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+  if (r0 >= r1) return;
+  const long long ntile = (r1 - r0 + TS_T - 1) / TS_T;
+  for (long long tt = ntile - 1; tt >= 0; tt--) {
+    const long long t0 = r0 + tt * TS_T, row = t0 + lane;
+    const bool first = tt == 0;
+    __syncthreads();
+    for (int c = wave; c < nc; c += TS_BLOCK / 64) Vt[c * 64 + lane] = (row < r1) ? V[(size_t)c * ld + row] : 0.0;
+    if (threadIdx.x < nc) ta[threadIdx.x] = tau_in[(size_t)(t0 / TS_T) * nc + threadIdx.x];
+    __syncthreads();
+    for (int c = wave; c < nc; c += TS_BLOCK / 64) {
+      double z = first ? (lane < nc ? Cc[c * 64 + lane] : 0.0) : 0.0;
+      for (int j = nc - 1; j >= 0; j--) {
+        const double tj = ta[j];
+        if (tj == 0.0) continue;
+        const double vj = Vt[j * 64 + lane];                               // first tile: zero in rows <= j
+        if (first) {
+          const double zj = __shfl(z, j, 64);
+          const double w = tj * (zj + wsum(vj * z));
+          z = (lane == j) ? z - w : z - w * vj;
+        } else {
+          const double w = tj * (Cc[c * 64 + j] + wsum(vj * z));
+          z -= w * vj;
+          if (lane == 0) Cc[c * 64 + j] -= w;
+        }
+      }
+      // the tile's reflectors are all in LDS (every wave reads every one of them): the panel's entries can take the result
+      if (row < r1) V[(size_t)c * ld + row] = z;
+    }
+  }
 }
 
 // R factor (host, nc x nc upper triangular, ldr) of V(:, s:s+nc): per-block factors, combined in block order, then in
@@ -85,7 +144,7 @@ int tsqr_r(ks_bv V, int s, int nc, double *R, int ldr)
   KS_HIP(hipMalloc(&dR, sizeof(double) * (size_t)nb * nc * nc));
   {
     KsProfScope ps(ctx, KS_K_OTHER, 8.0 * n * nc);
-    hipLaunchKernelGGL(k_tsqr_local, dim3((unsigned)nb), dim3(TS_BLOCK), 0, ctx->stream, V->array + (size_t)(V->nc + s) * V->ld, (long long)V->ld, n, nc, rpb, dR);
+    hipLaunchKernelGGL(k_tsqr_local<false>, dim3((unsigned)nb), dim3(TS_BLOCK), 0, ctx->stream, V->array + (size_t)(V->nc + s) * V->ld, (long long)V->ld, n, nc, rpb, dR, (double *)nullptr);
   }
   int rc = hipGetLastError() == hipSuccess ? KS_SUCCESS : KS_ERR_LIB;
   std::vector<double> h((size_t)nb * nc * nc);
@@ -102,6 +161,63 @@ int tsqr_r(ks_bv V, int s, int nc, double *R, int ldr)
   }
   for (int c = 0; c < nc; c++) for (int r = 0; r < nc; r++) R[(size_t)r + (size_t)c * ldr] = (r <= c) ? h[(size_t)r + (size_t)c * nc] : 0.0;
   return KS_SUCCESS;
+}
+
+// V(:, s:s+nc) = Q R with Q formed from the accumulated reflectors, in place; R (host, nc x nc, ldr) identical on every rank.
+// Two read-write passes over the panel: factor (reflectors left in place) and form-Q.
+int tsqr_q(ks_bv V, int s, int nc, double *R, int ldr)
+{
+  ks_ctx ctx = V->ctx;
+  KS_CHECK(nc >= 1 && nc <= 64, KS_ERR_SUP, "TSQR with %d columns (max 64)", nc);
+  const long long n = V->n;
+  long long nb = std::min<long long>((n + TS_T - 1) / TS_T, (long long)ctx->num_cu * 2);
+  if (nb < 1) nb = 1;
+  long long rpb = (n + nb - 1) / nb; rpb = (rpb + TS_T - 1) / TS_T * TS_T; if (rpb < TS_T) rpb = TS_T;
+  nb = std::max<long long>(1, (n + rpb - 1) / rpb);
+  const long long ntiles = (n + TS_T - 1) / TS_T + nb;      // (a block's last tile may be partial: tile indices are t0 / 64 with t0 a multiple of 64)
+  double *dR = nullptr, *dTau = nullptr, *panel = V->array + (size_t)(V->nc + s) * V->ld;
+  KS_HIP(hipMalloc(&dR, sizeof(double) * (size_t)nb * nc * nc));
+  KS_HIP(hipMalloc(&dTau, sizeof(double) * (size_t)std::max<long long>(ntiles, 1) * nc));
+  auto done = [&](int rc) { hipFree(dR); hipFree(dTau); (void)hipGetLastError(); return rc; };
+  {
+    KsProfScope ps(ctx, KS_K_OTHER, 16.0 * n * nc);
+    hipLaunchKernelGGL(k_tsqr_local<true>, dim3((unsigned)nb), dim3(TS_BLOCK), 0, ctx->stream, panel, (long long)V->ld, n, nc, rpb, dR, dTau);
+  }
+  if (hipGetLastError() != hipSuccess) return done(KS_ERR_LIB);
+  // the combine step on the host: the stack of the blocks' triangular factors, A = Qs Rs with Qs explicit (nb nc x nc)
+  const int M = (int)(nb * nc);
+  std::vector<double> h((size_t)nb * nc * nc), stack((size_t)M * nc), Qs((size_t)M * nc), Rs((size_t)nc * nc);
+  if (hipMemcpyAsync(h.data(), dR, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || ks_sync(ctx) != hipSuccess) return done(KS_ERR_LIB);
+  for (long long b = 0; b < nb; b++) for (int c = 0; c < nc; c++) for (int r = 0; r < nc; r++) stack[(size_t)(b * nc + r) + (size_t)c * M] = h[(size_t)b * nc * nc + (size_t)c * nc + r];
+  ksd::qr_explicit(M, nc, stack.data(), M, Rs.data(), nc, Qs.data(), M);
+  std::vector<double> Cb((size_t)nb * nc * nc);             // block b: Qs(b nc : (b+1) nc, :), column-major nc x nc
+  if (ks_is_multi(ctx) && ctx->comm.size > 1) {
+    // one more level across the ranks: the ranks' factors stacked in rank order, the same arithmetic on every rank
+    const int size = ctx->comm.size, Mr = size * nc;
+    std::vector<double> all((size_t)size * nc * nc), st2((size_t)Mr * nc), Q2((size_t)Mr * nc), R2((size_t)nc * nc);
+    int rc = ks_comm_allgather_host(ctx, Rs.data(), (int)(sizeof(double) * nc * nc), all.data());
+    if (rc) return done(rc);
+    for (int q = 0; q < size; q++) for (int c = 0; c < nc; c++) for (int r = 0; r < nc; r++) st2[(size_t)(q * nc + r) + (size_t)c * Mr] = all[(size_t)q * nc * nc + (size_t)c * nc + r];
+    ksd::qr_explicit(Mr, nc, st2.data(), Mr, R2.data(), nc, Q2.data(), Mr);
+    const double *Cr = Q2.data() + (size_t)ctx->comm.rank * nc;          // this rank's nc x nc block, leading dimension Mr
+    for (long long b = 0; b < nb; b++)
+      for (int c = 0; c < nc; c++) for (int r = 0; r < nc; r++) {
+        double t = 0.0;
+        for (int p = 0; p < nc; p++) t += Qs[(size_t)(b * nc + r) + (size_t)p * M] * Cr[(size_t)p + (size_t)c * Mr];
+        Cb[(size_t)b * nc * nc + (size_t)c * nc + r] = t;
+      }
+    Rs = R2;
+  } else {
+    for (long long b = 0; b < nb; b++) for (int c = 0; c < nc; c++) for (int r = 0; r < nc; r++) Cb[(size_t)b * nc * nc + (size_t)c * nc + r] = Qs[(size_t)(b * nc + r) + (size_t)c * M];
+  }
+  if (hipMemcpyAsync(dR, Cb.data(), sizeof(double) * Cb.size(), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return done(KS_ERR_LIB);
+  {
+    KsProfScope ps(ctx, KS_K_OTHER, 16.0 * n * nc);
+    hipLaunchKernelGGL(k_tsqr_formq, dim3((unsigned)nb), dim3(TS_BLOCK), 0, ctx->stream, panel, (long long)V->ld, n, nc, rpb, dR, dTau);
+  }
+  if (hipGetLastError() != hipSuccess || ks_sync(ctx) != hipSuccess) return done(KS_ERR_LIB);       // Cb is pageable: the upload must have left before it goes out of scope
+  for (int c = 0; c < nc; c++) for (int r = 0; r < nc; r++) R[(size_t)r + (size_t)c * ldr] = (r <= c) ? Rs[(size_t)r + (size_t)c * nc] : 0.0;
+  return done(KS_SUCCESS);
 }
 
 // BVOrthogonalize_BlockGS bvorthog.c:492-505: V2 -= V1 (V1' V2), coefficients into Rb(0:l, l:k)
@@ -206,23 +322,14 @@ extern "C" int ks_bv_orthogonalize(ks_bv V, double *R, int ldr)       // BVOrtho
     case KS_BV_ORTHOG_BLOCK_TSQR:
     case KS_BV_ORTHOG_BLOCK_TSQRCHOL: {
       KS_CHECK(!V->matrix, KS_ERR_SUP, "Orthogonalization method not available for non-standard inner product");   // bvorthog.c:750,754
-      KS_CALL(tsqr_r(V, l, nact, R22, ldb));
-      for (int j = 0; j < nact; j++) for (int i = 0; i < nact; i++) S22[(size_t)i + (size_t)j * ldb] = R22[(size_t)i + (size_t)j * ldb];
-      int info = ksd::trtri_upper(nact, S22, ldb);
-      KS_CHECK(!info, KS_ERR_LIB, "Error in LAPACK subroutine trtri: info=%d", info);
-      KS_CALL(ks_bv_multinplace(V, S.data(), ldb, l, k));
       if (V->orthog_block == KS_BV_ORTHOG_BLOCK_TSQR) {
-        // second pass on Q1 = V inv(R1): Q1 = Q2 R2, so V = Q2 (R2 R1)
-        std::vector<double> R2((size_t)nact * nact), S2((size_t)ldb * k, 0.0);
-        KS_CALL(tsqr_r(V, l, nact, R2.data(), nact));
-        double *S2b = S2.data() + (size_t)l * ldb + l;
-        for (int j = 0; j < nact; j++) for (int i = 0; i < nact; i++) S2b[(size_t)i + (size_t)j * ldb] = R2[(size_t)i + (size_t)j * nact];
-        info = ksd::trtri_upper(nact, S2b, ldb);
+        KS_CALL(tsqr_q(V, l, nact, R22, ldb));                     // Q from the accumulated reflectors (bvlapack.c:380-451)
+      } else {
+        KS_CALL(tsqr_r(V, l, nact, R22, ldb));                     // TSQRCHOL: R by TSQR only, Q = V inv(R) (bvlapack.c:483-565)
+        for (int j = 0; j < nact; j++) for (int i = 0; i < nact; i++) S22[(size_t)i + (size_t)j * ldb] = R22[(size_t)i + (size_t)j * ldb];
+        const int info = ksd::trtri_upper(nact, S22, ldb);
         KS_CHECK(!info, KS_ERR_LIB, "Error in LAPACK subroutine trtri: info=%d", info);
-        KS_CALL(ks_bv_multinplace(V, S2.data(), ldb, l, k));
-        std::vector<double> P((size_t)nact * nact, 0.0);
-        for (int j = 0; j < nact; j++) for (int i = 0; i <= j; i++) { double t = 0.0; for (int p = i; p <= j; p++) t += R2[(size_t)i + (size_t)p * nact] * R22[(size_t)p + (size_t)j * ldb]; P[(size_t)i + (size_t)j * nact] = t; }
-        for (int j = 0; j < nact; j++) for (int i = 0; i < nact; i++) R22[(size_t)i + (size_t)j * ldb] = P[(size_t)i + (size_t)j * nact];
+        KS_CALL(ks_bv_multinplace(V, S.data(), ldb, l, k));
       }
       store_block(V, Rb.data(), ldb, R, ldr, true);
       break;

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_spmv_csr_stream(int n, const int *__res
 // (16-byte loads of four consecutive entries per lane were tried for the streams: fewer instructions, no faster, and the gathers of such a
 // lane assignment touch still more lines.)
 constexpr int CW_PAD = 8;                                  // col / val allocations are this much longer than nnz
-constexpr int CW_STEPS_MAX = 8;                            // 64 entries per step, chunks of 512 (row side with 256-entry chunks: 62 registers, 8 waves per SIMD, and 237 us instead of 199)
+// CW_STEPS: 64 entries per step; 8 steps = chunks of 512 (row side with 256-entry chunks: 62 registers, 8 waves per SIMD, and 237 us instead of 199)
 __device__ __forceinline__ int cw_slot(int e) { return e + (e >> 5); }     // one slot of skew per 32 entries (rows whose length is a multiple of 32)
 // Load width matters more than instruction count here: 4-byte-per-lane streaming loads top out at 0.7 - 2.5 TB/s on this part, 8- and 16-byte
 // ones at 7 (scripts/micro/load_width.hip, profiles/r03_micro_load_width.txt). So the 4-byte column indices are loaded two per lane (a chunk

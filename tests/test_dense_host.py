@@ -30,6 +30,8 @@ def lib():
     lib.ksd_tsqr_combine.argtypes = [C.c_int, P, C.c_int, P, C.c_int]
     lib.ksd_tsqr_combine.restype = None
     lib.ksd_lu_solve_trans.argtypes = [C.c_int, P, C.c_int, P]
+    lib.ksd_qr_explicit.argtypes = [C.c_int, C.c_int, P, C.c_int, P, C.c_int, P, C.c_int]
+    lib.ksd_qr_explicit.restype = None
     return lib
 
 
@@ -209,3 +211,27 @@ def test_lu_solve_transposed_matches_lapack(lib, n):
     assert np.allclose(np.array([[0.0, 2.0], [3.0, 1.0]]).T @ c, [1.0, 1.0])
     S = np.asfortranarray(np.array([[1.0, 2.0], [2.0, 4.0]])); d = np.array([1.0, 0.0])
     assert lib.ksd_lu_solve_trans(2, p(S), 2, p(d)) == 2
+
+
+@pytest.mark.parametrize("M,n", [(1, 1), (5, 5), (12, 4), (64 * 7, 64), (300, 30), (96, 32)])
+def test_explicit_householder_qr_of_the_tsqr_stack(lib, M, n):
+    """ksd::qr_explicit (dgeqr2 + dorg2r): the combine step of the tall-skinny QR - the stack of the row blocks' triangular factors
+    factored with its orthogonal factor formed explicitly (bvlapack.c:421-433 does this per tree level with geqrf / orgqr). Against
+    numpy's LAPACK QR up to column signs, incl. a stack of triangles, a rank-deficient stack and a zero column."""
+    rng = np.random.default_rng(M * 100 + n)
+    eps = np.finfo(float).eps
+    cases = [rng.standard_normal((M, n))]
+    if M % n == 0 and M > n:
+        cases.append(np.vstack([np.triu(rng.standard_normal((n, n))) for _ in range(M // n)]))       # what the TSQR hands over
+    if n >= 3:
+        D = rng.standard_normal((M, n)); D[:, 2] = 2.0 * D[:, 0] - D[:, 1]; cases.append(D)           # dependent column
+        Z = rng.standard_normal((M, n)); Z[:, 1] = 0.0; cases.append(Z)
+    for A0 in cases:
+        A = np.asfortranarray(A0.copy()); R = np.zeros((n, n), order="F"); Q = np.zeros((M, n), order="F")
+        lib.ksd_qr_explicit(M, n, p(A), M, p(R), n, p(Q), M)
+        assert np.all(np.tril(R, -1) == 0)
+        assert np.abs(Q.T @ Q - np.eye(n)).max() <= 50 * max(M, 8) * eps
+        assert np.abs(Q @ R - A0).max() <= 50 * max(M, 8) * eps * max(np.abs(A0).max(), 1.0)
+        if np.linalg.matrix_rank(A0) == n:
+            Rref = np.linalg.qr(A0, mode="r")
+            assert np.abs(np.abs(R) - np.abs(Rref)).max() <= 1e3 * max(M, 8) * eps * np.abs(Rref).max()

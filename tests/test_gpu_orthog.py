@@ -75,7 +75,7 @@ def test_orthogonalize_properties(ctx, block, n, l, k):
 
 @pytest.mark.parametrize("block", ["tsqr", "tsqrchol", "chol"])
 def test_ill_conditioned_basis(ctx, block):
-    """cond(V) = 1e6: TSQR keeps Q orthonormal to working precision (its second pass); V inv(R) from one pass
+    """cond(V) = 1e6: TSQR keeps Q orthonormal to working precision (accumulated reflectors); V inv(R) from one pass
     (TSQRCHOL) or from the Gram matrix (CHOL, cond squared) loses orthogonality as the theory says."""
     import slepc_amd as ks
     n, k = 20000, 12
@@ -89,6 +89,33 @@ def test_ill_conditioned_basis(ctx, block):
     lvl = np.abs(Q.T @ Q - np.eye(k)).max()
     assert np.abs(X0 - Q @ R).max() < 1e-13
     assert lvl < {"tsqr": 1e-13, "tsqrchol": 1e-8, "chol": 1e-2}[block]
+
+
+@pytest.mark.parametrize("n,k", [(20000, 12), (100001, 40), (3, 3), (700, 64)])
+def test_tsqr_accumulates_its_reflectors(ctx, n, k):
+    """TSQR forms Q from the accumulated Householder reflectors, as the reference does (geqrf / orgqr per block and tree level,
+    bvlapack.c:380-451): orthonormal to working precision whatever the conditioning - cond(V) = 1e12 here, where Q = V inv(R), even
+    repeated, is no longer orthogonal - with V = Q R to rounding, also for a window l > 0 and sizes that leave partial tiles and blocks."""
+    import slepc_amd as ks
+    rng = np.random.default_rng(n + k)
+    U = np.linalg.qr(rng.standard_normal((n, k)))[0]; W = np.linalg.qr(rng.standard_normal((k, k)))[0]
+    X0 = U @ np.diag(np.logspace(0, -12, k)) @ W.T
+    V = ks.BV(ctx, n, k); V.set_dense(X0); V.SetOrthogBlock("tsqr")
+    R = np.zeros((k, k), order="F")
+    V.Orthogonalize(R)
+    Q = V.dense()
+    assert np.abs(Q.T @ Q - np.eye(k)).max() < 1e-13
+    assert np.abs(X0 - Q @ R).max() < 1e-13 and np.abs(np.tril(R, -1)).max() == 0.0
+    if k >= 6:
+        l = 3                                                   # leading columns stay, the rest is orthogonalised against them first
+        Y0 = rng.standard_normal((n, k)); Y0[:, :l] = np.linalg.qr(Y0[:, :l])[0]
+        V.set_dense(Y0); V.SetActiveColumns(l, k)
+        R2 = np.zeros((k, k), order="F")
+        V.Orthogonalize(R2)
+        Q2 = V.dense()
+        assert np.array_equal(Q2[:, :l], Y0[:, :l])
+        assert np.abs(Q2.T @ Q2 - np.eye(k)).max() < 1e-13
+        assert np.abs(Y0[:, l:] - Q2 @ R2[:, l:]).max() < 1e-12
 
 
 def test_breakdown_is_an_error_for_gs(ctx):
