@@ -155,6 +155,17 @@ int ks_ctx_memset(ks_ctx ctx, void *dev, int value, size_t bytes);
    rank; n_global = global size.  With one rank: row_start=0, n_local=n_global.               */
 int ks_mat_create_csr(ks_ctx ctx, int n_local, int row_start, int n_global,
                       const int *rowptr, const int *col, const double *val, ks_mat *A);
+/* The same with options. KS_MAT_KEEP_CSR: the matrix keeps a host copy of the arrays it was created from, as a PETSc AIJ Mat keeps its
+   own - what MatDuplicate / MatAXPY need later (ks_mat_create_axpy, ST_MATMODE_COPY); without it only the layout the product runs on
+   survives the assembly. Matrices read by ks_mat_load_petsc_binary keep theirs. */
+#define KS_MAT_KEEP_CSR 1u
+int ks_mat_create_csr_flags(ks_ctx ctx, int n_local, int row_start, int n_global,
+                            const int *rowptr, const int *col, const double *val, unsigned flags, ks_mat *A);
+/* P = A + alpha B as a new matrix: MatDuplicate(A,MAT_COPY_VALUES,&P) + MatAXPY(P,alpha,B,DIFFERENT_NONZERO_PATTERN), B == NULL:
+   MatShift(P,alpha) - the assembly of A - sigma B in ST_MATMODE_COPY (src/sys/classes/st/interface/stsolve.c:611-626). Entry by
+   entry p_ij = a_ij + (alpha b_ij); rows with ascending columns come out ascending. A and B must hold their CSR arrays
+   (KS_MAT_KEEP_CSR; KS_ERR_ORDER otherwise) and the same row block. flags as above, for P. */
+int ks_mat_create_axpy(ks_mat A, double alpha, ks_mat B, unsigned flags, ks_mat *P);
 /* Synthetic generators that build the SAME CSR arrays directly in device memory (bench inputs):
    3-D 7-pt Laplacian of ex19.c:47-78 (rows of z-planes [z0,z0+nz_local) of an nx*ny*nz grid) and
    2-D 5-pt Laplacian of ex2.c:44-51.                                                           */
@@ -378,6 +389,16 @@ int ks_st_get_shift(ks_st st, double *sigma);
 int ks_st_cayley_set_antishift(ks_st st, double nu);                      /* STCayleySetAntishift cayley.c:236 (default: the shift) */
 int ks_st_cayley_get_antishift(ks_st st, double *nu);
 int ks_st_set_matrices(ks_st st, ks_mat A, ks_mat B /* may be NULL */);   /* STSetMatrices */
+/* STSetMatMode (src/sys/classes/st/interface/stfunc.c): how the matrix of the linear solves, P = A - sigma B, exists.
+   KS_ST_MATMODE_SHELL (the default here, with the KSP that mode defaults to, stsles.c:51-53): never assembled, applied as two products and
+   an axpy (stshellmat.c). KS_ST_MATMODE_COPY (the reference's default mode): assembled once per shift by ks_mat_create_axpy (STMatMAXPY_Private
+   stsolve.c:603-631) - one product per application, the Jacobi diagonal is MatGetDiagonal of it; A and B need KS_MAT_KEEP_CSR. The solver
+   around it is the same (GMRES / BiCGStab + Jacobi). ST_MATMODE_INPLACE (A overwritten) is not built. The M of cayley / shift stays in the
+   term-by-term form in either mode. */
+#define KS_ST_MATMODE_COPY  0
+#define KS_ST_MATMODE_SHELL 2
+int ks_st_set_matmode(ks_st st, int mode);
+int ks_st_get_matmode(ks_st st, int *mode);
 enum { KS_KSP_GMRES = 0, KS_KSP_BCGS = 1 };
 int ks_st_set_ksp_type(ks_st st, int type);                                /* KSPSetType on STGetKSP: GMRES (restarted, the shell mode's default) or BiCGStab; both with Jacobi on the left */
 int ks_st_set_ksp(ks_st st, double rtol, int max_it, int restart);        /* KSPSetTolerances / KSPGMRESSetRestart on STGetKSP; 0 keeps */

@@ -208,7 +208,8 @@ class Mat:
         self.n, self.N, self.nnz = n.value, N.value, nnz.value
 
     @classmethod
-    def from_csr(cls, ctx, rowptr, col, val, row_start=0, n_global=None):
+    def from_csr(cls, ctx, rowptr, col, val, row_start=0, n_global=None, keep_csr=False):
+        """keep_csr: KS_MAT_KEEP_CSR - the matrix keeps the arrays it was created from (MatAXPY, ST_MATMODE_COPY)."""
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
         col = np.ascontiguousarray(col, dtype=np.int32)
         val = _f64(val)
@@ -216,8 +217,14 @@ class Mat:
         if n_global is None:
             n_global = n
         h = C.c_void_p()
-        _lib.check(ctx.L.ks_mat_create_csr(ctx.h, n, row_start, n_global, _pi(rowptr), _pi(col), _p(val), C.byref(h)))
+        _lib.check(ctx.L.ks_mat_create_csr_flags(ctx.h, n, row_start, n_global, _pi(rowptr), _pi(col), _p(val), 1 if keep_csr else 0, C.byref(h)))
         return cls(ctx, h)
+
+    def axpy_new(self, alpha, B=None, keep_csr=False):
+        """MatDuplicate(self) + MatAXPY(P, alpha, B, DIFFERENT_NONZERO_PATTERN); B None: MatShift(P, alpha)."""
+        h = C.c_void_p()
+        _lib.check(self.ctx.L.ks_mat_create_axpy(self.h, alpha, None if B is None else B.h, 1 if keep_csr else 0, C.byref(h)))
+        return Mat(self.ctx, h)
 
     @classmethod
     def laplacian3d(cls, ctx, nx, ny, nz, z0=0, nz_local=None):
@@ -663,6 +670,13 @@ class ST:
 
     def SetKSP(self, rtol=0.0, max_it=0, restart=0):
         _lib.check(self.ctx.L.ks_st_set_ksp(self.h, rtol, max_it, restart))
+
+    def SetMatMode(self, mode):
+        """STSetMatMode: "shell" (default here) or "copy" (P = A - sigma B assembled; the matrices need keep_csr)."""
+        _lib.check(self.ctx.L.ks_st_set_matmode(self.h, {"copy": 0, "shell": 2}.get(mode, mode)))
+
+    def GetMatMode(self):
+        v = C.c_int(); _lib.check(self.ctx.L.ks_st_get_matmode(self.h, C.byref(v))); return {0: "copy", 2: "shell"}[v.value]
 
     def SetKSPType(self, t):
         """KSPSetType on the ST's KSP: "gmres" (default) or "bcgs"."""

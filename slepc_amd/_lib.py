@@ -48,6 +48,8 @@ _SIG = {
     "ks_comm_allreduce_sum": [vp, vp, C.c_int],
     # mat
     "ks_mat_create_csr": [vp, C.c_int, C.c_int, C.c_int, ip, ip, dp, C.POINTER(vp)],
+    "ks_mat_create_csr_flags": [vp, C.c_int, C.c_int, C.c_int, ip, ip, dp, C.c_uint, C.POINTER(vp)],
+    "ks_mat_create_axpy": [vp, C.c_double, vp, C.c_uint, C.POINTER(vp)],
     "ks_mat_set_halo": [vp, C.c_int, ip],
     "ks_mat_get_halo": [vp, ip],
     "ks_mat_create_laplacian3d": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
@@ -192,6 +194,8 @@ _SIG = {
     "ks_st_set_matrices": [vp, vp, vp],
     "ks_st_set_ksp": [vp, C.c_double, C.c_int, C.c_int],
     "ks_st_set_ksp_type": [vp, C.c_int],
+    "ks_st_set_matmode": [vp, C.c_int],
+    "ks_st_get_matmode": [vp, C.POINTER(C.c_int)],
     "ks_st_setup": [vp],
     "ks_st_apply": [vp, vp, vp],
     "ks_st_backtransform": [vp, C.c_int, dp, dp],

@@ -17,6 +17,7 @@
 // so that rowptr -> (col,val) -> x[col] dependent chains of different rows overlap.
 // Algorithmic bytes per call: 12*nnz + 4*(n+1) + 16*n.
 #include "ks_sweeps.cuh"
+#include "ks_csr.h"
 #include <algorithm>
 #include <numeric>
 #include <thread>
@@ -1355,7 +1356,13 @@ int ks_mat_mult_dot_fused(ks_mat A, ks_bv bv, const double *x, int jy, bool gate
 
 extern "C" int ks_mat_create_csr(ks_ctx ctx, int n_local, int row_start, int n_global, const int *rowptr, const int *col, const double *val, ks_mat *out)
 {
+  return ks_mat_create_csr_flags(ctx, n_local, row_start, n_global, rowptr, col, val, 0u, out);
+}
+
+extern "C" int ks_mat_create_csr_flags(ks_ctx ctx, int n_local, int row_start, int n_global, const int *rowptr, const int *col, const double *val, unsigned flags, ks_mat *out)
+{
   KS_CHECK(ctx && out, KS_ERR_ARG_NULL, "ctx/out is NULL");
+  KS_CHECK((flags & ~KS_MAT_KEEP_CSR) == 0, KS_ERR_ARG_OUTOFRANGE, "unknown matrix creation flags 0x%x", flags);
   KS_CHECK(n_local >= 0 && row_start >= 0 && row_start + n_local <= n_global, KS_ERR_ARG_OUTOFRANGE, "bad row range [%d,%d) of %d", row_start, row_start + n_local, n_global);
   KS_CHECK(rowptr && (rowptr[n_local] == 0 || (col && val)), KS_ERR_ARG_NULL, "CSR arrays are NULL");
   KS_CHECK(rowptr[0] == 0, KS_ERR_ARG_WRONG, "rowptr[0] must be 0");
@@ -1400,8 +1407,25 @@ extern "C" int ks_mat_create_csr(ks_ctx ctx, int n_local, int row_start, int n_g
   if (!rc) rc = build_sliced(A);
   if (!rc) rc = build_sell(A);
   if (rc) { ks_mat_destroy(A); return rc; }
+  if (flags & KS_MAT_KEEP_CSR) {
+    A->keep_csr = true;
+    A->k_rowptr.assign(rowptr, rowptr + n_local + 1); A->k_col.assign(col, col + nnz); A->k_val.assign(val, val + nnz);
+  }
   *out = A;
   return KS_SUCCESS;
+}
+
+// MatDuplicate + MatAXPY / MatShift on the kept CSR arrays (ks_csr.cpp), then the ordinary assembly of the result
+extern "C" int ks_mat_create_axpy(ks_mat A, double alpha, ks_mat B, unsigned flags, ks_mat *out)
+{
+  KS_CHECK(A && out, KS_ERR_ARG_NULL, "A/out is NULL");
+  KS_CHECK(!A->shell_mult && (!B || !B->shell_mult), KS_ERR_SUP, "MatAXPY of a shell matrix");
+  KS_CHECK(A->keep_csr && (!B || B->keep_csr), KS_ERR_ORDER, "MatAXPY needs the CSR arrays of its operands: create them with KS_MAT_KEEP_CSR");
+  KS_CHECK(!B || (B->n == A->n && B->row_start == A->row_start && B->n_global == A->n_global && B->ctx == A->ctx), KS_ERR_ARG_INCOMP, "Mismatching row blocks of A (%d rows from %d) and B (%d rows from %d)", A->n, A->row_start, B ? B->n : 0, B ? B->row_start : 0);
+  std::vector<int> rp, col; std::vector<double> val;
+  const bool fits = ksc::csr_axpy(A->n, A->row_start, A->k_rowptr.data(), A->k_col.data(), A->k_val.data(), alpha, B ? B->k_rowptr.data() : nullptr, B ? B->k_col.data() : nullptr, B ? B->k_val.data() : nullptr, rp, col, val);
+  KS_CHECK(fits, KS_ERR_ARG_OUTOFRANGE, "the sum exceeds 32-bit PetscInt indices");
+  return ks_mat_create_csr_flags(A->ctx, A->n, A->row_start, A->n_global, rp.data(), col.data(), val.data(), flags, out);
 }
 
 extern "C" int ks_mat_create_laplacian3d(ks_ctx ctx, int nx, int ny, int nz, int z0, int nzl, ks_mat *out)
@@ -1747,7 +1771,7 @@ extern "C" int ks_mat_load_petsc_binary(ks_ctx ctx, const char *path, ks_mat *ou
   std::vector<double> va(ci.size());
   for (long long i = 0; i <= nloc; i++) rp[i] = (int)(start[r0 + i] - start[r0]);
   for (size_t e = 0; e < ci.size(); e++) { ci[e] = (int32_t)be32(pc + 4 * (start[r0] + e)); va[e] = be64f(pv + 8 * (start[r0] + e)); }
-  return ks_mat_create_csr(ctx, (int)nloc, (int)r0, (int)rows, rp.data(), ci.data(), va.data(), out);
+  return ks_mat_create_csr_flags(ctx, (int)nloc, (int)r0, (int)rows, rp.data(), ci.data(), va.data(), KS_MAT_KEEP_CSR, out);
 }
 
 // MatCreateShell + MatShellSetOperation(MATOP_MULT) (the matrix-free route of src/eps/tutorials/ex3.c)

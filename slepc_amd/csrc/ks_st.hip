@@ -69,6 +69,11 @@ int linop_apply(ks_st st, double a, ks_mat A, double b, ks_mat B, bool identity_
 // the matrix P of the table above, y = s .* P x
 int apply_P(ks_st st, const double *s, const double *x, double *out, double *tmp)
 {
+  if (st->Pmat) {                                            // ST_MATMODE_COPY: the assembled A - sigma B, one product
+    if (s && ks_mat_can_rowscale(st->Pmat)) return ks_mat_mult_internal(st->Pmat, x, out, s);
+    KS_CALL(ks_mat_mult_internal(st->Pmat, x, out));
+    return s ? lincomb(st->ctx, st->n, s, 1.0, out, 0.0, nullptr, out) : KS_SUCCESS;
+  }
   if (st->type == KS_ST_SINVERT || st->type == KS_ST_CAYLEY) return linop_apply(st, 1.0, st->A, -st->sigma, st->B, !st->B, s, x, out, tmp);
   return linop_apply(st, 0.0, nullptr, 1.0, st->B, false, s, x, out, tmp);           // shift, nmat=2: P = B
 }
@@ -234,6 +239,7 @@ int ks_st_setup_internal(ks_st st)
     KS_CHECK(st->nu != 0.0 || st->sigma != 0.0, KS_ERR_USER_INPUT, "Values of shift and antishift cannot be zero simultaneously");
     KS_CHECK(st->nu != -st->sigma, KS_ERR_USER_INPUT, "It is not allowed to set the antishift equal to minus the shift (the target)");
   }
+  if (st->Pmat) { ks_mat_destroy(st->Pmat); st->Pmat = nullptr; }           // the assembled P of an earlier shift / type / mode
   const bool need_solve = (st->type == KS_ST_SINVERT) || (st->type == KS_ST_CAYLEY) || (st->type == KS_ST_SHIFT && B);
   if (st->W) { int wn = 0; ks_bv_get_sizes(st->W, &wn, nullptr, nullptr, nullptr); if (wn != A->n) { ks_bv_destroy(st->W); ks_bv_destroy(st->K); ks_bv_destroy(st->Kb); st->W = st->K = st->Kb = nullptr; if (st->dinv) hipFree(st->dinv); st->dinv = nullptr; } }
   if (!st->W) KS_CALL(ks_bv_create(ctx, A->n, A->n_global, 3, 0, &st->W));
@@ -245,7 +251,13 @@ int ks_st_setup_internal(ks_st st)
     // Jacobi: diag(P)
     double *da = ks_bv_col(st->W, 1), *db = ks_bv_col(st->W, 2);
     const unsigned nb = (unsigned)std::max<long long>(1, std::min<long long>(((long long)A->n + 255) / 256, (long long)ctx->num_cu * 16));
-    if (st->type == KS_ST_SINVERT || st->type == KS_ST_CAYLEY) {
+    if (st->matmode == KS_ST_MATMODE_COPY && (st->type == KS_ST_SINVERT || st->type == KS_ST_CAYLEY)) {
+      // STMatMAXPY_Private, ST_MATMODE_COPY (stsolve.c:603-631): P = A - sigma B assembled (nmat = 1: MatShift); a zero shift takes A itself
+      // there (:611-614) - here a copy of it, so that the ST owns what it destroys
+      KS_CALL(ks_mat_create_axpy(A, -st->sigma, B, 0u, &st->Pmat));
+      KS_CALL(ks_mat_get_diagonal_internal(st->Pmat, da));
+      hipLaunchKernelGGL(k_jacobi_setup, dim3(nb), dim3(256), 0, ctx->stream, (long long)A->n, 1.0, da, 0.0, (const double *)nullptr, st->dinv);
+    } else if (st->type == KS_ST_SINVERT || st->type == KS_ST_CAYLEY) {
       KS_CALL(ks_mat_get_diagonal_internal(A, da));
       if (B) KS_CALL(ks_mat_get_diagonal_internal(B, db));
       hipLaunchKernelGGL(k_jacobi_setup, dim3(nb), dim3(256), 0, ctx->stream, (long long)A->n, 1.0, da, -st->sigma, B ? db : nullptr, st->dinv);
@@ -317,6 +329,7 @@ extern "C" int ks_st_destroy(ks_st st)
   if (st->dinv) hipFree(st->dinv);
   if (st->op) ks_mat_destroy(st->op);
   if (st->bil) ks_mat_destroy(st->bil);
+  if (st->Pmat) ks_mat_destroy(st->Pmat);
   delete st;
   return KS_SUCCESS;
 }
@@ -350,6 +363,14 @@ extern "C" int ks_st_set_matrices(ks_st st, ks_mat A, ks_mat B)      // STSetMat
   st->A = A; st->B = B; st->ready = false;
   return KS_SUCCESS;
 }
+extern "C" int ks_st_set_matmode(ks_st st, int mode)                 // STSetMatMode
+{
+  KS_CHECK(st, KS_ERR_ARG_NULL, "ST is NULL");
+  KS_CHECK(mode == KS_ST_MATMODE_COPY || mode == KS_ST_MATMODE_SHELL, KS_ERR_SUP, "only ST_MATMODE_COPY and ST_MATMODE_SHELL are built");
+  if (st->matmode != mode) { st->matmode = mode; st->ready = false; }
+  return KS_SUCCESS;
+}
+extern "C" int ks_st_get_matmode(ks_st st, int *mode) { KS_CHECK(st && mode, KS_ERR_ARG_NULL, "NULL argument"); *mode = st->matmode; return KS_SUCCESS; }
 extern "C" int ks_st_set_ksp(ks_st st, double rtol, int max_it, int restart)   // KSPSetTolerances / KSPGMRESSetRestart on STGetKSP
 {
   KS_CHECK(st, KS_ERR_ARG_NULL, "ST is NULL");

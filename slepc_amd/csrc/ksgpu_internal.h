@@ -136,6 +136,8 @@ struct ks_mat_s {
   int row_start = 0;     // first global row
   int n_global = 0;
   long long nnz = 0;     // local nonzeros (diag + offdiag blocks)
+  // the CSR arrays the matrix was created from (global columns), kept on the host for KS_MAT_KEEP_CSR: what MatDuplicate / MatAXPY need (ks_mat_create_axpy)
+  bool keep_csr = false; std::vector<int> k_rowptr, k_col; std::vector<double> k_val;
   // diagonal block (columns owned by this rank, LOCAL column indices)
   int *d_rowptr = nullptr; int *d_col = nullptr; double *d_val = nullptr; long long nnz_d = 0;
   int lanes_per_row = 8;
@@ -215,6 +217,8 @@ struct ks_st_s {
   ks_bv Kb = nullptr;                         // BiCGStab work vectors (7 columns)
   ks_bv K = nullptr, W = nullptr;             // GMRES basis (restart+1 columns), work vectors (3 columns)
   double *dinv = nullptr;                     // Jacobi: 1/diag(P)
+  int matmode = KS_ST_MATMODE_SHELL;          // STSetMatMode: how P = A - sigma B exists (shell: applied term by term; copy: assembled, stsolve.c:603-631)
+  ks_mat Pmat = nullptr;                      // ST_MATMODE_COPY: the assembled P (owned)
   ks_mat op = nullptr;                        // shell matrix whose MatMult is STApply
   int n = 0; bool ready = false;
   long long solves = 0, its = 0; double last_rnorm = 0.0;

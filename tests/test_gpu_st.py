@@ -484,3 +484,99 @@ def test_config5_against_the_independent_dense_fixture(ctx):
     for k in range(6):
         assert np.abs(want[:8] - got[k]).min() <= 1e-9 * abs(got[k]), (k, got[k])
     assert np.all(np.diff(np.abs(got - fx["target"])) >= -1e-9)
+
+
+# ---- ST_MATMODE_COPY: P = A - sigma B assembled (STSetMatMode; STMatMAXPY_Private stsolve.c:603-631) -------------------------------------
+def _mat_keep(ctx, Ao):
+    import slepc_amd as ks
+    return ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val, keep_csr=True)
+
+
+@pytest.mark.parametrize("withB,sigma", [(True, 35.0), (False, 1.3), (True, 0.0)])
+def test_matmode_copy_assembles_the_matrix_of_the_solves(ctx, withB, sigma):
+    """MatAXPY on the device side of the C ABI equals A - sigma B entry by entry (product against scipy's sum, diagonal exactly the
+    formula a_ii + (-sigma b_ii)); the solves of copy and shell mode agree with the LU oracle; copy mode takes one product of P per
+    GMRES iteration where shell mode takes one of A and one of B."""
+    import slepc_amd as ks
+    Ao, Bo = nc.config5_pencil(3000)
+    A = _mat_keep(ctx, Ao); B = _mat_keep(ctx, Bo) if withB else None
+    P = A.axpy_new(-sigma, B)
+    Sa = Ao.to_scipy(); Sb = Bo.to_scipy() if withB else __import__("scipy.sparse").sparse.identity(Ao.n, format="csr")
+    x = np.random.default_rng(5).standard_normal(Ao.n)
+    ref = (Sa - sigma * Sb) @ x
+    assert np.linalg.norm(P.mult(x) - ref) <= 1e-14 * np.linalg.norm(ref)
+    assert np.array_equal(P.get_diagonal(), Sa.diagonal() + (-sigma) * Sb.diagonal())
+    assert P.nnz == (abs(Sa) + abs(Sb)).nnz
+    ys = {}
+    for mode in ("copy", "shell"):
+        st = ks.ST(ctx)
+        st.SetType("sinvert"); st.SetShift(sigma); st.SetMatrices(A, B); st.SetKSP(rtol=1e-14); st.SetMatMode(mode)
+        assert st.GetMatMode() == mode
+        ctx.prof_enable(True); ctx.prof_reset()
+        ys[mode] = st.Apply(x)
+        prof = ctx.prof_get()
+        ctx.prof_enable(False)
+        its = st.GetKSPStats()["iterations"]
+        nprod = prof["spmv_csr"]["launches"]
+        nB = 1 if withB else 0                              # M = B applied once before the solve
+        if mode == "copy":
+            assert its + nB <= nprod <= its + nB + 2, (nprod, its)      # the residual of the zero guess costs no product; one of P per iteration (+ one enqueued ahead)
+        elif withB and sigma != 0.0:
+            assert nprod >= 2 * its + nB
+    y0 = O.ST(Ao, Bo if withB else None, "sinvert", sigma).apply(x)
+    for mode in ys:
+        assert np.linalg.norm(ys[mode] - y0) <= 1e-11 * np.linalg.norm(y0), mode
+
+
+def test_matmode_copy_follows_the_shift_and_needs_the_csr_arrays(ctx):
+    import slepc_amd as ks
+    Ao, Bo = nc.config5_pencil(2000)
+    A = _mat_keep(ctx, Ao); B = _mat_keep(ctx, Bo)
+    x = np.random.default_rng(6).standard_normal(Ao.n)
+    st = ks.ST(ctx)
+    st.SetType("sinvert"); st.SetMatrices(A, B); st.SetKSP(rtol=1e-13); st.SetMatMode("copy")
+    for sigma in (35.0, 36.5, 35.0):                         # STSetShift after STSetUp: P is assembled again (sinvert.c:121-141)
+        st.SetShift(sigma)
+        y = st.Apply(x); y0 = O.ST(Ao, Bo, "sinvert", sigma).apply(x)
+        assert np.linalg.norm(y - y0) <= 1e-10 * np.linalg.norm(y0), sigma
+    # cayley: P assembled, M = A + nu B term by term
+    st.SetType("cayley"); st.SetShift(35.0); st.CayleySetAntishift(2.0)
+    y = st.Apply(x); y0 = O.ST(Ao, Bo, "cayley", 35.0, nu=2.0).apply(x)
+    assert np.linalg.norm(y - y0) <= 1e-10 * np.linalg.norm(y0)
+    # back to shell mode: same operator
+    st.SetType("sinvert"); st.SetMatMode("shell")
+    y = st.Apply(x); y0 = O.ST(Ao, Bo, "sinvert", 35.0).apply(x)
+    assert np.linalg.norm(y - y0) <= 1e-10 * np.linalg.norm(y0)
+    # matrices created without KS_MAT_KEEP_CSR hold only the layout their product runs on
+    A2 = _mat(ctx, Ao)
+    st2 = ks.ST(ctx); st2.SetType("sinvert"); st2.SetShift(35.0); st2.SetMatrices(A2, B); st2.SetMatMode("copy")
+    with pytest.raises(ks.KsError) as e:
+        st2.SetUp()
+    assert e.value.rc == 58                                   # PETSC_ERR_ORDER
+    with pytest.raises(ks.KsError):
+        st2.SetMatMode(1)                                     # ST_MATMODE_INPLACE is not built
+    # MatLoad keeps the arrays it read
+    Af = ks.Mat.load(ctx, gi.matrix_path("bfw62a.petsc")); Bf = ks.Mat.load(ctx, gi.matrix_path("bfw62b.petsc"))
+    Pf = Af.axpy_new(-0.5, Bf)
+    Sa = O.load_petsc_binary(gi.matrix_path("bfw62a.petsc")).to_scipy(); Sb = O.load_petsc_binary(gi.matrix_path("bfw62b.petsc")).to_scipy()
+    xf = np.random.default_rng(7).standard_normal(Af.n)
+    ref = (Sa - 0.5 * Sb) @ xf
+    assert np.linalg.norm(Pf.mult(xf) - ref) <= 1e-14 * np.linalg.norm(ref)
+
+
+def test_config5_in_copy_mode_matches_the_oracle(ctx):
+    """The config-5 solve of test_config5_generalized_sinvert_vs_oracle with the matrix of the solves assembled (the reference's default
+    matmode; its LU is the oracle's)."""
+    import slepc_amd as ks
+    Ao, Bo = nc.config5_pencil(4000)
+    sigma = 38.0
+    A = _mat_keep(ctx, Ao); B = _mat_keep(ctx, Bo)
+    eps = ks.EPS(ctx)
+    eps.SetOperators(A, B); eps.SetProblemType(ks.EPS_GNHEP); eps.SetDimensions(6, 24); eps.SetTarget(sigma)
+    st = eps.GetST(); st.SetType("sinvert"); st.SetMatMode("copy"); st.SetKSP(rtol=1e-12)
+    eps.Solve()
+    r = O.eps_krylovschur_nhep(Ao, 6, ncv=24, which=O.which_target_magnitude(sigma), st=O.ST(Ao, Bo, "sinvert", sigma))
+    assert eps.GetConverged() >= 6 and eps.GetIterationNumber() == r.its
+    lam = np.array([complex(*eps.GetEigenvalue(i)) for i in range(6)])
+    ref = (r.eigr + 1j * r.eigi)[r.perm][:6]
+    assert np.allclose(lam, ref, rtol=1e-9, atol=0)
