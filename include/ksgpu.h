@@ -401,6 +401,9 @@ int ks_st_set_matmode(ks_st st, int mode);
 int ks_st_get_matmode(ks_st st, int *mode);
 enum { KS_KSP_GMRES = 0, KS_KSP_BCGS = 1 };
 int ks_st_set_ksp_type(ks_st st, int type);                                /* KSPSetType on STGetKSP: GMRES (restarted, the shell mode's default) or BiCGStab; both with Jacobi on the left */
+/* KSPGMRESSetCGSRefinementType on STGetKSP, with the BV constants: KS_BV_ORTHOG_REFINE_NEVER (PETSc's default for KSPGMRES: one pass of
+   classical Gram-Schmidt, then the norm), _IFNEEDED (PETSc's test is the BV's, eta 0.7071) or _ALWAYS */
+int ks_st_set_gmres_cgs_refinement(ks_st st, int refine);
 int ks_st_set_ksp(ks_st st, double rtol, int max_it, int restart);        /* KSPSetTolerances / KSPGMRESSetRestart on STGetKSP; 0 keeps */
 int ks_st_setup(ks_st st);                                                /* STSetUp */
 int ks_st_apply(ks_st st, const double *x_dev, double *y_dev);            /* STApply stsolve.c:44 */

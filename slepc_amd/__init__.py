@@ -671,6 +671,10 @@ class ST:
     def SetKSP(self, rtol=0.0, max_it=0, restart=0):
         _lib.check(self.ctx.L.ks_st_set_ksp(self.h, rtol, max_it, restart))
 
+    def SetGMRESCGSRefinement(self, t):
+        """KSPGMRESSetCGSRefinementType on the ST's KSP: "never" (PETSc's default), "ifneeded" or "always"."""
+        _lib.check(self.ctx.L.ks_st_set_gmres_cgs_refinement(self.h, {"ifneeded": 0, "never": 1, "always": 2}.get(t, t)))
+
     def SetMatMode(self, mode):
         """STSetMatMode: "shell" (default here) or "copy" (P = A - sigma B assembled; the matrices need keep_csr)."""
         _lib.check(self.ctx.L.ks_st_set_matmode(self.h, {"copy": 0, "shell": 2}.get(mode, mode)))

@@ -246,6 +246,7 @@ int ks_st_setup_internal(ks_st st)
   if (need_solve) {
     if (st->K) { int km = 0; ks_bv_get_sizes(st->K, nullptr, nullptr, &km, nullptr); if (km != st->restart + 1) { ks_bv_destroy(st->K); st->K = nullptr; } }
     if (!st->K) { KS_CALL(ks_bv_create(ctx, A->n, A->n_global, st->restart + 1, 0, &st->K)); st->K->row_start = A->row_start; }
+    KS_CALL(ks_bv_set_orthogonalization(st->K, KS_BV_ORTHOG_CGS, st->gmres_refine, 0.7071));      // KSPGMRESClassicalGramSchmidtOrthogonalization + refinement type
     if (st->ksp_type == KS_KSP_BCGS && !st->Kb) { KS_CALL(ks_bv_create(ctx, A->n, A->n_global, 7, 0, &st->Kb)); st->Kb->row_start = A->row_start; }
     if (!st->dinv) KS_HIP(hipMalloc(&st->dinv, sizeof(double) * std::max(A->n, 1)));
     // Jacobi: diag(P)
@@ -384,6 +385,13 @@ extern "C" int ks_st_set_ksp_type(ks_st st, int type)              // KSPSetType
   KS_CHECK(st, KS_ERR_ARG_NULL, "ST is NULL");
   KS_CHECK(type == KS_KSP_GMRES || type == KS_KSP_BCGS, KS_ERR_SUP, "only KSPGMRES and KSPBCGS are built");
   if (st->ksp_type != type) { st->ksp_type = type; st->ready = false; }
+  return KS_SUCCESS;
+}
+extern "C" int ks_st_set_gmres_cgs_refinement(ks_st st, int refine)   // KSPGMRESSetCGSRefinementType on STGetKSP
+{
+  KS_CHECK(st, KS_ERR_ARG_NULL, "ST is NULL");
+  KS_CHECK(refine == KS_BV_ORTHOG_REFINE_NEVER || refine == KS_BV_ORTHOG_REFINE_IFNEEDED || refine == KS_BV_ORTHOG_REFINE_ALWAYS, KS_ERR_ARG_OUTOFRANGE, "unknown refinement type %d", refine);
+  if (st->gmres_refine != refine) { st->gmres_refine = refine; st->ready = false; }
   return KS_SUCCESS;
 }
 extern "C" int ks_st_setup(ks_st st) { KS_CHECK(st, KS_ERR_ARG_NULL, "ST is NULL"); return ks_st_setup_internal(st); }

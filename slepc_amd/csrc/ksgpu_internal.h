@@ -214,6 +214,7 @@ struct ks_st_s {
   ks_mat A = nullptr, B = nullptr;            // borrowed
   double rtol = 1e-8; int max_it = 10000, restart = 30;   // KSP: SLEPC_DEFAULT_TOL (stsles.c:407), PETSc defaults
   int ksp_type = KS_KSP_GMRES;                // KSPGMRES (the default of the shell matrix mode) or KSPBCGS
+  int gmres_refine = KS_BV_ORTHOG_REFINE_NEVER;   // KSPGMRESSetCGSRefinementType: PETSc's default is classical Gram-Schmidt without refinement
   ks_bv Kb = nullptr;                         // BiCGStab work vectors (7 columns)
   ks_bv K = nullptr, W = nullptr;             // GMRES basis (restart+1 columns), work vectors (3 columns)
   double *dinv = nullptr;                     // Jacobi: 1/diag(P)

@@ -320,6 +320,9 @@ def test_eps_test11_sinvert_indefinite_shift_golden(ctx):
     eps.SetOperators(_mat(ctx, Ao)); eps.SetProblemType(ks.EPS_NHEP); eps.SetDimensions(4); eps.SetTolerances(1e-10, 0)
     eps.SetEigenvalueComparison(nc.right_of(0.5)); eps.SetInitialVector(np.ones(Ao.n))
     st = eps.GetST(); st.SetType("sinvert"); st.SetShift(0.5); st.SetKSP(rtol=1e-13, restart=Ao.n, max_it=10 * Ao.n)
+    # full GMRES on an indefinite matrix to 1e-13: the unrefined Gram-Schmidt of the KSP's default loses the basis's orthogonality here (196 instead
+    # of at most n = 120 iterations per solve, same eigenvalues): -st_ksp_gmres_cgs_refinement_type refine_ifneeded
+    st.SetGMRESCGSRefinement("ifneeded")
     eps.Solve()
     r = O.eps_krylovschur_nhep(Ao, 4, tol=1e-10, which=nc.right_of(0.5), st=O.ST(Ao, None, "sinvert", 0.5), v0=np.ones(Ao.n))
     lam = np.array([eps.GetEigenvalue(i)[0] for i in range(4)])
@@ -580,3 +583,25 @@ def test_config5_in_copy_mode_matches_the_oracle(ctx):
     lam = np.array([complex(*eps.GetEigenvalue(i)) for i in range(6)])
     ref = (r.eigr + 1j * r.eigi)[r.perm][:6]
     assert np.allclose(lam, ref, rtol=1e-9, atol=0)
+
+
+def test_gmres_refinement_types_give_the_same_solution(ctx):
+    """KSPGMRESSetCGSRefinementType: never (the default, PETSc's) / ifneeded / always - same solution to the solver's tolerance, same
+    iteration count on this well-conditioned preconditioned matrix; an unknown type is an error."""
+    import slepc_amd as ks
+    Ao, Bo = nc.config5_pencil(3000)
+    A = _mat(ctx, Ao); B = _mat(ctx, Bo)
+    x = np.random.default_rng(8).standard_normal(Ao.n)
+    y0 = O.ST(Ao, Bo, "sinvert", 35.0).apply(x)
+    its = {}
+    for t in (None, "never", "ifneeded", "always"):
+        st = ks.ST(ctx)
+        st.SetType("sinvert"); st.SetShift(35.0); st.SetMatrices(A, B); st.SetKSP(rtol=1e-13)
+        if t:
+            st.SetGMRESCGSRefinement(t)
+        y = st.Apply(x)
+        assert np.linalg.norm(y - y0) <= 1e-10 * np.linalg.norm(y0), t
+        its[t] = st.GetKSPStats()["iterations"]
+    assert its[None] == its["never"] and abs(its["never"] - its["always"]) <= 1 and abs(its["ifneeded"] - its["always"]) <= 1
+    with pytest.raises(ks.KsError):
+        st.SetGMRESCGSRefinement(7)
