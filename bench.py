@@ -404,7 +404,7 @@ def side_configs(ks, ctx, barrier, args):
             spmv_alg = sum(v["alg_bytes"] for (nm, _), v in sp.items() if nm == "spmv_csr")
             spmv_hbm = sum(v["hbm_bytes"] for (nm, _), v in sp.items() if nm == "spmv_csr")
             its_per_solve = kst["iterations"] / max(1, kst["solves"])
-            out["C5"] = {"workload": "random nonsymmetric CSR n=%d nnz=%d (+ tridiagonal B, nnz=%d), GNHEP shift-and-invert target 0, nev=20 m=60, GMRES(30)+Jacobi inner solves"
+            out["C5"] = {"workload": "random nonsymmetric CSR n=%d nnz=%d (+ tridiagonal B, nnz=%d), GNHEP shift-and-invert target 0, nev=20 m=60, GMRES(30)+Jacobi inner solves (classical Gram-Schmidt without refinement, the KSP default)"
                                      % (n5, nnz, nnzb),
                          "value": t["steps"] / t["seconds"], "unit": "steps/s", "steps": t["steps"], "ms_per_step": 1e3 * t["seconds"] / t["steps"],
                          "mean_k": round(t["mean_k"], 2), "cycles": t["cycles"], "inner_iterations_per_step": round(its_per_solve, 2),

@@ -209,6 +209,12 @@ int ksk_copy(ks_ctx ctx, const double *src, double *dst, size_t n)
   return KS_SUCCESS;
 }
 
+// dst (device) = src (pinned host memory as the device sees it): a few KB of coefficients
+__global__ void k_copy_mapped(const double *__restrict__ src, double *__restrict__ dst, size_t n)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 // stage host coefficients into the BV's device scratch (async from pinned memory when they fit)
 static int stage_coefs(ks_bv bv, const double *host, size_t len, double **dev)
 {
@@ -220,14 +226,27 @@ static int stage_coefs(ks_bv bv, const double *host, size_t len, double **dev)
     bv->coef_len = len + 64;
   }
   if (len <= KS_PINNED_H2D_DOUBLES) {
-    // through one of two pinned halves, no host wait: the event of a half says when the upload that last used it has left
+    // through one of two pinned halves, no host wait
     const int h = ctx->h2d_next; ctx->h2d_next ^= 1;
-    if (!ctx->ev_h2d[h]) KS_HIP(hipEventCreateWithFlags(&ctx->ev_h2d[h], hipEventDisableTiming));
-    else KS_HIP(hipEventSynchronize(ctx->ev_h2d[h]));
     double *pin = ctx->h_pinned + KS_PINNED_D2H_BYTES / sizeof(double) + (size_t)h * KS_PINNED_H2D_DOUBLES;
-    memcpy(pin, host, len * sizeof(double));
-    KS_HIP(hipMemcpyAsync(bv->coef, pin, len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    KS_HIP(hipEventRecord(ctx->ev_h2d[h], ctx->stream));
+    if (ctx->h_pinned_dev) {
+      // A kernel reads the mapped half instead of the runtime's host-to-device copy, whose call alone held the host for tens of microseconds per
+      // restart with the GPU idle all the while (config 2, profiles/r03_config2_restart_host_time.txt). The half is free again once the host has
+      // seen the stamp of a results kernel enqueued after that reader (every restart cycle waits for one); otherwise wait for the stream.
+      if (ctx->h2d_busy[h] && ctx->fetch_waited <= ctx->h2d_seq[h]) KS_HIP(ks_sync(ctx));
+      memcpy(pin, host, len * sizeof(double));
+      const double *pin_dev = (const double *)ctx->h_pinned_dev + (pin - ctx->h_pinned);
+      hipLaunchKernelGGL(k_copy_mapped, dim3((unsigned)std::min<size_t>(8, (len + 511) / 512)), dim3(256), 0, ctx->stream, pin_dev, bv->coef, len);
+      KS_HIP(hipGetLastError());
+      ctx->h2d_busy[h] = true; ctx->h2d_seq[h] = ctx->fetch_seq;
+    } else {
+      // the event of a half says when the upload that last used it has left
+      if (!ctx->ev_h2d[h]) KS_HIP(hipEventCreateWithFlags(&ctx->ev_h2d[h], hipEventDisableTiming));
+      else KS_HIP(hipEventSynchronize(ctx->ev_h2d[h]));
+      memcpy(pin, host, len * sizeof(double));
+      KS_HIP(hipMemcpyAsync(bv->coef, pin, len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      KS_HIP(hipEventRecord(ctx->ev_h2d[h], ctx->stream));
+    }
   } else {
     KS_HIP(hipMemcpyAsync(bv->coef, host, len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     KS_HIP(ks_sync(ctx));                               // pageable source: the caller may reuse it at once

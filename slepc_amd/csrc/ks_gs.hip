@@ -707,7 +707,7 @@ struct HostGs { KsGsState st; };
 // state, records and coefficient buffer straight into the pinned host area (mapped into the device's address space): one small launch
 // instead of three copy-engine transfers, which sat 16 us apart at the end of every Krylov run (profiles/r03_config2_kernel_trace_gaps.txt)
 __global__ __launch_bounds__(256) void k_results_to_host(const KsGsState *__restrict__ st, const KsStepRec *__restrict__ recs, int nrec, const double *__restrict__ coef, size_t coef_len,
-                                                         char *__restrict__ out, size_t off_rec, size_t off_coef)
+                                                         char *__restrict__ out, size_t off_rec, size_t off_coef, unsigned long long seq)
 {
   const unsigned *a = reinterpret_cast<const unsigned *>(st); unsigned *o = reinterpret_cast<unsigned *>(out);
   for (size_t i = threadIdx.x; i < sizeof(KsGsState) / 4; i += blockDim.x) o[i] = a[i];
@@ -715,14 +715,39 @@ __global__ __launch_bounds__(256) void k_results_to_host(const KsGsState *__rest
   for (size_t i = threadIdx.x; i < (size_t)nrec * sizeof(KsStepRec) / 4; i += blockDim.x) orr[i] = r[i];
   double *oc = reinterpret_cast<double *>(out + off_coef);
   for (size_t i = threadIdx.x; i < coef_len; i += blockDim.x) oc[i] = coef[i];
+  // the stamp goes last: the host polls it (results_wait) and reads the results as soon as it shows, a stream wait returned 15 - 20 us later
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned long long *>(out + KS_PINNED_STAMP_OFF), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 static_assert(sizeof(KsGsState) % 4 == 0 && sizeof(KsStepRec) % 4 == 0, "word copies");
 bool enqueue_results_to_host(ks_bv bv, int j0, size_t nrec, size_t coef_len, size_t off_rec, size_t off_coef)
 {
   ks_ctx ctx = bv->ctx;
   if (!ctx->h_pinned_dev) return false;
-  hipLaunchKernelGGL(k_results_to_host, dim3(1), dim3(256), 0, ctx->stream, bv->gs, nrec ? bv->recs + j0 : bv->recs, (int)nrec, bv->buffer, coef_len, (char *)ctx->h_pinned_dev, off_rec, off_coef);
-  return hipGetLastError() == hipSuccess;
+  if (!ctx->ev_fetch && hipEventCreateWithFlags(&ctx->ev_fetch, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->ev_fetch = nullptr; return false; }
+  hipLaunchKernelGGL(k_results_to_host, dim3(1), dim3(256), 0, ctx->stream, bv->gs, nrec ? bv->recs + j0 : bv->recs, (int)nrec, bv->buffer, coef_len, (char *)ctx->h_pinned_dev, off_rec, off_coef, ++ctx->fetch_seq);
+  if (hipGetLastError() != hipSuccess) return false;
+  return hipEventRecord(ctx->ev_fetch, ctx->stream) == hipSuccess;      // the wait's fallback: cannot fail to arrive
+}
+// Wait for the results a k_results_to_host launch wrote: its stamp in the pinned area, the event behind the launch as the fallback (everything a
+// finished launch wrote to host memory is visible). The stream itself is not waited for: in-order, everything before that launch has finished.
+int results_wait(ks_ctx ctx)
+{
+  const unsigned long long *stamp = reinterpret_cast<const unsigned long long *>((const char *)ctx->h_pinned + KS_PINNED_STAMP_OFF);
+  ctx->nsync++;
+  for (unsigned spins = 1;; spins++) {
+    if (__atomic_load_n(stamp, __ATOMIC_ACQUIRE) == ctx->fetch_seq) break;
+    if ((spins & 255u) == 0) {
+      const hipError_t q = hipEventQuery(ctx->ev_fetch);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) { ks_set_error("waiting for the results of a run: %s", hipGetErrorString(q)); return KS_ERR_LIB; }
+    }
+    __builtin_ia32_pause();
+  }
+  KS_CHECK(__atomic_load_n(stamp, __ATOMIC_ACQUIRE) == ctx->fetch_seq, KS_ERR_LIB, "the results of a run arrived without their stamp (%llu expected)", ctx->fetch_seq);
+  ctx->fetch_waited = ctx->fetch_seq;
+  return ks_oneshot_error(ctx);                  // a one-shot allreduce / halo exchange that gave up shows at every host wait, this one included (ksgpu.h)
 }
 
 // One host wait for everything the host wants to know after an enqueued run: the device state, the records of columns j0..j1 and
@@ -736,13 +761,14 @@ int fetch_state(ks_bv bv, KsGsState *st, KsStepRec *recs, int j0, int j1, double
   const size_t off_rec = (sizeof(KsGsState) + 63) / 64 * 64, off_coef = (off_rec + nrec * sizeof(KsStepRec) + 63) / 64 * 64;
   const size_t need = off_coef + coef_len * sizeof(double);
   char *pin = (char *)ctx->h_pinned;
-  if (need <= KS_PINNED_D2H_BYTES) {
-    if (!enqueue_results_to_host(bv, j0, nrec, coef_len, off_rec, off_coef)) {
+  if (need <= KS_PINNED_STAMP_OFF) {
+    if (enqueue_results_to_host(bv, j0, nrec, coef_len, off_rec, off_coef)) KS_CALL(results_wait(ctx));
+    else {
       KS_HIP(hipMemcpyAsync(pin, bv->gs, sizeof(KsGsState), hipMemcpyDeviceToHost, ctx->stream));
       if (nrec) KS_HIP(hipMemcpyAsync(pin + off_rec, bv->recs + j0, sizeof(KsStepRec) * nrec, hipMemcpyDeviceToHost, ctx->stream));
       if (coef_len) KS_HIP(hipMemcpyAsync(pin + off_coef, bv->buffer, sizeof(double) * coef_len, hipMemcpyDeviceToHost, ctx->stream));
+      KS_HIP(ks_sync(ctx));
     }
-    KS_HIP(ks_sync(ctx));
     memcpy(st, pin, sizeof(KsGsState));
     if (nrec) memcpy(recs, pin + off_rec, sizeof(KsStepRec) * nrec);
     if (coef_len) memcpy(coef_out, pin + off_coef, sizeof(double) * coef_len);
@@ -765,16 +791,17 @@ bool fetch_state_begin(ks_bv bv, int j0, int j1, size_t coef_len, int *rc)
   *rc = KS_SUCCESS;
   const size_t nrec = (j1 >= j0) ? (size_t)(j1 - j0 + 1) : 0;
   const size_t off_rec = (sizeof(KsGsState) + 63) / 64 * 64, off_coef = (off_rec + nrec * sizeof(KsStepRec) + 63) / 64 * 64;
-  if (off_coef + coef_len * sizeof(double) > KS_PINNED_D2H_BYTES) return false;
+  if (off_coef + coef_len * sizeof(double) > KS_PINNED_STAMP_OFF) return false;
   char *pin = (char *)ctx->h_pinned;
   auto chk = [&](hipError_t e) { if (e != hipSuccess && *rc == KS_SUCCESS) { ks_set_error("fetch_state_begin: %s", hipGetErrorString(e)); *rc = KS_ERR_LIB; } };
-  if (!ctx->ev_fetch) chk(hipEventCreateWithFlags(&ctx->ev_fetch, hipEventDisableTiming));
-  if (!enqueue_results_to_host(bv, j0, nrec, coef_len, off_rec, off_coef)) {
+  ctx->fetch_by_kernel = enqueue_results_to_host(bv, j0, nrec, coef_len, off_rec, off_coef);      // (records the event behind its launch itself)
+  if (!ctx->fetch_by_kernel) {
+    if (!ctx->ev_fetch) chk(hipEventCreateWithFlags(&ctx->ev_fetch, hipEventDisableTiming));
     chk(hipMemcpyAsync(pin, bv->gs, sizeof(KsGsState), hipMemcpyDeviceToHost, ctx->stream));
     if (nrec) chk(hipMemcpyAsync(pin + off_rec, bv->recs + j0, sizeof(KsStepRec) * nrec, hipMemcpyDeviceToHost, ctx->stream));
     if (coef_len) chk(hipMemcpyAsync(pin + off_coef, bv->buffer, sizeof(double) * coef_len, hipMemcpyDeviceToHost, ctx->stream));
+    if (*rc == KS_SUCCESS) chk(hipEventRecord(ctx->ev_fetch, ctx->stream));
   }
-  if (*rc == KS_SUCCESS) chk(hipEventRecord(ctx->ev_fetch, ctx->stream));
   return true;
 }
 int fetch_state_end(ks_bv bv, KsGsState *st, KsStepRec *recs, int j0, int j1, double *coef_out, size_t coef_len)
@@ -783,9 +810,12 @@ int fetch_state_end(ks_bv bv, KsGsState *st, KsStepRec *recs, int j0, int j1, do
   const size_t nrec = (recs && j1 >= j0) ? (size_t)(j1 - j0 + 1) : 0;
   const size_t off_rec = (sizeof(KsGsState) + 63) / 64 * 64, off_coef = (off_rec + nrec * sizeof(KsStepRec) + 63) / 64 * 64;
   const char *pin = (const char *)ctx->h_pinned;
-  ctx->nsync++;
-  KS_HIP(hipEventSynchronize(ctx->ev_fetch));
-  KS_CALL(ks_oneshot_error(ctx));                  // a one-shot allreduce that gave up shows at every host wait, this one included (ksgpu.h)
+  if (ctx->fetch_by_kernel) KS_CALL(results_wait(ctx));
+  else {
+    ctx->nsync++;
+    KS_HIP(hipEventSynchronize(ctx->ev_fetch));
+    KS_CALL(ks_oneshot_error(ctx));                // a one-shot allreduce that gave up shows at every host wait, this one included (ksgpu.h)
+  }
   memcpy(st, pin, sizeof(KsGsState));
   if (nrec) memcpy(recs, pin + off_rec, sizeof(KsStepRec) * nrec);
   if (coef_len) memcpy(coef_out, pin + off_coef, sizeof(double) * coef_len);

@@ -85,6 +85,10 @@ struct ks_ctx_s {
   double *h_pinned = nullptr; size_t h_pinned_len = 0;
   void *h_pinned_dev = nullptr;        // the same area as the device sees it (results written by a kernel instead of the copy engine); nullptr: not mapped
   hipEvent_t ev_h2d[2] = {nullptr, nullptr}; int h2d_next = 0;
+  unsigned long long fetch_waited = 0;  // the newest stamp the host has seen: every launch enqueued before that results kernel has finished
+  unsigned long long h2d_seq[2] = {0, 0}; bool h2d_busy[2] = {false, false};   // fetch_seq when a kernel was last enqueued to read that pinned half
+  bool fetch_by_kernel = false;         // the batch enqueued by fetch_state_begin was written by the kernel (wait on its stamp) rather than by copies (wait on the event)
+  unsigned long long fetch_seq = 0;     // stamp of the last batch of results a kernel wrote into the pinned area (its last word): the host polls it instead of waiting on the stream
   hipEvent_t ev_fetch = nullptr;        // marks the end of a batch of result copies that was enqueued ahead of further work (ks_gs.hip: fetch_state_begin / _end)
   KsGsMail *gs_mail = nullptr, *gs_mail_dev = nullptr;   // ops->gramschmidt slot: host mailbox and its device address (allocated on first use)
   unsigned long long gs_mail_seq = 0;
@@ -295,6 +299,7 @@ struct ks_bv_s {
 };
 
 constexpr size_t KS_PINNED_D2H_BYTES = 65536;
+constexpr size_t KS_PINNED_STAMP_OFF = KS_PINNED_D2H_BYTES - 64;      // the results' stamp (8 bytes); results may use the area below it
 constexpr size_t KS_PINNED_H2D_DOUBLES = 4096;
 constexpr int KS_MAX_COLS   = 64;     // max columns handled by the register-tiled sweeps (k+1 <= 64)
 constexpr int KS_PSTRIDE    = 72;     // doubles per block in the partials array
