@@ -249,6 +249,50 @@ def update_kernel_roofline(ks, prof_timed):
                     "that exit at their device-side gate: compare avg_launch_us_all_launches."}
 
 
+def live_traffic(kname, limit=150.0):
+    """HBM bytes per executed launch of kernel symbol `kname`, measured NOW: two child runs of this same command under rocprofv3
+    (--kernel-trace --pmc FETCH_SIZE, then WRITE_SIZE: separate passes, no other trace domain), the counters reduced as
+    scripts/pmc_traffic.py does - KiB units, FETCH_SIZE x 2 on gfx950 (it counts half of a 128-byte request; calibration in
+    profiles/r01b_pmc_calibration_and_mfma_summary.txt), launches that exit at their device-side gate (fetch < 1 MB) left out.
+    Returns (bytes, note) or (None, reason); never raises."""
+    import csv, glob, re, shutil, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 is not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself under a profiler"
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="ks_pmc_", dir="/tmp")
+            try:
+                env = dict(os.environ); env["TMPDIR"] = "/tmp"
+                cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", "python3", os.path.abspath(__file__),
+                       "--steps", "60", "--warmup", "20", "--min-steps", "60", "--no-cpu-baseline", "--no-configs", "--no-pmc"]
+                subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=limit)
+                got = []
+                for path in glob.glob(d + "/*/*counter_collection.csv"):
+                    for r in csv.DictReader(open(path)):
+                        if r["Counter_Name"] != ctr:
+                            continue
+                        name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).replace("void ", "").replace("ksk::", "").split("(")[0]
+                        if name == kname:
+                            got.append(float(r["Counter_Value"]))
+                vals[ctr] = got
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+        f, w = vals.get("FETCH_SIZE", []), vals.get("WRITE_SIZE", [])
+        ex = [v for v in f if v > 1024.0]
+        if not ex:
+            return None, "no executed launch of %s in the counter pass" % kname
+        exw = sorted(w)[len(w) - len(ex):] if len(w) >= len(ex) else w          # the executed launches are the ones that write
+        fb = 2.0 * 1024.0 * sum(ex) / len(ex); wb = 1024.0 * (sum(exw) / len(exw) if exw else 0.0)
+        return fb + wb, ("measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate child passes of this command with --steps 60 "
+                         "--warmup 20 --min-steps 60), (2*FETCH_SIZE + WRITE_SIZE)*1024 per executed launch, %d launches: fetched %.1f MB + written %.1f MB"
+                         % (len(ex), fb / 1e6, wb / 1e6))
+    except Exception as e:       # noqa: BLE001 - the counters must not take the headline down with them
+        return None, "counter pass failed: %r" % (e,)
+
+
 def measured_copy_ceiling(torch, gib=1.0, reps=10):
     """the spec peak confirmed on the box - a device-to-device copy of `gib` GiB (hipMemcpyDtoD through torch, timed
     with events on torch's stream, where the copy runs), read + write bytes over the time. Not a library kernel: the yardstick."""
@@ -516,6 +560,7 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the side legs (configs C2 / C5, SpMV layouts)")
     ap.add_argument("--no-c5", action="store_true")
     ap.add_argument("--c5-n", type=int, default=5000000)
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic (the committed summary is used instead)")
     ap.add_argument("--no-oneshot", action="store_true", help="N>1: skip the side leg that repeats the measurement with the one-shot allreduce")
     ap.add_argument("--oneshot-leg", action="store_true", help=argparse.SUPPRESS)     # the side leg itself (a child process of every rank)
     args = ap.parse_args()
@@ -632,6 +677,14 @@ def main():
                                            "stand-alone kernel reaches 6.8-7.0 TB/s (profiles/r02_micro_update_write*.txt)")
                 except Exception as e:       # noqa: BLE001
                     rl["measured_copy_GBps"] = None; rl["measured_note"] = "copy probe failed: %r" % (e,)
+                if world == 1 and not force_dist and not args.no_pmc:
+                    tb, tnote = live_traffic(rl["kernel"])
+                    if tb is not None:
+                        rl["traffic_lookup"] = rl["traffic"]
+                        rl["traffic"] = tb; rl["traffic_kind"] = "measured"; rl["traffic_source"] = tnote
+                        rl["traffic_over_bytes_per_executed_launch"] = round(tb / rl["bytes_per_executed_launch"], 4)
+                    else:
+                        rl["traffic_live_note"] = tnote
                 out["roofline"] = rl
         if prof:
             kernels = []

@@ -9,7 +9,7 @@ missing = [n for n in list(_lib._SIG) if not hasattr(so, n)]
 for n in missing:
     del _lib._SIG[n]
 import bench
-sys.argv = ["bench.py", "--no-cpu-baseline", "--no-configs"] + sys.argv[1:]
+sys.argv = ["bench.py", "--no-cpu-baseline", "--no-configs", "--no-pmc"] + sys.argv[1:]
 r, w = os.pipe()
 saved = os.dup(1)
 os.dup2(w, 1)
