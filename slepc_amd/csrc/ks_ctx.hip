@@ -153,7 +153,9 @@ extern "C" const char *ks_prof_class_name(int k) { return (k >= 0 && k < KS_K_CO
 static int get_event(ks_ctx ctx, hipEvent_t *e)
 {
   if (!ctx->event_pool.empty()) { *e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return KS_SUCCESS; }
-  KS_HIP(hipEventCreate(e));
+  // timing only: no system-scope fence (cache write-back and invalidation) when the event completes - it would cost the launches around it
+  // more than the event itself (hip_runtime_api.h, hipEventDisableSystemFence)
+  if (hipEventCreateWithFlags(e, hipEventDisableSystemFence) != hipSuccess) { (void)hipGetLastError(); KS_HIP(hipEventCreate(e)); }
   return KS_SUCCESS;
 }
 
