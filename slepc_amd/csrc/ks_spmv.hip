@@ -1408,8 +1408,9 @@ extern "C" int ks_mat_create_csr_flags(ks_ctx ctx, int n_local, int row_start, i
   if (!rc) rc = build_sell(A);
   if (rc) { ks_mat_destroy(A); return rc; }
   if (flags & KS_MAT_KEEP_CSR) {
+    try { A->k_rowptr.assign(rowptr, rowptr + n_local + 1); A->k_col.assign(col, col + nnz); A->k_val.assign(val, val + nnz); }
+    catch (const std::exception &e) { ks_mat_destroy(A); KS_FAIL(KS_ERR_MEM, "KS_MAT_KEEP_CSR: %s", e.what()); }
     A->keep_csr = true;
-    A->k_rowptr.assign(rowptr, rowptr + n_local + 1); A->k_col.assign(col, col + nnz); A->k_val.assign(val, val + nnz);
   }
   *out = A;
   return KS_SUCCESS;
@@ -1423,7 +1424,9 @@ extern "C" int ks_mat_create_axpy(ks_mat A, double alpha, ks_mat B, unsigned fla
   KS_CHECK(A->keep_csr && (!B || B->keep_csr), KS_ERR_ORDER, "MatAXPY needs the CSR arrays of its operands: create them with KS_MAT_KEEP_CSR");
   KS_CHECK(!B || (B->n == A->n && B->row_start == A->row_start && B->n_global == A->n_global && B->ctx == A->ctx), KS_ERR_ARG_INCOMP, "Mismatching row blocks of A (%d rows from %d) and B (%d rows from %d)", A->n, A->row_start, B ? B->n : 0, B ? B->row_start : 0);
   std::vector<int> rp, col; std::vector<double> val;
-  const bool fits = ksc::csr_axpy(A->n, A->row_start, A->k_rowptr.data(), A->k_col.data(), A->k_val.data(), alpha, B ? B->k_rowptr.data() : nullptr, B ? B->k_col.data() : nullptr, B ? B->k_val.data() : nullptr, rp, col, val);
+  bool fits = false;
+  try { fits = ksc::csr_axpy(A->n, A->row_start, A->k_rowptr.data(), A->k_col.data(), A->k_val.data(), alpha, B ? B->k_rowptr.data() : nullptr, B ? B->k_col.data() : nullptr, B ? B->k_val.data() : nullptr, rp, col, val); }
+  catch (const std::exception &e) { KS_FAIL(KS_ERR_MEM, "MatAXPY on the host: %s", e.what()); }
   KS_CHECK(fits, KS_ERR_ARG_OUTOFRANGE, "the sum exceeds 32-bit PetscInt indices");
   return ks_mat_create_csr_flags(A->ctx, A->n, A->row_start, A->n_global, rp.data(), col.data(), val.data(), flags, out);
 }
