@@ -74,6 +74,7 @@ extern "C" int ks_ctx_create(int device, void *stream, ks_ctx *out)
     delete ctx;
     KS_FAIL(KS_ERR_MEM, "hipHostMalloc of the staging area failed: %s", hipGetErrorString(e));
   }
+  memset(ctx->h_pinned, 0, ctx->h_pinned_len * sizeof(double));      // the results' stamp starts at 0: the first batch carries 1
   if (hipHostGetDevicePointer(&ctx->h_pinned_dev, ctx->h_pinned, 0) != hipSuccess) { (void)hipGetLastError(); ctx->h_pinned_dev = nullptr; }     // nullptr: results come back through the copy engine
   *out = ctx;
   return KS_SUCCESS;
