@@ -157,6 +157,20 @@ def _worker(rank, world, port, q):
         e4.Solve()
         res["c5_eig"] = [list(e4.GetEigenvalue(i)) for i in range(4)]; res["c5_its"] = e4.GetIterationNumber()
         res["c5_err"] = [e4.ComputeError(i) for i in range(4)]
+        # (5b) the same solve with the matrix of the inner solves assembled (ST_MATMODE_COPY): MatAXPY on every rank's row block (global
+        # columns), the halo plan of the sum built like any other matrix's
+        Ak = ks.Mat.from_csr(ctx, *P.local_block(Ag.rowptr, Ag.col, Ag.val, q0, q1), row_start=q0, n_global=Ag.n, keep_csr=True)
+        Bk = ks.Mat.from_csr(ctx, *P.local_block(Bg.rowptr, Bg.col, Bg.val, q0, q1), row_start=q0, n_global=Bg.n, keep_csr=True)
+        Pk = Ak.axpy_new(-36.0, Bk)
+        xg = np.random.default_rng(12).standard_normal(Ag.n)
+        Xp = ks.BV(ctx, q1 - q0, 2, N=Ag.n); Xp.set_column(0, xg[q0:q1])
+        Pk.mult_dev(Xp.column_ptr(0), Xp.column_ptr(1))
+        yp = (Ag.to_scipy() - 36.0 * Bg.to_scipy()) @ xg
+        res["copy_axpy"] = float(np.abs(Xp.column(1) - yp[q0:q1]).max() / np.abs(yp).max())
+        e4c = ks.EPS(ctx); e4c.SetOperators(Ak, Bk); e4c.SetProblemType(ks.EPS_GNHEP); e4c.SetDimensions(4, 20); e4c.SetTarget(36.0)
+        s4c = e4c.GetST(); s4c.SetType("sinvert"); s4c.SetMatMode("copy"); s4c.SetKSP(rtol=1e-13)
+        e4c.Solve()
+        res["c5copy_eig"] = [list(e4c.GetEigenvalue(i)) for i in range(4)]; res["c5copy_its"] = e4c.GetIterationNumber()
         # (6) test39.c: one solver, two solves with matrices whose LOCAL sizes differ (the 10x11 2-D Laplacian with one row moved
         # from rank 1 to rank 0, then the other way); EPSSetOperators drops what was sized by the first matrix
         L2 = O.laplacian2d(10, 11)
@@ -264,6 +278,8 @@ def test_ranks_sharing_one_gpu_against_oracle(world):
     for rk in range(world):
         assert out[rk]["c5_its"] == r5.its and np.allclose(np.array(out[rk]["c5_eig"]), ref5, rtol=1e-8, atol=1e-9)
         assert max(out[rk]["c5_err"]) < 1e-6
+        assert out[rk]["copy_axpy"] < 1e-14                                                     # (5b) P = A - 36 B assembled per row block
+        assert out[rk]["c5copy_its"] == r5.its and np.allclose(np.array(out[rk]["c5copy_eig"]), ref5, rtol=1e-8, atol=1e-9)
     import golden_inputs as gi
     r39 = O.eps_krylovschur_hep(O.laplacian2d(10, 11), 3, which="smallest_real")
     g39 = gi.eigenvalue_lines(gi.read("eps/eps_test39_1.out"))                  # first and second solve
