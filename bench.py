@@ -477,10 +477,10 @@ def side_configs(ks, ctx, barrier, args):
                                       "own_bytes_GBps": round(spmv_hbm / spmv_ms / 1e6, 1) if spmv_ms else None,
                                       "own_bytes_frac": round(spmv_hbm / spmv_ms / 1e6 / HBM_PEAK_GBS, 4) if spmv_ms else None,
                                       "avg_launch_us": round(1e3 * spmv_ms / max(1, spmv_n), 1), "launches_per_step": round(spmv_n / tail_steps, 2),
-                                      "pmc_bytes_per_product_of_A": {"fetched_GB": 0.40 + 3.34, "written_GB": 1.37 + 0.04, "kind": "lookup",
+                                      "pmc_bytes_per_product_of_A": {"fetched_GB": 0.40 + 3.25, "written_GB": 1.37 + 0.04, "kind": "lookup",
                                                                      "source": "profiles/r03_pmc_binned_spmv.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                                                                                "k_binned_gather + k_binned_reduce; FETCH_SIZE x2 on gfx950)",
-                                                                     "ratio_to_survey8d_bytes": round((0.40 + 3.34 + 1.37 + 0.04) / 2.08, 2)},
+                                                                     "ratio_to_survey8d_bytes": round((0.40 + 3.25 + 1.37 + 0.04) / 2.08, 2)},
                                       "structural_note": "2.4-2.5x the SURVEY 8d bytes by design: a (column slice, wave-bin) tile of a uniformly random matrix holds about 157 "
                                                          "entries, so no one-pass kernel can keep both its piece of x and its rows of y in LDS; the layout pays an 8 B per nonzero "
                                                          "round trip of the gathered x between two streaming phases (28 B per nonzero) for having no random access leave the CU "

@@ -891,6 +891,9 @@ __global__ void k_sum_parts(int n, const double *__restrict__ ypart, double *__r
 // the values and adds into rows of y in LDS. 28 bytes per nonzero of pure streams instead of 12 bytes + a line (profiles/r02_micro_binned_spmv*).
 constexpr int BN_MAXSEG = 12;            // segments a 1024-entry window may touch on the fast path
 constexpr int BN_CS_MAX = 9984;          // columns of a slice: 78 KB of LDS next to the two offset rows
+constexpr int BN_SEG_PAD = 8;            // a (slice, wave-bin) segment holds a multiple of 8 entries (padding: value 0 into the spare accumulator): every segment then
+                                         // starts on a 64-byte boundary of G / the values in both orders. Against padding to pairs only, same box: gather 385 -> 343-357 us,
+                                         // reduce 511 -> 493 us with 2.5 % more entries (profiles/r03_ab_binned.txt); 4: 370-377 / 508, 16: 346-362 / 497
 // phase 1: grid = slices, 1024 threads; LDS: x piece [cs], off1 row [wb + 1], off2t row [wb]
 __global__ __launch_bounds__(1024) void k_binned_gather(int n, int cs, int wb, int nwin, const long long *__restrict__ sbase, const unsigned short *__restrict__ col16,
                                                         const int *__restrict__ off1, const int *__restrict__ off2t, const int *__restrict__ wseg,
@@ -1007,7 +1010,7 @@ static int build_binned(ks_mat A)
   const int wb = 4 * ns, wr = (n + wb - 1) / wb;
   if (cs > 65535 || wr + 1 > 65535) return KS_SUCCESS;
   if ((size_t)cs * 8 + (size_t)(2 * wb + 1) * 4 > 156 * 1024 || (size_t)4 * (wr + 1) * 8 > 156 * 1024) return KS_SUCCESS;   // the offset rows of more than ~20 M local rows no longer fit LDS next to the piece of x: the XCD-sliced layout takes those
-  if (A->nnz_d + (long long)ns * wb >= 2147483647LL) return KS_SUCCESS;          // bin-major positions are 32-bit
+  if (A->nnz_d + (long long)ns * wb * (BN_SEG_PAD - 1) >= 2147483647LL) return KS_SUCCESS;          // bin-major positions are 32-bit
   const long long nnz = A->nnz_d;
   try {                                               // the build holds about 25 bytes per nonzero in host memory: without it the sliced layout takes the matrix
   std::vector<int> rp(n + 1), col(nnz); std::vector<double> val(nnz);
@@ -1031,13 +1034,13 @@ static int build_binned(ks_mat A)
     for (unsigned t = started; t < nthr; t++) for (int b = (int)t; b < wb; b += (int)nthr) fn(b);      // strides whose thread did not start
     for (auto &x : th) x.join();
   };
-  // segment lengths (padded to even), bin-major [wb][ns]
+  // segment lengths (padded to BN_SEG_PAD entries), bin-major [wb][ns]
   std::vector<int> len((size_t)wb * ns, 0);
   parallel_bins([&](int b) {
     int *L = len.data() + (size_t)b * ns;
     const int r0 = std::min((long long)b * wr, (long long)n), r1 = std::min((long long)(b + 1) * wr, (long long)n);
     for (int p = rp[r0]; p < rp[r1]; p++) L[col[p] / cs]++;
-    for (int s = 0; s < ns; s++) L[s] = (L[s] + 1) & ~1;
+    for (int s = 0; s < ns; s++) L[s] = (L[s] + BN_SEG_PAD - 1) / BN_SEG_PAD * BN_SEG_PAD;
   });
   // Bin-major order, GROUPED: `grp` consecutive wave-bins are interleaved slice by slice - [group][slice][wave-bin of the group]
   // - so that the segments a slice's workgroup writes in phase 1 for `grp` consecutive wave-bins are one contiguous run (80 KB instead of 64

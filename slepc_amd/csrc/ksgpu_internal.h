@@ -169,8 +169,8 @@ struct ks_mat_s {
   // Binned ("propagation blocking") copy of the diagonal block for wide-scatter matrices, the successor of the XCD-sliced one: the product
   // runs in two streaming phases with every random access in LDS. Columns are cut into bn_ns slices of bn_cs, rows into bn_wb wave-bins of
   // bn_wr. Entries are stored twice over: the 16-bit slice-local column in SLICE-major order (slice, wave-bin, row), the value and the 16-bit
-  // bin-local row in BIN-major order (wave-bin, slice, row); a (slice, wave-bin) segment is contiguous in both and starts at an even position
-  // (one padding entry with value 0 where needed). Phase 1 (a workgroup per slice, its piece of x in LDS) writes G = x[col] in bin-major
+  // bin-local row in BIN-major order (wave-bin, slice, row); a (slice, wave-bin) segment is contiguous in both, holds a multiple of 8
+  // entries (padding entries with value 0 where needed) and so starts on a 64-byte boundary of the 8-byte streams. Phase 1 (a workgroup per slice, its piece of x in LDS) writes G = x[col] in bin-major
   // order; phase 2 (a wave per wave-bin, its rows of y in LDS) streams G, val and row and adds val * G into its rows.
   bool use_binned = false;
   int bn_ns = 0, bn_cs = 0, bn_wb = 0, bn_wr = 0, bn_nwin = 0, bn_nwin2 = 0;
