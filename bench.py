@@ -264,7 +264,7 @@ def update_kernel_roofline(ks, prof_timed):
                     "that exit at their device-side gate: compare avg_launch_us_all_launches."}
 
 
-def live_traffic(kname, limit=150.0):
+def live_traffic(kname, limit=90.0):
     """HBM bytes per executed launch of kernel symbol `kname`, measured NOW: two child runs of this same command under rocprofv3
     (--kernel-trace --pmc FETCH_SIZE, then WRITE_SIZE: separate passes, no other trace domain), the counters reduced as
     scripts/pmc_traffic.py does - KiB units, FETCH_SIZE x 2 on gfx950 (it counts half of a 128-byte request; calibration in
@@ -283,7 +283,10 @@ def live_traffic(kname, limit=150.0):
                 env = dict(os.environ); env["TMPDIR"] = "/tmp"
                 cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", "python3", os.path.abspath(__file__),
                        "--steps", "60", "--warmup", "20", "--min-steps", "60", "--no-cpu-baseline", "--no-configs", "--no-pmc"]
-                subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=limit)
+                try:
+                    subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=limit)
+                except subprocess.TimeoutExpired:
+                    return None, "the %s pass was stopped after %.0f s" % (ctr, limit)
                 got = []
                 for path in glob.glob(d + "/*/*counter_collection.csv"):
                     for r in csv.DictReader(open(path)):
