@@ -47,6 +47,7 @@ extern "C" {
 #define KS_ERR_FILE_UNEXPECTED 79
 #define KS_ERR_ARG_WRONG       62
 #define KS_ERR_ARG_OUTOFRANGE  63
+#define KS_ERR_MAT_LU_ZRPVT    71   /* zero pivot in a block of the block-Jacobi preconditioner */
 #define KS_ERR_USER_INPUT      71   /* BV_SafeSqrt "Invalid inner product" bvimpl.h:137 */
 #define KS_ERR_ARG_WRONGSTATE  73
 #define KS_ERR_ARG_INCOMP      75
@@ -404,6 +405,14 @@ int ks_st_set_ksp_type(ks_st st, int type);                                /* KS
 /* KSPGMRESSetCGSRefinementType on STGetKSP, with the BV constants: KS_BV_ORTHOG_REFINE_NEVER (PETSc's default for KSPGMRES: one pass of
    classical Gram-Schmidt, then the norm), _IFNEEDED (PETSc's test is the BV's, eta 0.7071) or _ALWAYS */
 int ks_st_set_gmres_cgs_refinement(ks_st st, int refine);
+/* PCSetType on KSPGetPC(STGetKSP): KS_PC_JACOBI (the default: PCJACOBI, what the shell matrix mode defaults to, stsles.c:51-53) or
+   KS_PC_BJACOBI - PCBJACOBI (the reference's choice with a split preconditioner, stsles.c:46-48; -st_pc_type bjacobi in ex46.c:113,
+   test34.c:113) with blocks of block_size consecutive local rows (-pc_bjacobi_local_blocks n_local/block_size) solved exactly
+   (-sub_pc_type lu): the dense diagonal blocks of P = A - sigma B are inverted on the host at STSetUp and applied by one kernel.
+   2 <= block_size <= 32; the matrices must hold their CSR arrays (KS_MAT_KEEP_CSR); a singular block is KS_ERR_MAT_LU_ZRPVT. */
+#define KS_PC_JACOBI  0
+#define KS_PC_BJACOBI 1
+int ks_st_set_pc(ks_st st, int type, int block_size);
 int ks_st_set_ksp(ks_st st, double rtol, int max_it, int restart);        /* KSPSetTolerances / KSPGMRESSetRestart on STGetKSP; 0 keeps */
 int ks_st_setup(ks_st st);                                                /* STSetUp */
 int ks_st_apply(ks_st st, const double *x_dev, double *y_dev);            /* STApply stsolve.c:44 */

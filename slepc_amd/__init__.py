@@ -675,6 +675,10 @@ class ST:
         """KSPGMRESSetCGSRefinementType on the ST's KSP: "never" (PETSc's default), "ifneeded" or "always"."""
         _lib.check(self.ctx.L.ks_st_set_gmres_cgs_refinement(self.h, {"ifneeded": 0, "never": 1, "always": 2}.get(t, t)))
 
+    def SetPC(self, t, block_size=0):
+        """PCSetType on the ST's KSP: "jacobi" (default) or "bjacobi" with blocks of block_size consecutive local rows, solved exactly."""
+        _lib.check(self.ctx.L.ks_st_set_pc(self.h, {"jacobi": 0, "bjacobi": 1}.get(t, t), block_size))
+
     def SetMatMode(self, mode):
         """STSetMatMode: "shell" (default here) or "copy" (P = A - sigma B assembled; the matrices need keep_csr)."""
         _lib.check(self.ctx.L.ks_st_set_matmode(self.h, {"copy": 0, "shell": 2}.get(mode, mode)))

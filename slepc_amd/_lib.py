@@ -195,6 +195,7 @@ _SIG = {
     "ks_st_set_ksp": [vp, C.c_double, C.c_int, C.c_int],
     "ks_st_set_ksp_type": [vp, C.c_int],
     "ks_st_set_matmode": [vp, C.c_int],
+    "ks_st_set_pc": [vp, C.c_int, C.c_int],
     "ks_st_set_gmres_cgs_refinement": [vp, C.c_int],
     "ks_st_get_matmode": [vp, C.POINTER(C.c_int)],
     "ks_st_setup": [vp],

@@ -13,6 +13,7 @@
 // the same device kernels as the outer iteration: the Krylov basis is a BV, its Gram-Schmidt is the fused CGS of
 // ks_gs.hip, the update x += K y is BVMultVec.
 #include "ksgpu_internal.h"
+#include "ks_csr.h"
 #include <algorithm>
 
 namespace {
@@ -32,6 +33,18 @@ __global__ void k_jacobi_setup(long long n, double a, const double *__restrict__
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const double t = (da ? a * da[i] : 0.0) + b * (db ? db[i] : 1.0);
     d[i] = (t != 0.0) ? 1.0 / t : 1.0;
+  }
+}
+
+// out = M^-1 in for the block-Jacobi M: row i of out is row i of its block's inverse times the block's piece of in (binv: n x bs, row-major)
+__global__ void k_bjacobi_apply(long long n, int bs, const double *__restrict__ binv, const double *__restrict__ in, double *__restrict__ out)
+{
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long b0 = i / bs * bs;
+    const double *row = binv + i * bs;
+    double acc = 0.0;
+    for (int c = 0; c < bs && b0 + c < n; c++) acc = fma(row[c], in[b0 + c], acc);
+    out[i] = acc;
   }
 }
 
@@ -78,6 +91,29 @@ int apply_P(ks_st st, const double *s, const double *x, double *out, double *tmp
   return linop_apply(st, 0.0, nullptr, 1.0, st->B, false, s, x, out, tmp);           // shift, nmat=2: P = B
 }
 
+int bjacobi_apply(ks_st st, const double *in, double *out)
+{
+  if (st->n == 0) return KS_SUCCESS;
+  const unsigned nb = (unsigned)std::min<long long>(((long long)st->n + 255) / 256, (long long)st->ctx->num_cu * 16);
+  hipLaunchKernelGGL(k_bjacobi_apply, dim3(nb), dim3(256), 0, st->ctx->stream, (long long)st->n, st->pc_bs, st->binv, in, out);
+  KS_HIP(hipGetLastError());
+  return KS_SUCCESS;
+}
+// out = M^-1 (a u + b v) with the left preconditioner M of the KSP: diag(P) (one fused kernel) or the diagonal blocks of P
+int pc_lincomb(ks_st st, double a, const double *u, double b, const double *v, double *out)
+{
+  if (st->pc_type == KS_PC_JACOBI) return lincomb(st->ctx, st->n, st->dinv, a, u, b, v, out);
+  KS_CALL(lincomb(st->ctx, st->n, nullptr, a, u, b, v, st->pcwork));
+  return bjacobi_apply(st, st->pcwork, out);
+}
+// out = M^-1 P x
+int apply_MP(ks_st st, const double *x, double *out, double *tmp)
+{
+  if (st->pc_type == KS_PC_JACOBI) return apply_P(st, st->dinv, x, out, tmp);
+  KS_CALL(apply_P(st, nullptr, x, st->pcwork, tmp));
+  return bjacobi_apply(st, st->pcwork, out);
+}
+
 // Left-preconditioned restarted GMRES for P y = rhs (KSPGMRES defaults: restart 30, classical Gram-Schmidt)
 int gmres_solve(ks_st st, const double *rhs, double *y)
 {
@@ -88,7 +124,7 @@ int gmres_solve(ks_st st, const double *rhs, double *y)
   std::vector<double> H((size_t)(m + 1) * m, 0.0), g(m + 1, 0.0), cs(m, 0.0), sn(m, 0.0), h(m + 1, 0.0), yc(m, 0.0);
   st->solves++;
   KS_HIP(hipMemsetAsync(y, 0, sizeof(double) * std::max<long long>(n, 1), ctx->stream));
-  KS_CALL(lincomb(ctx, n, st->dinv, 1.0, rhs, 0.0, nullptr, ks_bv_col(K, 0)));
+  KS_CALL(pc_lincomb(st, 1.0, rhs, 0.0, nullptr, ks_bv_col(K, 0)));
   double beta = 0.0;
   const bool split = ks_bv_orthonormalize_can_split(K);
   bool k0_normalised = false, applied0 = false;
@@ -97,7 +133,7 @@ int gmres_solve(ks_st st, const double *rhs, double *y)
     // the host learns beta while the product runs
     int lin0 = 0, late0 = 0;
     KS_CALL(ks_bv_orthonormalize_enqueue(K, 0));
-    KS_CALL(apply_P(st, st->dinv, ks_bv_col(K, 0), ks_bv_col(K, 1), t1));
+    KS_CALL(apply_MP(st, ks_bv_col(K, 0), ks_bv_col(K, 1), t1));
     KS_CALL(ks_bv_orthonormalize_collect(K, 0, nullptr, &beta, &lin0, &late0));
     k0_normalised = true; applied0 = !late0;
   } else KS_CALL(ks_bv_normcolumn(K, 0, KS_NORM_2, &beta));
@@ -113,7 +149,7 @@ int gmres_solve(ks_st st, const double *rhs, double *y)
     bool applied = applied0;                        // K(:, j+1) = P K(:, j) already enqueued (speculatively, during the previous iteration)
     applied0 = false;
     for (int j = 0; j < m; j++) {
-      if (!applied) KS_CALL(apply_P(st, st->dinv, ks_bv_col(K, j), ks_bv_col(K, j + 1), t1));
+      if (!applied) KS_CALL(apply_MP(st, ks_bv_col(K, j), ks_bv_col(K, j + 1), t1));
       applied = false;
       double hn = 0.0; int lindep = 0;
       if (split) {
@@ -124,7 +160,7 @@ int gmres_solve(ks_st st, const double *rhs, double *y)
         const bool spec = (j + 1 < m) && (its + 1 < st->max_it) && predicted > 3.0 * tol;
         int late = 0;
         KS_CALL(ks_bv_orthonormalize_enqueue(K, j + 1));
-        if (spec) KS_CALL(apply_P(st, st->dinv, ks_bv_col(K, j + 1), ks_bv_col(K, j + 2), t1));
+        if (spec) KS_CALL(apply_MP(st, ks_bv_col(K, j + 1), ks_bv_col(K, j + 2), t1));
         KS_CALL(ks_bv_orthonormalize_collect(K, j + 1, h.data(), &hn, &lindep, &late));
         applied = spec && !late;                    // a column completed late was multiplied unfinished: apply again
       } else KS_CALL(ks_bv_orthonormalize_coefs(K, j + 1, h.data(), &hn, &lindep));       // the 1/hn scaling rides in the final update; h, hn and the flag arrive in one host wait
@@ -152,7 +188,7 @@ int gmres_solve(ks_st st, const double *rhs, double *y)
     KS_CHECK(its < st->max_it, KS_ERR_NOT_CONVERGED, "KSPSolve has not converged: GMRES reached %d iterations, preconditioned residual %g > %g", its, res, tol);
     // restart from the true preconditioned residual
     KS_CALL(apply_P(st, nullptr, y, t1, t2));
-    KS_CALL(lincomb(ctx, n, st->dinv, 1.0, rhs, -1.0, t1, ks_bv_col(K, 0)));
+    KS_CALL(pc_lincomb(st, 1.0, rhs, -1.0, t1, ks_bv_col(K, 0)));
     KS_CALL(ks_bv_normcolumn(K, 0, KS_NORM_2, &beta));
     st->last_rnorm = beta;
     if (beta <= tol) break;
@@ -171,7 +207,7 @@ int bcgs_solve(ks_st st, const double *rhs, double *y)
   double *r = ks_bv_col(K, 0), *rh = ks_bv_col(K, 1), *p = ks_bv_col(K, 2), *v = ks_bv_col(K, 3), *s = ks_bv_col(K, 4), *t = ks_bv_col(K, 5);
   st->solves++;
   KS_HIP(hipMemsetAsync(y, 0, sizeof(double) * std::max<long long>(n, 1), ctx->stream));
-  KS_CALL(lincomb(ctx, n, st->dinv, 1.0, rhs, 0.0, nullptr, r));                   // r = D^-1 b (zero initial guess)
+  KS_CALL(pc_lincomb(st, 1.0, rhs, 0.0, nullptr, r));                   // r = D^-1 b (zero initial guess)
   double beta0 = 0.0;
   KS_CALL(ks_bv_normcolumn(K, 0, KS_NORM_2, &beta0));
   st->last_rnorm = beta0;
@@ -190,13 +226,13 @@ int bcgs_solve(ks_st st, const double *rhs, double *y)
     const double bt = (rho_new / rho) * (alpha / omega);
     KS_CALL(lincomb(ctx, n, nullptr, 1.0, p, -omega, v, p));                         // p = r + beta (p - omega v)
     KS_CALL(lincomb(ctx, n, nullptr, bt, p, 1.0, r, p));
-    KS_CALL(apply_P(st, st->dinv, p, v, t1));                                        // v = D^-1 P p
+    KS_CALL(apply_MP(st, p, v, t1));                                                // v = D^-1 P p
     KS_CALL(ks_bv_set_active_columns(K, 3, 4));
     KS_CALL(ks_bv_dotvec(K, rh, d));                                                 // (rhat, v)
     KS_CHECK(d[0] != 0.0, KS_ERR_NOT_CONVERGED, "KSPSolve has not converged: BiCGStab breakdown ((rhat,v) = 0)");
     alpha = rho_new / d[0];
     KS_CALL(lincomb(ctx, n, nullptr, 1.0, r, -alpha, v, s));                         // s = r - alpha v
-    KS_CALL(apply_P(st, st->dinv, s, t, t1));                                        // t = D^-1 P s
+    KS_CALL(apply_MP(st, s, t, t1));                                                // t = D^-1 P s
     KS_CALL(ks_bv_set_active_columns(K, 4, 6));
     KS_CALL(ks_bv_dotvec(K, t, d));                                                  // (s,t), (t,t) in one reduction
     omega = d[1] != 0.0 ? d[0] / d[1] : 0.0;
@@ -223,6 +259,57 @@ int st_bilinear_mult(void *user, const double *x, double *y)
 }
 
 } // namespace
+
+// Block Jacobi set-up (PCSetUp_BJacobi with LU sub-solves, PETSc): the dense diagonal blocks of P - pc_bs consecutive local rows each - from the
+// CSR arrays the matrices keep (entry by entry a_ij + (-sigma b_ij), ks_csr.cpp, as the assembled P of ST_MATMODE_COPY has them), inverted on
+// the host by Gauss-Jordan elimination with partial pivoting, uploaded row by row.
+static int bjacobi_setup(ks_st st)
+{
+  ks_ctx ctx = st->ctx; ks_mat A = st->A, B = st->B;
+  const int n = st->n, bs = st->pc_bs;
+  const bool p_is_b = (st->type == KS_ST_SHIFT);                   // shift, nmat = 2: P = B
+  ks_mat M0 = p_is_b ? B : A;
+  KS_CHECK(M0 && M0->keep_csr && (p_is_b || !B || B->keep_csr), KS_ERR_ORDER, "the block-Jacobi preconditioner takes its blocks from the CSR arrays of the matrices: create them with KS_MAT_KEEP_CSR");
+  std::vector<int> rp, col; std::vector<double> val;
+  const int *prp; const int *pcol; const double *pval;
+  if (p_is_b) { prp = B->k_rowptr.data(); pcol = B->k_col.data(); pval = B->k_val.data(); }
+  else {
+    bool fits = false;
+    try { fits = ksc::csr_axpy(n, A->row_start, A->k_rowptr.data(), A->k_col.data(), A->k_val.data(), -st->sigma, B ? B->k_rowptr.data() : nullptr, B ? B->k_col.data() : nullptr, B ? B->k_val.data() : nullptr, rp, col, val); }
+    catch (const std::exception &e) { KS_FAIL(KS_ERR_MEM, "block Jacobi set-up: %s", e.what()); }
+    KS_CHECK(fits, KS_ERR_ARG_OUTOFRANGE, "A - sigma B exceeds 32-bit PetscInt indices");
+    prp = rp.data(); pcol = col.data(); pval = val.data();
+  }
+  std::vector<double> inv;
+  try { inv.assign((size_t)n * bs, 0.0); } catch (const std::exception &e) { KS_FAIL(KS_ERR_MEM, "block Jacobi set-up: %s", e.what()); }
+  std::vector<double> Mb((size_t)bs * 2 * bs);
+  const long long base = M0->row_start;
+  for (int b0 = 0; b0 < n; b0 += bs) {
+    const int bl = std::min(bs, n - b0), w = 2 * bl;
+    std::fill(Mb.begin(), Mb.end(), 0.0);
+    for (int r = 0; r < bl; r++) {                                 // [block | I]
+      for (int p = prp[b0 + r]; p < prp[b0 + r + 1]; p++) { const long long c = (long long)pcol[p] - base - b0; if (c >= 0 && c < bl) Mb[(size_t)r * w + c] += pval[p]; }
+      Mb[(size_t)r * w + bl + r] = 1.0;
+    }
+    for (int k = 0; k < bl; k++) {
+      int piv = k; double big = fabs(Mb[(size_t)k * w + k]);
+      for (int r = k + 1; r < bl; r++) if (fabs(Mb[(size_t)r * w + k]) > big) { big = fabs(Mb[(size_t)r * w + k]); piv = r; }
+      KS_CHECK(big != 0.0, KS_ERR_MAT_LU_ZRPVT, "Zero pivot in the block of local rows %d..%d (column %d)", b0, b0 + bl - 1, b0 + k);
+      if (piv != k) for (int c = 0; c < w; c++) std::swap(Mb[(size_t)k * w + c], Mb[(size_t)piv * w + c]);
+      const double d = 1.0 / Mb[(size_t)k * w + k];
+      for (int c = 0; c < w; c++) Mb[(size_t)k * w + c] *= d;
+      for (int r = 0; r < bl; r++) if (r != k) { const double f = Mb[(size_t)r * w + k]; if (f != 0.0) for (int c = 0; c < w; c++) Mb[(size_t)r * w + c] -= f * Mb[(size_t)k * w + c]; }
+    }
+    for (int r = 0; r < bl; r++) for (int c = 0; c < bl; c++) inv[(size_t)(b0 + r) * bs + c] = Mb[(size_t)r * w + bl + c];
+  }
+  if (st->binv) { hipFree(st->binv); st->binv = nullptr; }
+  if (st->pcwork) { hipFree(st->pcwork); st->pcwork = nullptr; }
+  KS_HIP(hipMalloc(&st->binv, sizeof(double) * std::max<size_t>(inv.size(), 1)));
+  KS_HIP(hipMalloc(&st->pcwork, sizeof(double) * std::max(n, 1)));
+  KS_HIP(hipMemcpyAsync(st->binv, inv.data(), sizeof(double) * inv.size(), hipMemcpyHostToDevice, ctx->stream));
+  KS_HIP(ks_sync(ctx));
+  return KS_SUCCESS;
+}
 
 bool ks_st_is_plain(ks_st st) { return !st || (st->type == KS_ST_SHIFT && st->sigma == 0.0 && !st->B); }
 
@@ -267,6 +354,7 @@ int ks_st_setup_internal(ks_st st)
       hipLaunchKernelGGL(k_jacobi_setup, dim3(nb), dim3(256), 0, ctx->stream, (long long)A->n, 0.0, (const double *)nullptr, 1.0, db, st->dinv);
     }
     KS_HIP(hipGetLastError());
+    if (st->pc_type == KS_PC_BJACOBI) KS_CALL(bjacobi_setup(st));
   }
   if (!st->op) KS_CALL(ks_mat_create_shell(ctx, A->n, A->row_start, A->n_global, st_shell_mult, st, &st->op));
   st->op->n = A->n; st->op->row_start = A->row_start; st->op->n_global = A->n_global;
@@ -331,6 +419,8 @@ extern "C" int ks_st_destroy(ks_st st)
   if (st->op) ks_mat_destroy(st->op);
   if (st->bil) ks_mat_destroy(st->bil);
   if (st->Pmat) ks_mat_destroy(st->Pmat);
+  if (st->binv) hipFree(st->binv);
+  if (st->pcwork) hipFree(st->pcwork);
   delete st;
   return KS_SUCCESS;
 }
@@ -385,6 +475,15 @@ extern "C" int ks_st_set_ksp_type(ks_st st, int type)              // KSPSetType
   KS_CHECK(st, KS_ERR_ARG_NULL, "ST is NULL");
   KS_CHECK(type == KS_KSP_GMRES || type == KS_KSP_BCGS, KS_ERR_SUP, "only KSPGMRES and KSPBCGS are built");
   if (st->ksp_type != type) { st->ksp_type = type; st->ready = false; }
+  return KS_SUCCESS;
+}
+extern "C" int ks_st_set_pc(ks_st st, int type, int block_size)       // PCSetType (+ PCBJacobiSetLocalBlocks, -sub_pc_type lu) on the KSP's PC
+{
+  KS_CHECK(st, KS_ERR_ARG_NULL, "ST is NULL");
+  KS_CHECK(type == KS_PC_JACOBI || type == KS_PC_BJACOBI, KS_ERR_SUP, "only PCJACOBI and PCBJACOBI are built");
+  KS_CHECK(type == KS_PC_JACOBI || (block_size >= 2 && block_size <= 32), KS_ERR_ARG_OUTOFRANGE, "block size %d (2..32)", block_size);
+  if (type == KS_PC_JACOBI) block_size = 0;
+  if (st->pc_type != type || st->pc_bs != block_size) { st->pc_type = type; st->pc_bs = block_size; st->ready = false; }
   return KS_SUCCESS;
 }
 extern "C" int ks_st_set_gmres_cgs_refinement(ks_st st, int refine)   // KSPGMRESSetCGSRefinementType on STGetKSP

@@ -222,6 +222,9 @@ struct ks_st_s {
   ks_bv Kb = nullptr;                         // BiCGStab work vectors (7 columns)
   ks_bv K = nullptr, W = nullptr;             // GMRES basis (restart+1 columns), work vectors (3 columns)
   double *dinv = nullptr;                     // Jacobi: 1/diag(P)
+  int pc_type = KS_PC_JACOBI, pc_bs = 0;      // PCSetType on the KSP's PC: point Jacobi, or block Jacobi with blocks of pc_bs consecutive local rows
+  double *binv = nullptr;                     // block Jacobi: row i holds the pc_bs coefficients of row i of its block's inverse (n x pc_bs, zero beyond a short last block)
+  double *pcwork = nullptr;                   // block Jacobi: the vector the blocks are applied to (n)
   int matmode = KS_ST_MATMODE_SHELL;          // STSetMatMode: how P = A - sigma B exists (shell: applied term by term; copy: assembled, stsolve.c:603-631)
   ks_mat Pmat = nullptr;                      // ST_MATMODE_COPY: the assembled P (owned)
   ks_mat op = nullptr;                        // shell matrix whose MatMult is STApply

@@ -171,6 +171,13 @@ def _worker(rank, world, port, q):
         s4c = e4c.GetST(); s4c.SetType("sinvert"); s4c.SetMatMode("copy"); s4c.SetKSP(rtol=1e-13)
         e4c.Solve()
         res["c5copy_eig"] = [list(e4c.GetEigenvalue(i)) for i in range(4)]; res["c5copy_its"] = e4c.GetIterationNumber()
+        # (5c) block Jacobi on the row-sharded P: every rank inverts the diagonal blocks of ITS rows (global columns minus its row offset)
+        s5 = ks.ST(ctx); s5.SetType("sinvert"); s5.SetShift(36.0); s5.SetMatrices(Ak, Bk); s5.SetKSP(rtol=1e-13); s5.SetPC("bjacobi", 5)
+        Xq = ks.BV(ctx, q1 - q0, 2, N=Ag.n); Xq.set_column(0, xg[q0:q1])
+        import ctypes
+        ks._lib.check(ctx.L.ks_st_apply(s5.h, ctypes.c_void_p(Xq.column_ptr(0)), ctypes.c_void_p(Xq.column_ptr(1))))
+        yq = O.ST(Ag, Bg, "sinvert", 36.0).apply(xg)
+        res["bj_err"] = float(np.abs(Xq.column(1) - yq[q0:q1]).max() / np.abs(yq).max()); res["bj_its"] = s5.GetKSPStats()["iterations"]
         # (6) test39.c: one solver, two solves with matrices whose LOCAL sizes differ (the 10x11 2-D Laplacian with one row moved
         # from rank 1 to rank 0, then the other way); EPSSetOperators drops what was sized by the first matrix
         L2 = O.laplacian2d(10, 11)
@@ -278,6 +285,7 @@ def test_ranks_sharing_one_gpu_against_oracle(world):
     for rk in range(world):
         assert out[rk]["c5_its"] == r5.its and np.allclose(np.array(out[rk]["c5_eig"]), ref5, rtol=1e-8, atol=1e-9)
         assert max(out[rk]["c5_err"]) < 1e-6
+        assert out[rk]["bj_err"] < 1e-10 and 0 < out[rk]["bj_its"] < 100                        # (5c)
         assert out[rk]["copy_axpy"] < 1e-14                                                     # (5b) P = A - 36 B assembled per row block
         assert out[rk]["c5copy_its"] == r5.its and np.allclose(np.array(out[rk]["c5copy_eig"]), ref5, rtol=1e-8, atol=1e-9)
     import golden_inputs as gi

@@ -605,3 +605,76 @@ def test_gmres_refinement_types_give_the_same_solution(ctx):
     assert its[None] == its["never"] and abs(its["never"] - its["always"]) <= 1 and abs(its["ifneeded"] - its["always"]) <= 1
     with pytest.raises(ks.KsError):
         st.SetGMRESCGSRefinement(7)
+
+
+# ---- PCBJACOBI on the ST's KSP (ks_st_set_pc): dense diagonal blocks of P, solved exactly -------------------------------------------------
+def _line_pencil(nx, ny):
+    """A = 2-D 5-point Laplacian with a convective term (non-symmetric), B = a diagonal mass matrix: P = A - sigma B couples a grid line
+    (nx consecutive rows) strongly - the case block Jacobi with one block per line is made for."""
+    import scipy.sparse as sp
+    n = nx * ny
+    T = sp.diags([np.full(nx - 1, -1.3), np.full(nx, 4.0), np.full(nx - 1, -0.7)], [-1, 0, 1])
+    A = (sp.kron(sp.identity(ny), T) + sp.kron(sp.diags([np.full(ny - 1, -0.2), np.full(ny - 1, -0.2)], [-1, 1]), sp.identity(nx))).tocsr()
+    B = sp.diags([1.0 + 0.1 * np.cos(np.arange(n))], [0]).tocsr()
+    A.sort_indices(); B.sort_indices()
+    return (O.CSR(n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)),
+            O.CSR(n, B.indptr.astype(np.int32), B.indices.astype(np.int32), B.data.astype(np.float64)))
+
+
+@pytest.mark.parametrize("ksp", ["gmres", "bcgs"])
+def test_block_jacobi_preconditioner(ctx, ksp):
+    """Solves with PCBJACOBI agree with the LU oracle; one block per grid line takes fewer iterations than point Jacobi; block sizes that do
+    not divide n leave a short last block; both matrix modes give the same blocks."""
+    import slepc_amd as ks
+    nx, ny = 24, 30
+    Ao, Bo = _line_pencil(nx, ny)
+    A = _mat_keep(ctx, Ao); B = _mat_keep(ctx, Bo)
+    sigma = -0.5
+    x = np.random.default_rng(21).standard_normal(Ao.n)
+    y0 = O.ST(Ao, Bo, "sinvert", sigma).apply(x)
+    its = {}
+    for label, pc, bs, mode in (("jacobi", "jacobi", 0, "shell"), ("line", "bjacobi", nx, "shell"), ("line_copy", "bjacobi", nx, "copy"),
+                                ("bs7", "bjacobi", 7, "shell"), ("bs32", "bjacobi", 32, "copy"), ("bs2", "bjacobi", 2, "shell")):
+        st = ks.ST(ctx)
+        st.SetType("sinvert"); st.SetShift(sigma); st.SetMatrices(A, B); st.SetKSP(rtol=1e-12); st.SetKSPType(ksp); st.SetMatMode(mode); st.SetPC(pc, bs)
+        y = st.Apply(x)
+        assert np.linalg.norm(y - y0) <= 1e-9 * np.linalg.norm(y0), label
+        its[label] = st.GetKSPStats()["iterations"]
+    assert its["line"] < its["jacobi"] and its["line"] == its["line_copy"], its
+    assert its["bs32"] <= its["bs7"] <= its["bs2"] <= its["jacobi"], its
+    # shift with two matrices: P = B (diagonal here: every block inverse is exact, one iteration)
+    st = ks.ST(ctx); st.SetType("shift"); st.SetShift(0.3); st.SetMatrices(A, B); st.SetKSP(rtol=1e-13); st.SetKSPType(ksp); st.SetPC("bjacobi", 8)
+    y = st.Apply(x); y1 = O.ST(Ao, Bo, "shift", 0.3).apply(x)
+    assert np.linalg.norm(y - y1) <= 1e-12 * np.linalg.norm(y1) and st.GetKSPStats()["iterations"] <= 2
+
+
+def test_block_jacobi_errors_and_a_whole_solve(ctx):
+    import slepc_amd as ks
+    import scipy.sparse as sp
+    Ao, Bo = _line_pencil(16, 20)
+    A = _mat_keep(ctx, Ao); B = _mat_keep(ctx, Bo)
+    st = ks.ST(ctx); st.SetType("sinvert"); st.SetShift(-0.5); st.SetMatrices(_mat(ctx, Ao), B); st.SetPC("bjacobi", 4)
+    with pytest.raises(ks.KsError) as e:
+        st.SetUp()
+    assert e.value.rc == 58                                   # PETSC_ERR_ORDER: the blocks come from the kept CSR arrays
+    for bad in (1, 33):
+        with pytest.raises(ks.KsError) as e:
+            st.SetPC("bjacobi", bad)
+        assert e.value.rc == 63
+    # a singular diagonal block: rows 0 and 1 of P equal inside the first 2 x 2 block
+    S = sp.lil_matrix(Ao.to_scipy()); S[0, :] = 0.0; S[1, :] = 0.0; S[0, 0] = S[0, 1] = S[1, 0] = S[1, 1] = 1.0; S[0, 5] = 2.0; S[1, 6] = 3.0
+    S = S.tocsr(); S.sort_indices()
+    As = ks.Mat.from_csr(ctx, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data, keep_csr=True)
+    st2 = ks.ST(ctx); st2.SetType("sinvert"); st2.SetShift(0.0); st2.SetMatrices(As); st2.SetPC("bjacobi", 2)
+    with pytest.raises(ks.KsError) as e:
+        st2.SetUp()
+    assert e.value.rc == 71                                   # PETSC_ERR_MAT_LU_ZRPVT
+    # the whole eigensolve through the block-preconditioned inner solves
+    sigma = -0.5
+    eps = ks.EPS(ctx); eps.SetOperators(A, B); eps.SetProblemType(ks.EPS_GNHEP); eps.SetDimensions(4, 16); eps.SetTarget(sigma)
+    s3 = eps.GetST(); s3.SetType("sinvert"); s3.SetKSP(rtol=1e-12); s3.SetPC("bjacobi", 16)
+    eps.Solve()
+    r = O.eps_krylovschur_nhep(Ao, 4, ncv=16, which=O.which_target_magnitude(sigma), st=O.ST(Ao, Bo, "sinvert", sigma))
+    assert eps.GetConverged() >= 4 and eps.GetIterationNumber() == r.its
+    lam = np.array([complex(*eps.GetEigenvalue(i)) for i in range(4)])
+    assert np.allclose(lam, (r.eigr + 1j * r.eigi)[r.perm][:4], rtol=1e-9, atol=0)
