@@ -83,7 +83,7 @@ enum { KS_EPS_HEP = 1, KS_EPS_GHEP = 2, KS_EPS_NHEP = 3, KS_EPS_GNHEP = 4 };   /
 enum { KS_ST_SHIFT = 0, KS_ST_SINVERT = 1, KS_ST_CAYLEY = 2 };   /* STType "shift", "sinvert", "cayley" */
 enum { KS_EPS_ERROR_ABSOLUTE = 0, KS_EPS_ERROR_RELATIVE = 1, KS_EPS_ERROR_BACKWARD = 2 };   /* EPSErrorType */
 enum { KS_EPS_RITZ = 0, KS_EPS_HARMONIC = 1, KS_EPS_HARMONIC_RELATIVE, KS_EPS_HARMONIC_RIGHT, KS_EPS_HARMONIC_LARGEST, KS_EPS_REFINED, KS_EPS_REFINED_HARMONIC };  /* EPSExtraction slepceps.h:94-100; Krylov-Schur offers the first two */
-enum { KS_EPS_BALANCE_NONE = 0, KS_EPS_BALANCE_ONESIDE = 1, KS_EPS_BALANCE_TWOSIDE = 2, KS_EPS_BALANCE_USER = 3 };   /* EPSBalance slepceps.h; the one-sided form is built */
+enum { KS_EPS_BALANCE_NONE = 0, KS_EPS_BALANCE_ONESIDE = 1, KS_EPS_BALANCE_TWOSIDE = 2, KS_EPS_BALANCE_USER = 3 };   /* EPSBalance slepceps.h; the two-sided form needs the transposed product (ks_mat_mult_transpose) */
 enum { KS_EPS_CONV_ABS = 0, KS_EPS_CONV_REL = 1, KS_EPS_CONV_NORM = 2, KS_EPS_CONV_USER = 3 };   /* EPSConv slepceps.h:153-156 */
 /* user callbacks of the solver (slepceps.h EPSConvergenceTestFn, EPSStoppingTestFn, EPSMonitorFn); non-zero return = error */
 typedef int (*ks_eps_converged_fn)(ks_eps eps, double eigr, double eigi, double res, double *errest, void *ctx);
@@ -193,6 +193,12 @@ int ks_mat_get_layout(ks_mat A, int *layout);
 /* MatMult: y = A x on device pointers (x, y: n_local doubles owned by this rank).
    Multi-rank: performs the halo exchange of x (PETSc VecScatter inside MatMult_MPIAIJ).        */
 int ks_mat_mult(ks_mat A, const double *x_dev, double *y_dev);
+/* MatMultTranspose: y = A^T x. An assembled matrix builds its transpose on first use (MatTranspose on the host from the kept CSR arrays:
+   KS_MAT_KEEP_CSR, KS_ERR_ORDER otherwise; one rank - the transpose of a row-sharded matrix is a redistribution, KS_ERR_SUP) and multiplies
+   with it like any other matrix; a shell matrix needs ks_mat_shell_set_mult_transpose (MATOP_MULT_TRANSPOSE, as ex9.c:88 sets it).
+   Used by the two-sided balancing (EPSBuildBalance_Krylov epsdefault.c:402-411). */
+int ks_mat_mult_transpose(ks_mat A, const double *x_dev, double *y_dev);
+int ks_mat_shell_set_mult_transpose(ks_mat A, ks_shell_mult_fn mult_transpose);
 int ks_mat_mult_host(ks_mat A, const double *x_host, double *y_host);  /* convenience for tests (single rank) */
 /* How MatMult moves the boundary entries of x between ranks. KS_HALO_PROVIDER: packed into a send buffer and handed to the
  * communicator's exchange (grouped ncclSend / ncclRecv with the RCCL provider; PETSc's VecScatter is the reference's). KS_HALO_PEER: the pack
@@ -416,6 +422,9 @@ int ks_st_set_pc(ks_st st, int type, int block_size);
 int ks_st_set_ksp(ks_st st, double rtol, int max_it, int restart);        /* KSPSetTolerances / KSPGMRESSetRestart on STGetKSP; 0 keeps */
 int ks_st_setup(ks_st st);                                                /* STSetUp */
 int ks_st_apply(ks_st st, const double *x_dev, double *y_dev);            /* STApply stsolve.c:44 */
+/* STApplyHermitianTranspose (stsolve.c:153-162) for the transformations without a solve: shift with one matrix, y = (A - sigma I)^T x
+   (MatMultTranspose of A); the ones with a solve would need it with the transposed matrix: KS_ERR_SUP */
+int ks_st_apply_transpose(ks_st st, const double *x_dev, double *y_dev);
 int ks_st_backtransform(ks_st st, int n, double *eigr, double *eigi);     /* STBackTransform stsolve.c:563 */
 int ks_st_get_ksp_stats(ks_st st, long long *solves, long long *iterations, double *last_rnorm);
 

@@ -1240,7 +1240,7 @@ class ST:
 
 def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, which="largest_magnitude", keep=0.5,
                          seed=0x12345678, v0=None, max_steps=None, st=None, lock=True, conv="rel", B=None, harmonic=None,
-                         trueres=False, stopping=None, monitor=None, balance_its=0):
+                         trueres=False, stopping=None, monitor=None, balance_its=0, balance="oneside", balance_cutoff=1e-8):
     """EPSSolve_KrylovSchur_Default with the Arnoldi expansion (krylovschur.c:227-337, non-Hermitian branch),
     EPSKrylovConvergence for conjugate pairs (epskrylov.c:262-287), EPSComputeVectors_Schur (epsdefault.c:105-169).
     With st (an ST): the Krylov operator is st.apply, the DS sorts through the back-transformation
@@ -1281,16 +1281,27 @@ def eps_krylovschur_nhep(A, nev, ncv=None, mpd=None, tol=1e-8, max_it=None, whic
             V.ScaleColumn(i, 1.0 / norm)
         return lindep or norm == 0.0
 
-    # EPSSetBalance(ONESIDE): EPSBuildBalance_Krylov epsdefault.c:370-434, then the expansion runs on D Op D^-1 (stsolve.c:252-256)
+    # EPSSetBalance(ONESIDE / TWOSIDE): EPSBuildBalance_Krylov epsdefault.c:370-434, then the expansion runs on D Op D^-1 (stsolve.c:252-256)
     D = None
     base_op = st.apply if st is not None else (lambda x: A.mult(x))
     if balance_its:
         D = np.ones(n)
         scratch = BV(n, 5)
+        if balance == "twoside":                     # STApplyHermitianTranspose: built for the operators without a solve (A itself, or a shift of it)
+            assert st is None or (st.kind == "shift" and st.lu is None)
+            Mt = (A.to_scipy() if st is None else st.M).T.tocsr()
+        norma = 0.0
         for j in range(balance_its):
             scratch.SetRandomColumn(3, seed + 7919 * (j + 1))
             z = np.where(np.array(scratch.column(3)) < 0.5, -1.0, 1.0)
             p = base_op(z / D) * D
+            if balance == "twoside":                 # epsdefault.c:402-421
+                if j == 0:
+                    norma = np.abs(p).max()
+                r = (Mt @ (z * D)) / D
+                sel = (np.abs(p) > balance_cutoff * norma) & (r != 0.0)
+                D[sel] = D[sel] * np.sqrt(np.abs(r[sel] / p[sel]))
+                continue
             nz = p != 0.0
             D[nz] = D[nz] / np.abs(p[nz])
         bal_op = lambda x: base_op(x / D) * D                # noqa: E731

@@ -261,6 +261,29 @@ class Mat:
         m._cb = cb                      # keep the trampoline alive as long as the matrix
         return m
 
+    def shell_set_mult_transpose(self, mult_t):
+        """MATOP_MULT_TRANSPOSE of a shell matrix: mult_t(x_ptr, y_ptr) = A^T x on device pointers."""
+        def tramp(_user, x, y):
+            try:
+                mult_t(x, y)
+                return 0
+            except KsError as e:
+                return e.rc
+        self._cb_t = SHELL_MULT_FN(tramp)
+        _lib.check(self.ctx.L.ks_mat_shell_set_mult_transpose(self.h, C.cast(self._cb_t, C.c_void_p)))
+
+    def mult_transpose_dev(self, x_ptr, y_ptr):
+        """MatMultTranspose on device pointers."""
+        _lib.check(self.ctx.L.ks_mat_mult_transpose(self.h, C.c_void_p(x_ptr), C.c_void_p(y_ptr)))
+
+    def mult_transpose(self, x):
+        """y = A^T x with host vectors (test convenience, single rank)."""
+        x = _f64(x)
+        W = BV(self.ctx, len(x), 2)
+        W.set_column(0, x)
+        self.mult_transpose_dev(W.column_ptr(0), W.column_ptr(1))
+        return W.column(1)
+
     def set_enqueue_only(self, flag=True):
         _lib.check(self.ctx.L.ks_mat_shell_set_enqueue_only(self.h, int(bool(flag))))
 
@@ -699,6 +722,14 @@ class ST:
         W = BV(self.ctx, len(x), 2)
         W.set_column(0, x)
         _lib.check(self.ctx.L.ks_st_apply(self.h, C.c_void_p(W.column_ptr(0)), C.c_void_p(W.column_ptr(1))))
+        return W.column(1)
+
+    def ApplyTranspose(self, x):
+        """y = Op^T x with host vectors (STApplyHermitianTranspose, real scalars; test convenience, single rank)."""
+        x = _f64(x)
+        W = BV(self.ctx, len(x), 2)
+        W.set_column(0, x)
+        _lib.check(self.ctx.L.ks_st_apply_transpose(self.h, C.c_void_p(W.column_ptr(0)), C.c_void_p(W.column_ptr(1))))
         return W.column(1)
 
     def BackTransform(self, eigr, eigi):

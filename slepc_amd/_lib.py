@@ -51,6 +51,9 @@ _SIG = {
     "ks_mat_create_csr_flags": [vp, C.c_int, C.c_int, C.c_int, ip, ip, dp, C.c_uint, C.POINTER(vp)],
     "ks_mat_create_axpy": [vp, C.c_double, vp, C.c_uint, C.POINTER(vp)],
     "ks_mat_set_halo": [vp, C.c_int, ip],
+    "ks_mat_mult_transpose": [vp, vp, vp],
+    "ks_mat_shell_set_mult_transpose": [vp, vp],
+    "ks_st_apply_transpose": [vp, vp, vp],
     "ks_mat_get_halo": [vp, ip],
     "ks_mat_create_laplacian3d": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
     "ks_mat_create_laplacian2d": [vp, C.c_int, C.c_int, C.POINTER(vp)],

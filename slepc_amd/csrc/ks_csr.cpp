@@ -74,10 +74,27 @@ bool csr_axpy(int n, int row_start, const int *rpa, const int *ca, const double 
   parallel(true);
   return true;
 }
+void csr_transpose(int nrows, int ncols, const int *rp, const int *col, const double *val, std::vector<int> &rpt, std::vector<int> &colt, std::vector<double> &valt)
+{
+  const size_t nnz = (size_t)rp[nrows];
+  rpt.assign((size_t)ncols + 1, 0); colt.resize(nnz); valt.resize(nnz);
+  for (size_t p = 0; p < nnz; p++) rpt[(size_t)col[p] + 1]++;
+  for (int c = 0; c < ncols; c++) rpt[c + 1] += rpt[c];
+  std::vector<int> cur(rpt.begin(), rpt.end() - 1);
+  for (int r = 0; r < nrows; r++)
+    for (int p = rp[r]; p < rp[r + 1]; p++) { const int q = cur[col[p]]++; colt[q] = r; valt[q] = val[p]; }
+}
 } // namespace ksc
 
 #ifdef KSD_TEST_HOOKS
 extern "C" {
+// test hook: B = A^T (square blocks of order n); rpt has n + 1 entries, colt / valt nnz
+void ksc_csr_transpose(int n, const int *rp, const int *col, const double *val, int *rpt, int *colt, double *valt)
+{
+  std::vector<int> r, c; std::vector<double> v;
+  ksc::csr_transpose(n, n, rp, col, val, r, c, v);
+  std::copy(r.begin(), r.end(), rpt); std::copy(c.begin(), c.end(), colt); std::copy(v.begin(), v.end(), valt);
+}
 // test hook: P = A + alpha B (B arrays NULL: the identity); returns nnz(P), fills rp always and col/val when they are given (capacity cap entries)
 long long ksc_csr_axpy(int n, int row_start, const int *rpa, const int *ca, const double *va, double alpha, const int *rpb, const int *cb, const double *vb,
                        int *rp, int *col, double *val, long long cap)

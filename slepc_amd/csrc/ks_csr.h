@@ -12,4 +12,7 @@ namespace ksc {
 // to the first entry of A with its column, or to the end of the row. Returns false (nothing built) when the result has more than 2^31 - 1 entries.
 bool csr_axpy(int n, int row_start, const int *rpa, const int *ca, const double *va, double alpha, const int *rpb, const int *cb, const double *vb,
               std::vector<int> &rp, std::vector<int> &col, std::vector<double> &val);
+// B = A^T for a CSR block of nrows x ncols (MatTranspose, MAT_INITIAL_MATRIX): a counting sort by column; the rows of B list their entries in
+// ascending row order of A (sorted columns out whatever the order inside A's rows; repeated entries of A stay separate entries).
+void csr_transpose(int nrows, int ncols, const int *rp, const int *col, const double *val, std::vector<int> &rpt, std::vector<int> &colt, std::vector<double> &valt);
 }

@@ -709,6 +709,12 @@ __global__ void k_bal_update(long long n, double *__restrict__ D, const double *
 {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) if (p[i] != 0.0) D[i] /= fabs(p[i]);
 }
+// two-sided form (epsdefault.c:419-421): D_i *= sqrt(|r_i / p_i|) where |p_i| > cutoff * norma and r_i != 0
+__global__ void k_bal_update2(long long n, double *__restrict__ D, const double *__restrict__ p, const double *__restrict__ r, double thr)
+{
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    if (fabs(p[i]) > thr && r[i] != 0.0) D[i] *= sqrt(fabs(r[i] / p[i]));
+}
 __global__ void k_fill(long long n, double *__restrict__ x, double v)
 {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] = v;
@@ -731,7 +737,9 @@ static int balanced_mult(void *user, const double *x, double *y)
   KS_CALL(ks_mat_mult_internal(eps->op_inner, eps->wb, y));
   return pointwise(eps, y, eps->D, y, true);
 }
-// EPSBuildBalance_Krylov epsdefault.c:370-434, one-sided form: D <- D ./ |D Op D^-1 z| over balance_its random +-1 vectors
+// EPSBuildBalance_Krylov epsdefault.c:370-434 over balance_its random +-1 vectors z. One-sided: D <- D ./ |p|, p = D Op D^-1 z. Two-sided: also
+// r = D^-1 Op^T D z (STApplyHermitianTranspose: ks_mat_mult_transpose on the operator), D_i *= sqrt(|r_i / p_i|) where |p_i| exceeds cutoff times the
+// infinity norm of the first p
 static int build_balance(ks_eps eps)
 {
   ks_ctx ctx = eps->ctx; const long long n = eps->V->n;
@@ -741,11 +749,18 @@ static int build_balance(ks_eps eps)
   if (n) hipLaunchKernelGGL(k_fill, dim3(nb), dim3(256), 0, ctx->stream, n, eps->D, 1.0);
   double *z = ks_bv_col(eps->W, 3), *p = ks_bv_col(eps->W, 4);
   eps->W->row_start = eps->V->row_start;
+  double norma = 0.0;
   for (int j = 0; j < eps->balance_its; j++) {
     KS_CALL(ks_bv_set_random_column(eps->W, 3, eps->seed + 7919ULL * (uint64_t)(j + 1)));           // a random vector of +-1's
     if (n) hipLaunchKernelGGL(k_sign_half, dim3(nb), dim3(256), 0, ctx->stream, n, z);
     KS_CALL(balanced_mult(eps, z, p));                                                               // p = D Op (D \ z)
-    if (n) hipLaunchKernelGGL(k_bal_update, dim3(nb), dim3(256), 0, ctx->stream, n, eps->D, p);
+    if (eps->balance == KS_EPS_BALANCE_TWOSIDE) {
+      if (j == 0) KS_CALL(ks_bv_normcolumn(eps->W, 4, KS_NORM_INFINITY, &norma));                    // VecAbs + VecMax: the estimate of the matrix infinity norm
+      KS_CALL(pointwise(eps, z, eps->D, z, true));                                                    // r = D \ (Op' (D z))
+      KS_CALL(ks_mat_mult_transpose_internal(eps->op_inner, z, eps->wb));
+      KS_CALL(pointwise(eps, eps->wb, eps->D, eps->wb, false));
+      if (n) hipLaunchKernelGGL(k_bal_update2, dim3(nb), dim3(256), 0, ctx->stream, n, eps->D, p, eps->wb, eps->balance_cutoff * norma);
+    } else if (n) hipLaunchKernelGGL(k_bal_update, dim3(nb), dim3(256), 0, ctx->stream, n, eps->D, p);
     KS_HIP(hipGetLastError());
   }
   return KS_SUCCESS;
@@ -1074,9 +1089,8 @@ extern "C" int ks_eps_solve(ks_eps eps)   // EPSSolve epssolve.c:119 -> EPSSolve
   // balancing of non-symmetric problems (epssetup.c:383-391): build D, then expand with D Op D^-1
   eps->balanced = false;
   if ((ptype == KS_EPS_NHEP || ptype == KS_EPS_GNHEP) && eps->balance != KS_EPS_BALANCE_NONE) {
-    KS_CHECK(eps->balance == KS_EPS_BALANCE_ONESIDE || eps->balance == KS_EPS_BALANCE_USER, KS_ERR_SUP, "only one-sided and user-provided balancing are built (the two-sided form needs the transposed operator)");
     eps->op_inner = eps->op;
-    if (eps->balance == KS_EPS_BALANCE_ONESIDE) KS_CALL(build_balance(eps));
+    if (eps->balance == KS_EPS_BALANCE_ONESIDE || eps->balance == KS_EPS_BALANCE_TWOSIDE) KS_CALL(build_balance(eps));
     else KS_CHECK(eps->D && eps->D_n == A->n, KS_ERR_ORDER, "EPS_BALANCE_USER: the balancing matrix does not match the operator");
     if (!eps->bal_op) KS_CALL(ks_mat_create_shell(eps->ctx, A->n, A->row_start, A->n_global, balanced_mult, eps, &eps->bal_op));
     eps->bal_op->n = A->n; eps->bal_op->row_start = A->row_start; eps->bal_op->n_global = A->n_global;

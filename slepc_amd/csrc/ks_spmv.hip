@@ -1503,6 +1503,7 @@ extern "C" int ks_mat_create_laplacian2d(ks_ctx ctx, int n, int m, ks_mat *out)
 extern "C" int ks_mat_destroy(ks_mat A)
 {
   if (!A) return KS_SUCCESS;
+  if (A->At) { ks_mat_destroy(A->At); A->At = nullptr; }
   hipSetDevice(A->ctx->device);
   ks_sync(A->ctx);
   hipFree(A->d_rowptr); hipFree(A->d_col); hipFree(A->d_val);
@@ -1797,6 +1798,40 @@ extern "C" int ks_mat_mult(ks_mat A, const double *x_dev, double *y_dev)
   KS_CHECK(x_dev != y_dev, KS_ERR_ARG_WRONG, "x and y must be different vectors");   // MatMult requirement
   KS_HIP(hipSetDevice(A->ctx->device));
   return ks_mat_mult_internal(A, x_dev, y_dev);
+}
+
+// MatMultTranspose: through the transposed matrix, built once (MatTranspose on the host, ks_csr.cpp) and multiplied like any other
+int ks_mat_mult_transpose_internal(ks_mat A, const double *x, double *y)
+{
+  if (A->shell_mult) {
+    KS_CHECK(A->shell_mult_t, KS_ERR_SUP, "the shell matrix has no MATOP_MULT_TRANSPOSE (ks_mat_shell_set_mult_transpose)");
+    const int rc = A->shell_mult_t(A->shell_user, x, y);
+    KS_CHECK(rc == 0, rc > 0 ? rc : KS_ERR_LIB, "the shell matrix's transposed product returned %d", rc);
+    return KS_SUCCESS;
+  }
+  if (!A->At) {
+    KS_CHECK(A->ctx->comm.size == 1 && A->n == A->n_global, KS_ERR_SUP, "MatMultTranspose of a row-sharded matrix is not built (the transpose is a redistribution)");
+    KS_CHECK(A->keep_csr, KS_ERR_ORDER, "MatMultTranspose builds the transpose from the CSR arrays of the matrix: create it with KS_MAT_KEEP_CSR");
+    std::vector<int> rp, col; std::vector<double> val;
+    try { ksc::csr_transpose(A->n, A->n_global, A->k_rowptr.data(), A->k_col.data(), A->k_val.data(), rp, col, val); }
+    catch (const std::exception &e) { KS_FAIL(KS_ERR_MEM, "MatTranspose on the host: %s", e.what()); }
+    KS_CALL(ks_mat_create_csr_flags(A->ctx, A->n, 0, A->n_global, rp.data(), col.data(), val.data(), 0u, &A->At));
+  }
+  return ks_mat_mult_internal(A->At, x, y);
+}
+extern "C" int ks_mat_mult_transpose(ks_mat A, const double *x_dev, double *y_dev)
+{
+  KS_CHECK(A && x_dev && y_dev, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(x_dev != y_dev, KS_ERR_ARG_WRONG, "x and y must be different vectors");
+  KS_HIP(hipSetDevice(A->ctx->device));
+  return ks_mat_mult_transpose_internal(A, x_dev, y_dev);
+}
+extern "C" int ks_mat_shell_set_mult_transpose(ks_mat A, ks_shell_mult_fn mult_transpose)
+{
+  KS_CHECK(A, KS_ERR_ARG_NULL, "A is NULL");
+  KS_CHECK(A->shell_mult, KS_ERR_ARG_WRONG, "not a shell matrix");
+  A->shell_mult_t = mult_transpose;
+  return KS_SUCCESS;
 }
 
 extern "C" int ks_mat_mult_host(ks_mat A, const double *x_host, double *y_host)

@@ -251,6 +251,7 @@ int bcgs_solve(ks_st st, const double *rhs, double *y)
 int inner_solve(ks_st st, const double *rhs, double *y) { return st->ksp_type == KS_KSP_BCGS ? bcgs_solve(st, rhs, y) : gmres_solve(st, rhs, y); }
 
 int st_shell_mult(void *user, const double *x, double *y) { return ks_st_apply_internal((ks_st)user, x, y); }
+int st_shell_mult_transpose(void *user, const double *x, double *y) { return ks_st_apply_transpose_internal((ks_st)user, x, y); }
 // y = (A + nu B) x, MatMult_Cayley cayley.c:21-44
 int st_bilinear_mult(void *user, const double *x, double *y)
 {
@@ -358,6 +359,7 @@ int ks_st_setup_internal(ks_st st)
   }
   if (!st->op) KS_CALL(ks_mat_create_shell(ctx, A->n, A->row_start, A->n_global, st_shell_mult, st, &st->op));
   st->op->n = A->n; st->op->row_start = A->row_start; st->op->n_global = A->n_global;
+  st->op->shell_mult_t = st_shell_mult_transpose;
   st->op->shell_nosync = !need_solve;                         // a plain shift is two kernel launches: Krylov runs stay enqueued ahead
   if (st->type == KS_ST_CAYLEY) {
     if (!st->bil) KS_CALL(ks_mat_create_shell(ctx, A->n, A->row_start, A->n_global, st_bilinear_mult, st, &st->bil));
@@ -501,6 +503,23 @@ extern "C" int ks_st_apply(ks_st st, const double *x_dev, double *y_dev)        
   KS_CHECK(st->A, KS_ERR_ORDER, "STSetMatrices must be called first");
   KS_HIP(hipSetDevice(st->ctx->device));
   return ks_st_apply_internal(st, x_dev, y_dev);
+}
+// STApplyHermitianTranspose_Generic (stsolve.c:153-162), real scalars: only the branch without a solve (st->M alone: shift with one matrix)
+int ks_st_apply_transpose_internal(ks_st st, const double *x, double *y)
+{
+  KS_CALL(ks_st_setup_internal(st));
+  KS_CHECK(st->type == KS_ST_SHIFT && !st->B, KS_ERR_SUP, "STApplyHermitianTranspose is built for STSHIFT with one matrix (the others need a solve with the transposed matrix)");
+  KS_CALL(ks_mat_mult_transpose_internal(st->A, x, y));
+  if (st->sigma != 0.0) KS_CALL(ksk_lincomb(st->ctx, st->n, nullptr, 1.0, y, -st->sigma, x, y));      // (A - sigma I)^T x
+  return KS_SUCCESS;
+}
+extern "C" int ks_st_apply_transpose(ks_st st, const double *x_dev, double *y_dev)
+{
+  KS_CHECK(st && x_dev && y_dev, KS_ERR_ARG_NULL, "NULL argument");
+  KS_CHECK(x_dev != y_dev, KS_ERR_ARG_IDN, "x and y must be different vectors");
+  KS_CHECK(st->A, KS_ERR_ORDER, "STSetMatrices must be called first");
+  KS_HIP(hipSetDevice(st->ctx->device));
+  return ks_st_apply_transpose_internal(st, x_dev, y_dev);
 }
 extern "C" int ks_st_backtransform(ks_st st, int n, double *eigr, double *eigi) // STBackTransform stsolve.c:563
 {

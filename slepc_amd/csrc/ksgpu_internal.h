@@ -142,6 +142,7 @@ struct ks_mat_s {
   long long nnz = 0;     // local nonzeros (diag + offdiag blocks)
   // the CSR arrays the matrix was created from (global columns), kept on the host for KS_MAT_KEEP_CSR: what MatDuplicate / MatAXPY need (ks_mat_create_axpy)
   bool keep_csr = false; std::vector<int> k_rowptr, k_col; std::vector<double> k_val;
+  ks_mat At = nullptr;                        // MatMultTranspose: the transpose, built on first use from the kept arrays (owned)
   // diagonal block (columns owned by this rank, LOCAL column indices)
   int *d_rowptr = nullptr; int *d_col = nullptr; double *d_val = nullptr; long long nnz_d = 0;
   int lanes_per_row = 8;
@@ -199,10 +200,13 @@ struct ks_mat_s {
            int ridx[KS_HALO_MAX_PEERS] = {}, remote_off[KS_HALO_MAX_PEERS] = {}, remote_nghost[KS_HALO_MAX_PEERS] = {}; unsigned *tickets = nullptr; long long timeout_ticks = 0; } hp;
   // matrix-free operator (MATSHELL with MATOP_MULT): y = shell_mult(user, x); may synchronise the host
   int (*shell_mult)(void *user, const double *x_dev, double *y_dev) = nullptr;
+  int (*shell_mult_t)(void *user, const double *x_dev, double *y_dev) = nullptr;      // MATOP_MULT_TRANSPOSE
   bool shell_nosync = false;                  // the callback only enqueues work on the context's stream: a Krylov run may be enqueued ahead through it
   void *shell_user = nullptr;
 };
 int ks_mat_get_diagonal_internal(ks_mat A, double *d_dev);
+int ks_mat_mult_transpose_internal(ks_mat A, const double *x, double *y);
+int ks_st_apply_transpose_internal(ks_st st, const double *x, double *y);
 void ks_halo_release(ks_mat A);
 int ks_halo_peer_exchange(ks_mat A, const double *x, hipStream_t hs);     // pack into the neighbours' mailboxes, unpack this rank's own (ks_halo.hip)
 

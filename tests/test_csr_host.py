@@ -121,3 +121,23 @@ def test_empty_matrix_and_empty_rows(lib):
     brp = np.array([0, 0, 1, 1], dtype=np.int32); bc = np.array([0], dtype=np.int32); bv = np.array([7.0])
     r2, c2, v2 = axpy(lib, (rp, e, ev), 2.0, (brp, bc, bv))
     assert r2.tolist() == [0, 0, 1, 1] and c2.tolist() == [0] and v2.tolist() == [14.0]
+
+
+def test_transpose_by_counting_sort(lib):
+    """MatTranspose on the host: sorted rows out, repeated entries stay separate (their sum is what a product sees)."""
+    lib.ksc_csr_transpose.argtypes = [C.c_int, IP, IP, DP, IP, IP, DP]
+    lib.ksc_csr_transpose.restype = None
+    rng = np.random.default_rng(3)
+    for n in (1, 6, 300):
+        A = sp.random(n, n, density=min(1.0, 5.0 / n), random_state=rng, format="csr") + sp.identity(n) * 2.0
+        a = _arrays(A)
+        nnz = len(a[1])
+        rpt = np.zeros(n + 1, dtype=np.int32); ct = np.zeros(max(nnz, 1), dtype=np.int32); vt = np.zeros(max(nnz, 1))
+        lib.ksc_csr_transpose(n, _i(a[0]), _i(a[1]), _d(a[2]), _i(rpt), _i(ct), _d(vt))
+        T = A.T.tocsr(); T.sort_indices()
+        assert np.array_equal(rpt, T.indptr) and np.array_equal(ct[:nnz], T.indices) and np.array_equal(vt[:nnz], T.data)
+    # unordered row with a repeated column
+    rp = np.array([0, 3, 4], dtype=np.int32); col = np.array([1, 0, 1, 0], dtype=np.int32); val = np.array([1.0, 2.0, 3.0, 4.0])
+    rpt = np.zeros(3, dtype=np.int32); ct = np.zeros(4, dtype=np.int32); vt = np.zeros(4)
+    lib.ksc_csr_transpose(2, _i(rp), _i(col), _d(val), _i(rpt), _i(ct), _d(vt))
+    assert rpt.tolist() == [0, 2, 4] and ct.tolist() == [0, 1, 0, 0] and vt.tolist() == [2.0, 4.0, 1.0, 3.0]

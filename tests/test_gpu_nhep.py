@@ -586,11 +586,11 @@ def test_eps_test22_balance_oneside_golden(ctx):
     assert np.abs(S @ Q - Q @ (Q.T @ (S @ Q))).max() < 1e-5 * np.abs(S @ Q).max()
     r = O.eps_krylovschur_nhep(Ao, 4, tol=1e-7, which="largest_real", trueres=True, balance_its=5)
     _check_against_oracle(eps, r, Ao, tol=1e-6)
-    # balancing is for non-symmetric problems only; the two-sided form needs the transposed operator
+    # the two-sided form needs the transposed product, which an assembled matrix builds from its kept CSR arrays (test below): PETSC_ERR_ORDER without them
     eps.SetBalance("twoside")
     with pytest.raises(ks.KsError) as e:
         eps.Solve()
-    assert e.value.rc == 56
+    assert e.value.rc == 58
     eps.SetBalance("none"); eps.Solve()
     assert eps.GetConverged() >= 4
     # EPS_BALANCE_USER: the caller's diagonal (here a row-norm scaling) instead of the Krylov-built one
@@ -600,3 +600,48 @@ def test_eps_test22_balance_oneside_golden(ctx):
     assert np.allclose(np.sort_complex(lam2), np.sort_complex(lam), rtol=1e-6)
     for i in range(4):
         assert eps.ComputeError(i) < 1e-6
+
+
+def test_eps_ex9_two_sided_balance_golden(ctx):
+    """ex9 suffix 3: -n 50 -eps_nev 4 -eps_balance twoside (output_file ex9_1.out). MatMultTranspose through the transposed matrix built from the
+    kept CSR arrays, and - as ex9.c itself does it (MATOP_MULT_TRANSPOSE, ex9.c:88) - through a shell matrix's transposed callback; the diagonal,
+    the restart count and the eigenvalues are the oracle's; with a shift the transposed operator is (A - sigma I)'."""
+    import slepc_amd as ks
+    Ao = nc.brusselator(50)
+    S = Ao.to_scipy()
+    A = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val, keep_csr=True)
+    x = np.random.default_rng(2).standard_normal(Ao.n)
+    assert np.linalg.norm(A.mult_transpose(x) - S.T @ x) <= 1e-14 * np.linalg.norm(S.T @ x)
+    r = O.eps_krylovschur_nhep(Ao, 4, which="largest_real", balance_its=5, balance="twoside")
+    gold = gi.complex_eigenvalue_lines(gi.read("eps/ex9_1.out"))[0]
+
+    def solve(M):
+        eps = ks.EPS(ctx)
+        eps.SetOperators(M); eps.SetProblemType(ks.EPS_NHEP); eps.SetDimensions(4); eps.SetWhichEigenpairs("largest_real"); eps.SetBalance("twoside")
+        eps.Solve()
+        lam = np.array([complex(*eps.GetEigenvalue(i)) for i in range(4)])
+        assert np.allclose(np.round(lam, 5), gold, atol=1.5e-5)
+        assert eps.GetIterationNumber() == r.its and eps.GetConverged() == r.nconv
+        assert np.allclose(lam, [complex(r.eigr[j], r.eigi[j]) for j in r.perm[:4]], rtol=1e-9)
+        assert max(eps.ComputeError(i) for i in range(4)) < 1e-7
+        return eps
+    solve(A)
+    # the matrix-free route of ex9.c: MATOP_MULT and MATOP_MULT_TRANSPOSE as callbacks
+    At = ks.Mat.from_csr(ctx, *(lambda T: (T.indptr.astype(np.int32), T.indices.astype(np.int32), T.data))(S.T.tocsr()))
+    A0 = ks.Mat.from_csr(ctx, Ao.rowptr, Ao.col, Ao.val)
+    Sh = ks.Mat.shell(ctx, Ao.n, lambda xp, yp: A0.mult_dev(xp, yp))
+    eps = ks.EPS(ctx); eps.SetOperators(Sh); eps.SetProblemType(ks.EPS_NHEP); eps.SetDimensions(4); eps.SetWhichEigenpairs("largest_real"); eps.SetBalance("twoside")
+    with pytest.raises(ks.KsError) as e:
+        eps.Solve()
+    assert e.value.rc == 56                                   # no MATOP_MULT_TRANSPOSE yet
+    Sh.shell_set_mult_transpose(lambda xp, yp: At.mult_dev(xp, yp))
+    solve(Sh)
+    # STApplyHermitianTranspose: shift with one matrix
+    st = ks.ST(ctx); st.SetType("shift"); st.SetShift(0.7); st.SetMatrices(A)
+    y = st.ApplyTranspose(x)
+    ref = S.T @ x - 0.7 * x
+    assert np.linalg.norm(y - ref) <= 1e-14 * np.linalg.norm(ref)
+    st.SetType("sinvert")
+    with pytest.raises(ks.KsError) as e:
+        st.ApplyTranspose(x)
+    assert e.value.rc == 56

@@ -626,6 +626,18 @@ def test_eps_test22_brusselator_golden(trueres):
     assert np.allclose(np.round(_as_complex(r, 4), 5), gi.complex_eigenvalue_lines(gi.read("eps/eps_test22_1.out"))[0], atol=1.5e-5)
 
 
+def test_eps_ex9_two_sided_balance_golden():
+    """ex9 suffix 3: -n 50 -eps_nev 4 -eps_balance twoside, output_file ex9_1.out (the balanced solve finds the values of suffix 1): the
+    diagonal built from p = D A D^-1 z and r = D^-1 A' D z (epsdefault.c:402-421) differs from the one-sided one and from the identity."""
+    import nhep_cases as nc
+    Ao = nc.brusselator(50)
+    r = O.eps_krylovschur_nhep(Ao, 4, which="largest_real", balance_its=5, balance="twoside")
+    assert r.nconv >= 4
+    assert np.allclose(np.round(_as_complex(r, 4), 5), gi.complex_eigenvalue_lines(gi.read("eps/ex9_1.out"))[0], atol=1.5e-5)
+    r0 = O.eps_krylovschur_nhep(Ao, 4, which="largest_real")
+    assert np.allclose(_as_complex(r, 4), _as_complex(r0, 4), rtol=1e-8)
+
+
 def test_eps_test22_balance_oneside_golden():
     """test22 suffix 2: -eps_nev 4 -eps_true_residual -eps_balance oneside -eps_tol 1e-7 (Brusselator n = 30)."""
     import nhep_cases as nc
