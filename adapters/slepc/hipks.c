@@ -581,6 +581,24 @@ static PetscErrorCode MatMult_HIPKS(Mat S,Vec x,Vec y)
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+/* MATOP_MULT_TRANSPOSE (what EPS_BALANCE_TWOSIDE asks of the operator, epsdefault.c:409): the library builds the transpose once from the CSR arrays
+   the matrix keeps (one rank; on more ranks it returns PETSC_ERR_SUP) */
+static PetscErrorCode MatMultTranspose_HIPKS(Mat S,Vec x,Vec y)
+{
+  MatHIPKS          *c;
+  const PetscScalar *d_px;
+  PetscScalar       *d_py;
+
+  PetscFunctionBegin;
+  PetscCall(MatShellGetContext(S,&c));
+  PetscCall(VecHIPGetArrayRead(x,&d_px));
+  PetscCall(VecHIPGetArrayWrite(y,&d_py));
+  KS(ks_mat_mult_transpose(c->A,d_px,d_py));
+  PetscCall(VecHIPRestoreArrayRead(x,&d_px));
+  PetscCall(VecHIPRestoreArrayWrite(y,&d_py));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
 static PetscErrorCode MatGetDiagonal_HIPKS(Mat S,Vec d)
 {
   MatHIPKS    *c;
@@ -642,10 +660,11 @@ SLEPC_EXTERN PetscErrorCode MatCreateHIPKSFromAIJ(Mat A,Mat *S)
   PetscCallMPI(MPI_Comm_size(comm,&size));
   c->comm.comm = comm;
   if (size>1) KS(ks_comm_set_ops(c->kctx,(int)rank,(int)size,&SlepcKsMpiOps,&c->comm));
-  KS(ks_mat_create_csr(c->kctx,(int)nloc,(int)rstart,(int)N,ia,ja,aa,&c->A));
+  KS(ks_mat_create_csr_flags(c->kctx,(int)nloc,(int)rstart,(int)N,ia,ja,aa,KS_MAT_KEEP_CSR,&c->A));   /* the arrays stay with the matrix: MatMultTranspose, MatAXPY */
   PetscCall(PetscFree3(ia,ja,aa));
   PetscCall(MatCreateShell(comm,nloc,nloc,N,N,c,S));
   PetscCall(MatShellSetOperation(*S,MATOP_MULT,(void(*)(void))MatMult_HIPKS));
+  PetscCall(MatShellSetOperation(*S,MATOP_MULT_TRANSPOSE,(void(*)(void))MatMultTranspose_HIPKS));
   PetscCall(MatShellSetOperation(*S,MATOP_GET_DIAGONAL,(void(*)(void))MatGetDiagonal_HIPKS));
   PetscCall(MatShellSetOperation(*S,MATOP_DESTROY,(void(*)(void))MatDestroy_HIPKS));
   PetscCall(MatShellSetVecType(*S,VECHIP));                     /* the BV inherits the HIP vector type from the operator (stsolve.c:349-353) */

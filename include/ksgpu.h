@@ -195,7 +195,7 @@ int ks_mat_get_layout(ks_mat A, int *layout);
 int ks_mat_mult(ks_mat A, const double *x_dev, double *y_dev);
 /* MatMultTranspose: y = A^T x. An assembled matrix builds its transpose on first use (MatTranspose on the host from the kept CSR arrays:
    KS_MAT_KEEP_CSR, KS_ERR_ORDER otherwise; one rank - the transpose of a row-sharded matrix is a redistribution, KS_ERR_SUP) and multiplies
-   with it like any other matrix; a shell matrix needs ks_mat_shell_set_mult_transpose (MATOP_MULT_TRANSPOSE, as ex9.c:88 sets it).
+   with it like any other matrix; a shell matrix needs ks_mat_shell_set_mult_transpose (MATOP_MULT_TRANSPOSE, as ex9.c:123 sets it).
    Used by the two-sided balancing (EPSBuildBalance_Krylov epsdefault.c:402-411). */
 int ks_mat_mult_transpose(ks_mat A, const double *x_dev, double *y_dev);
 int ks_mat_shell_set_mult_transpose(ks_mat A, ks_shell_mult_fn mult_transpose);

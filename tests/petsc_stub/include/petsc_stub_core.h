@@ -35,7 +35,7 @@ typedef int64_t PetscObjectState;          /* bvimpl.h:87 PetscObjectState xstat
 typedef enum { PETSC_FALSE, PETSC_TRUE } PetscBool;
 typedef enum { NORM_1 = 0, NORM_2 = 1, NORM_FROBENIUS = 2, NORM_INFINITY = 3 } NormType;     /* bvglobal.c:496, svec.c:164 */
 typedef const char *VecType; typedef const char *MatType;
-typedef enum { MATOP_MULT = 3, MATOP_GET_DIAGONAL = 17, MATOP_DESTROY = 250 } MatOperation;   /* ex3.c:47 */
+typedef enum { MATOP_MULT = 3, MATOP_MULT_TRANSPOSE = 5, MATOP_GET_DIAGONAL = 17, MATOP_DESTROY = 250 } MatOperation;   /* ex3.c:47, ex9.c:123 */
 #define PETSC_SUCCESS 0
 #define PETSC_ERR_SUP 56
 #define PETSC_DECIDE (-1)

@@ -604,7 +604,7 @@ def test_eps_test22_balance_oneside_golden(ctx):
 
 def test_eps_ex9_two_sided_balance_golden(ctx):
     """ex9 suffix 3: -n 50 -eps_nev 4 -eps_balance twoside (output_file ex9_1.out). MatMultTranspose through the transposed matrix built from the
-    kept CSR arrays, and - as ex9.c itself does it (MATOP_MULT_TRANSPOSE, ex9.c:88) - through a shell matrix's transposed callback; the diagonal,
+    kept CSR arrays, and - as ex9.c itself does it (MATOP_MULT_TRANSPOSE, ex9.c:123) - through a shell matrix's transposed callback; the diagonal,
     the restart count and the eigenvalues are the oracle's; with a shift the transposed operator is (A - sigma I)'."""
     import slepc_amd as ks
     Ao = nc.brusselator(50)
