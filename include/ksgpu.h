@@ -48,7 +48,7 @@ extern "C" {
 #define KS_ERR_ARG_WRONG       62
 #define KS_ERR_ARG_OUTOFRANGE  63
 #define KS_ERR_MAT_LU_ZRPVT    71   /* zero pivot in a block of the block-Jacobi preconditioner */
-#define KS_ERR_USER_INPUT      71   /* BV_SafeSqrt "Invalid inner product" bvimpl.h:137 */
+#define KS_ERR_USER_INPUT      95   /* BV_SafeSqrt "Invalid inner product" bvimpl.h:137 (PETSC_ERR_USER_INPUT; 71, used until round 3, is PETSC_ERR_MAT_LU_ZRPVT) */
 #define KS_ERR_ARG_WRONGSTATE  73
 #define KS_ERR_ARG_INCOMP      75
 #define KS_ERR_LIB             76   /* HIP / RCCL runtime failure (PetscCallHIP analogue) */

@@ -145,7 +145,7 @@ def test_argument_errors_mirror_reference(ctx, gpu):
     assert e.value.rc == 60
     with pytest.raises(ks.KsError) as e:
         ks.BV(ctx, 10, 3, ld=8)                       # leading dimension smaller than n
-    assert e.value.rc == 71
+    assert e.value.rc == 95
     with pytest.raises(ks.KsError) as e:
         X.Norm(ks.NORM_2)                             # "Requested norm not available" for a whole BV
     assert e.value.rc == 56

@@ -379,7 +379,7 @@ def test_invalid_inner_product_is_an_error(ctx):
     V.set_column(0, np.full(100, np.nan))
     with pytest.raises(ks.KsError) as e:
         V.OrthogonalizeColumn(0)
-    assert e.value.rc == 71
+    assert e.value.rc == 95
 
 
 # ---- Lanczos / Arnoldi ---------------------------------------------------------------------------------------

@@ -306,7 +306,7 @@ def test_mpd_limits_the_projected_problem(ctx, ptype):
         assert abs(complex(*eps.GetEigenvalue(i)) - ref) <= 1e-10 * abs(ref)
     with pytest.raises(ks.KsError) as e:
         bad = ks.EPS(ctx); bad.SetOperators(A); bad.SetDimensions(8, 30, 12); bad.Solve()      # ncv > nev + mpd
-    assert e.value.rc == 71
+    assert e.value.rc == 95
 
 
 def test_eps_interface_getters_and_defaults(ctx):

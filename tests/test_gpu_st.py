@@ -253,7 +253,7 @@ def test_sinvert_requires_target_which(ctx):
     eps.GetST().SetType("sinvert")
     with pytest.raises(ks.KsError) as e:
         eps.Solve()
-    assert e.value.rc == 71
+    assert e.value.rc == 95
 
 
 def test_config5_large_properties(ctx):
@@ -393,7 +393,7 @@ def test_cayley_standard_nonsymmetric_and_backtransform(ctx):
         assert err < 1e-4 and abs(err - O.eps_compute_error_nhep(Ao, r, i)) < 1e-8
     with pytest.raises(ks.KsError) as e:
         s3 = ks.ST(ctx); s3.SetType("cayley"); s3.SetShift(2.0); s3.CayleySetAntishift(-2.0); s3.SetMatrices(A, None); s3.SetUp()
-    assert e.value.rc == 71
+    assert e.value.rc == 95
 
 
 @pytest.mark.parametrize("kind,withB,sigma", [("shift", True, 0.3), ("sinvert", False, 1.3), ("sinvert", True, 0.0), ("sinvert", True, 35.0), ("cayley", True, 35.0)])
