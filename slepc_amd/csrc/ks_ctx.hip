@@ -26,6 +26,7 @@ extern "C" const char *ks_error_string(int rc)
     case KS_ERR_ARG_WRONG: return "wrong argument";
     case KS_ERR_ARG_OUTOFRANGE: return "argument out of range";
     case KS_ERR_USER_INPUT: return "invalid user input (invalid inner product)";
+    case KS_ERR_MAT_LU_ZRPVT: return "zero pivot in LU factorization";
     case KS_ERR_ARG_WRONGSTATE: return "object in wrong state";
     case KS_ERR_ARG_INCOMP: return "arguments are incompatible";
     case KS_ERR_LIB: return "error in external library (HIP/RCCL)";

@@ -14,7 +14,8 @@ def test_library_is_in_tree_and_loads():
     assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
     L = _lib.lib()
     assert L.ks_error_string(0) == b"success"
-    assert b"inner product" in L.ks_error_string(71)
+    assert b"inner product" in L.ks_error_string(95)          # PETSC_ERR_USER_INPUT
+    assert b"pivot" in L.ks_error_string(71)                  # PETSC_ERR_MAT_LU_ZRPVT
 
 
 def test_every_header_symbol_is_exported():
