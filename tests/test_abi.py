@@ -50,12 +50,13 @@ def test_gfx950_code_object_present():
 
 
 def test_fails_loudly_without_gpu():
-    import torch
-    if torch.cuda.is_available():
-        pytest.skip("a GPU is present")
-    with pytest.raises(ks.KsError) as ei:
+    # (no torch here: its bundled HIP runtime beside the library's own in one process costs later launches their scratch memory)
+    try:
         ks.Context(0)
-    assert ei.value.rc == 97          # KS_ERR_GPU, no CPU fallback
+    except ks.KsError as e:
+        assert e.rc == 97             # KS_ERR_GPU, no CPU fallback
+        return
+    pytest.skip("a GPU is present")
 
 
 def test_product_does_not_import_oracle():
@@ -89,9 +90,8 @@ def test_header_is_plain_c_and_library_links_from_c(tmp_path):
     """include/ksgpu.h compiles as strict C99 (-pedantic -Werror) and a C program links against libksgpu.so; without a
     GPU the program stops at ks_ctx_create with the PETSc-numbered error and says there is no CPU fallback."""
     import subprocess
-    import torch
     exe = _build_c_example(tmp_path)
-    if torch.cuda.is_available():
-        pytest.skip("the run itself is checked by tests/test_gpu_krylov.py::test_c_program_against_the_abi")
     r = subprocess.run([exe], capture_output=True, text=True)
+    if r.returncode == 0:
+        pytest.skip("a GPU is present: the run itself is checked by tests/test_gpu_krylov.py::test_c_program_against_the_abi")
     assert r.returncode == 1 and "97" in r.stderr and "no CPU fallback" in r.stderr
