@@ -128,7 +128,7 @@ int ks_sweep_grid_for(ks_ctx ctx, int n, int vec, const void *kernel, int force_
     for (auto &e : cache) if (e.first == kernel) { per_cu = e.second; found = true; break; }
     if (!found) {
       int nb = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, SW_BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, SW_BLOCK, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 4; }      // (a failed query must not show up as the next launch's error)
       per_cu = std::min(nb, 8);
       cache.push_back({kernel, per_cu});
     }

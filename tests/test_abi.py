@@ -50,7 +50,7 @@ def test_gfx950_code_object_present():
 
 
 def test_fails_loudly_without_gpu():
-    # (no torch here: its bundled HIP runtime beside the library's own in one process costs later launches their scratch memory)
+    # (no torch here: once its bundled HIP runtime is initialised beside the library's own in one process, occupancy queries of the library's kernels fail)
     try:
         ks.Context(0)
     except ks.KsError as e:
