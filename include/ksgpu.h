@@ -99,8 +99,21 @@ enum { KS_EPS_CONVERGED_TOL = 1, KS_EPS_CONVERGED_USER = 2, KS_EPS_DIVERGED_ITS 
 int ks_ctx_create(int device, void *stream, ks_ctx *ctx);
 int ks_ctx_destroy(ks_ctx ctx);
 int ks_ctx_synchronize(ks_ctx ctx);
+/* Test hooks (compiled with -DKSD_TEST_HOOKS, which the in-tree build sets): each makes a test run the path the fast one replaces, to compare bits,
+ * or a multi-rank path on one rank. Set BEFORE the objects they affect are created: NO_FUSED_GS is read at ks_bv_create, FORCE_MULTI at
+ * ks_comm_init_rccl / ks_comm_set_ops, ONESHOT_SEQ0 (first stamp of the one-shot allreduce) at ks_comm_set_allreduce; the others per call. */
+enum { KS_DEBUG_NO_FUSED_GS = 0, KS_DEBUG_NO_MFMA = 1, KS_DEBUG_NO_SPMV_DOT = 2, KS_DEBUG_FORCE_MULTI = 3, KS_DEBUG_HALO_OVERLAP = 4, KS_DEBUG_ONESHOT_SEQ0 = 5 };
+int ks_ctx_set_debug(ks_ctx ctx, int key, long long value);
 int ks_ctx_sync_count(ks_ctx ctx, long long *count);   /* instrumentation: host waits on the context's stream made by the library so far */
 int ks_ctx_device_info(ks_ctx ctx, char *arch, int arch_len, int *num_cu, size_t *mem_total);
+/* Which HIP runtime the library's calls are bound to. A process can map TWO copies of libamdhip64 (PyTorch wheels bundle one under the file name
+ * libamdhip64.so with the SONAME libamdhip64.so.7: loaded AFTER this library they become a second runtime, loaded BEFORE it the dynamic linker binds
+ * this library to that copy). ks_ctx_create refuses a process that maps more than one; a process that gains a second one later is reported here and by
+ * one warning on stderr at the first occupancy query that fails. Writes a JSON object: {"hip_runtime_path", "hip_runtime_version",
+ * "hip_runtimes_mapped": [paths], "occupancy_query_failures", "occupancy_last_error"}. No context needed; never initialises the GPU. */
+int ks_runtime_info(char *json, int len);
+/* Diagnosis only: let ks_ctx_create proceed in a process that maps two HIP runtimes (scripts/hip_runtime_probe.py reproduces round 3's failures with it). */
+int ks_runtime_allow_multiple(int allow);
 
 /* Row-wise distribution (PetscLayout, bvbasic.c:129-134).  Reductions inside BV ops
    (bvblas.c:218,255; bvlapack.c:50) become an allreduce over all ranks; MatMult exchanges the
@@ -127,6 +140,9 @@ int ks_comm_rank_size(ks_ctx ctx, int *rank, int *size);
  * on a single rank without forced collectives. (The reference leans on MPI's own correctness here; a communicator handed in
  * through ks_comm_set_ops is foreign code, so the library offers the check an integrator runs once after installing it.) */
 int ks_comm_check(ks_ctx ctx);
+/* Host wall time spent so far in the broadcast of rank 0's projected problem (one per restart with KS_DS_PARALLEL_SYNCHRONIZED, the DSSynchronize analogue,
+   dshep.c:673-713): number of broadcasts and their seconds (upload, ncclBroadcast or the provider's allgather, download, host wait); reset != 0 clears them. */
+int ks_comm_bcast_stats(ks_ctx ctx, long long *calls, double *seconds, int reset);
 /* Which allreduce the Gram-Schmidt passes use. KS_ALLREDUCE_PROVIDER: the communicator's own (ncclAllReduce with the
  * RCCL provider; what bvblas.c:255 MPIU_Allreduce is to the reference). KS_ALLREDUCE_ONESHOT: one kernel per rank writes the k+1
  * values into a mailbox of every rank (peer-mapped uncached device memory: hipIpc between processes, xGMI between GPUs) and adds
@@ -206,7 +222,10 @@ int ks_mat_mult_host(ks_mat A, const double *x_host, double *y_host);  /* conven
  * hipIpc between processes, xGMI between GPUs), stamped and acknowledged per product, and the receiver copies its mailbox into its ghost
  * array - no library call per product. Collective; *active returns what was installed: the peer path only if every rank could map all
  * its neighbours' mailboxes (at most 16 neighbours per rank). A rank that waits longer than KSGPU_ONESHOT_TIMEOUT_MS (default 2000) for a
- * neighbour fills its ghosts with NaN and the next host wait fails with KS_ERR_LIB - never a hang. */
+ * neighbour fills its ghosts with NaN and the next host wait fails with KS_ERR_LIB - never a hang.
+ * Taking the peer path down is collective too: ks_mat_set_halo(A, KS_HALO_PROVIDER) (or a new KS_HALO_PEER set-up) lets every rank finish, closes the
+ * mapped mailboxes and only then frees its own. Call it before ks_mat_destroy on a matrix whose peer halo is active; a destroy without it waits (bounded)
+ * for the neighbours' last acknowledgements before freeing the mailbox, but cannot wait for them to unmap it. */
 #define KS_HALO_PROVIDER 0
 #define KS_HALO_PEER 1
 int ks_mat_set_halo(ks_mat A, int kind, int *active);
@@ -443,6 +462,9 @@ int ks_prof_reset(ks_ctx ctx);
    HBM bytes (what the kernel as designed must move) of one class; variant<0 sums over all variants */
 int ks_prof_get(ks_ctx ctx, int kclass, int variant, long long *launches, double *ms, double *alg_bytes, double *hbm_bytes);
 const char *ks_prof_class_name(int kclass);
+/* the reference's log event under which -log_view shows that class's work (bvfunc.c:69-86: BVMatMultVec, BVDotVec, BVMultVec, BVScale, BVMultInPlace,
+   BVOrthogonalizeV ...; a fused launch names both events it does the work of, e.g. "BVMultVec+BVDotVec") */
+const char *ks_prof_event_name(int kclass);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,11 @@ EPS_MONITOR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.
 
 KCLASSES = ["spmv_csr", "bv_dot_sweep", "gs_bookkeeping", "gs_update_fused_dot", "gs_update", "bv_scale", "bv_multinplace",
             "bv_copy", "bv_mult", "bv_dot_panel", "bv_norm", "halo_exchange", "allreduce", "gated_noop", "other", "spmv_dot_fused"]
+def event_name(name):
+    """The reference's log event (bvfunc.c:69-86) under which -log_view shows the work of profiling class `name` (ks_prof_event_name)."""
+    return _lib.lib().ks_prof_event_name(KCLASSES.index(name)).decode() if name in KCLASSES else "-"
+
+
 # kernel symbol behind each (class, variant) as rocprofv3 --kernel-trace names it (16-byte-load forms)
 def kernel_symbol(name, var):
     if name == "spmv_csr":
@@ -102,6 +107,12 @@ class Context:
     def synchronize(self):
         _lib.check(self.L.ks_ctx_synchronize(self.h))
 
+    DEBUG_KEYS = {"no_fused_gs": 0, "no_mfma": 1, "no_spmv_dot": 2, "force_multi": 3, "halo_overlap": 4, "oneshot_seq0": 5}
+
+    def set_debug(self, key, value=1):
+        """Test hooks (ks_ctx_set_debug): run the path a fast one replaces, or the multi-rank path on one rank."""
+        _lib.check(self.L.ks_ctx_set_debug(self.h, self.DEBUG_KEYS[key], int(value)))
+
     def sync_count(self):
         v = C.c_longlong(); _lib.check(self.L.ks_ctx_sync_count(self.h, C.byref(v))); return v.value
 
@@ -160,6 +171,12 @@ class Context:
     def comm_check(self):
         """Known-answer run of the installed communicator (collective): allreduce, allgather, ring exchange."""
         _lib.check(self.L.ks_comm_check(self.h))
+
+    def bcast_stats(self, reset=False):
+        """(calls, seconds): host wall time in the per-restart broadcast of rank 0's projected problem (ks_comm_bcast_stats)."""
+        n = C.c_longlong(); s = C.c_double()
+        _lib.check(self.L.ks_comm_bcast_stats(self.h, C.byref(n), C.byref(s), int(reset)))
+        return n.value, s.value
 
     def memcpy_h2d(self, dev_ptr, host_array, stream=None):
         """stream: the `stream` argument a communicator callback received (None: the context's own)."""

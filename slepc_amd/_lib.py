@@ -34,7 +34,10 @@ _SIG = {
     "ks_ctx_destroy": [vp],
     "ks_ctx_synchronize": [vp],
     "ks_ctx_sync_count": [vp, llp],
+    "ks_ctx_set_debug": [vp, C.c_int, C.c_longlong],
     "ks_ctx_device_info": [vp, C.c_char_p, C.c_int, ip, C.POINTER(C.c_size_t)],
+    "ks_runtime_info": [C.c_char_p, C.c_int],
+    "ks_runtime_allow_multiple": [C.c_int],
     "ks_comm_get_unique_id": [C.c_char_p],
     "ks_comm_init_rccl": [vp, C.c_int, C.c_int, C.c_char_p],
     "ks_comm_set_ops": [vp, C.c_int, C.c_int, C.POINTER(CommOps), vp],
@@ -43,6 +46,7 @@ _SIG = {
     "ks_ctx_memset": [vp, vp, C.c_int, C.c_size_t],
     "ks_comm_rank_size": [vp, ip, ip],
     "ks_comm_check": [vp],
+    "ks_comm_bcast_stats": [vp, llp, dp, C.c_int],
     "ks_comm_set_allreduce": [vp, C.c_int, ip],
     "ks_comm_get_allreduce": [vp, ip],
     "ks_comm_allreduce_sum": [vp, vp, C.c_int],
@@ -210,7 +214,7 @@ _SIG = {
     "ks_prof_reset": [vp],
     "ks_prof_get": [vp, C.c_int, C.c_int, llp, dp, dp, dp],
 }
-_STR_FUNCS = ("ks_error_string", "ks_last_error_message", "ks_prof_class_name")
+_STR_FUNCS = ("ks_error_string", "ks_last_error_message", "ks_prof_class_name", "ks_prof_event_name")
 
 
 def header_symbols():
@@ -220,10 +224,59 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(ks_[a-z0-9_]+)\s*\(", txt)) - {"ks_comm_ops"})
 
 
+def mapped_hip_runtimes():
+    """Distinct libamdhip64 files this process maps (the C side's view: ks_runtime_info)."""
+    out = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                i = line.find("/")
+                if i < 0:
+                    continue
+                path = line[i:].strip()
+                if os.path.basename(path).startswith("libamdhip64.so") and path not in out:
+                    out.append(path)
+    except OSError:
+        pass
+    return out
+
+
+def _torch_bundled_runtime():
+    """Path of the libamdhip64.so a PyTorch wheel bundles, without importing torch; None if torch is absent or bundles none."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    return path if os.path.exists(path) else None
+
+
+_preloaded_runtime = None
+
+
+def bind_hip_runtime():
+    """ONE HIP runtime per process, whatever the import order. libksgpu.so NEEDs the SONAME libamdhip64.so.7; its RUNPATH finds /opt/rocm's copy.
+    PyTorch's wheel bundles its own copy under the FILE name libamdhip64.so with that same SONAME: imported before the library, torch's copy is the one
+    the library binds to (SONAME match); imported after it, torch asks for the file name, which matches no loaded SONAME, and a second HIP + HSA runtime
+    pair comes up in the process (round 3: later occupancy queries of the library failed). So when nothing is mapped yet and torch is installed with a
+    bundled runtime, that copy is mapped first, deliberately: the library binds to it and a later `import torch` finds the same file already mapped."""
+    global _preloaded_runtime
+    if mapped_hip_runtimes():
+        return
+    path = _torch_bundled_runtime()
+    if path is not None:
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+        _preloaded_runtime = path
+
+
 def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libksgpu.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    bind_hip_runtime()
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, args in _SIG.items():
         f = getattr(lib, name)
@@ -235,6 +288,8 @@ def load():
     lib.ks_last_error_message.restype = C.c_char_p
     lib.ks_prof_class_name.argtypes = [C.c_int]
     lib.ks_prof_class_name.restype = C.c_char_p
+    lib.ks_prof_event_name.argtypes = [C.c_int]
+    lib.ks_prof_event_name.restype = C.c_char_p
     return lib
 
 
@@ -246,6 +301,16 @@ def lib():
     if _lib is None:
         _lib = load()
     return _lib
+
+
+def runtime_info():
+    """ks_runtime_info as a dict: the HIP runtime the library is bound to, every libamdhip64 the process maps, failed occupancy queries so far."""
+    import json
+    buf = C.create_string_buffer(2048)
+    check(lib().ks_runtime_info(buf, 2048))
+    d = json.loads(buf.value.decode())
+    d["preloaded_by_binding"] = _preloaded_runtime
+    return d
 
 
 def check(rc):

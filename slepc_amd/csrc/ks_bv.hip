@@ -127,8 +127,7 @@ int ks_sweep_grid_for(ks_ctx ctx, int n, int vec, const void *kernel, int force_
     bool found = false;
     for (auto &e : cache) if (e.first == kernel) { per_cu = e.second; found = true; break; }
     if (!found) {
-      int nb = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, SW_BLOCK, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 4; }      // (a failed query must not show up as the next launch's error)
+      const int nb = ks_occupancy(kernel, SW_BLOCK, 0, 4);
       per_cu = std::min(nb, 8);
       cache.push_back({kernel, per_cu});
     }
@@ -263,7 +262,7 @@ extern "C" int ks_bv_create(ks_ctx ctx, int n_local, int n_global, int m, int ld
   KS_HIP(hipSetDevice(ctx->device));
   ks_bv bv = new ks_bv_s();
   bv->ctx = ctx; bv->n = n_local; bv->N = n_global; bv->m = m; bv->l = 0; bv->k = m; bv->nc = 0;
-  bv->fused_gs = !getenv("KSGPU_NO_FUSED_GS");
+  bv->fused_gs = !ctx->dbg.no_fused_gs;
   if (ld) {   // BV_SetDefaultLD bvimpl.h:471-484: a user value must be >= n
     if (ld < n_local) { delete bv; KS_FAIL(KS_ERR_USER_INPUT, "The leading dimension %d should be larger or equal to the local number of rows %d", ld, n_local); }
     bv->ld = ld;
@@ -579,7 +578,7 @@ static int panel_mult64(ks_ctx ctx, int kclass, const double *A, int lda, int n,
 {
   if (n == 0 || nout == 0) return KS_SUCCESS;
   KS_CHECK(kin >= 1 && kin <= KS_MAX_COLS, KS_ERR_SUP, "panel product with %d inner columns (max %d)", kin, KS_MAX_COLS);
-  const bool use_mfma = !getenv("KSGPU_NO_MFMA");
+  const bool use_mfma = !ctx->dbg.no_mfma;
   if (use_mfma && nout <= 64 && lda % 2 == 0 && aligned16(A))       // FP64 matrix cores; the VALU kernel below is the unaligned fallback
     return ksp_mult_mfma(ctx, kclass, A, lda, n, kin, Qdev, transq ? ldq : 1, transq ? 1 : ldq, nout, alpha, beta, C, ldc);
   const int grid = (int)std::min<long long>(((long long)n + SW_BLOCK - 1) / SW_BLOCK, (long long)ctx->num_cu * 8);
@@ -781,7 +780,7 @@ int ksb_dot_range(ks_bv X, int xs, int xe, ks_bv Y, int ys, int ye, double *M, i
     ks_bv_destroy(W);
     return rc;
   }
-  const bool use_mfma = !getenv("KSGPU_NO_MFMA");
+  const bool use_mfma = !ctx->dbg.no_mfma;
   const double *px0 = X->array + (size_t)(X->nc + xs) * X->ld;
   if (use_mfma && X->n > 0 && nx <= 64 && X->ld % 2 == 0 && Y->ld % 2 == 0 && aligned16(py) && aligned16(px0)) {
     KS_CALL(ksp_dot_mfma(X, py, Y->ld, my, px0, X->ld, nx, X->n, X->coef));      // one sweep over both panels on the matrix cores

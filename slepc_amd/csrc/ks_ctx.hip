@@ -2,6 +2,8 @@
 #include "ksgpu_internal.h"
 #include "ks_oneshot.cuh"
 #include <cstdarg>
+#include <atomic>
+#include <chrono>
 #include <dlfcn.h>
 #include <unistd.h>
 #include <cstdint>
@@ -42,9 +44,70 @@ extern "C" const char *ks_error_string(int rc)
   }
 }
 
+// ---- which HIP runtime(s) this process maps ------------------------------------------------------------------------------------------
+// PyTorch wheels bundle a libamdhip64.so whose SONAME is libamdhip64.so.7, the name this library NEEDs: loaded first, it is the runtime this
+// library binds to; loaded after this library (whose RUNPATH finds /opt/rocm's copy), it is a SECOND runtime in the process, because torch
+// asks for the file name libamdhip64.so, which matches no loaded SONAME.
+static int mapped_hip_runtimes(char paths[][256], int max)
+{
+  FILE *f = fopen("/proc/self/maps", "r");
+  if (!f) return 0;
+  char line[1024]; int n = 0;
+  while (fgets(line, sizeof(line), f)) {
+    char *p = strchr(line, '/');
+    if (!p) continue;
+    char *nl = strchr(p, '\n'); if (nl) *nl = 0;
+    const char *base = strrchr(p, '/'); base = base ? base + 1 : p;
+    if (strncmp(base, "libamdhip64.so", 14) != 0) continue;
+    bool seen = false;
+    for (int i = 0; i < n; i++) if (!strcmp(paths[i], p)) { seen = true; break; }
+    if (!seen && n < max) { snprintf(paths[n], 256, "%s", p); n++; }
+  }
+  fclose(f);
+  return n;
+}
+static std::atomic<int> g_allow_two_runtimes{0};
+extern "C" int ks_runtime_allow_multiple(int allow) { g_allow_two_runtimes.store(allow ? 1 : 0); return KS_SUCCESS; }
+static std::atomic<long long> g_occ_failures{0};
+static char g_occ_last[128] = "";
+int ks_occupancy(const void *kernel, int block_threads, size_t lds_bytes, int fallback)
+{
+  int nb = 0;
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block_threads, lds_bytes);
+  if (e == hipSuccess && nb >= 1) return nb;
+  (void)hipGetLastError();                                   // a failed query must not show up as the next launch's error
+  snprintf(g_occ_last, sizeof(g_occ_last), "%s (blocks %d, %d threads, %zu B LDS)", e == hipSuccess ? "success with 0 blocks" : hipGetErrorName(e), nb, block_threads, lds_bytes);
+  if (g_occ_failures.fetch_add(1) == 0) {
+    char paths[4][256]; const int np = mapped_hip_runtimes(paths, 4);
+    fprintf(stderr, "libksgpu: warning: an occupancy query failed: %s; grids fall back to %d workgroup(s) per CU for that kernel. HIP runtimes mapped: %d", g_occ_last, fallback, np);
+    for (int i = 0; i < np; i++) fprintf(stderr, "%s%s", i ? ", " : " (", paths[i]);
+    fprintf(stderr, "%s\n", np ? ")" : "");
+  }
+  return fallback;
+}
+extern "C" int ks_runtime_info(char *json, int len)
+{
+  KS_CHECK(json && len > 0, KS_ERR_ARG_NULL, "NULL buffer");
+  Dl_info di; memset(&di, 0, sizeof(di));
+  const char *bound = (dladdr((void *)&hipGetDeviceCount, &di) && di.dli_fname) ? di.dli_fname : "?";
+  int ver = 0; if (hipRuntimeGetVersion(&ver) != hipSuccess) { (void)hipGetLastError(); ver = 0; }
+  char paths[4][256]; const int np = mapped_hip_runtimes(paths, 4);
+  int o = snprintf(json, len, "{\"hip_runtime_path\": \"%s\", \"hip_runtime_version\": %d, \"hip_runtimes_mapped\": [", bound, ver);
+  for (int i = 0; i < np && o < len; i++) o += snprintf(json + o, len - o, "%s\"%s\"", i ? ", " : "", paths[i]);
+  if (o < len) o += snprintf(json + o, len - o, "], \"occupancy_query_failures\": %lld, \"occupancy_last_error\": \"%s\"}", (long long)g_occ_failures.load(), g_occ_last);
+  KS_CHECK(o < len, KS_ERR_ARG_SIZ, "buffer of %d bytes too short", len);
+  return KS_SUCCESS;
+}
+
 extern "C" int ks_ctx_create(int device, void *stream, ks_ctx *out)
 {
   KS_CHECK(out, KS_ERR_ARG_NULL, "ctx output pointer is NULL");
+  {
+    char paths[4][256];
+    if (mapped_hip_runtimes(paths, 4) > 1 && !g_allow_two_runtimes.load())
+      KS_FAIL(KS_ERR_LIB, "two HIP runtimes are mapped in this process (%s and %s): each would drive the GPU through its own HSA runtime. Load the other HIP user "
+              "(e.g. `import torch`) BEFORE libksgpu.so, which then binds to that runtime (same SONAME), or keep it out of this process", paths[0], paths[1]);
+  }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) KS_FAIL(KS_ERR_GPU, "no HIP device available (%s); libksgpu has no CPU fallback", hipGetErrorString(e));
@@ -67,7 +130,6 @@ extern "C" int ks_ctx_create(int device, void *stream, ks_ctx *out)
     if (e != hipSuccess) { delete ctx; KS_FAIL(KS_ERR_LIB, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(e)); }
     ctx->own_stream = true;
   }
-  { const char *ho = getenv("KSGPU_HALO_OVERLAP"); ctx->halo_overlap = !(ho && atoi(ho) == 0); }   // safety switch of a path no multi-GPU box has run yet
   ctx->h_pinned_len = KS_PINNED_D2H_BYTES / sizeof(double) + 2 * KS_PINNED_H2D_DOUBLES;
   e = hipHostMalloc((void **)&ctx->h_pinned, ctx->h_pinned_len * sizeof(double), hipHostMallocMapped);
   if (e != hipSuccess) {
@@ -129,6 +191,23 @@ extern "C" int ks_ctx_synchronize(ks_ctx ctx)
   return KS_SUCCESS;
 }
 
+#ifdef KSD_TEST_HOOKS
+extern "C" int ks_ctx_set_debug(ks_ctx ctx, int key, long long value)
+{
+  KS_CHECK(ctx, KS_ERR_ARG_NULL, "ctx is NULL");
+  switch (key) {
+    case KS_DEBUG_NO_FUSED_GS: ctx->dbg.no_fused_gs = value != 0; break;
+    case KS_DEBUG_NO_MFMA: ctx->dbg.no_mfma = value != 0; break;
+    case KS_DEBUG_NO_SPMV_DOT: ctx->dbg.no_spmv_dot = value != 0; break;
+    case KS_DEBUG_FORCE_MULTI: ctx->dbg.force_multi = value != 0; break;
+    case KS_DEBUG_HALO_OVERLAP: ctx->halo_overlap = value != 0; break;
+    case KS_DEBUG_ONESHOT_SEQ0: ctx->dbg.oneshot_seq0 = (unsigned)value; break;
+    default: KS_FAIL(KS_ERR_ARG_OUTOFRANGE, "unknown debug key %d", key);
+  }
+  return KS_SUCCESS;
+}
+#endif
+
 extern "C" int ks_ctx_sync_count(ks_ctx ctx, long long *count)
 {
   KS_CHECK(ctx && count, KS_ERR_ARG_NULL, "NULL argument");
@@ -151,6 +230,13 @@ static const char *g_class_names[KS_K_COUNT] = {
   "bv_mult", "bv_dot_panel", "bv_norm", "halo_exchange", "allreduce", "gated_noop", "other", "spmv_dot_fused" };
 
 extern "C" const char *ks_prof_class_name(int k) { return (k >= 0 && k < KS_K_COUNT) ? g_class_names[k] : "?"; }
+
+// The reference's log event (PetscLogEventRegister names, bvfunc.c:69-86; PETSc's own for the product's halo and the reduction) under which a
+// -log_view of the reference shows the work of each class. A fused launch does the work of two events and says so.
+static const char *g_event_names[KS_K_COUNT] = {
+  "BVMatMultVec", "BVDotVec", "BVOrthogonalizeV", "BVMultVec+BVDotVec", "BVMultVec+BVScale", "BVScale", "BVMultInPlace", "BVCopy",
+  "BVMult", "BVDot", "BVNormVec", "VecScatterBegin+VecScatterEnd", "MPIU_Allreduce (in BVDotVec)", "-", "-", "BVMatMultVec+BVDotVec" };
+extern "C" const char *ks_prof_event_name(int k) { return (k >= 0 && k < KS_K_COUNT) ? g_event_names[k] : "?"; }
 
 static int get_event(ks_ctx ctx, hipEvent_t *e)
 {
@@ -362,7 +448,7 @@ extern "C" int ks_comm_init_rccl(ks_ctx ctx, int rank, int size, const unsigned 
   ctx->comm.rccl_lib = h; ctx->comm.nccl_comm = comm; ctx->comm.rank = rank; ctx->comm.size = size;
   ctx->comm.ops.allreduce_sum = rccl_allreduce_sum; ctx->comm.ops.allgather_host = rccl_allgather_host; ctx->comm.ops.exchange = rccl_exchange;
   ctx->comm.user = ctx;
-  ctx->comm.force_collectives = getenv("KSGPU_FORCE_MULTI") != nullptr;
+  ctx->comm.force_collectives = ctx->dbg.force_multi;
   return KS_SUCCESS;
 }
 
@@ -374,7 +460,7 @@ extern "C" int ks_comm_set_ops(ks_ctx ctx, int rank, int size, const ks_comm_ops
   ctx->comm.rank = rank; ctx->comm.size = size;
   if (ops) ctx->comm.ops = *ops;
   ctx->comm.user = user;
-  ctx->comm.force_collectives = ops && ops->allreduce_sum && getenv("KSGPU_FORCE_MULTI") != nullptr;
+  ctx->comm.force_collectives = ops && ops->allreduce_sum && ctx->dbg.force_multi;
   return KS_SUCCESS;
 }
 
@@ -542,7 +628,7 @@ extern "C" int ks_comm_set_allreduce(ks_ctx ctx, int kind, int *active)
   const char *tm = getenv("KSGPU_ONESHOT_TIMEOUT_MS");
   const long long ms = tm && atoll(tm) > 0 ? atoll(tm) : 2000;
   os.timeout_ticks = ms * khz;
-  { const char *s0 = getenv("KSGPU_ONESHOT_SEQ0"); os.seq = s0 ? (unsigned)strtoul(s0, nullptr, 0) : 0u; }     // test hook: start the stamps near their 32-bit wrap
+  os.seq = ctx->dbg.oneshot_seq0;                              // test hook (KS_DEBUG_ONESHOT_SEQ0): start the stamps near their 32-bit wrap
   os.par = 0;
   os.enabled = true;
   if (active) *active = KS_ALLREDUCE_ONESHOT;
@@ -585,9 +671,27 @@ int ks_comm_allgather_host(ks_ctx ctx, const void *send, int bytes, void *recv)
   return KS_SUCCESS;
 }
 
+extern "C" int ks_comm_bcast_stats(ks_ctx ctx, long long *calls, double *seconds, int reset)
+{
+  KS_CHECK(ctx, KS_ERR_ARG_NULL, "ctx is NULL");
+  if (calls) *calls = ctx->comm.bcast_calls;
+  if (seconds) *seconds = ctx->comm.bcast_seconds;
+  if (reset) { ctx->comm.bcast_calls = 0; ctx->comm.bcast_seconds = 0.0; }
+  return KS_SUCCESS;
+}
+
+static int bcast0_host(ks_ctx ctx, void *buf, int bytes);
 int ks_comm_bcast0_host(ks_ctx ctx, void *buf, int bytes)
 {
   if ((ctx->comm.size == 1 && !ctx->comm.force_collectives) || bytes <= 0) return KS_SUCCESS;
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = bcast0_host(ctx, buf, bytes);
+  ctx->comm.bcast_calls++;
+  ctx->comm.bcast_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return rc;
+}
+static int bcast0_host(ks_ctx ctx, void *buf, int bytes)
+{
   if (ctx->comm.nccl_comm && g_rccl.bcast && ctx->comm.ops.allgather_host == rccl_allgather_host) {
     // native provider: ONE ncclBroadcast of rank 0's bytes through the device staging area and one host wait (the allgather form below
     // ships size x bytes and is what a caller-supplied provider, which has no broadcast slot, is left with)
@@ -623,7 +727,7 @@ int ks_comm_exchange(ks_ctx ctx, int npeers, const int *peers, const void *dev_s
 // Known-answer run of the three provider operations (what an integrator calls once after installing a communicator, and
 // what bench.py calls before the timed region): allreduces whose sums are known in closed form (64 of them enqueued back to
 // back, so that a one-shot path goes through its slot parities without a host wait in between), allgathers of one int per
-// rank, and a ring exchange with the neighbours rank+1 and rank-1 (with itself at size 1 under KSGPU_FORCE_MULTI).
+// rank, and a ring exchange with the neighbours rank+1 and rank-1 (with itself at size 1 under the force_multi test hook).
 // Every rank runs every stage whatever it has seen so far, and the verdict is agreed through a last allgather: the call
 // returns the same on all ranks and leaves no rank waiting in a collective the others skipped.
 extern "C" int ks_comm_check(ks_ctx ctx)

@@ -123,19 +123,51 @@ struct HaloHello {
 
 } // namespace
 
-void ks_halo_release(ks_mat A)
+// Release in the order that keeps every remote store inside live memory: this rank's own streams are idle (the callers synchronise them), but a
+// neighbour's last unpack may still be writing its acknowledgement into THIS rank's mailbox, and the neighbours hold this mailbox mapped.
+//   collective = true (ks_mat_set_halo, every rank is in the call): barrier (all ranks' streams idle: nobody stores any more) -> close the imported
+//     mailboxes -> barrier (nobody maps mine any more) -> free mine.
+//   collective = false (ks_mat_destroy without a ks_mat_set_halo(A, KS_HALO_PROVIDER) before it): wait, bounded, until every destination has
+//     acknowledged this rank's last product - the only store a neighbour can still owe this mailbox - then release. The neighbours' mappings of the
+//     freed mailbox are theirs to close; the documented way to take the peer halo down is the collective call (include/ksgpu.h).
+static void halo_close_imports(ks_mat A)
 {
   auto &h = A->hp;
-  h.enabled = false;
   for (int i = 0; i < KS_HALO_MAX_PEERS; i++) {
     if (h.opened[i] && h.peer_base[i]) hipIpcCloseMemHandle(h.peer_base[i]);
     h.peer_base[i] = nullptr; h.opened[i] = false;
   }
+}
+static void halo_free_own(ks_mat A)
+{
+  auto &h = A->hp;
   if (h.mine) hipFree(h.mine);
   h.mine = nullptr;
   if (h.tickets) hipFree(h.tickets);
   h.tickets = nullptr;
   (void)hipGetLastError();
+}
+static void halo_wait_last_acks(ks_mat A)
+{
+  auto &h = A->hp;
+  if (!h.mine || h.seq == 0) return;
+  const int np = std::min((int)A->peers.size(), KS_HALO_MAX_PEERS);
+  unsigned long long acks[KS_HALO_MAX_PEERS];
+  for (int spin = 0; spin < 2000; spin++) {                 // at most ~2 s, the peer waits' own limit
+    if (hipMemcpy(acks, h.mine + hm_ack_off(A->nghost), sizeof(acks), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return; }
+    bool all = true;
+    for (int i = 0; i < np; i++) if (A->send_cnt[i] > 0 && acks[i] < h.seq) all = false;
+    if (all) return;
+    usleep(1000);
+  }
+}
+void ks_halo_release(ks_mat A)
+{
+  auto &h = A->hp;
+  if (h.enabled) halo_wait_last_acks(A);
+  h.enabled = false;
+  halo_close_imports(A);
+  halo_free_own(A);
 }
 
 static int halo_err_words(ks_ctx ctx)
@@ -161,7 +193,15 @@ extern "C" int ks_mat_set_halo(ks_mat A, int kind, int *active)
   KS_HIP(ks_sync(ctx));
   if (ctx->halo_stream) KS_HIP(hipStreamSynchronize(ctx->halo_stream));
   if (active) *active = KS_HALO_PROVIDER;
-  ks_halo_release(A);
+  if (A->hp.enabled && ctx->comm.size > 1 && ctx->comm.ops.allgather_host) {
+    // the peer halo is on, on every rank (it is only ever switched on by agreement): take it down in step with the others
+    std::vector<int> tok(ctx->comm.size, 0); int one = 1;
+    KS_CALL(ks_comm_allgather_host(ctx, &one, (int)sizeof(int), tok.data()));       // every rank's streams are idle: no store into any mailbox is pending
+    A->hp.enabled = false;
+    halo_close_imports(A);
+    KS_CALL(ks_comm_allgather_host(ctx, &one, (int)sizeof(int), tok.data()));       // nobody maps this rank's mailbox any more
+    halo_free_own(A);
+  } else ks_halo_release(A);
   if (kind == KS_HALO_PROVIDER || ctx->comm.size <= 1 || A->shell_mult) return KS_SUCCESS;
   KS_CHECK(ctx->comm.ops.allgather_host, KS_ERR_ORDER, "no communicator installed");
   const int size = ctx->comm.size, rank = ctx->comm.rank, np = (int)A->peers.size();

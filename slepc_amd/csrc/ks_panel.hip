@@ -25,9 +25,7 @@ int occ_blocks(const void *kernel, size_t lds_bytes)
 {
   static thread_local std::vector<std::pair<const void *, int>> cache;
   for (auto &e : cache) if (e.first == kernel) return e.second;
-  int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, PB, lds_bytes) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }      // (a failed query must not show up as the next launch's error)
-  nb = std::min(nb, 8);
+  const int nb = std::min(ks_occupancy(kernel, PB, lds_bytes, 1), 8);
   cache.push_back({kernel, nb});
   return nb;
 }

@@ -1336,7 +1336,7 @@ int ks_mat_mult_dot_fused(ks_mat A, ks_bv bv, const double *x, int jy, bool gate
   if (!A->use_dict || A->shell_mult || ks_is_multi(ctx) || A->n_orows > 0 || bv->matrix || A->n != bv->n) return KS_SUCCESS;
   if (ncols < 1 || ncols > KS_MAX_COLS || bv->ld % 2 || (((uintptr_t)Vb) & 15) || (((uintptr_t)y) & 15)) return KS_SUCCESS;
   if (!ksk::ks_basis_is_cache_resident((size_t)(bv->nc + bv->m), (size_t)bv->ld)) return KS_SUCCESS;
-  if (getenv("KSGPU_NO_SPMV_DOT")) return KS_SUCCESS;        // A/B switch
+  if (ctx->dbg.no_spmv_dot) return KS_SUCCESS;        // test hook: the separate launches, to compare bits
   const int dot_per_cu = std::max(1, std::min(4, (30 + ncols - 1) / ncols));          // the grid ksk_dot would use: the partials, and so the bits, are the same
   const int grid = ks_sweep_grid_for(ctx, bv->n, 2, nullptr, dot_per_cu);
   const int rev = bv->sweep_dir; bv->sweep_dir ^= 1;
@@ -1508,7 +1508,8 @@ extern "C" int ks_mat_destroy(ks_mat A)
   ks_sync(A->ctx);
   hipFree(A->d_rowptr); hipFree(A->d_col); hipFree(A->d_val);
   hipFree(A->o_rowptr); hipFree(A->o_col); hipFree(A->o_val); hipFree(A->o_rows);
-  ks_halo_release(A);
+  if (A->ctx->halo_stream) hipStreamSynchronize(A->ctx->halo_stream);
+  ks_halo_release(A);                 // not collective: waits for the neighbours' last acknowledgements (ks_halo.hip); ks_mat_set_halo(A, KS_HALO_PROVIDER) first is the collective way
   hipFree(A->ghost); hipFree(A->send_idx); hipFree(A->send_buf);
   hipFree(A->s_ptr); hipFree(A->s_len); hipFree(A->s_col); hipFree(A->s_val);
   hipFree(A->dc_codes); hipFree(A->dc_val); hipFree(A->dc_off); hipFree(A->dc_codes8); hipFree(A->dc_vals);

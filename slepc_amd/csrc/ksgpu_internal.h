@@ -11,6 +11,9 @@
 
 // ---- error plumbing ---------------------------------------------------------------------------
 void ks_set_error(const char *fmt, ...);
+// resident workgroups per CU of a kernel symbol; a query that fails is COUNTED (ks_runtime_info), reported once on stderr with the HIP runtimes the
+// process maps, and answered with `fallback` - never silently (round 3's failures: profiles/r04_hip_runtime_probe.txt)
+int ks_occupancy(const void *kernel, int block_threads, size_t lds_bytes, int fallback);
 #define KS_FAIL(rc, ...) do { ks_set_error(__VA_ARGS__); return (rc); } while (0)
 #define KS_CHECK(cond, rc, ...) do { if (!(cond)) KS_FAIL(rc, __VA_ARGS__); } while (0)
 #define KS_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
@@ -31,10 +34,11 @@ struct KsGsMail { double onrm, nrm; int fused, err; unsigned long long seq; };
 #define KS_HALO_MAX_PEERS 16
 struct KsComm {
   int rank = 0, size = 1;
-  bool force_collectives = false;   // KSGPU_FORCE_MULTI=1: take the multi-rank code path even with one rank (tests)
+  bool force_collectives = false;   // ks_ctx_set_debug(KS_DEBUG_FORCE_MULTI): take the multi-rank code path even with one rank (tests)
   // native RCCL (resolved with dlopen so that a process that already holds librccl reuses it)
   void *rccl_lib = nullptr;
   void *nccl_comm = nullptr;
+  long long bcast_calls = 0; double bcast_seconds = 0.0;   // host wall time inside the broadcast of the projected problem (ks_comm_bcast_stats)
   char *ag_dev = nullptr; size_t ag_len = 0;   // device staging of the host allgather (kept: the projected solve is broadcast through it at every restart)
   // active provider (RCCL fills these with its own implementations)
   ks_comm_ops ops = {nullptr, nullptr, nullptr};
@@ -65,6 +69,8 @@ struct ks_ctx_s {
   // ev_x orders it after the producer of x on the main stream, ev_halo lets the off-diagonal rows wait for the ghosts
   hipStream_t halo_stream = nullptr; hipEvent_t ev_x = nullptr, ev_halo = nullptr;
   bool halo_overlap = true;
+  // test hooks (ks_ctx_set_debug; each makes a test run the path the fast one replaces, or a multi-rank path on one rank)
+  struct { bool no_fused_gs = false, no_mfma = false, no_spmv_dot = false, force_multi = false; unsigned oneshot_seq0 = 0; } dbg;
   long long nsync = 0;              // host synchronisations of the context's stream made by the library (ks_ctx_sync_count)
   int num_cu = 256;
   char arch[64] = {0};
@@ -279,7 +285,7 @@ struct ks_bv_s {
   struct { bool armed = false, valid = false; unsigned long long token = 0, token_at = 0; int col = -1, pass_idx = 0; long long chained = 0, fresh = 0; } spec;
   double *pend = nullptr;    // [3][KS_PSTRIDE] coefficients of the passes since the vector was last written back (what the next update applies, pass by pass)
   double orthog_eta = 0.7071;
-  bool fused_gs = true;      // the device-resident Gram-Schmidt program may be used (KSGPU_NO_FUSED_GS, a test switch, is read when the BV is created)
+  bool fused_gs = true;      // the device-resident Gram-Schmidt program may be used (the no_fused_gs test hook is read when the BV is created)
   double deftol = 10 * 2.220446049250313e-16;
   double *array = nullptr;      // m*ld
   double *buffer = nullptr;     // (nc+m)*m ; column 0 = scratch c

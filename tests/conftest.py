@@ -19,3 +19,16 @@ def ctx():
     c = ks.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture
+def debug(ctx):
+    """Test hooks of the session's context (ks_ctx_set_debug) for ONE test: every hook touched is back at its default afterwards."""
+    touched = []
+
+    def set_(key, value=1):
+        touched.append(key)
+        ctx.set_debug(key, value)
+    yield set_
+    for key in touched:
+        ctx.set_debug(key, 1 if key == "halo_overlap" else 0)

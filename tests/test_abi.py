@@ -95,3 +95,71 @@ def test_header_is_plain_c_and_library_links_from_c(tmp_path):
     if r.returncode == 0:
         pytest.skip("a GPU is present: the run itself is checked by tests/test_gpu_krylov.py::test_c_program_against_the_abi")
     assert r.returncode == 1 and "97" in r.stderr and "no CPU fallback" in r.stderr
+
+
+_ONE_RUNTIME_CHILD = r"""
+import json, sys
+sys.path.insert(0, %r)
+order = sys.argv[1]
+if order == "torch_first":
+    import torch
+from slepc_amd import _lib
+_lib.lib()
+before = _lib.runtime_info()
+if order == "library_first":
+    import torch
+after = _lib.runtime_info()
+print(json.dumps({"before": before, "after": after, "torch_lib": torch.__file__}))
+"""
+
+
+@pytest.mark.parametrize("order", ["library_first", "torch_first"])
+def test_one_hip_runtime_per_process_whatever_the_import_order(order):
+    """PyTorch's wheel bundles a libamdhip64.so under the SONAME libksgpu.so needs. Imported AFTER the library it used to become a second
+    HIP + HSA runtime in the process (round 3: 15 GPU tests failed that way); the binding now maps torch's copy first when nothing is
+    mapped yet, so the process ends up with ONE runtime in either order and ks_runtime_info says which the library is bound to."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, "-c", _ONE_RUNTIME_CHILD % os.path.dirname(os.path.dirname(_lib.LIB_PATH)), order], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    for when in ("before", "after"):
+        info = d[when]
+        assert len(info["hip_runtimes_mapped"]) == 1, info
+        assert os.path.realpath(info["hip_runtime_path"]) == os.path.realpath(info["hip_runtimes_mapped"][0]), info
+        assert info["occupancy_query_failures"] == 0
+    torch_rt = os.path.join(os.path.dirname(d["torch_lib"]), "lib", "libamdhip64.so")
+    if os.path.exists(torch_rt):          # a wheel with a bundled runtime: that is the one both end up on
+        assert os.path.realpath(d["after"]["hip_runtime_path"]) == os.path.realpath(torch_rt), d
+
+
+def test_context_creation_refuses_a_process_with_two_hip_runtimes():
+    """The policy defeated on purpose (the system runtime mapped before the binding loads, torch imported afterwards): ks_ctx_create says so
+    instead of running beside a second runtime. No GPU needed: the check comes before the first HIP call."""
+    import sys
+    system_rt = "/opt/rocm/lib/libamdhip64.so.7"
+    if not os.path.exists(system_rt):
+        pytest.skip("no system HIP runtime to map first")
+    code = r"""
+import ctypes, sys
+sys.path.insert(0, %r)
+ctypes.CDLL(%r, mode=ctypes.RTLD_GLOBAL)
+import slepc_amd as ks
+from slepc_amd import _lib
+_lib.lib()
+import torch
+info = _lib.runtime_info()
+if len(info["hip_runtimes_mapped"]) < 2:
+    print("SKIP one runtime only"); sys.exit(0)
+try:
+    ks.Context(0)
+    print("CREATED")
+except ks.KsError as e:
+    print("REFUSED", e.rc, e)
+""" % (os.path.dirname(os.path.dirname(_lib.LIB_PATH)), system_rt)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    if last.startswith("SKIP"):
+        pytest.skip("torch bundles no second runtime here")
+    assert last.startswith("REFUSED 76") and "two HIP runtimes" in last, last

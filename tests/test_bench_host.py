@@ -146,3 +146,52 @@ def test_wall_time_budget_of_an_n8_run_fits_the_drivers_limit():
     assert limit <= 180.0
     headline_worst = 120.0            # imports, RCCL bootstrap, matrix build and the three phases, generously
     assert headline_worst + limit + 30.0 <= 600.0
+
+
+def test_breakdown_and_strong_leg_of_the_n_gt_1_line_from_faked_ranks():
+    """The per-phase table of the N > 1 line from one record per rank (what rank_record produces: timed seconds, restart broadcasts, per-class
+    HIP-event time of the instrumented pass), and the strong-scaling entry beside the weak headline. Rank 1 is the slow one here: it shows as the
+    maximum of the timed seconds and as the SMALLEST allreduce time (the others wait for it)."""
+    import json
+    nc = len(bench.BREAKDOWN_CLASSES)
+
+    def rec(seconds, bcasts, bcast_s, tail_steps, ms, calls):
+        return [seconds, float(bcasts), bcast_s, float(tail_steps)] + [ms.get(c, 0.0) for c in bench.BREAKDOWN_CLASSES] + [float(calls.get(c, 0)) for c in bench.BREAKDOWN_CLASSES]
+    calls = {"allreduce": 420, "halo_exchange": 210, "spmv_csr": 210, "bv_dot_sweep": 210}
+    r0 = rec(0.2500, 14, 14 * 60e-6, 210, {"allreduce": 8.4, "halo_exchange": 6.3, "spmv_csr": 14.7, "bv_dot_sweep": 66.0, "gs_update": 72.0, "gs_update_fused_dot": 62.0}, calls)
+    r1 = rec(0.2531, 14, 14 * 55e-6, 210, {"allreduce": 2.1, "halo_exchange": 6.1, "spmv_csr": 14.9, "bv_dot_sweep": 67.0, "gs_update": 73.0, "gs_update_fused_dot": 63.0}, calls)
+    assert len(r0) == 4 + 2 * nc
+    b = bench.comm_breakdown([r0, r1], 210, "weak")
+    assert b["ranks"] == 2 and b["leg"] == "weak" and b["rank_seconds_max"] == 0.2531 and b["rank_seconds_min"] == 0.25
+    assert abs(b["rank_skew_pct"] - 100 * 0.0031 / 0.2531) < 1e-3
+    assert b["per_rank_us_per_step"]["allreduce"] == [40.0, 10.0] and b["per_step_us"]["allreduce"] == 25.0
+    assert b["per_rank_us_per_step"]["halo_exchange"] == [30.0, 29.05] and b["allreduce_calls_per_step"] == 2.0 and b["halo_exchanges_per_step"] == 1.0
+    assert b["restart_bcasts"] == 14 and b["restart_bcast_us_each"] == 60.0
+    assert b["per_rank_us_per_step"]["restart_bcast"] == [4.0, 3.67] and abs(b["per_step_us"]["restart_bcast"] - 3.835) < 0.006
+    assert abs(b["per_step_us"]["update"] - (1e3 * (72.0 + 73.0) / 2 / 210 + 1e3 * (62.0 + 63.0) / 2 / 210)) < 0.02
+    t = _fake_timed()
+    s = bench.strong_entry(2, 210, 0.14, t, "3-D 7-pt Laplacian 216^3 in 2 z-slab(s) of 108/108 planes", {"n": 5038848, "nnz": 0, "N": 10077696, "layout": "dict"}, b)
+    assert s["scaling"] == "strong" and abs(s["value"] - 1500.0) < 1e-9 and s["n_gpus"] == 2 and s["n_global"] == 10077696 and s["multi_gpu_breakdown"]["ranks"] == 2
+    json.loads(json.dumps({"multi_gpu_breakdown": b, "strong_scaling": s}))
+
+
+def test_slab_problems_of_the_weak_and_the_strong_leg():
+    """Which slab of which grid a rank assembles: weak = N slabs of 216^3 rows each (432 x 432 x 54 N), strong = the 216^3 grid itself cut as
+    PetscSplitOwnership cuts it (uneven when N does not divide the planes)."""
+    made = []
+
+    class FakeMat:
+        @staticmethod
+        def laplacian3d(ctx, nx, ny, nz, z0=0, nz_local=None):
+            made.append((nx, ny, nz, z0, nz_local)); return "A"
+    ks = types.SimpleNamespace(Mat=FakeMat)
+    _, w = bench.slab_problem(ks, None, 216, 8, 3, "weak")
+    assert made[-1] == (432, 432, 432, 3 * 54, 54) and "8 z-slabs of 54 planes" in w
+    _, w = bench.slab_problem(ks, None, 216, 8, 7, "strong")
+    assert made[-1] == (216, 216, 216, 7 * 27, 27) and "n = 10077696" in w
+    _, w = bench.slab_problem(ks, None, 216, 5, 0, "strong")                   # 216 = 5 * 43 + 1: the first rank takes the extra plane
+    assert made[-1] == (216, 216, 216, 0, 44) and "44/43/43/43/43" in w
+    _, w = bench.slab_problem(ks, None, 216, 1, 0, "weak")
+    assert made[-1] == (216, 216, 216, 0, None)
+    _, w = bench.slab_problem(ks, None, 216, 1, 0, "weak", force_dist=True)    # the N > 1 code path rehearsed on one rank
+    assert made[-1] == (432, 432, 54, 0, 54)

@@ -167,12 +167,11 @@ def test_empty_active_window_is_noop(ctx, gpu):
 
 @pytest.mark.parametrize("mfma", [True, False])
 @pytest.mark.parametrize("n,my,nx", [(1, 1, 1), (130, 5, 3), (4097, 17, 31), (20000, 31, 31), (9000, 64, 33), (3000, 48, 64)])
-def test_panel_contractions_mfma_and_valu(ctx, gpu, cpu, monkeypatch, mfma, n, my, nx):
+def test_panel_contractions_mfma_and_valu(ctx, gpu, cpu, debug, mfma, n, my, nx):
     """BVDot / BVMult / BVMultInPlace on the FP64 matrix cores (v_mfma_f64_16x16x4) and on the VALU fallback
     against the oracle; tile edges (1..64 columns, ragged row tiles)."""
     if not mfma:
-        monkeypatch.setenv("KSGPU_NO_MFMA", "1")
-    import importlib
+        debug("no_mfma")                                     # test hook: the VALU kernels the matrix-core ones replace
     rng = np.random.default_rng(n + my + nx)
     Xh = rng.standard_normal((n, nx)); Yh = rng.standard_normal((n, my))
     Q = np.asfortranarray(rng.standard_normal((nx, my)))

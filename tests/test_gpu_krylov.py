@@ -330,19 +330,18 @@ def test_fused_gs_matches_oracle(ctx, refine, n, m):
         assert np.abs(Q.T @ Q - np.eye(m)).max() < 1e-13
 
 
-def test_fused_gs_generic_agree(ctx, monkeypatch):
-    """The host-driven literal restatement (KSGPU_NO_FUSED_GS=1) and the fused kernels give the same result."""
+def test_fused_gs_generic_agree(ctx, debug):
+    """The host-driven literal restatement (test hook no_fused_gs, read at BV creation) and the fused kernels give the same result."""
     import slepc_amd as ks
     n, m = 2000, 10
     Xh = np.random.default_rng(0).standard_normal((n, m))
     outs = []
     for fused in (True, False):
         if not fused:
-            monkeypatch.setenv("KSGPU_NO_FUSED_GS", "1")
+            debug("no_fused_gs")
         V = ks.BV(ctx, n, m); V.set_dense(Xh)
         nr = [V.OrthonormalizeColumn(j)[0] for j in range(m)]
         outs.append((np.array(nr), V.dense(), V.buffer()))
-    monkeypatch.delenv("KSGPU_NO_FUSED_GS")
     assert np.allclose(outs[0][0], outs[1][0], rtol=1e-13)
     assert np.allclose(outs[0][1], outs[1][1], atol=1e-13)
     assert np.allclose(np.triu(outs[0][2])[:, 1:], np.triu(outs[1][2])[:, 1:], atol=1e-12)
@@ -726,10 +725,10 @@ def test_c_program_against_the_abi(tmp_path):
 
 
 @pytest.mark.parametrize("shape", [("2d", 300), ("3d", 40), ("2d_odd", 301)])
-def test_spmv_fused_into_the_dot_sweep_gives_the_same_bits(ctx, monkeypatch, shape):
+def test_spmv_fused_into_the_dot_sweep_gives_the_same_bits(ctx, debug, shape):
     """Small problems (basis resident in the Infinity Cache, dictionary layout) run y = A x inside the dot sweep that follows it
     (k_dot_spmv_dict): same entry order and fma chain for y, same tiles and grid for the dots - the Lanczos coefficients and the basis are
-    bit for bit those of the separate launches (KSGPU_NO_SPMV_DOT=1), and both match the oracle."""
+    bit for bit those of the separate launches (test hook no_spmv_dot), and both match the oracle."""
     import slepc_amd as ks
     kind, N = shape
     if kind.startswith("2d"):
@@ -740,7 +739,7 @@ def test_spmv_fused_into_the_dot_sweep_gives_the_same_bits(ctx, monkeypatch, sha
     outs = []
     for fused in (True, False):
         if not fused:
-            monkeypatch.setenv("KSGPU_NO_SPMV_DOT", "1")
+            debug("no_spmv_dot")
         A = mk(); assert A.layout() == "dict"
         V = ks.BV(ctx, A.n, m + 1)
         V.SetRandomColumn(0)
@@ -751,7 +750,6 @@ def test_spmv_fused_into_the_dot_sweep_gives_the_same_bits(ctx, monkeypatch, sha
         ctx.synchronize()
         p = ctx.prof_get(); ctx.prof_enable(False)
         outs.append((T.copy(), V.dense(), r, p))
-    monkeypatch.delenv("KSGPU_NO_SPMV_DOT")
     assert outs[0][3].get("spmv_dot_fused", {}).get("launches", 0) == m and outs[0][3].get("spmv_csr", {}).get("launches", 0) == 0
     assert outs[1][3].get("spmv_dot_fused", {}).get("launches", 0) == 0 and outs[1][3].get("spmv_csr", {}).get("launches", 0) == m
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]

@@ -4,7 +4,7 @@
   exchange) are served by torch.distributed/gloo through host staging -> exercises the row-slab Mat (diag/off-diag
   split, halo plan, ghost indexing), the split reduce | allreduce | bookkeeping Gram-Schmidt kernels and the
   replicated host control flow of the Krylov-Schur driver, against the single-rank CPU oracle;
-* one process with the NATIVE RCCL provider at size 1 and KSGPU_FORCE_MULTI=1 -> exercises ncclCommInitRank /
+* one process with the NATIVE RCCL provider at size 1 and the force_multi test hook -> exercises ncclCommInitRank /
   ncclAllReduce on the library stream in the same split-kernel path.
 (8-GPU runs over xGMI are the driver's job; this is what one GPU can prove.)"""
 import ctypes
@@ -311,11 +311,11 @@ def test_ranks_sharing_one_gpu_against_oracle(world):
 
 def _rccl_worker(q):
     sys.path.insert(0, ROOT)
-    os.environ["KSGPU_FORCE_MULTI"] = "1"
     try:
         import slepc_amd as ks
         from oracle import oracle as O
         ctx = ks.Context(0)
+        ctx.set_debug("force_multi")           # test hook: the collectives really issued on a communicator of one rank
         ctx.init_rccl(0, 1, ks.Context.get_unique_id())
         ctx.comm_check()                  # ncclAllReduce, ncclAllGather (staging buffer reused by a second call), ncclSend/ncclRecv with itself
         ctx.comm_check()
@@ -497,8 +497,6 @@ def _peer_halo_worker(rank, world, port, q, mode):
     sys.path.insert(0, ROOT)
     if mode == "absent":
         os.environ["KSGPU_ONESHOT_TIMEOUT_MS"] = "300"
-    if mode == "wrap":
-        os.environ["KSGPU_ONESHOT_SEQ0"] = "0xFFFFFFE0"
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -511,6 +509,7 @@ def _peer_halo_worker(rank, world, port, q, mode):
         _install_gloo_ops(ks, ctx, dist, torch, rank, world)
         res = {}
         if mode == "wrap":
+            ctx.set_debug("oneshot_seq0", 0xFFFFFFE0)           # test hook: first stamp of the one-shot allreduce
             res["active"] = ctx.set_allreduce("oneshot")
             ctx.comm_check()                                   # 64 back-to-back calls: the stamps run through 0xFFFFFFFF -> 1
             X = ks.BV(ctx, 64, 12, N=64 * world)
