@@ -604,16 +604,28 @@ def headline(world, steps, dt, warm_steps, t, args, workload, mat):
     }
 
 
-def attach_oneshot_leg(out, leg):
-    """The N>1 side leg (one-shot allreduce + peer-mapped halo, measured by a child process of every rank) into the line; never fatal."""
-    if leg is None:
+def attach_side_legs(out, legs):
+    """The N>1 side legs (measured by ONE child process of every rank, after the headline has been taken) into the line; never fatal.
+    legs: {"strong_rccl": {...}, "oneshot_weak": {...}, "oneshot_strong": {...}, "child": {...}} - whatever the child got to before it ended."""
+    if legs is None:
         return out
+    child = legs.get("child") or {}
+    st = legs.get("strong_rccl")
+    out["strong_scaling"] = st if st is not None else {"scaling": "strong", "value": None, "reason": child.get("reason", "the side-leg child did not report this leg")}
+    ow, os_ = legs.get("oneshot_weak"), legs.get("oneshot_strong")
+    leg = dict(ow) if ow is not None else {"active": child.get("oneshot_active", "unknown"), "reason": child.get("oneshot_reason") or child.get("reason", "the side-leg child did not report this leg")}
     if leg.get("value"):
         leg["vs_provider_allreduce"] = round(leg["value"] / out["value"], 4)
-    leg["note"] = ("the same measurement in a child process of every rank with ks_comm_set_allreduce(ONESHOT) and ks_mat_set_halo(PEER): the "
+    if os_ is not None:
+        leg["strong_scaling"] = os_
+        if os_.get("value") and st is not None and st.get("value"):
+            leg["strong_vs_provider_allreduce"] = round(os_["value"] / st["value"], 4)
+    leg["note"] = ("the same measurements in a child process of every rank with ks_comm_set_allreduce(ONESHOT) and ks_mat_set_halo(PEER): the "
                    "Gram-Schmidt sums go through peer-mapped mailboxes, one kernel per rank, instead of ncclAllReduce, and the boundary entries "
                    "of x go straight into the neighbours' ghost mailboxes instead of grouped ncclSend / ncclRecv; `value` above is the RCCL path")
     out["oneshot_allreduce"] = leg
+    if child:
+        out["side_legs_child"] = child
     return out
 
 
@@ -630,25 +642,47 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def oneshot_child(args, limit=180.0):
-    """The N>1 measurement once more with the one-shot allreduce, in a child process per rank (same launcher environment, another
-    rendezvous port): whatever happens to that path - mailboxes that cannot be mapped, a check that fails, a hang - stays in the
-    children, which are stopped at `limit` seconds; the headline number has been taken before and is reported regardless."""
+def parse_side_legs(stdout_bytes):
+    """{"leg name": report} from what the side-leg child printed: one JSON object per finished leg, each with a "leg" key."""
+    legs = {}
+    for ln in (stdout_bytes or b"").decode(errors="replace").splitlines():
+        if ln.startswith("{"):
+            try:
+                d = json.loads(ln)
+            except ValueError:
+                continue
+            if isinstance(d, dict) and "leg" in d:
+                legs[d.pop("leg")] = d
+    return legs
+
+
+def side_legs_child(args, limit=240.0):
+    """Everything of the N>1 line that is not the headline, in ONE child process per rank (same launcher environment, another rendezvous port):
+    the strong-scaling leg with the RCCL provider, then the weak and the strong leg once more with the one-shot allreduce and the peer-mapped
+    halo. The child prints one JSON line per finished leg; whatever happens to a later leg - mailboxes that cannot be mapped, a check that fails,
+    a hang - stays in the children, which are stopped at `limit` seconds, and the legs finished before that are still reported. The headline
+    has been taken before and is printed regardless."""
     env = dict(os.environ)
     env["MASTER_PORT"] = str(20000 + (int(env.get("MASTER_PORT", "29511")) + 1789) % 20000)
     env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # under torchrun the ranks would look for the agent's store on the old port: rank 0's child opens its own
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--min-steps", str(args.min_steps), "--side", str(args.side), "--no-configs", "--no-cpu-baseline", "--oneshot-leg"]
+           "--min-steps", str(args.min_steps), "--side", str(args.side), "--no-configs", "--no-cpu-baseline", "--side-legs"]
+    if getattr(args, "no_oneshot", False):
+        cmd.append("--no-oneshot")
+    t0 = time.time()
     try:
         p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=None if env.get("RANK", "0") == "0" else subprocess.DEVNULL, timeout=limit)
-        lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
-        if lines:
-            return json.loads(lines[-1])
-        return {"active": "unknown", "reason": "the child left no report (exit code %d)" % p.returncode}
-    except subprocess.TimeoutExpired:
-        return {"active": "unknown", "reason": "the child was stopped after %.0f s" % limit}
-    except Exception as e:       # noqa: BLE001 - the side leg must not take the headline down with it
-        return {"active": "unknown", "reason": "%r" % (e,)}
+        legs = parse_side_legs(p.stdout)
+        legs.setdefault("child", {}).update({"exit_code": p.returncode, "seconds": round(time.time() - t0, 1)})
+        if not any(k != "child" for k in legs):
+            legs["child"]["reason"] = "the child left no report (exit code %d)" % p.returncode
+        return legs
+    except subprocess.TimeoutExpired as e:
+        legs = parse_side_legs(e.stdout)
+        legs.setdefault("child", {}).update({"reason": "the child was stopped after %.0f s" % limit, "seconds": round(time.time() - t0, 1)})
+        return legs
+    except Exception as e:       # noqa: BLE001 - the side legs must not take the headline down with them
+        return {"child": {"reason": "%r" % (e,)}}
 
 
 def main():
@@ -664,8 +698,9 @@ def main():
     ap.add_argument("--no-c5", action="store_true")
     ap.add_argument("--c5-n", type=int, default=5000000)
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic (the committed summary is used instead)")
-    ap.add_argument("--no-oneshot", action="store_true", help="N>1: skip the side leg that repeats the measurement with the one-shot allreduce")
-    ap.add_argument("--oneshot-leg", action="store_true", help=argparse.SUPPRESS)     # the side leg itself (a child process of every rank)
+    ap.add_argument("--no-oneshot", action="store_true", help="N>1: skip the side legs that repeat the measurements with the one-shot allreduce")
+    ap.add_argument("--no-side-legs", action="store_true", help="N>1: the weak headline only (no strong-scaling leg, no one-shot legs)")
+    ap.add_argument("--side-legs", action="store_true", help=argparse.SUPPRESS)       # the side legs themselves (a child process of every rank)
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -703,27 +738,8 @@ def main():
         dist.broadcast(idt, 0)
         ctx.init_rccl(rank, world, bytes(idt.cpu().numpy().tobytes()))
         ctx.comm_check()                  # allreduce / allgather / neighbour exchange against known answers before anything is timed
-    oneshot = None
-    if args.oneshot_leg and dist is None:
-        raise SystemExit("--oneshot-leg is the N>1 side leg")
-    if args.oneshot_leg:
-        # every rank's verdict is the same at each of these exits (set_allreduce and comm_check agree among the ranks)
-        oneshot = {"active": ctx.set_allreduce("oneshot")}
-        oneshot["halo_requested"] = "peer"                      # applied to the matrix below, once it exists
-        if oneshot["active"] == "oneshot":
-            try:
-                ctx.comm_check()
-            except RuntimeError as e:
-                oneshot = {"active": "provider", "reason": "known-answer check failed with the one-shot path: %s" % e}
-                ctx.set_allreduce("provider")
-        else:
-            oneshot["reason"] = "some rank could not map the other ranks' mailboxes"
-        if oneshot["active"] != "oneshot":
-            if rank == 0:
-                os.dup2(real_stdout, 1); print(json.dumps(oneshot), flush=True); os.dup2(2, 1)
-            dist.barrier(); dist.destroy_process_group()
-            return
-
+    if args.side_legs and dist is None:
+        raise SystemExit("--side-legs is the N>1 child")
     side = args.side
 
     def barrier():
@@ -741,11 +757,11 @@ def main():
         dist.all_gather(parts, tt)
         return [p.cpu().tolist() for p in parts]
 
-    def run_leg(scaling, prof):
+    def run_leg(scaling, prof, peer_halo=False):
         """One phased measurement on this rank's slab of the weak or the strong problem; every rank leaves with all ranks' records, so dt (the
         maximum over the ranks, as the contract asks) and the breakdown are the same everywhere."""
         A, workload = slab_problem(ks, ctx, side, world, rank, scaling, force_dist)
-        halo = A.set_halo("peer") if args.oneshot_leg else None          # collective: boundary entries straight into the neighbours' ghost mailboxes
+        halo = A.set_halo("peer") if peer_halo else None          # collective: boundary entries straight into the neighbours' ghost mailboxes
         eps, ph, t = measure(ks, ctx, A, None, barrier, args.warmup, args.steps, args.min_steps, NEV, NCV, ks.EPS_HEP, prof=prof)
         tail_steps = (ph.marks["t2"][0] - ph.marks["t1"][0]) if "t2" in ph.marks else 0
         recs = gather_records(rank_record(ph, t, tail_steps))
@@ -760,46 +776,57 @@ def main():
         gc.collect()
         L["A"].destroy()
 
+    def report(name, d):
+        if rank == 0:
+            d = dict(d); d["leg"] = name
+            os.dup2(real_stdout, 1); print(json.dumps(d), flush=True); os.dup2(2, 1)
+
+    def weak_entry(L):
+        st = L["t"]
+        return {"value": world * st["steps"] / L["dt"], "unit": "steps/s", "ms_per_step": 1e3 * L["dt"] / st["steps"], "steps": st["steps"],
+                "gs_passes_per_step": st["gs_passes"] / st["steps"], "multi_gpu_breakdown": comm_breakdown(L["recs"], st["steps"], "weak")}
+
+    def strong_of(L):
+        st = L["t"]
+        return strong_entry(world, st["steps"], L["dt"], st, L["workload"], L["mat"], comm_breakdown(L["recs"], st["steps"], "strong"))
+
+    if args.side_legs:
+        # (1) the metric's literal reading beside the weak headline: the SAME 216^3 problem cut into N slabs (total work fixed), RCCL provider
+        L = run_leg("strong", prof=True)
+        report("strong_rccl", strong_of(L))
+        close_leg(L)
+        if not args.no_oneshot:
+            # (2), (3) both legs again with the one-shot allreduce and the peer-mapped halo; every rank's verdict is the same at each exit
+            # (set_allreduce and comm_check agree among the ranks)
+            info = {"oneshot_active": ctx.set_allreduce("oneshot")}
+            if info["oneshot_active"] == "oneshot":
+                try:
+                    ctx.comm_check()
+                except RuntimeError as e:
+                    info = {"oneshot_active": "provider", "oneshot_reason": "known-answer check failed with the one-shot path: %s" % e}
+                    ctx.set_allreduce("provider")
+            else:
+                info["oneshot_reason"] = "some rank could not map the other ranks' mailboxes"
+            report("child", info)
+            if info["oneshot_active"] == "oneshot":
+                for scaling in ("weak", "strong"):
+                    L = run_leg(scaling, prof=True, peer_halo=True)
+                    d = weak_entry(L) if scaling == "weak" else strong_of(L)
+                    d.update({"active": "oneshot", "halo_active": L["halo"]})
+                    report("oneshot_" + scaling, d)
+                    close_leg(L)
+        dist.barrier(); dist.destroy_process_group()
+        return
+
     weak = run_leg("weak", prof=not args.no_prof)
     A, eps, ph, t, dt, workload = weak["A"], weak["eps"], weak["ph"], weak["t"], weak["dt"], weak["workload"]
     steps = t["steps"]
-    strong = None
-    if dist is not None:
-        # the metric's literal reading beside the weak headline: the SAME 216^3 problem cut into N slabs (total work fixed)
-        try:
-            strong = run_leg("strong", prof=not args.no_prof)
-        except Exception as e:       # noqa: BLE001 - a side leg: the headline has been taken
-            strong = {"error": repr(e)}
-    if args.oneshot_leg:
-        if rank == 0:
-            oneshot.update({"halo_active": weak["halo"], "value": world * steps / dt, "unit": "steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
-                            "gs_passes_per_step": t["gs_passes"] / steps, "multi_gpu_breakdown": comm_breakdown(weak["recs"], steps, "weak")})
-            if strong is not None and "error" not in strong:
-                st = strong["t"]
-                oneshot["strong_scaling"] = strong_entry(world, st["steps"], strong["dt"], st, strong["workload"], strong["mat"], comm_breakdown(strong["recs"], st["steps"], "strong"))
-            elif strong is not None:
-                oneshot["strong_scaling"] = strong
-            os.dup2(real_stdout, 1); print(json.dumps(oneshot), flush=True); os.dup2(2, 1)
-        eps = ph = None
-        if strong is not None and "error" not in strong:
-            close_leg(strong)
-        close_leg(weak)
-        dist.barrier(); dist.destroy_process_group()
-        return
     prof_timed, prof = ph.prof_timed, ph.prof_tail
     tail_steps = weak["tail_steps"]
-    strong_line = None
-    if strong is not None:
-        if "error" in strong:
-            strong_line = strong
-        else:
-            st = strong["t"]
-            strong_line = strong_entry(world, st["steps"], strong["dt"], st, strong["workload"], strong["mat"], comm_breakdown(strong["recs"], st["steps"], "strong"))
-            close_leg(strong)
 
-    leg = None
-    if dist is not None and not args.no_oneshot:
-        leg = oneshot_child(args)         # every rank starts its own child; rank 0's child reports
+    legs = None
+    if dist is not None and not args.no_side_legs:
+        legs = side_legs_child(args)      # every rank starts its own child; rank 0's child reports, one line per finished leg
     if rank == 0:
         out = headline(world, steps, dt, ph.marks["t0"][0], t, args, workload, weak["mat"])
         try:
@@ -812,7 +839,6 @@ def main():
             out["hip_runtime"] = {"error": repr(e)}
         if dist is not None:
             out["multi_gpu_breakdown"] = comm_breakdown(weak["recs"], steps, "weak")
-            out["strong_scaling"] = strong_line
         if prof_timed:
             rl = update_kernel_roofline(ks, prof_timed)
             if rl:
@@ -897,7 +923,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(side)
             except Exception as e:       # noqa: BLE001 - the baseline must not take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
-        attach_oneshot_leg(out, leg)
+        attach_side_legs(out, legs)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

@@ -41,6 +41,8 @@ def _build_if_needed():
 
 
 def _load(name):
+    if name == "liboracle_asan.so":
+        subprocess.check_call(["make", "-C", _HERE, "asan"], stdout=subprocess.DEVNULL)
     _build_if_needed()
     lib = C.CDLL(os.path.join(_HERE, name))
     vp = C.c_void_p
@@ -98,6 +100,8 @@ _libs = {}
 
 def lib(omp=False):
     name = "liboracle_omp.so" if omp else "liboracle.so"
+    if not omp and os.environ.get("ORACLE_LIB") == "asan":       # tests/test_sanitizers.py: the single-thread oracle under ASan + UBSan (make -C oracle asan)
+        name = "liboracle_asan.so"
     if name not in _libs:
         _libs[name] = _load(name)
     return _libs[name]

@@ -614,7 +614,7 @@ extern "C" int ks_eps_get_ds_parallel(ks_eps eps, int *pmode) { KS_CHECK(eps && 
 static int ds_synchronize(ks_eps eps, std::vector<double> *M1, std::vector<double> *M2, double *beta, int *nv, int *breakdown)
 {
   ks_ctx ctx = eps->ctx;
-  if (ctx->comm.size <= 1 || eps->ds_parallel != KS_DS_PARALLEL_SYNCHRONIZED) return KS_SUCCESS;
+  if (!ks_is_multi(ctx) || eps->ds_parallel != KS_DS_PARALLEL_SYNCHRONIZED) return KS_SUCCESS;      // (the force_multi test hook issues it on one rank too)
   std::vector<double> pack;
   pack.reserve(M1->size() + M2->size() + 2 * eps->eigr.size() + 3);
   pack.insert(pack.end(), M1->begin(), M1->end());

@@ -90,6 +90,9 @@ __device__ void gs1_bookkeep(const GsArgs a, const double *c, KsGsState *st, Boo
   // Will the caller's refinement loop (BVOrthogonalizeGS bvorthog.c:176-202, same policy and eta: mirrored by the adapter) ask for another
   // pass? Then this update also leaves the dots of that pass behind (they are row-local, ks_gs.hip header). A wrong guess costs nothing
   // but the unused partial sums: the host only chains the next call to them when nothing touched the BV in between.
+  // The test below is the caller's own: in the classical Gram-Schmidt loop every pass is called with &onrm (bvorthog.c:183: NULL only for MGS
+  // and indefinite inner products, which do not come through this function), CGS1 returns *onorm = beta of THAT pass (bvorthog.c:117), and the
+  // loop condition :179 compares the pass's nrm with it - so beta here is not a stand-in for an earlier pass's estimate, it is the operand.
   if (a.spec_ok && k > 0) {
     if (a.refine == KS_BV_ORTHOG_REFINE_IFNEEDED && a.gs1 == 2 && r.nrm > 0.0) {
       const double nrm = sqrt(r.nrm);

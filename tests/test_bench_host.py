@@ -99,53 +99,59 @@ def test_n_gt_1_line_assembles_from_a_faked_two_rank_result():
     assert out["config"]["global_steps_per_s"] == 210 / dt and out["config"]["parallelism"] == "row-slab x2"
     assert out["config"]["steps_requested"] == 20 and out["config"]["min_steps"] == 200
     assert out["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
-    # the side leg: a child that reported, one that was stopped, none at all
-    leg = {"active": "oneshot", "halo_active": "peer", "value": 1.01 * out["value"], "unit": "steps/s", "ms_per_step": 0.9, "steps": 210, "gs_passes_per_step": 2.0}
-    line = json.loads(json.dumps(bench.attach_oneshot_leg(dict(out), leg)))
+    # the side legs: a child that reported every leg, one that was stopped after the first, none at all
+    strong = {"scaling": "strong", "value": 3000.0, "unit": "steps/s", "n_gpus": 2}
+    ow = {"active": "oneshot", "halo_active": "peer", "value": 1.01 * out["value"], "unit": "steps/s", "ms_per_step": 0.9, "steps": 210, "gs_passes_per_step": 2.0}
+    os_ = {"scaling": "strong", "value": 3300.0, "active": "oneshot", "halo_active": "peer"}
+    legs = {"strong_rccl": strong, "oneshot_weak": ow, "oneshot_strong": os_, "child": {"oneshot_active": "oneshot", "exit_code": 0, "seconds": 61.2}}
+    line = json.loads(json.dumps(bench.attach_side_legs(dict(out), legs)))
+    assert line["strong_scaling"]["value"] == 3000.0 and line["scaling"] == "weak"
     assert line["oneshot_allreduce"]["vs_provider_allreduce"] == 1.01 and "note" in line["oneshot_allreduce"]
-    line = json.loads(json.dumps(bench.attach_oneshot_leg(dict(out), {"active": "unknown", "reason": "the child was stopped after 180 s"})))
-    assert "vs_provider_allreduce" not in line["oneshot_allreduce"]
-    assert "oneshot_allreduce" not in bench.attach_oneshot_leg(dict(out), None)
+    assert line["oneshot_allreduce"]["strong_scaling"]["value"] == 3300.0 and line["oneshot_allreduce"]["strong_vs_provider_allreduce"] == 1.1
+    assert line["side_legs_child"]["exit_code"] == 0
+    stopped = {"strong_rccl": strong, "child": {"oneshot_active": "oneshot", "reason": "the child was stopped after 240 s", "seconds": 240.0}}
+    line = json.loads(json.dumps(bench.attach_side_legs(dict(out), stopped)))
+    assert line["strong_scaling"]["value"] == 3000.0                        # the leg finished before the stop is kept
+    assert "vs_provider_allreduce" not in line["oneshot_allreduce"] and "stopped after" in line["oneshot_allreduce"]["reason"]
+    line = json.loads(json.dumps(bench.attach_side_legs(dict(out), {"child": {"reason": "the child left no report (exit code 3)"}})))
+    assert line["strong_scaling"]["value"] is None and "no report" in line["strong_scaling"]["reason"]
+    assert "oneshot_allreduce" not in bench.attach_side_legs(dict(out), None) and "strong_scaling" not in bench.attach_side_legs(dict(out), None)
 
 
-def test_oneshot_child_command_report_and_time_limit(monkeypatch):
-    """The child leg: its command line (same sizes, no side legs, --oneshot-leg), another rendezvous port, the report parsed from its
-    stdout; a child that prints nothing or is stopped at the limit becomes a reason string, never an exception."""
+def test_side_legs_child_command_reports_and_time_limit(monkeypatch):
+    """The child of the N>1 run: its command line (same sizes, no single-GPU side legs, --side-legs), another rendezvous port, one JSON line per
+    finished leg parsed from its stdout; a child that prints nothing, or is stopped at the limit after some legs, becomes a reason string next to
+    the legs it did finish - never an exception."""
     import json
     import subprocess
     seen = {}
+    l1 = json.dumps({"leg": "strong_rccl", "scaling": "strong", "value": 3000.0}).encode()
+    l2 = json.dumps({"leg": "child", "oneshot_active": "oneshot"}).encode()
+    l3 = json.dumps({"leg": "oneshot_weak", "active": "oneshot", "halo_active": "peer", "value": 7000.0}).encode()
 
     def fake_run(cmd, env=None, stdout=None, stderr=None, timeout=None):
         seen.update(cmd=cmd, env=env, timeout=timeout)
-        return types.SimpleNamespace(returncode=0, stdout=(b"RCCL banner\n" + json.dumps({"active": "oneshot", "halo_active": "peer", "value": 7000.0}).encode() + b"\n"))
+        return types.SimpleNamespace(returncode=0, stdout=b"RCCL banner\n" + l1 + b"\n" + l2 + b"\n{not json\n" + l3 + b"\n")
     monkeypatch.setattr(bench.subprocess, "run", fake_run)
     monkeypatch.setenv("MASTER_PORT", "29511"); monkeypatch.setenv("RANK", "0")
-    args = types.SimpleNamespace(gpus=8, steps=20, warmup=5, min_steps=200, side=216)
-    leg = bench.oneshot_child(args)
-    assert leg == {"active": "oneshot", "halo_active": "peer", "value": 7000.0}
+    args = types.SimpleNamespace(gpus=8, steps=20, warmup=5, min_steps=200, side=216, no_oneshot=False)
+    legs = bench.side_legs_child(args)
+    assert legs["strong_rccl"] == {"scaling": "strong", "value": 3000.0} and legs["oneshot_weak"]["value"] == 7000.0 and "oneshot_strong" not in legs
+    assert legs["child"]["oneshot_active"] == "oneshot" and legs["child"]["exit_code"] == 0
     cmd = seen["cmd"]
-    assert cmd[cmd.index("--gpus") + 1] == "8" and "--oneshot-leg" in cmd and "--no-configs" in cmd and "--no-cpu-baseline" in cmd
-    assert seen["env"]["MASTER_PORT"] != "29511" and seen["timeout"] == 180.0
+    assert cmd[cmd.index("--gpus") + 1] == "8" and "--side-legs" in cmd and "--no-configs" in cmd and "--no-cpu-baseline" in cmd and "--no-oneshot" not in cmd
+    assert seen["env"]["MASTER_PORT"] != "29511" and seen["timeout"] == 240.0
 
     def silent(cmd, env=None, stdout=None, stderr=None, timeout=None):
         return types.SimpleNamespace(returncode=3, stdout=b"")
     monkeypatch.setattr(bench.subprocess, "run", silent)
-    assert "no report" in bench.oneshot_child(args)["reason"]
+    assert "no report" in bench.side_legs_child(args)["child"]["reason"]
 
     def hung(cmd, env=None, stdout=None, stderr=None, timeout=None):
-        raise subprocess.TimeoutExpired(cmd, timeout)
+        raise subprocess.TimeoutExpired(cmd, timeout, output=l1 + b"\n")
     monkeypatch.setattr(bench.subprocess, "run", hung)
-    assert "stopped after" in bench.oneshot_child(args)["reason"]
-
-
-def test_wall_time_budget_of_an_n8_run_fits_the_drivers_limit():
-    """--gpus 8 = headline (a 216^3 slab per rank: set-up, 45 + 210 + 210 steps at about 1.2 ms, a few seconds) + at most one child leg of
-    180 s: the worst case must stay well inside the driver's 600 s."""
-    import inspect
-    limit = inspect.signature(bench.oneshot_child).parameters["limit"].default
-    assert limit <= 180.0
-    headline_worst = 120.0            # imports, RCCL bootstrap, matrix build and the three phases, generously
-    assert headline_worst + limit + 30.0 <= 600.0
+    legs = bench.side_legs_child(args)
+    assert "stopped after" in legs["child"]["reason"] and legs["strong_rccl"]["value"] == 3000.0
 
 
 def test_breakdown_and_strong_leg_of_the_n_gt_1_line_from_faked_ranks():

@@ -2,6 +2,7 @@
 / MatShift of ST_MATMODE_COPY (src/sys/classes/st/interface/stsolve.c:611-626). CPU only: the hook is exported by libksgpu.so and does not
 touch the GPU."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -15,7 +16,7 @@ DP = C.POINTER(C.c_double)
 
 @pytest.fixture(scope="module")
 def lib():
-    lib = C.CDLL(L.LIB_PATH)
+    lib = C.CDLL(os.environ.get("KS_HOST_HOOKS_LIB") or L.LIB_PATH)      # tests/test_sanitizers.py points this at the ASan + UBSan build of the host sources
     lib.ksc_csr_axpy.argtypes = [C.c_int, C.c_int, IP, IP, DP, C.c_double, IP, IP, DP, IP, IP, DP, C.c_longlong]
     lib.ksc_csr_axpy.restype = C.c_longlong
     return lib

@@ -2,6 +2,7 @@
 real Schur form, Schur reordering, eigenvectors) against LAPACK through the oracle and against defining
 properties. CPU only: the C hooks are exported by libksgpu.so and do not touch the GPU."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -18,7 +19,7 @@ def p(a):
 
 @pytest.fixture(scope="module")
 def lib():
-    lib = C.CDLL(L.LIB_PATH)
+    lib = C.CDLL(os.environ.get("KS_HOST_HOOKS_LIB") or L.LIB_PATH)      # tests/test_sanitizers.py points this at the ASan + UBSan build of the host sources
     lib.ksd_hess_reduce.argtypes = [C.c_int, C.c_int, P, C.c_int, P]
     lib.ksd_hess_reduce.restype = None
     lib.ksd_real_schur.argtypes = [C.c_int, C.c_int, P, C.c_int, P, P, P]
