@@ -19,7 +19,11 @@ Workload (config.workload):
   N=1 : BASELINE config 3 - 3-D 7-point Laplacian 216^3 (n = 10 077 696, nnz = 70 263 936)
   N>1 : weak scaling towards config 4 - 432 x 432 x (54 N) grid, each rank owns a 54-plane z-slab
         (10 077 696 rows per GPU; N=8 is the 432^3 = 80.6 M row problem); allreduce of the CGS
-        coefficients and the SpMV halo go through RCCL over xGMI.
+        coefficients and the SpMV halo go through RCCL over xGMI. That is `value`. Beside it, measured by ONE child process of
+        every rank after the headline (one JSON line per finished leg, stopped after 240 s): `strong_scaling` - the SAME 216^3
+        problem cut into N z-slabs (the metric's literal "n=10M ... 1/2/4/8 GPU") - and `oneshot_allreduce` - both legs again with
+        the one-shot allreduce and the peer-mapped halo. Every leg carries `multi_gpu_breakdown` (allreduce / halo / restart
+        broadcast per step and per rank, rank skew).
 Launch: `python bench.py --gpus N ...` starts its N ranks itself (one fresh child process per GPU through
         torch.distributed.run, before this process touches the GPU); under an existing launcher
         (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`) it is one of the ranks.
@@ -39,7 +43,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
 NEV, NCV = 10, 30
 UPD_CLASSES = ["gs_update_fused_dot", "gs_update", "gated_noop"]
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_r03.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this command
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_r04.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this command
 
 
 class Phases:
@@ -188,8 +192,10 @@ def cpu_baseline(n_side, max_seconds=30.0):
         dt = sorted(reps)[1]; steps = per_rep * (NCV - k0); cycles = per_rep
         sample = ("median of 3 repetitions of %d restart cycles each (BVMultInPlace 30 -> 15 columns + BVCopyColumn + expansion k=%d..%d, CGS2) of the %d^3 "
                   "workload after its first Lanczos run; repetition times %s s; the projected solve (O(m^3) on the host) is not in the CPU sample; "
-                  "the restart product is the reference's 64-row-block algorithm (bvblas.c:74-106) on plain loops with OpenMP over the blocks, NOT a BLAS gemm as a SLEPc build would call"
-                  % (cycles, k0 + 1, NCV, n_side, ", ".join("%.2f" % r for r in reps)))
+                  "%s"
+                  % (cycles, k0 + 1, NCV, n_side, ", ".join("%.2f" % r for r in reps),
+                     "the restart product is the reference's 64-row-block algorithm (bvblas.c:74-106) on plain loops with OpenMP over the blocks, not the BLAS gemm a SLEPc build "
+                     "calls (the same product as numpy / OpenBLAS dgemm over row blocks of the basis' storage took 2.7x as long on 8 cores when tried: the loops are the stronger baseline here)"))
         first = {"value": NCV / dt_first, "unit": "steps/s", "sample": "first Lanczos run, k=1..%d" % NCV}
     else:
         dt, steps, first = dt6, m1, None
