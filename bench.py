@@ -725,19 +725,31 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    # BENCH_PROVIDER=gloo: REHEARSAL of the N>1 line with several ranks on ONE GPU (RCCL refuses two ranks on a device): torch.distributed over gloo and the
+    # host-staged provider of slepc_amd/gloo_provider.py instead of RCCL. Everything above the transport is the real thing - slabs, halo plans, the split
+    # bookkeeping, the records of every rank, the side-leg child with its one-shot allreduce and peer-mapped halo (hipIpc between the processes). Not a measurement.
+    rehearsal = os.environ.get("BENCH_PROVIDER") == "gloo"
+    device = local_rank % max(1, torch.cuda.device_count()) if rehearsal else local_rank
+    torch.cuda.set_device(device)
     dist = None
     force_dist = os.environ.get("BENCH_FORCE_DIST") == "1"     # rehearse the N>1 code path (RCCL comm, slab grid) on one GPU
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    ctx = ks.Context(local_rank)
+    ctx = ks.Context(device)
     if force_dist:
         ctx.set_debug("force_multi")        # ... with the collectives really issued (allreduce per pass, broadcast per restart)
-    if world > 1 or force_dist:
+    if (world > 1 or force_dist) and rehearsal:
+        from slepc_amd import gloo_provider
+        gloo_provider.install(ctx, dist, torch, rank, world)
+        ctx.comm_check()
+    elif world > 1 or force_dist:
         idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             idt.copy_(torch.frombuffer(bytearray(ks.Context.get_unique_id()), dtype=torch.uint8))
@@ -758,7 +770,7 @@ def main():
     def gather_records(rec):
         if dist is None:
             return [rec]
-        tt = torch.tensor(rec, dtype=torch.float64, device="cuda")
+        tt = torch.tensor(rec, dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         parts = [torch.empty_like(tt) for _ in range(world)]
         dist.all_gather(parts, tt)
         return [p.cpu().tolist() for p in parts]
@@ -835,6 +847,9 @@ def main():
         legs = side_legs_child(args)      # every rank starts its own child; rank 0's child reports, one line per finished leg
     if rank == 0:
         out = headline(world, steps, dt, ph.marks["t0"][0], t, args, workload, weak["mat"])
+        if rehearsal:
+            out["rehearsal"] = ("BENCH_PROVIDER=gloo: %d rank(s) sharing device %d through a host-staged gloo provider - the N>1 code paths exercised, "
+                                "NOT a measurement of anything" % (world, device))
         try:
             from slepc_amd import _lib as _kslib
             ri = _kslib.runtime_info()
