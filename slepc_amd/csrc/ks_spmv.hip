@@ -1059,22 +1059,10 @@ static int build_binned(ks_mat A)
     for (int s = 0; s < ns; s++)
       for (int wl = 0; wl < grp; wl++) { const int b = grp * g + wl; off2[(size_t)b * ns + s] = (int)run; run += len[(size_t)b * ns + s]; }
   const long long entries = run;
-  int nwin2 = 1;
   for (int b = 0; b < wb; b++) {
     int lrun = 0;
     for (int s = 0; s < ns; s++) { log2[(size_t)b * (ns + 1) + s] = lrun; lrun += len[(size_t)b * ns + s]; }
     log2[(size_t)b * (ns + 1) + ns] = lrun;
-    nwin2 = std::max(nwin2, (lrun + 511) / 512);
-  }
-  std::vector<int> wseg2((size_t)wb * nwin2, 0);          // segment in which the 512-entry window of wave-bin wb begins
-  for (int b = 0; b < wb; b++) {
-    const int *lg = log2.data() + (size_t)b * (ns + 1);
-    int sg = 0;
-    for (int wdw = 0; wdw < nwin2; wdw++) {
-      const int base = wdw * 512;
-      while (sg < ns - 1 && lg[sg + 1] <= base) sg++;
-      wseg2[(size_t)b * nwin2 + wdw] = sg;
-    }
   }
   std::vector<int> off1((size_t)ns * (wb + 1)), off2t((size_t)ns * wb);
   std::vector<long long> sbase(ns + 1);
@@ -1121,7 +1109,7 @@ static int build_binned(ks_mat A)
   };
   KS_CALL(up(&A->bn_col16, col16)); KS_CALL(up(&A->bn_row16, row16)); KS_CALL(up(&A->bn_val, val2));
   KS_CALL(up(&A->bn_off1, off1)); KS_CALL(up(&A->bn_off2t, off2t)); KS_CALL(up(&A->bn_wseg, wseg));
-  KS_CALL(up(&A->bn_sbase, sbase)); KS_CALL(up(&A->bn_off2, off2)); KS_CALL(up(&A->bn_log2, log2)); KS_CALL(up(&A->bn_wseg2, wseg2));
+  KS_CALL(up(&A->bn_sbase, sbase)); KS_CALL(up(&A->bn_off2, off2)); KS_CALL(up(&A->bn_log2, log2));
   KS_HIP(hipMalloc(&A->bn_g, sizeof(double) * std::max<long long>(entries, 1)));
   KS_HIP(hipMemset(A->bn_g, 0, sizeof(double) * std::max<long long>(entries, 1)));
   const int lds1 = cs * 8 + (2 * wb + 1) * 4, lds2 = 4 * (wr + 1) * 8;
@@ -1134,11 +1122,11 @@ static int build_binned(ks_mat A)
   double nrm = 0.0;
   KS_CALL(ks_mat_norm_inf_local(A, &nrm));
   A->norm_inf_cache = nrm;
-  A->use_binned = true; A->bn_ns = ns; A->bn_cs = cs; A->bn_wb = wb; A->bn_wr = wr; A->bn_nwin = nwin; A->bn_nwin2 = nwin2; A->bn_entries = entries;
+  A->use_binned = true; A->bn_ns = ns; A->bn_cs = cs; A->bn_wb = wb; A->bn_wr = wr; A->bn_nwin = nwin; A->bn_entries = entries;
   hipFree(A->d_col); hipFree(A->d_val); A->d_col = nullptr; A->d_val = nullptr;
   } catch (const std::exception &) {                    // out of host memory (or anything else the build throws): the other layouts take the matrix
-    hipFree(A->bn_col16); hipFree(A->bn_row16); hipFree(A->bn_val); hipFree(A->bn_g); hipFree(A->bn_off1); hipFree(A->bn_off2t); hipFree(A->bn_wseg); hipFree(A->bn_sbase); hipFree(A->bn_off2); hipFree(A->bn_log2); hipFree(A->bn_wseg2);
-    A->bn_col16 = A->bn_row16 = nullptr; A->bn_val = A->bn_g = nullptr; A->bn_off1 = A->bn_off2t = A->bn_wseg = nullptr; A->bn_sbase = nullptr; A->bn_off2 = A->bn_log2 = A->bn_wseg2 = nullptr;
+    hipFree(A->bn_col16); hipFree(A->bn_row16); hipFree(A->bn_val); hipFree(A->bn_g); hipFree(A->bn_off1); hipFree(A->bn_off2t); hipFree(A->bn_wseg); hipFree(A->bn_sbase); hipFree(A->bn_off2); hipFree(A->bn_log2);
+    A->bn_col16 = A->bn_row16 = nullptr; A->bn_val = A->bn_g = nullptr; A->bn_off1 = A->bn_off2t = A->bn_wseg = nullptr; A->bn_sbase = nullptr; A->bn_off2 = A->bn_log2 = nullptr;
     hipFree(A->diag_cache); A->diag_cache = nullptr;
     (void)hipGetLastError();
   }
@@ -1514,7 +1502,7 @@ extern "C" int ks_mat_destroy(ks_mat A)
   hipFree(A->s_ptr); hipFree(A->s_len); hipFree(A->s_col); hipFree(A->s_val);
   hipFree(A->dc_codes); hipFree(A->dc_val); hipFree(A->dc_off); hipFree(A->dc_codes8); hipFree(A->dc_vals);
   hipFree(A->sl_rowptr); hipFree(A->sl_col); hipFree(A->sl_val); hipFree(A->sl_base); hipFree(A->ypart); hipFree(A->diag_cache);
-  hipFree(A->bn_col16); hipFree(A->bn_row16); hipFree(A->bn_val); hipFree(A->bn_g); hipFree(A->bn_off1); hipFree(A->bn_off2t); hipFree(A->bn_wseg); hipFree(A->bn_sbase); hipFree(A->bn_off2); hipFree(A->bn_log2); hipFree(A->bn_wseg2);
+  hipFree(A->bn_col16); hipFree(A->bn_row16); hipFree(A->bn_val); hipFree(A->bn_g); hipFree(A->bn_off1); hipFree(A->bn_off2t); hipFree(A->bn_wseg); hipFree(A->bn_sbase); hipFree(A->bn_off2); hipFree(A->bn_log2);
   delete A;
   return KS_SUCCESS;
 }

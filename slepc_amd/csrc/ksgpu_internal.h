@@ -180,7 +180,7 @@ struct ks_mat_s {
   // entries (padding entries with value 0 where needed) and so starts on a 64-byte boundary of the 8-byte streams. Phase 1 (a workgroup per slice, its piece of x in LDS) writes G = x[col] in bin-major
   // order; phase 2 (a wave per wave-bin, its rows of y in LDS) streams G, val and row and adds val * G into its rows.
   bool use_binned = false;
-  int bn_ns = 0, bn_cs = 0, bn_wb = 0, bn_wr = 0, bn_nwin = 0, bn_nwin2 = 0;
+  int bn_ns = 0, bn_cs = 0, bn_wb = 0, bn_wr = 0, bn_nwin = 0;
   long long bn_entries = 0;                   // entries incl. padding
   unsigned short *bn_col16 = nullptr, *bn_row16 = nullptr;
   double *bn_val = nullptr, *bn_g = nullptr;
@@ -190,7 +190,6 @@ struct ks_mat_s {
   long long *bn_sbase = nullptr;              // [ns + 1]     start of slice s in bn_col16
   int *bn_off2 = nullptr;                     // [wb][ns]     physical start of segment (wb, s): bin-major order GROUPED by phase-2 workgroup, [wb / 4][ns][wb % 4]
   int *bn_log2 = nullptr;                     // [wb][ns + 1] logical start of that segment inside its wave-bin (piece after piece); [ns] = entries of the wave-bin
-  int *bn_wseg2 = nullptr;                    // [wb][nwin2]  segment in which the 512-entry logical window of wave-bin wb begins
   // off-diagonal block (columns owned by other ranks), compressed to ghost indices [0,nghost)
   int *o_rowptr = nullptr; int *o_col = nullptr; double *o_val = nullptr; long long nnz_o = 0;
   int nghost = 0;

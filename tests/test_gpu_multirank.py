@@ -625,3 +625,30 @@ def test_oneshot_allreduce_across_the_wrap_of_its_stamps():
     out = _run_peer(2, "wrap")
     for rk in (0, 1):
         assert out[rk]["active"] == "oneshot" and out[rk]["back"] == "provider"
+
+
+# ---- the N > 1 bench line, end to end, with two ranks sharing the GPU -------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_bench_n_gt_1_line_with_two_ranks_on_one_gpu():
+    """`bench.py --gpus 2` as the driver will start it on a multi-GPU node, rehearsed here with both ranks on the one GPU and a gloo provider in
+    place of RCCL (BENCH_PROVIDER=gloo; small slabs): the weak headline with its per-rank breakdown, and from the side-leg child the strong-scaling
+    leg and both legs again with the one-shot allreduce and the peer-mapped halo between the two processes. The numbers mean nothing; the line does."""
+    import json
+    import subprocess
+    env = dict(os.environ); env["BENCH_PROVIDER"] = "gloo"; env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--min-steps", "60", "--side", "96"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "rehearsal" in d
+    assert d["config"]["rows_per_gpu"] == 96 ** 3 and d["config"]["n_global"] == 2 * 96 ** 3 and d["config"]["gs_passes_per_step"] == 2.0
+    b = d["multi_gpu_breakdown"]
+    assert b["ranks"] == 2 and len(b["rank_timed_seconds"]) == 2 and b["allreduce_calls_per_step"] == 2.0 and b["halo_exchanges_per_step"] == 1.0
+    assert b["restart_bcasts"] == d["config"]["cycles"] and all(x > 0 for x in b["per_rank_us_per_step"]["allreduce"])
+    s = d["strong_scaling"]
+    assert s["scaling"] == "strong" and s["value"] > 0 and s["n_global"] == 96 ** 3 and s["rows_per_gpu"] == 96 ** 3 // 2 and s["multi_gpu_breakdown"]["ranks"] == 2
+    o = d["oneshot_allreduce"]
+    assert o["active"] == "oneshot" and o["halo_active"] == "peer" and o["value"] > 0 and o["strong_scaling"]["value"] > 0, o
+    assert d["side_legs_child"]["exit_code"] == 0
