@@ -728,6 +728,7 @@ def main():
     # BENCH_PROVIDER=gloo: REHEARSAL of the N>1 line with several ranks on ONE GPU (RCCL refuses two ranks on a device): torch.distributed over gloo and the
     # host-staged provider of slepc_amd/gloo_provider.py instead of RCCL. Everything above the transport is the real thing - slabs, halo plans, the split
     # bookkeeping, the records of every rank, the side-leg child with its one-shot allreduce and peer-mapped halo (hipIpc between the processes). Not a measurement.
+    # Keep it to --gpus 2 on a one-GPU box: every rank and every rank's child hold the GPU open (a GPU box admits six processes on its card).
     rehearsal = os.environ.get("BENCH_PROVIDER") == "gloo"
     device = local_rank % max(1, torch.cuda.device_count()) if rehearsal else local_rank
     torch.cuda.set_device(device)
