@@ -15,6 +15,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+
+def _free_port():
+    """A rendezvous port the OS says is free right now (ports computed from the pid collided with the ephemeral ports of earlier tests' gloo pairs:
+    EADDRINUSE on the box, round 4)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def _worker(rank, world, port, shape, m, out):
     import torch
     import torch.distributed as dist
@@ -78,11 +90,16 @@ def test_two_rank_lanczos_matches_single_rank():
     shape, m = (6, 5, 8), 10
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = [ctxm.Process(target=_worker, args=(r, 2, port, shape, m, q)) for r in range(2)]
     for p in procs: p.start()
-    nrm_diag, betas, alphas, beta, passes = q.get(timeout=240)
-    for p in procs: p.join(60); assert p.exitcode == 0
+    try:
+        nrm_diag, betas, alphas, beta, passes = q.get(timeout=240)
+        for p in procs: p.join(60); assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate(); p.join(10)
     # single-rank oracle
     A = O.laplacian3d(*shape)
     V = O.BV(A.n, m + 1); V.SetRandomColumn(0)

@@ -18,6 +18,46 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+
+
+def _collect(q, procs, n, timeout=400):
+    """n results from the workers' queue; whatever happens, no worker outlives the test (a rank left waiting for a peer that failed would keep the
+    interpreter from exiting, and the GPU run behind it from starting)."""
+    import queue
+    import time
+    t0, out = time.time(), []
+    try:
+        while len(out) < n:
+            try:
+                out.append(q.get(timeout=2))
+            except queue.Empty:
+                dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+                if dead:             # a rank that died before reporting: fail now, not after the full wait (the peers are reaped below)
+                    raise RuntimeError("a worker exited with code %s before reporting (%d of %d results in)" % (dead, len(out), n))
+                if time.time() - t0 > timeout:
+                    raise
+        return out
+    finally:
+        for p in procs:
+            p.join(20 if p.is_alive() else 0)
+        for p in procs:
+            if p.is_alive():
+                p.terminate(); p.join(10)
+            if p.is_alive():
+                p.kill(); p.join(5)
+
+
+def _free_port():
+    """A rendezvous port the OS says is free right now (ports computed from the pid collided with the ephemeral ports of earlier tests' gloo pairs:
+    EADDRINUSE on the box, round 4)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def _install_gloo_ops(ks, ctx, dist, torch, rank, size, perturb=False):
     from slepc_amd import gloo_provider
     gloo_provider.install(ctx, dist, torch, rank, size, perturb=perturb)
@@ -183,11 +223,10 @@ def test_ranks_sharing_one_gpu_against_oracle(world):
     from oracle import oracle as O
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    port = 29700 + (os.getpid() % 1500) + 7 * world
+    port = _free_port()
     procs = [mpc.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs: p.start()
-    out = dict(q.get(timeout=400) for _ in range(world))
-    for p in procs: p.join(120)
+    out = dict(_collect(q, procs, world))
     for r in range(world):
         assert "error" not in out[r], out[r].get("error")
     # single-rank oracle reference
@@ -305,8 +344,7 @@ def test_native_rccl_provider_single_rank_forced_collectives():
     q = mpc.Queue()
     p = mpc.Process(target=_rccl_worker, args=(q,))
     p.start()
-    out = q.get(timeout=400)
-    p.join(120)
+    out = _collect(q, [p], 1)[0]
     assert "error" not in out, out.get("error")
     assert out["ok"]
     assert out["allreduces"] >= 2 * out["steps"]          # one ncclAllReduce per executed Gram-Schmidt pass went through RCCL
@@ -401,11 +439,10 @@ def _run_oneshot(world, absent_rank=-1):
     import torch.multiprocessing as mp
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    port = 31300 + (os.getpid() % 1500) + 11 * world + (3 if absent_rank >= 0 else 0)
+    port = _free_port()
     procs = [mpc.Process(target=_oneshot_worker, args=(r, world, port, q, absent_rank)) for r in range(world)]
     for p in procs: p.start()
-    out = dict(q.get(timeout=400) for _ in range(world))
-    for p in procs: p.join(120)
+    out = dict(_collect(q, procs, world))
     for r in range(world):
         assert "error" not in out[r], out[r].get("error")
     return out
@@ -574,11 +611,10 @@ def _run_peer(world, mode):
     import torch.multiprocessing as mp
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    port = 33100 + (os.getpid() % 1500) + 13 * world + {"halo": 0, "absent": 5, "wrap": 9}[mode]
+    port = _free_port()
     procs = [mpc.Process(target=_peer_halo_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs: p.start()
-    out = dict(q.get(timeout=400) for _ in range(world))
-    for p in procs: p.join(120)
+    out = dict(_collect(q, procs, world))
     for r in range(world):
         assert "error" not in out[r], out[r].get("error")
     return out
