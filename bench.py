@@ -662,14 +662,21 @@ def parse_side_legs(stdout_bytes):
     return legs
 
 
-def side_legs_child(args, limit=240.0):
+def free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def side_legs_child(args, limit=240.0, port=None):
     """Everything of the N>1 line that is not the headline, in ONE child process per rank (same launcher environment, another rendezvous port):
     the strong-scaling leg with the RCCL provider, then the weak and the strong leg once more with the one-shot allreduce and the peer-mapped
     halo. The child prints one JSON line per finished leg; whatever happens to a later leg - mailboxes that cannot be mapped, a check that fails,
     a hang - stays in the children, which are stopped at `limit` seconds, and the legs finished before that are still reported. The headline
     has been taken before and is printed regardless."""
     env = dict(os.environ)
-    env["MASTER_PORT"] = str(20000 + (int(env.get("MASTER_PORT", "29511")) + 1789) % 20000)
+    # the children's rendezvous port: one the OS reported free on rank 0 and the ranks agreed on (port=), else derived from the parents' port
+    env["MASTER_PORT"] = str(port) if port else str(20000 + (int(env.get("MASTER_PORT", "29511")) + 1789) % 20000)
     env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # under torchrun the ranks would look for the agent's store on the old port: rank 0's child opens its own
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--min-steps", str(args.min_steps), "--side", str(args.side), "--no-configs", "--no-cpu-baseline", "--side-legs"]
@@ -845,7 +852,11 @@ def main():
 
     legs = None
     if dist is not None and not args.no_side_legs:
-        legs = side_legs_child(args)      # every rank starts its own child; rank 0's child reports, one line per finished leg
+        pt = torch.zeros(1, dtype=torch.int64, device="cpu" if rehearsal else "cuda")
+        if rank == 0:
+            pt[0] = free_port()
+        dist.broadcast(pt, 0)             # rank 0 asks the OS for a free port, every rank's child meets there
+        legs = side_legs_child(args, port=int(pt.item()))      # every rank starts its own child; rank 0's child reports, one line per finished leg
     if rank == 0:
         out = headline(world, steps, dt, ph.marks["t0"][0], t, args, workload, weak["mat"])
         if rehearsal:

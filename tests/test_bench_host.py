@@ -141,6 +141,8 @@ def test_side_legs_child_command_reports_and_time_limit(monkeypatch):
     cmd = seen["cmd"]
     assert cmd[cmd.index("--gpus") + 1] == "8" and "--side-legs" in cmd and "--no-configs" in cmd and "--no-cpu-baseline" in cmd and "--no-oneshot" not in cmd
     assert seen["env"]["MASTER_PORT"] != "29511" and seen["timeout"] == 240.0
+    bench.side_legs_child(args, port=31234)                     # the port rank 0 asked the OS for and broadcast to the others
+    assert seen["env"]["MASTER_PORT"] == "31234"
 
     def silent(cmd, env=None, stdout=None, stderr=None, timeout=None):
         return types.SimpleNamespace(returncode=3, stdout=b"")
