@@ -163,3 +163,15 @@ except ks.KsError as e:
     if last.startswith("SKIP"):
         pytest.skip("torch bundles no second runtime here")
     assert last.startswith("REFUSED 76") and "two HIP runtimes" in last, last
+
+
+def test_runtime_info_needs_no_gpu_and_checks_its_buffer():
+    """ks_runtime_info works without a context or a GPU (it never initialises the runtime beyond asking its version) and refuses a short buffer."""
+    L = _lib.lib()
+    info = _lib.runtime_info()
+    assert set(info) >= {"hip_runtime_path", "hip_runtime_version", "hip_runtimes_mapped", "occupancy_query_failures", "occupancy_last_error"}
+    assert os.path.exists(info["hip_runtime_path"]) and info["hip_runtime_version"] > 0
+    small = ctypes.create_string_buffer(16)
+    assert L.ks_runtime_info(small, 16) == 60                       # KS_ERR_ARG_SIZ
+    assert L.ks_runtime_info(None, 0) == 85                          # KS_ERR_ARG_NULL
+    assert ks.event_name("bv_dot_sweep") == "BVDotVec" and ks.event_name("gs_update_fused_dot") == "BVMultVec+BVDotVec" and ks.event_name("spmv_csr") == "BVMatMultVec"

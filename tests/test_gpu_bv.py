@@ -295,3 +295,15 @@ def test_norm_is_overflow_and_underflow_safe(ctx):
     X.SetActiveColumns(0, 1)
     assert abs(X.Norm(ks.NORM_FROBENIUS) / 1e200 / ref - 1.0) < 1e-13
     assert abs(X.Norm(ks.NORM_INFINITY) - 1e200 * np.abs(x).max()) <= 1e185
+
+
+def test_debug_hooks_and_broadcast_counters(ctx):
+    """ks_ctx_set_debug takes the six documented keys and nothing else; ks_comm_bcast_stats counts nothing on a single rank without the force_multi hook."""
+    from slepc_amd import _lib
+    for key in ctx.DEBUG_KEYS:
+        ctx.set_debug(key, 0 if key != "halo_overlap" else 1)       # every hook at its default
+    assert ctx.L.ks_ctx_set_debug(ctx.h, 99, 1) == 63               # KS_ERR_ARG_OUTOFRANGE
+    assert "unknown debug key" in ctx.L.ks_last_error_message().decode()
+    n0, s0 = ctx.bcast_stats(reset=True)
+    assert ctx.bcast_stats() == (0, 0.0)
+    _lib.check(ctx.L.ks_comm_bcast_stats(ctx.h, None, None, 0))     # NULL outputs are allowed

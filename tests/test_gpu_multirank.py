@@ -329,9 +329,11 @@ def _rccl_worker(q):
         ok = (eps.GetConverged() == r.nconv and eps.GetIterationNumber() == r.its and
               np.allclose([eps.GetEigenvalue(i)[0] for i in range(4)], r.eigr[r.perm][:4], rtol=1e-10))
         ctx.prof_enable(True); ctx.prof_reset()
+        ctx.bcast_stats(reset=True)
         eps.Solve()
         n_allreduce = ctx.prof_get().get("allreduce", {}).get("launches", 0)
-        q.put({"ok": bool(ok), "allreduces": n_allreduce, "steps": eps.GetStats()["arnoldi_steps"]})
+        nb, sb = ctx.bcast_stats()           # one ncclBroadcast of the projected problem per restart (DSSynchronize), counted with its host time
+        q.put({"ok": bool(ok), "allreduces": n_allreduce, "steps": eps.GetStats()["arnoldi_steps"], "bcasts": nb, "bcast_seconds": sb, "its": eps.GetIterationNumber()})
     except Exception:      # noqa: BLE001
         import traceback
         q.put({"error": traceback.format_exc()})
@@ -348,6 +350,7 @@ def test_native_rccl_provider_single_rank_forced_collectives():
     assert "error" not in out, out.get("error")
     assert out["ok"]
     assert out["allreduces"] >= 2 * out["steps"]          # one ncclAllReduce per executed Gram-Schmidt pass went through RCCL
+    assert out["bcasts"] == out["its"] and out["bcast_seconds"] > 0.0      # and one broadcast of the projected problem per restart (ks_comm_bcast_stats)
 
 
 def _oneshot_worker(rank, world, port, q, absent_rank):
