@@ -266,6 +266,10 @@ def bind_hip_runtime():
     global _preloaded_runtime
     if mapped_hip_runtimes():
         return
+    if os.environ.get("SLEPC_AMD_HIP_RUNTIME") == "system":
+        # harness option: leave the choice to the library's RUNPATH (/opt/rocm's runtime, what a SLEPc build without PyTorch runs on) - for running the
+        # GPU suite on that runtime too. Only safe in a process that does not import torch afterwards (ks_ctx_create refuses two runtimes anyway).
+        return
     path = _torch_bundled_runtime()
     if path is not None:
         C.CDLL(path, mode=C.RTLD_GLOBAL)
