@@ -917,7 +917,7 @@ def main():
         if world == 1 and not force_dist and not args.no_configs:
             try:
                 legs = {}
-                for fmt in ("dict", "odict", "sell", "csr", "csrvec"):
+                for fmt in ("dict", "odict", "sell", "csr", "csrregs", "csrvec"):
                     os.environ["KSGPU_SPMV"] = fmt
                     try:
                         legs[fmt] = spmv_leg(ks, ctx, lambda: ks.Mat.laplacian3d(ctx, side, side, side))
@@ -925,7 +925,8 @@ def main():
                         os.environ.pop("KSGPU_SPMV", None)
                 out["spmv_layouts"] = {"workload": "MatMult of the %d^3 7-pt Laplacian alone, each device layout (KSGPU_SPMV=...)" % side, "legs": legs,
                                        "note": "dict needs <= 255 distinct values and <= 256 distinct column offsets, odict only the offsets; "
-                                               "sell = SELL-64 for any stencil-like matrix; csr = CSR row blocks streamed through wave-private LDS (a wave per 64 rows), for ragged ones; csrvec = the CSR-vector kernel it replaced"}
+                                               "sell = SELL-64 for any stencil-like matrix; csr = CSR row blocks streamed through wave-private LDS (a wave per 64 rows), for ragged ones - for short rows by LDS-DMA "
+                                               "(global_load_lds_dwordx4, round 4), csrregs = its register-staged form; csrvec = the CSR-vector kernel it replaced"}
             except Exception as e:      # noqa: BLE001
                 out["spmv_layouts"] = {"error": repr(e)}
             # the same measurement with the general-matrix SpMV (CSR row blocks; nothing Laplacian-specific in the layout): untimed for the headline

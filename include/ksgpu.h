@@ -201,7 +201,7 @@ int ks_mat_get_diagonal(ks_mat A, double *d_dev);                      /* MatGet
 int ks_mat_shell_set_enqueue_only(ks_mat A, int flag);   /* the callback only enqueues work on the context's stream: Krylov runs are then enqueued ahead through it */
 int ks_mat_destroy(ks_mat A);
 int ks_mat_get_sizes(ks_mat A, int *n_local, int *n_global, long long *nnz_local);
-/* device layout chosen at assembly for the local diagonal block (KSGPU_SPMV=csr|csrvec|sell|dict|odict|binned|sliced overrides the choice): dictionary forms for
+/* device layout chosen at assembly for the local diagonal block (KSGPU_SPMV=csr|csrregs|csrblock|csrvec|sell|dict|odict|binned|sliced overrides the choice): dictionary forms for
    stencil-like matrices with few distinct values / offsets, SELL-64 for short regular rows, CSR row blocks for ragged ones, BINNED (two streaming phases, every
    random access in LDS) for matrices whose columns scatter over a vector much larger than an L2; SLICED is round 1's layout for those */
 enum { KS_MAT_LAYOUT_CSR = 0, KS_MAT_LAYOUT_SELL = 1, KS_MAT_LAYOUT_SLICED = 2, KS_MAT_LAYOUT_SHELL = 3, KS_MAT_LAYOUT_DICT = 4, KS_MAT_LAYOUT_ODICT = 5, KS_MAT_LAYOUT_BINNED = 6 };

@@ -253,6 +253,71 @@ __global__ __launch_bounds__(256, ROWSIDE ? 5 : 4) void k_spmv_csr_wave(int n, c
   }
 }
 
+// ---- the same with the col / val streams going STRAIGHT into LDS (global_load_lds_dwordx4: no register staging, no ds_write pass) ----
+// Row side only (short rows). A chunk of 512 entries is six LDS-DMA instructions per wave (four for the values: lane l of instruction i brings
+// entries 128 i + 2 l, + 1; two for the columns: 256 i + 4 l .. + 3) into a lane-linear image - the DMA's destination is base + lane x 16, so
+// the image cannot be skewed; rows whose length is a multiple of 16 would meet on one bank, which is why the register-staged form above stays
+// for those (chosen at assembly). The registers the staged form spends on two chunks in flight (48 of its 96) are free here: more waves per
+// SIMD take over the latency hiding. A chunk starts on a multiple of four entries (16-byte aligned in both streams; up to three entries of
+// the rows before it are fetched and ignored).
+typedef __attribute__((address_space(3))) void ks_lds_void;
+typedef const __attribute__((address_space(1))) void ks_glb_void;
+template <int CW_STEPS, int WPS, int GU>
+__global__ __launch_bounds__(256, WPS) void k_spmv_csr_wave_dma(int n, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
+                                                                const double *__restrict__ x, double *__restrict__ y, int xcd_remap)
+{
+  constexpr int CH = 64 * CW_STEPS;
+  __shared__ __attribute__((aligned(16))) double sa_all[4][CH];
+  __shared__ __attribute__((aligned(16))) int sc_all[4][CH];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double *sa = sa_all[w];
+  int *sc = sc_all[w];
+  const int NG = (n + 255) / 256;
+  int g, gend, gstep;
+  if (xcd_remap) {
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3, lc = gridDim.x >> 3;
+    g = (int)((long long)NG * xcd / 8) + li; gend = (int)((long long)NG * (xcd + 1) / 8); gstep = lc;
+  } else { g = blockIdx.x; gend = NG; gstep = gridDim.x; }
+  if (g >= gend) return;
+  CwRows cu = cw_rows(n, rp, g, w, lane);
+  CwRows nx = g + gstep < gend ? cw_rows(n, rp, g + gstep, w, lane) : CwRows{0, 0, 0, 0, 0, false};
+  for (;;) {
+    double acc = 0.0;
+    for (int e0 = cu.E0 & ~3; e0 < cu.E1; e0 += CH) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the row lanes' reads of the previous chunk are done before this one may land
+#pragma unroll
+      for (int i = 0; i < CH / 128; i++) {
+        const int e = e0 + 128 * i + 2 * lane;
+        if (e < cu.E1) __builtin_amdgcn_global_load_lds((ks_glb_void *)(val + e), (ks_lds_void *)(sa + 128 * i), 16, 0, 2);       // aux 2 = nt: the default policy cost 10 % (profiles/r04_csr_lds_dma.txt)      // may take one entry past E1: CW_PAD
+      }
+#pragma unroll
+      for (int i = 0; i < CH / 256; i++) {
+        const int e = e0 + 256 * i + 4 * lane;
+        if (e < cu.E1) __builtin_amdgcn_global_load_lds((ks_glb_void *)(col + e), (ks_lds_void *)(sc + 256 * i), 16, 0, 2);      // up to three past E1: CW_PAD
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // an LDS-DMA is a pending LDS write on the VM counter
+      const int lo = max(cu.p0, e0), hi = min(cu.p1, e0 + CH);
+      for (int p = lo; __builtin_amdgcn_ballot_w64(p < hi) != 0; p += GU) {
+        double av[GU], xv[GU];
+#pragma unroll
+        for (int j = 0; j < GU; j++) {
+          const bool ok = p + j < hi;
+          const int sl = ok ? p + j - e0 : 0;
+          av[j] = sa[sl];
+          xv[j] = ok ? x[sc[sl]] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < GU; j++) if (p + j < hi) acc = fma(av[j], xv[j], acc);
+      }
+    }
+    if (cu.has) __builtin_nontemporal_store(acc, y + cu.r);
+    g += gstep;
+    if (g >= gend) break;
+    cu = nx;
+    nx = g + gstep < gend ? cw_rows(n, rp, g + gstep, w, lane) : CwRows{0, 0, 0, 0, 0, false};
+  }
+}
+
 // ---- sliced ELL (SELL-64) ---------------------------------------------------------------------------
 // lane <-> row: every val/col load of a wavefront is one contiguous 512 B / 256 B run, the x gather of a
 // stencil matrix is contiguous too (consecutive rows -> consecutive columns), y is stored 512 B per wave,
@@ -1270,6 +1335,7 @@ int build_sell(ks_mat A)
   const char *force = getenv("KSGPU_SPMV");
   if (force && !strcmp(force, "csrvec")) { A->force_csr_vector = true; return KS_SUCCESS; }     // the CSR-vector kernel at any size (A/B against the row-block kernel)
   if (force && !strcmp(force, "csrblock")) { A->force_csr_block = true; return KS_SUCCESS; }    // the workgroup-per-256-rows form of the row-block kernel (A/B against the wave form)
+  if (force && !strcmp(force, "csrregs")) { A->force_csr_regs = true; return KS_SUCCESS; }      // the register-staged form of the wave kernel also for short rows (A/B against the LDS-DMA form)
   if (force && !strcmp(force, "csr")) return KS_SUCCESS;
   if (A->n == 0 || A->nnz_d == 0) return KS_SUCCESS;
   KS_CALL(build_dict(A));                                   // independent of the SELL decision below; needs the CSR arrays
@@ -1614,7 +1680,14 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y, const double *row
       long long nb = std::min<long long>(NG, (long long)ctx->num_cu * (rowside ? 5 : 4));
       const int remap = nb >= 64 ? 1 : 0;
       if (remap) nb = (nb / 8) * 8;
-      if (rowside) hipLaunchKernelGGL((k_spmv_csr_wave<true, 8>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, remap);
+      if (rowside && !A->force_csr_regs) {
+        // short rows: the LDS-DMA form (six workgroups of four waves per CU: 144 KB of LDS; 33 registers). 216^3 Laplacian: 191 us against the
+        // register-staged form's 207 on the same box (profiles/r04_csr_lds_dma.txt)
+        long long nd = std::min<long long>(NG, (long long)ctx->num_cu * 6);
+        const int rd = nd >= 64 ? 1 : 0;
+        if (rd) nd = (nd / 8) * 8;
+        hipLaunchKernelGGL((k_spmv_csr_wave_dma<8, 6, 8>), dim3((unsigned)nd), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, rd);
+      } else if (rowside) hipLaunchKernelGGL((k_spmv_csr_wave<true, 8>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, remap);
       else hipLaunchKernelGGL((k_spmv_csr_wave<false, 8>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, remap);
     } else if (A->n >= 2048 && !A->force_csr_vector) {
       const unsigned nb = (unsigned)std::min<long long>(((long long)A->n + 255) / 256, (long long)ctx->num_cu * 8);

@@ -153,7 +153,7 @@ struct ks_mat_s {
   int *d_rowptr = nullptr; int *d_col = nullptr; double *d_val = nullptr; long long nnz_d = 0;
   int lanes_per_row = 8;
   bool force_csr_vector = false;   // KSGPU_SPMV=csrvec
-  bool force_csr_block = false;    // KSGPU_SPMV=csrblock
+  bool force_csr_regs = false, force_csr_block = false;    // KSGPU_SPMV=csrblock
   // sliced-ELL copy of the diagonal block (slice = 64 rows = one wavefront), chosen at assembly when the
   // padding it needs is small; val/col stored column-major inside a slice: entry j of row 64s+lane at (sp[s]+j)*64+lane
   bool use_sell = false;

@@ -85,6 +85,34 @@ def test_spmv_csr_row_block_kernel(ctx, monkeypatch):
     monkeypatch.setenv("KSGPU_SPMV", "csr"); yc = ks.Mat.laplacian3d(ctx, 40, 30, 20).mult(xs)
     monkeypatch.setenv("KSGPU_SPMV", "sell"); ys = ks.Mat.laplacian3d(ctx, 40, 30, 20).mult(xs)
     assert np.array_equal(yc, ys)
+    monkeypatch.setenv("KSGPU_SPMV", "csrregs"); yr = ks.Mat.laplacian3d(ctx, 40, 30, 20).mult(xs)
+    assert np.array_equal(yr, ys)
+
+
+@pytest.mark.parametrize("n", [4999, 70001])
+def test_spmv_csr_short_rows_lds_dma_form(ctx, monkeypatch, n):
+    """Short rows (at most 12 entries on average) take the LDS-DMA form of the wave kernel (round 4: the col / val streams go straight into a lane-linear
+    LDS image, global_load_lds_dwordx4): empty rows, stretches of rows of 8 and of 16 entries (all lanes of a row-side read on one bank group: slower, not
+    wrong), one row far longer than a 512-entry chunk, a last group of fewer than 64 rows, a row pointer run that does not start on a multiple of four. The
+    register-staged form (KSGPU_SPMV=csrregs) runs the same rows: bit for bit the same sums (same entry order, same fma chain), both at the oracle's."""
+    import slepc_amd as ks
+    rng = np.random.default_rng(n)
+    lens = rng.integers(0, 11, n); lens[::5] = 0; lens[200:328] = 8; lens[1000:1128] = 16; lens[3] = 1; lens[n // 2] = 3000; lens[n - 1] = 5
+    assert lens.sum() <= 12 * n
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate([np.sort(rng.choice(n, l, replace=False)) for l in lens] + [np.empty(0, int)]).astype(np.int32)
+    val = rng.uniform(-1, 1, rowptr[-1])
+    Ao = O.CSR(n, rowptr, col, val)
+    x = rng.standard_normal(n)
+    y0 = Ao.mult(x)
+    out = {}
+    for fmt in ("csr", "csrregs", "csrvec"):
+        monkeypatch.setenv("KSGPU_SPMV", fmt)
+        A = ks.Mat.from_csr(ctx, rowptr, col, val); assert A.layout() == "csr"
+        out[fmt] = A.mult(x)
+        assert np.allclose(out[fmt], y0, rtol=0, atol=1e-12) and np.all(out[fmt][lens == 0] == 0.0), fmt
+        A.destroy()
+    assert np.array_equal(out["csr"], out["csrregs"])
 
 
 @pytest.mark.parametrize("fmt", ["csr", "csrvec", "sell"])
