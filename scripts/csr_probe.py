@@ -1,6 +1,6 @@
 """The general-matrix CSR kernels on the bench matrix (216^3 7-point Laplacian) and on ragged random matrices: us per product and
-CSR-algorithmic TB/s (SURVEY 8d bytes) for KSGPU_SPMV = csr (wave-per-64-rows row-block kernel), csrblock (workgroup per 256 rows),
-csrvec, sell."""
+CSR-algorithmic TB/s (SURVEY 8d bytes) for KSGPU_SPMV = csr (wave-per-64-rows row-block kernel; short rows: its LDS-DMA form), csrregs (the register-staged form also for short rows),
+csrblock (workgroup per 256 rows), csrvec, sell."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
