@@ -1676,17 +1676,25 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y, const double *row
     } else if (A->n >= 2048 && !A->force_csr_vector && !A->force_csr_block) {
       // 4 or 5 workgroups of 4 waves per CU (registers; forcing 6 spills: 259 us); a multiple of 8 so that every XCD gets its eighth of the rows
       const long long NG = ((long long)A->n + 255) / 256;
-      const bool rowside = A->nnz_d <= 12LL * A->n;          // short rows: gather on the row side
+      const bool rowside = A->nnz_d <= 12LL * A->n;          // short rows: gather on the row side (register-staged form)
+      const bool dma = A->nnz_d <= 16LL * A->n && !A->force_csr_regs;      // the LDS-DMA form gathers on the row side up to 16 entries per row on average
       long long nb = std::min<long long>(NG, (long long)ctx->num_cu * (rowside ? 5 : 4));
       const int remap = nb >= 64 ? 1 : 0;
       if (remap) nb = (nb / 8) * 8;
-      if (rowside && !A->force_csr_regs) {
+      if (dma) {
         // short rows: the LDS-DMA form (six workgroups of four waves per CU: 144 KB of LDS; 33 registers). 216^3 Laplacian: 191 us against the
         // register-staged form's 207 on the same box (profiles/r04_csr_lds_dma.txt)
-        long long nd = std::min<long long>(NG, (long long)ctx->num_cu * 6);
+        // 64 rows of up to 8 entries fit one 512-entry chunk; up to 12 entries one of 768 (9 KB of LDS per wave: four workgroups per CU), up to 16 one of
+        // 1024 (three per CU) - a second chunk per row group is a second serialised DMA wait (rows of 9: 56.6 -> 48.2 us with the wider chunk; beyond
+        // 16 entries per row the entry-side register form is as fast or faster: profiles/r04_csr_lds_dma.txt)
+        const bool wide = A->nnz_d > 8LL * A->n;
+        const bool wider = A->nnz_d > 12LL * A->n;
+        long long nd = std::min<long long>(NG, (long long)ctx->num_cu * (wider ? 3 : wide ? 4 : 6));
         const int rd = nd >= 64 ? 1 : 0;
         if (rd) nd = (nd / 8) * 8;
-        hipLaunchKernelGGL((k_spmv_csr_wave_dma<8, 6, 8>), dim3((unsigned)nd), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, rd);
+        if (wider) hipLaunchKernelGGL((k_spmv_csr_wave_dma<16, 3, 8>), dim3((unsigned)nd), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, rd);
+        else if (wide) hipLaunchKernelGGL((k_spmv_csr_wave_dma<12, 4, 8>), dim3((unsigned)nd), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, rd);
+        else hipLaunchKernelGGL((k_spmv_csr_wave_dma<8, 6, 8>), dim3((unsigned)nd), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, rd);
       } else if (rowside) hipLaunchKernelGGL((k_spmv_csr_wave<true, 8>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, remap);
       else hipLaunchKernelGGL((k_spmv_csr_wave<false, 8>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, A->n, A->d_rowptr, A->d_col, A->d_val, x, y, remap);
     } else if (A->n >= 2048 && !A->force_csr_vector) {

@@ -89,16 +89,17 @@ def test_spmv_csr_row_block_kernel(ctx, monkeypatch):
     assert np.array_equal(yr, ys)
 
 
-@pytest.mark.parametrize("n", [4999, 70001])
-def test_spmv_csr_short_rows_lds_dma_form(ctx, monkeypatch, n):
-    """Short rows (at most 12 entries on average) take the LDS-DMA form of the wave kernel (round 4: the col / val streams go straight into a lane-linear
-    LDS image, global_load_lds_dwordx4): empty rows, stretches of rows of 8 and of 16 entries (all lanes of a row-side read on one bank group: slower, not
+@pytest.mark.parametrize("n,hi", [(4999, 11), (70001, 11), (30011, 25), (30011, 35)])
+def test_spmv_csr_short_rows_lds_dma_form(ctx, monkeypatch, n, hi):
+    """Short rows (at most 16 entries on average) take the LDS-DMA form of the wave kernel (round 4: the col / val streams go straight into a lane-linear
+    LDS image, global_load_lds_dwordx4; chunks of 512 entries up to 8 per row, 768 up to 12, 1024 up to 16 - hi = 11 / 25 / 35 lands in each): empty rows, stretches of rows of 8 and of 16 entries (all lanes of a row-side read on one bank group: slower, not
     wrong), one row far longer than a 512-entry chunk, a last group of fewer than 64 rows, a row pointer run that does not start on a multiple of four. The
     register-staged form (KSGPU_SPMV=csrregs) runs the same rows: bit for bit the same sums (same entry order, same fma chain), both at the oracle's."""
     import slepc_amd as ks
     rng = np.random.default_rng(n)
-    lens = rng.integers(0, 11, n); lens[::5] = 0; lens[200:328] = 8; lens[1000:1128] = 16; lens[3] = 1; lens[n // 2] = 3000; lens[n - 1] = 5
-    assert lens.sum() <= 12 * n
+    lens = rng.integers(0, hi, n); lens[::5] = 0; lens[200:328] = 8; lens[1000:1128] = 16; lens[3] = 1; lens[n // 2] = 3000; lens[n - 1] = 5
+    mean = lens.sum() / n
+    assert {11: mean <= 8, 25: 8 < mean <= 12, 35: 12 < mean <= 16}[hi], mean
     rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     col = np.concatenate([np.sort(rng.choice(n, l, replace=False)) for l in lens] + [np.empty(0, int)]).astype(np.int32)
     val = rng.uniform(-1, 1, rowptr[-1])
