@@ -136,6 +136,8 @@ __global__ __launch_bounds__(256) void k_spmv_csr_stream(int n, const int *__res
 // pays only while a chunk spans most of the wave's rows, i.e. for short rows: chosen at assembly from the mean row length.
 // (16-byte loads of four consecutive entries per lane were tried for the streams: fewer instructions, no faster, and the gathers of such a
 // lane assignment touch still more lines.)
+typedef __attribute__((address_space(3))) void ks_lds_void;          // operands of __builtin_amdgcn_global_load_lds (LDS-DMA)
+typedef const __attribute__((address_space(1))) void ks_glb_void;
 constexpr int CW_PAD = 8;                                  // col / val allocations are this much longer than nnz
 // CW_STEPS: 64 entries per step; 8 steps = chunks of 512 (row side with 256-entry chunks: 62 registers, 8 waves per SIMD, and 237 us instead of 199)
 __device__ __forceinline__ int cw_slot(int e) { return e + (e >> 5); }     // one slot of skew per 32 entries (rows whose length is a multiple of 32)
@@ -260,8 +262,6 @@ __global__ __launch_bounds__(256, ROWSIDE ? 5 : 4) void k_spmv_csr_wave(int n, c
 // for those (chosen at assembly). The registers the staged form spends on two chunks in flight (48 of its 96) are free here: more waves per
 // SIMD take over the latency hiding. A chunk starts on a multiple of four entries (16-byte aligned in both streams; up to three entries of
 // the rows before it are fetched and ignored).
-typedef __attribute__((address_space(3))) void ks_lds_void;
-typedef const __attribute__((address_space(1))) void ks_glb_void;
 template <int CW_STEPS, int WPS, int GU>
 __global__ __launch_bounds__(256, WPS) void k_spmv_csr_wave_dma(int n, const int *__restrict__ rp, const int *__restrict__ col, const double *__restrict__ val,
                                                                 const double *__restrict__ x, double *__restrict__ y, int xcd_remap)
@@ -959,7 +959,14 @@ constexpr int BN_CS_MAX = 9984;          // columns of a slice: 78 KB of LDS nex
 constexpr int BN_SEG_PAD = 8;            // a (slice, wave-bin) segment holds a multiple of 8 entries (padding: value 0 into the spare accumulator): every segment then
                                          // starts on a 64-byte boundary of G / the values in both orders. Against padding to pairs only, same box: gather 385 -> 343-357 us,
                                          // reduce 511 -> 493 us with 2.5 % more entries (profiles/r03_ab_binned.txt); 4: 370-377 / 508, 16: 346-362 / 497
-// phase 1: grid = slices, 1024 threads; LDS: x piece [cs], off1 row [wb + 1], off2t row [wb]
+// phase 1: grid = slices, 1024 threads; LDS: x piece [cs], off1 row [wb + 1], off2t row [wb] (+ DMA: 2 KB per wave for the window's column codes)
+// DMA (round 4): the window's 1024 column codes come by two global_load_lds_dwordx4 per wave (16 bytes per lane) into a wave-private piece of LDS and the
+// lanes read their pairs from there. The register form (DMA = false, kept for reference) loads a pair per lane and instruction - 4 bytes per lane, and
+// 4-byte-per-lane streaming loads top out at 0.7 - 2.4 TB/s on this part (profiles/r03_micro_load_width.txt). Worth 2 - 8 % of this kernel depending on the
+// box (334-350 against 363-365 us; 336-341 against 343-351): it stays bound by its store. A second buffer with the next window's codes in flight (counted
+// vmcnt behind the window's eight stores) measured no better than the register form: profiles/r04_binned_gather_dma.txt.
+// Slices start on multiples of 8 entries (every segment is padded to 8): the 16-byte DMA is aligned.
+template <bool DMA>
 __global__ __launch_bounds__(1024) void k_binned_gather(int n, int cs, int wb, int nwin, const long long *__restrict__ sbase, const unsigned short *__restrict__ col16,
                                                         const int *__restrict__ off1, const int *__restrict__ off2t, const int *__restrict__ wseg,
                                                         const double *__restrict__ x, double *__restrict__ G)
@@ -975,12 +982,26 @@ __global__ __launch_bounds__(1024) void k_binned_gather(int n, int cs, int wb, i
   for (int i = tid; i < wb; i += blockDim.x) o2[i] = off2t[(size_t)s * wb + i];
   __syncthreads();
   const unsigned *cp = reinterpret_cast<const unsigned *>(col16 + sbase[s]);     // slices start at even positions: 4-byte aligned
-  const int total = o1[wb];                                                       // even
+  const unsigned short *cg = col16 + sbase[s];
+  unsigned *cw = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(bn_lds) + ((((size_t)cs * 8 + (size_t)(2 * wb + 1) * 4) + 15) & ~(size_t)15)) + (size_t)w * 512;
+  const int total = o1[wb];                                                       // a multiple of 8
   for (int win = w; win * 1024 < total; win += nw) {
     const int base = win * 1024;
     unsigned c[8];
+    if (DMA) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the reads of the previous window's codes are done before the next ones may land
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int e8 = base + 512 * i + 8 * lane;
+        if (e8 < total) __builtin_amdgcn_global_load_lds((ks_glb_void *)(cg + e8), (ks_lds_void *)(cw + 256 * i), 16, 0, 2);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 8; k++) { const int e = base + k * 128 + 2 * lane; c[k] = e < total ? cw[k * 64 + lane] : 0u; }
+    } else {
 #pragma unroll
     for (int k = 0; k < 8; k++) { const int e = base + k * 128 + 2 * lane; c[k] = e < total ? __builtin_nontemporal_load(cp + (e >> 1)) : 0u; }
+    }
     const int lo = wseg[(size_t)s * nwin + win];
     int bnd[BN_MAXSEG], dlt[BN_MAXSEG];
 #pragma unroll
@@ -1074,7 +1095,7 @@ static int build_binned(ks_mat A)
   const int cs = (n + ns - 1) / ns;
   const int wb = 4 * ns, wr = (n + wb - 1) / wb;
   if (cs > 65535 || wr + 1 > 65535) return KS_SUCCESS;
-  if ((size_t)cs * 8 + (size_t)(2 * wb + 1) * 4 > 156 * 1024 || (size_t)4 * (wr + 1) * 8 > 156 * 1024) return KS_SUCCESS;   // the offset rows of more than ~20 M local rows no longer fit LDS next to the piece of x: the XCD-sliced layout takes those
+  if ((size_t)cs * 8 + (size_t)(2 * wb + 1) * 4 + 16 + 16 * 2048 > 156 * 1024 || (size_t)4 * (wr + 1) * 8 > 156 * 1024) return KS_SUCCESS;   // the offset rows of more than ~20 M local rows no longer fit LDS next to the piece of x: the XCD-sliced layout takes those
   if (A->nnz_d + (long long)ns * wb * (BN_SEG_PAD - 1) >= 2147483647LL) return KS_SUCCESS;          // bin-major positions are 32-bit
   const long long nnz = A->nnz_d;
   try {                                               // the build holds about 25 bytes per nonzero in host memory: without it the sliced layout takes the matrix
@@ -1177,8 +1198,8 @@ static int build_binned(ks_mat A)
   KS_CALL(up(&A->bn_sbase, sbase)); KS_CALL(up(&A->bn_off2, off2)); KS_CALL(up(&A->bn_log2, log2));
   KS_HIP(hipMalloc(&A->bn_g, sizeof(double) * std::max<long long>(entries, 1)));
   KS_HIP(hipMemset(A->bn_g, 0, sizeof(double) * std::max<long long>(entries, 1)));
-  const int lds1 = cs * 8 + (2 * wb + 1) * 4, lds2 = 4 * (wr + 1) * 8;
-  KS_HIP(hipFuncSetAttribute((const void *)k_binned_gather, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+  const int lds1 = cs * 8 + (2 * wb + 1) * 4 + 16 + 16 * 2048, lds2 = 4 * (wr + 1) * 8;      // (+ 2 KB of column codes per wave)
+  KS_HIP(hipFuncSetAttribute((const void *)k_binned_gather<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
   KS_HIP(hipFuncSetAttribute((const void *)k_binned_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
   // diagonal and infinity norm are taken from the CSR arrays before they are released
   KS_HIP(hipMalloc(&A->diag_cache, sizeof(double) * n));
@@ -1637,8 +1658,8 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y, const double *row
                    : A->use_dict ? (2.0 * A->dict_w + 16.0) * A->n + 12.0 * A->nnz_o
                    : (A->use_odict ? 8.0 * A->nnz_d + (A->dict_w + 16.0) * A->n + 12.0 * A->nnz_o : -1.0));   // the dictionary layouts' own compulsory bytes
     if (A->use_binned) {
-      hipLaunchKernelGGL(k_binned_gather, dim3((unsigned)A->bn_ns), dim3(1024), (size_t)A->bn_cs * 8 + (size_t)(2 * A->bn_wb + 1) * 4, ctx->stream, A->n, A->bn_cs, A->bn_wb, A->bn_nwin,
-                         A->bn_sbase, A->bn_col16, A->bn_off1, A->bn_off2t, A->bn_wseg, x, A->bn_g);
+      hipLaunchKernelGGL(k_binned_gather<true>, dim3((unsigned)A->bn_ns), dim3(1024), (size_t)A->bn_cs * 8 + (size_t)(2 * A->bn_wb + 1) * 4 + 16 + 16 * 2048, ctx->stream,
+                         A->n, A->bn_cs, A->bn_wb, A->bn_nwin, A->bn_sbase, A->bn_col16, A->bn_off1, A->bn_off2t, A->bn_wseg, x, A->bn_g);
       hipLaunchKernelGGL(k_binned_reduce, dim3((unsigned)(A->bn_wb / 4)), dim3(256), (size_t)4 * (A->bn_wr + 1) * 8, ctx->stream, A->n, A->bn_wr, A->bn_ns, A->bn_log2, A->bn_off2,
                          A->bn_g, A->bn_val, A->bn_row16, y, rowscale);
     } else if (A->use_sliced) {
