@@ -49,7 +49,7 @@ def event_name(name):
 def kernel_symbol(name, var):
     if name == "spmv_csr":
         return ("k_spmv_dict<W>" if var == 16 else "k_spmv_odict<W>" if var == 17 else "k_binned_gather + k_binned_reduce" if var == 18
-                else "k_spmv_sell<8>" if var == 8 else "k_spmv_csr_wave_dma<8, 6, 8> | k_spmv_csr_wave<ROWSIDE, 8> | k_spmv_csr<G, 4, false, false>")
+                else "k_spmv_sell<4>" if var == 8 else "k_spmv_csr_wave_dma<8, 6, 8> | k_spmv_csr_wave<ROWSIDE, 8> | k_spmv_csr<G, 4, false, false>")
     if name == "bv_dot_sweep":
         return "k_dot_sweep<%d, 2>" % var
     if name == "spmv_dot_fused":

@@ -319,11 +319,20 @@ __global__ __launch_bounds__(256, WPS) void k_spmv_csr_wave_dma(int n, const int
 }
 
 // ---- sliced ELL (SELL-64) ---------------------------------------------------------------------------
-// lane <-> row: every val/col load of a wavefront is one contiguous 512 B / 256 B run, the x gather of a
+// lane <-> row: every val/col load of a wavefront is one contiguous run, the x gather of a
 // stencil matrix is contiguous too (consecutive rows -> consecutive columns), y is stored 512 B per wave,
 // no cross-lane reduction. Row lengths (int32 per row, the same 4n bytes CSR spends on rowptr) mask the
 // padding, so padded slots are never multiplied (no 0*NaN pollution, empty rows give exactly 0).
-template <int UNR>
+// Round 4: entries are stored in PAIRS - entries 2q and 2q + 1 of a lane's row side by side, 128 entries per pair index q - so that a lane
+// fetches two columns with one 8-byte load and two values with one 16-byte load (a wave: 512 B and 1 KB contiguous): 4-byte-per-lane streaming
+// loads top out at 0.7 - 2.4 TB/s on this part (profiles/r03_micro_load_width.txt), and a third of this kernel's load instructions were such.
+// A slice of odd width keeps its last entry as a column of singles behind its pairs: same storage as before, same entry order, same fma chain
+// - the same bits (asserted against the CSR kernels and the dictionary layouts).
+__device__ __forceinline__ long long sell_pos(long long sbase, int w, int j, int lane)
+{
+  return (j | 1) < w ? sbase + (long long)(j >> 1) * 128 + lane * 2 + (j & 1) : sbase + (long long)(w >> 1) * 128 + lane;
+}
+template <int UNR>           // pairs in flight per lane
 __global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_sell(int nrows, int nslices, const int *__restrict__ sp, const int *__restrict__ rlen,
                                                           const int *__restrict__ col, const double *__restrict__ val,
                                                           const double *__restrict__ x, double *__restrict__ y, int xcd_remap)
@@ -341,18 +350,32 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_spmv_sell(int nrows, int nslices
     const long long s = g * wpb + (threadIdx.x >> 6);
     if (s >= nslices) continue;
     const long long r = s * 64 + lane;
-    const int w = sp[s + 1] - sp[s];
+    const int w = sp[s + 1] - sp[s], wp = w >> 1;
     const int len = (r < nrows) ? rlen[r] : 0;
-    const long long base = (long long)sp[s] * 64 + lane;
+    const long long sb = (long long)sp[s] * 64;
     double acc = 0.0;
-    for (int j = 0; j < w; j += UNR) {          // fully predicated batches: all loads of a batch are independent
-      int c[UNR]; double a[UNR], xv[UNR];
+    for (int q = 0; q < wp; q += UNR) {         // fully predicated batches: all loads of a batch are independent
+      ks_i2v c[UNR]; ksk::ks_d2v a[UNR]; double x0[UNR], x1[UNR];
 #pragma unroll
-      for (int u = 0; u < UNR; u++) { const bool ok = j + u < len; c[u] = ok ? ksk::ldstream(col + base + (long long)(j + u) * 64) : -1; a[u] = ok ? ksk::ldstream(val + base + (long long)(j + u) * 64) : 0.0; }
+      for (int u = 0; u < UNR; u++) {
+        const int j = 2 * (q + u);
+        const bool ok = q + u < wp && j < len;
+        const long long p = sb + (long long)(q + u) * 128 + lane * 2;
+        c[u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const ks_i2v *>(col + p)) : ks_i2v{-1, -1};
+        a[u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const ksk::ks_d2v *>(val + p)) : ksk::ks_d2v{0.0, 0.0};
+        if (j + 1 >= len) { c[u].y = -1; a[u].y = 0.0; }         // the pair's second slot is padding: never gathered, never multiplied
+      }
 #pragma unroll
-      for (int u = 0; u < UNR; u++) xv[u] = c[u] >= 0 ? x[c[u]] : 0.0;
+      for (int u = 0; u < UNR; u++) { x0[u] = c[u].x >= 0 ? x[c[u].x] : 0.0; x1[u] = c[u].y >= 0 ? x[c[u].y] : 0.0; }
 #pragma unroll
-      for (int u = 0; u < UNR; u++) acc = fma(a[u], xv[u], acc);
+      for (int u = 0; u < UNR; u++) { acc = fma(a[u].x, x0[u], acc); acc = fma(a[u].y, x1[u], acc); }
+    }
+    if (w & 1) {                                 // the slice's last entry slot: singles
+      const bool ok = w - 1 < len;
+      const long long p = sb + (long long)wp * 128 + lane;
+      const int c = ok ? ksk::ldstream(col + p) : -1;
+      const double a = ok ? ksk::ldstream(val + p) : 0.0;
+      acc = fma(a, c >= 0 ? x[c] : 0.0, acc);
     }
     if (r < nrows) __builtin_nontemporal_store(acc, y + r);
   }
@@ -610,10 +633,11 @@ __global__ void k_sell_fill(int n, int nslices, const int *__restrict__ rowptr, 
   const long long r = s * 64 + lane;
   const int w = sp[s + 1] - sp[s];
   const int p0 = (r < n) ? rowptr[r] : 0, len = (r < n) ? rowptr[r + 1] - p0 : 0;
-  const long long base = (long long)sp[s] * 64 + lane;
+  const long long sb = (long long)sp[s] * 64;
   for (int j = 0; j < w; j++) {
-    scol[base + (long long)j * 64] = (j < len) ? col[p0 + j] : 0;
-    sval[base + (long long)j * 64] = (j < len) ? val[p0 + j] : 0.0;
+    const long long p = sell_pos(sb, w, j, lane);
+    scol[p] = (j < len) ? col[p0 + j] : 0;
+    sval[p] = (j < len) ? val[p0 + j] : 0.0;
   }
 }
 
@@ -1693,7 +1717,7 @@ int ks_mat_mult_internal(ks_mat A, const double *x, double *y, const double *row
       blocks = std::min<long long>(groups, (long long)ctx->num_cu * bmul);
       const dim3 gr((unsigned)std::max<long long>(blocks, 1));
       const int remap = (remap_env && blocks == groups && blocks >= 64) ? 1 : 0;     // only with one slice group per workgroup (a strided loop would interleave the ranges again)
-      hipLaunchKernelGGL((k_spmv_sell<8>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->nslices, A->s_ptr, A->s_len, A->s_col, A->s_val, x, y, remap);
+      hipLaunchKernelGGL((k_spmv_sell<4>), gr, dim3(SPMV_BLOCK), 0, ctx->stream, A->n, A->nslices, A->s_ptr, A->s_len, A->s_col, A->s_val, x, y, remap);
     } else if (A->n >= 2048 && !A->force_csr_vector && !A->force_csr_block) {
       // 4 or 5 workgroups of 4 waves per CU (registers; forcing 6 spills: 259 us); a multiple of 8 so that every XCD gets its eighth of the rows
       const long long NG = ((long long)A->n + 255) / 256;
@@ -1744,9 +1768,10 @@ __global__ void k_diag_sell(int n, const int *__restrict__ sp, const int *__rest
 {
   const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
-  const long long s = r >> 6, base = (long long)sp[s] * 64 + (r & 63);
+  const long long s = r >> 6, sb = (long long)sp[s] * 64;
+  const int w = sp[s + 1] - sp[s], lane = (int)(r & 63);
   double v = 0.0;
-  for (int j = 0; j < rlen[r]; j++) if (col[base + (long long)j * 64] == r) v += val[base + (long long)j * 64];
+  for (int j = 0; j < rlen[r]; j++) { const long long p = sell_pos(sb, w, j, lane); if (col[p] == r) v += val[p]; }
   d[r] = v;
 }
 int ks_mat_get_diagonal_internal(ks_mat A, double *d)
@@ -1774,9 +1799,10 @@ __global__ void k_rowabs_sell(int n, const int *__restrict__ sp, const int *__re
 {
   const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
-  const long long base = (long long)sp[r >> 6] * 64 + (r & 63);
+  const long long s = r >> 6, sb = (long long)sp[s] * 64;
+  const int w = sp[s + 1] - sp[s], lane = (int)(r & 63);
   double v = 0.0;
-  for (int j = 0; j < rlen[r]; j++) v += fabs(val[base + (long long)j * 64]);
+  for (int j = 0; j < rlen[r]; j++) v += fabs(val[sell_pos(sb, w, j, lane)]);
   out[r] = v;
 }
 __global__ void k_rowabs_rows(int nrows, const int *__restrict__ rows, const int *__restrict__ rp, const double *__restrict__ val, double *__restrict__ out)
