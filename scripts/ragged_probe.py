@@ -11,12 +11,18 @@ rng = np.random.default_rng(0)
 lens = rng.integers(10, 41, n)
 rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
 nnz = int(rowptr[-1])
-col = (np.repeat(np.arange(n), lens) + rng.integers(-2000, 2001, nnz)).clip(0, n - 1).astype(np.int32)
+# PROBE_COLS=near: entry j of a row sits at column row + j - len / 2 (a variable-width band: the gathers of neighbouring rows share their lines);
+# default: a random column within +-2000 of the row (every lane of a gather its own line)
+if os.environ.get("PROBE_COLS") == "near":
+    j = np.arange(nnz) - np.repeat(rowptr[:-1].astype(np.int64), lens)
+    col = (np.repeat(np.arange(n), lens) + j - np.repeat(lens // 2, lens)).clip(0, n - 1).astype(np.int32)
+else:
+    col = (np.repeat(np.arange(n), lens) + rng.integers(-2000, 2001, nnz)).clip(0, n - 1).astype(np.int32)
 val = rng.uniform(-1, 1, nnz)
 x = rng.standard_normal(n)
 ref = None
-for fmt in ("csr", "sell", "csrvec"):
-    os.environ["KSGPU_SPMV"] = fmt
+for fmt in ("auto", "csr", "sell", "csrvec"):
+    os.environ.pop("KSGPU_SPMV", None) if fmt == "auto" else os.environ.__setitem__("KSGPU_SPMV", fmt)
     A = ks.Mat.from_csr(ctx, rowptr, col, val)
     y = A.mult(x)
     if ref is None:
